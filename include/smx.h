@@ -1,0 +1,231 @@
+/*
+ * smx.h -- C-ABI of the MI355X-native surfel-integration library (libsmx.so).
+ *
+ * This is the drop-in boundary for the hot path of puzzlepaint/surfelmeshing:
+ * every entry point replaces one piece of the reference's CUDA-side interface
+ * (cited per declaration; paths relative to the reference checkout,
+ * APP = applications/surfel_meshing/src/surfel_meshing, VIS = libvis/src/libvis).
+ * Plain C types only: opaque handles, POD descriptors, pointers and sizes.
+ * The C++ shim include/smx_shim.hpp re-creates the reference's class names
+ * (CUDABuffer<T>, CUDASurfelReconstruction, CUDASurfelsCPU) on top of it; the
+ * Python mirror is surfelmeshing_amd/api.py.  See INTEGRATION.md.
+ *
+ * Conventions:
+ *  - every function returns 0 on success or a negative smx_status; the last
+ *    error text is available from smx_last_error().  The reference aborts via
+ *    LOG(FATAL) (VIS/cuda/cuda_util.h:35-49); the shims convert non-zero into
+ *    an abort / exception to keep that behaviour.
+ *  - all work is enqueued on the HIP stream passed in (a hipStream_t cast to
+ *    void*; NULL = the default stream).  Calls return asynchronously; unlike
+ *    the reference, Integrate does not block the host (the surfel count lives
+ *    in device memory), so counts are read with smx_recon_counts(), which
+ *    synchronises the stream.
+ *  - single caller thread per object; no process-global state (the reference's
+ *    function-local static buffer at APP/cuda_surfel_reconstruction_kernels.cc:479
+ *    is per-object here), so one object per GPU / per stream works.
+ *  - camera cx, cy are in the pixel-CORNER convention, as
+ *    PinholeCamera4f::parameters()[2..3] in the reference.
+ */
+#ifndef SMX_H_
+#define SMX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  SMX_OK = 0,
+  SMX_ERR_INVALID_ARGUMENT = -1,
+  SMX_ERR_HIP = -2,          /* a HIP runtime call failed */
+  SMX_ERR_NO_DEVICE = -3,    /* no usable gfx950 device */
+  SMX_ERR_UNSUPPORTED = -4
+} smx_status;
+
+typedef void* smx_stream;                 /* hipStream_t */
+typedef struct smx_buffer_s* smx_buffer;  /* owns pitched device memory */
+typedef struct smx_recon_s* smx_recon;    /* CUDASurfelReconstruction */
+typedef struct smx_nn_s* smx_nn;          /* radius-neighbor search index */
+
+/* POD passed to kernels by value, identical in layout to the reference's
+ * CUDABuffer_<T> {T* address_; int height_; int width_; size_t pitch_;}
+ * (VIS/cuda/cuda_buffer.cuh:44-119). */
+typedef struct {
+  void* address;
+  int32_t height;
+  int32_t width;
+  size_t pitch;   /* bytes */
+} smx_buffer_desc;
+
+const char* smx_last_error(void);
+/* Number of visible HIP devices / select one for the calling thread. */
+int smx_device_count(int* count);
+int smx_set_device(int device);
+int smx_device_name(int device, char* name, size_t capacity);
+int smx_stream_create(smx_stream* out);
+int smx_stream_destroy(smx_stream s);
+int smx_stream_synchronize(smx_stream s);
+
+/* ---- CUDABuffer<T>  (VIS/cuda/cuda_buffer.h:45-129, cuda_buffer_inl.h:36-172) ---- */
+/* CUDABuffer(int height, int width): cudaMallocPitch */
+int smx_buffer_create(int32_t height, int32_t width, int32_t elem_bytes, smx_buffer* out);
+int smx_buffer_destroy(smx_buffer b);
+/* ToCUDA() */
+int smx_buffer_get_desc(smx_buffer b, smx_buffer_desc* out);
+/* UploadAsync / UploadPitchedAsync (src_pitch = 0: dense rows of width*elem_bytes) */
+int smx_buffer_upload(smx_buffer b, smx_stream s, const void* src, size_t src_pitch);
+/* DownloadAsync / DownloadPitchedAsync */
+int smx_buffer_download(smx_buffer b, smx_stream s, void* dst, size_t dst_pitch);
+/* UploadPartAsync / DownloadPartAsync: byte range [start, start+length) of the allocation */
+int smx_buffer_upload_part(smx_buffer b, smx_stream s, size_t start, size_t length, const void* src);
+int smx_buffer_download_part(smx_buffer b, smx_stream s, size_t start, size_t length, void* dst);
+/* Clear(T value, stream): pattern points at one element (elem_bytes bytes) */
+int smx_buffer_clear(smx_buffer b, smx_stream s, const void* pattern);
+/* SetTo(const CUDABuffer<T>& other, stream) */
+int smx_buffer_set_to(smx_buffer dst, smx_buffer src, smx_stream s);
+
+/* ---- depth preprocessing free functions (APP/cuda_depth_processing.cuh:43-122) ---- */
+/* BilateralFilteringAndDepthCutoffCUDA, APP/cuda_depth_processing.cu:120-158 */
+int smx_bilateral_filtering_and_depth_cutoff(
+    smx_stream s, float sigma_xy, float sigma_value_factor, uint16_t value_to_ignore,
+    float radius_factor, uint16_t max_depth, float depth_valid_region_radius,
+    const smx_buffer_desc* input_depth /*u16*/, const smx_buffer_desc* output_depth /*u16*/);
+/* OutlierDepthMapFusionCUDA<count,u16>, both overloads (cu:229-285 and :399-455):
+ * other_count = count-1 in {2,4,6,8}; required_count < 0 selects the
+ * all-must-agree overload.  others_TR_reference: other_count row-major 3x4. */
+int smx_outlier_depth_map_fusion(
+    smx_stream s, int32_t other_count, int32_t required_count, float tolerance,
+    const smx_buffer_desc* input_depth, float fx, float fy, float cx, float cy,
+    const smx_buffer_desc* other_depths /*[other_count]*/, const float* others_TR_reference,
+    const smx_buffer_desc* output_depth);
+/* ErodeDepthMapCUDA (radius 1..3), cu:540-579; CopyWithoutBorderCUDA, cu:609-633 */
+int smx_erode_depth_map(smx_stream s, int32_t radius, const smx_buffer_desc* input_depth,
+                        const smx_buffer_desc* output_depth);
+int smx_copy_without_border(smx_stream s, const smx_buffer_desc* input_depth,
+                            const smx_buffer_desc* output_depth);
+/* ComputeNormalsAndDropBadPixelsCUDA, cu:720-762 */
+int smx_compute_normals_and_drop_bad_pixels(
+    smx_stream s, float observation_angle_threshold_deg, float depth_scaling,
+    float fx, float fy, float cx, float cy,
+    const smx_buffer_desc* in_depth, const smx_buffer_desc* out_depth,
+    const smx_buffer_desc* out_normals /*float2*/);
+/* ComputePointRadiiAndRemoveIsolatedPixelsCUDA, cu:839-883 */
+int smx_compute_point_radii_and_remove_isolated_pixels(
+    smx_stream s, float point_radius_extension_factor, float point_radius_clamp_factor,
+    float depth_scaling, float fx, float fy, float cx, float cy,
+    const smx_buffer_desc* depth_buffer, const smx_buffer_desc* radius_buffer /*float*/,
+    const smx_buffer_desc* out_depth);
+
+/* ---- CUDASurfelReconstruction (APP/cuda_surfel_reconstruction.h:44-176) ---- */
+/* trailing arguments of Integrate(), .h:59-77; defaults APP/main.cc:323-368 */
+typedef struct {
+  float sensor_noise_factor;
+  float max_surfel_confidence;
+  float regularizer_weight;
+  int32_t regularization_frame_window_size;
+  int32_t do_blending;
+  int32_t measurement_blending_radius;
+  int32_t regularization_iterations_per_integration_iteration;
+  float radius_factor_for_regularization_neighbors;
+  float normal_compatibility_threshold_deg;
+  int32_t surfel_integration_active_window_size;
+} smx_integrate_params;
+
+/* CUDASurfelBuffersCPU, APP/cuda_surfels_cpu.h:40-74 */
+typedef struct {
+  uint32_t frame_index;
+  size_t surfel_count;
+  float* surfel_x_buffer;
+  float* surfel_y_buffer;
+  float* surfel_z_buffer;
+  float* surfel_radius_squared_buffer;
+  float* surfel_normal_x_buffer;
+  float* surfel_normal_y_buffer;
+  float* surfel_normal_z_buffer;
+  uint32_t* surfel_last_update_stamp_buffer;
+} smx_surfel_buffers_cpu;
+
+/* ctor, .h:47-53 / .cc:44-91 (the three GL resources and the render window are dropped) */
+int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
+                     float fx, float fy, float cx, float cy, smx_recon* out);
+int smx_recon_destroy(smx_recon r);
+/* Integrate, .h:59-77 / .cc:112-320.  depth is MUTATED by blending as in the
+ * reference; global_T_local is row-major 3x4 (SE3f::matrix3x4()). */
+int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float depth_scaling,
+                        const smx_buffer_desc* depth /*u16*/, const smx_buffer_desc* normals /*float2*/,
+                        const smx_buffer_desc* radius /*float*/, const smx_buffer_desc* color /*uchar3*/,
+                        const float global_T_local[12], const smx_integrate_params* params);
+/* Regularize, .h:82-87 / .cc:322-337 */
+int smx_recon_regularize(smx_recon r, smx_stream s, uint32_t frame_index, float regularizer_weight,
+                         float radius_factor_for_regularization_neighbors,
+                         int32_t regularization_frame_window_size);
+/* TransferAllToCPU, .h:91-94 / .cc:339-359.  Fills frame_index and surfel_count,
+ * enqueues the 8 row downloads; the caller synchronises the stream
+ * (APP/main.cc:1266-1267).  Reads the device-side count first (one small
+ * blocking copy). */
+int smx_recon_transfer_all_to_cpu(smx_recon r, smx_stream s, uint32_t frame_index,
+                                  smx_surfel_buffers_cpu* buffers);
+/* ExportVertices, .h:109-112 / .cc:405-410: position 1 x 3N float, colour 1 x 3N u8 */
+int smx_recon_export_vertices(smx_recon r, smx_stream s, const smx_buffer_desc* position_buffer,
+                              const smx_buffer_desc* color_buffer);
+/* GetTimings, .h:115-122 / .cc:412-429: data association, merging, blending,
+ * integration, neighbor update, new surfel creation, regularization (ms). */
+int smx_recon_get_timings(smx_recon r, float out_ms[7]);
+int smx_recon_set_timing_enabled(smx_recon r, int32_t enabled);
+/* surfel_count() = slots - merged, surfels_size() = slots, .h:125-128.  Synchronises s. */
+int smx_recon_counts(smx_recon r, smx_stream s, uint32_t* surfel_count, uint32_t* surfels_size);
+
+/* Value distributions of the last Integrate call: synchronises s. */
+typedef struct {
+  uint32_t surfels_size, merge_count;
+  uint32_t n_visible;      /* slots projecting into the image with z > 0 */
+  uint32_t n_new, n_merged, n_recent, n_edges;
+  uint32_t n_integrated, n_replaced, n_conflict_hits;
+  uint32_t capacity_clamped;  /* 1 if new-surfel creation hit max_surfel_count */
+} smx_recon_stats;
+int smx_recon_get_stats(smx_recon r, smx_stream s, smx_recon_stats* out);
+
+/* Test / benchmark hooks (not part of the reference interface): raw access to
+ * the surfel SoA rows (25 rows as in APP/cuda_surfel_reconstruction_kernels.cuh:49-78,
+ * dense [25][count] on the host side) and to the per-pixel association images. */
+int smx_recon_debug_download_surfels(smx_recon r, smx_stream s, float* rows, uint32_t count);
+int smx_recon_debug_upload_surfels(smx_recon r, smx_stream s, const float* rows, uint32_t count,
+                                   uint32_t merge_count);
+enum {
+  SMX_SCRATCH_SUPPORTING = 0,      /* u32 [H][W] */
+  SMX_SCRATCH_SUPPORT_COUNTS = 1,  /* u32 */
+  SMX_SCRATCH_DEPTH_SUMS = 2,      /* i64, 2^-32 fixed point */
+  SMX_SCRATCH_CONFLICTING = 3,     /* u32, decoded index or 0xFFFFFFFF */
+  SMX_SCRATCH_FIRST_DEPTH = 4,     /* f32 */
+  SMX_SCRATCH_NEW_FLAGS = 5,       /* u8 [W*H] */
+  SMX_SCRATCH_NEW_INDICES = 6      /* u32 [W*H], exclusive ranks */
+};
+int smx_recon_debug_download_scratch(smx_recon r, smx_stream s, int32_t which, void* dst);
+/* 0 = list-driven kernels (default), 1 = every surfel kernel scans all slots
+ * like the reference does; results are identical, used for A/B checks. */
+int smx_recon_set_scan_mode(smx_recon r, int32_t mode);
+
+/* ---- radius-neighbor search (replaces CompressedOctree::FindNearestSurfelsWithinRadius,
+ * APP/octree.h:470-477, APP/octree.cc:313-470, for batched queries) ---- */
+/* Build a uniform-grid index over n points given as three device or host rows.
+ * cell_size > 0; queries with radius <= cell_size touch at most 27 cells. */
+int smx_nn_create(smx_nn* out);
+int smx_nn_destroy(smx_nn nn);
+int smx_nn_build(smx_nn nn, smx_stream s, const float* x, const float* y, const float* z,
+                 uint32_t n, float cell_size, int32_t rows_on_device);
+/* For each query: up to k nearest points with dist^2 <= r2[q], ascending by
+ * (dist^2, index).  state (may be NULL): points whose state byte has a bit of
+ * skip_mask set are skipped (octree.cc:330-335).  Outputs are device or host
+ * pointers according to outputs_on_device; out_idx/out_d2 are [nq][k]. */
+int smx_nn_query_batch(smx_nn nn, smx_stream s, uint32_t nq, const float* qx, const float* qy,
+                       const float* qz, const float* r2, int32_t k, const uint8_t* state,
+                       uint8_t skip_mask, int32_t queries_on_device,
+                       uint32_t* out_idx, float* out_d2, int32_t* out_count,
+                       int32_t outputs_on_device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

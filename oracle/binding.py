@@ -1,0 +1,292 @@
+"""ctypes binding of oracle/libsmx_oracle.so (TEST INFRASTRUCTURE ONLY).
+
+The shapes and names mirror oracle/smx_oracle.h; images are dense row-major
+numpy arrays (depth u16 [H,W], normals f32 [H,W,2], radius f32 [H,W],
+colour u8 [H,W,3]); poses are row-major 3x4 float32.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libsmx_oracle.so")
+
+INVALID = 0xFFFFFFFF
+ROWS = 25
+(ROW_X, ROW_Y, ROW_Z, ROW_SMOOTH_X, ROW_SMOOTH_Y, ROW_SMOOTH_Z, ROW_CONFIDENCE, ROW_RADIUS_SQ,
+ ROW_NORMAL_X, ROW_NORMAL_Y, ROW_NORMAL_Z, ROW_GRAD_X, ROW_GRAD_Y, ROW_GRAD_Z,
+ ROW_ACCUM_X, ROW_ACCUM_Y, ROW_ACCUM_Z, ROW_CREATION_STAMP, ROW_LAST_UPDATE_STAMP,
+ ROW_NEIGHBOR0, ROW_NEIGHBOR1, ROW_NEIGHBOR2, ROW_NEIGHBOR3, ROW_GRAD_COUNT, ROW_COLOR) = range(25)
+# rows that are scratch in both implementations and excluded from parity
+SCRATCH_ROWS = (11, 12, 13, 14, 15, 16, 23)
+SUM_EXACT, SUM_FLOAT_ASCENDING = 0, 1
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_SO) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_SO)
+            for f in os.listdir(_HERE) if f.endswith((".c", ".h"))):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
+    return _SO
+
+
+class IntegrateParams(C.Structure):
+    _fields_ = [("sensor_noise_factor", C.c_float),
+                ("max_surfel_confidence", C.c_float),
+                ("regularizer_weight", C.c_float),
+                ("regularization_frame_window_size", C.c_int32),
+                ("do_blending", C.c_int32),
+                ("measurement_blending_radius", C.c_int32),
+                ("regularization_iterations_per_integration_iteration", C.c_int32),
+                ("radius_factor_for_regularization_neighbors", C.c_float),
+                ("normal_compatibility_threshold_deg", C.c_float),
+                ("surfel_integration_active_window_size", C.c_int32)]
+
+    @classmethod
+    def defaults(cls, **kw):
+        # APP/main.cc:323-368
+        p = cls(0.05, 5.0, 10.0, 30, 1, 12, 1, 2.0, 40.0, 2147483647)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+
+class _Recon(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("max_surfels", C.c_uint32), ("surfel_count", C.c_uint32), ("merge_count", C.c_uint32),
+                ("sum_mode", C.c_int32),
+                ("surfels", C.POINTER(C.c_float)), ("grad_acc", C.POINTER(C.c_int64)),
+                ("supporting", C.POINTER(C.c_uint32)), ("support_counts", C.POINTER(C.c_uint32)),
+                ("depth_sums_f", C.POINTER(C.c_float)), ("depth_sums_q", C.POINTER(C.c_int64)),
+                ("conflicting", C.POINTER(C.c_uint32)), ("conflicting_key", C.POINTER(C.c_uint32)),
+                ("first_depth", C.POINTER(C.c_float)),
+                ("distance_map", C.POINTER(C.c_uint8)), ("new_distance_map", C.POINTER(C.c_uint8)),
+                ("deltas", C.POINTER(C.c_float)), ("new_deltas", C.POINTER(C.c_float)),
+                ("new_flags", C.POINTER(C.c_uint8)), ("new_indices", C.POINTER(C.c_uint32)),
+                ("merge_decision", C.POINTER(C.c_uint8)),
+                ("last_n_visible", C.c_uint32), ("last_n_new", C.c_uint32), ("last_n_merged", C.c_uint32),
+                ("last_n_recent", C.c_uint32), ("last_n_edges", C.c_uint32),
+                ("last_n_integrated", C.c_uint32), ("last_n_replaced", C.c_uint32),
+                ("last_n_conflict_hits", C.c_uint32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.orc_expf.restype = C.c_float
+        L.orc_expf.argtypes = [C.c_float]
+        L.orc_recon_create.restype = C.POINTER(_Recon)
+        L.orc_recon_create.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]
+        L.orc_recon_destroy.argtypes = [C.POINTER(_Recon)]
+        L.orc_nn_bruteforce.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a, t=None):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+def expf(x):
+    x = np.asarray(x, np.float32)
+    out = np.empty_like(x)
+    f = lib().orc_expf
+    flat, o = x.ravel(), out.ravel()
+    for i in range(flat.size):
+        o[i] = f(float(flat[i]))
+    return out
+
+
+# ---- depth preprocessing -------------------------------------------------------------------
+def bilateral_filter_and_cutoff(depth, sigma_xy=3.0, sigma_value_factor=0.05, value_to_ignore=0,
+                                radius_factor=2.0, max_depth=15000, depth_valid_region_radius=333.0):
+    depth = _c(depth, np.uint16)
+    h, w = depth.shape
+    out = np.empty_like(depth)
+    lib().orc_bilateral_filter_and_cutoff(
+        C.c_float(sigma_xy), C.c_float(sigma_value_factor), C.c_uint16(value_to_ignore),
+        C.c_float(radius_factor), C.c_uint16(max_depth), C.c_float(depth_valid_region_radius),
+        C.c_int(w), C.c_int(h), _p(depth), _p(out))
+    return out
+
+
+def outlier_depth_map_fusion(depth, others, others_TR_reference, fx, fy, cx, cy, tolerance=0.02,
+                             required_count=-1):
+    depth = _c(depth, np.uint16)
+    h, w = depth.shape
+    others = [_c(o, np.uint16) for o in others]
+    T = _c(np.asarray(others_TR_reference, np.float32).reshape(len(others), 12), np.float32)
+    ptrs = (C.c_void_p * len(others))(*[o.ctypes.data for o in others])
+    out = np.empty_like(depth)
+    lib().orc_outlier_depth_map_fusion(
+        C.c_int(len(others)), C.c_int(required_count), C.c_float(tolerance), C.c_int(w), C.c_int(h),
+        _p(depth), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), ptrs, _p(T), _p(out))
+    return out
+
+
+def erode_depth_map(depth, radius):
+    depth = _c(depth, np.uint16)
+    h, w = depth.shape
+    out = np.empty_like(depth)
+    if radius == 0:
+        lib().orc_copy_without_border(C.c_int(w), C.c_int(h), _p(depth), _p(out))
+    else:
+        lib().orc_erode_depth_map(C.c_int(radius), C.c_int(w), C.c_int(h), _p(depth), _p(out))
+    return out
+
+
+def compute_normals_and_drop_bad_pixels(depth, fx, fy, cx, cy, observation_angle_threshold_deg=85.0,
+                                        depth_scaling=5000.0):
+    depth = _c(depth, np.uint16)
+    h, w = depth.shape
+    out = np.empty_like(depth)
+    normals = np.zeros((h, w, 2), np.float32)
+    lib().orc_compute_normals_and_drop_bad_pixels(
+        C.c_float(observation_angle_threshold_deg), C.c_float(depth_scaling),
+        C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
+        C.c_int(w), C.c_int(h), _p(depth), _p(out), _p(normals))
+    return out, normals
+
+
+def compute_point_radii_and_remove_isolated_pixels(depth, fx, fy, cx, cy, point_radius_extension_factor=1.5,
+                                                   point_radius_clamp_factor=float("inf"),
+                                                   depth_scaling=5000.0, radius_init=None):
+    depth = _c(depth, np.uint16)
+    h, w = depth.shape
+    out = np.empty_like(depth)
+    # the kernel leaves radius untouched where depth == 0; callers compare only where out > 0
+    radius = np.zeros((h, w), np.float32) if radius_init is None else _c(radius_init, np.float32).copy()
+    lib().orc_compute_point_radii_and_remove_isolated_pixels(
+        C.c_float(point_radius_extension_factor), C.c_float(point_radius_clamp_factor), C.c_float(depth_scaling),
+        C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
+        C.c_int(w), C.c_int(h), _p(depth), _p(radius), _p(out))
+    return out, radius
+
+
+# ---- reconstruction object -----------------------------------------------------------------
+class Recon:
+    """Mirror of CUDASurfelReconstruction (APP/cuda_surfel_reconstruction.h:44-176) on the CPU."""
+
+    def __init__(self, max_surfels, width, height, fx, fy, cx, cy, sum_mode=SUM_EXACT):
+        self._r = lib().orc_recon_create(max_surfels, width, height, fx, fy, cx, cy, sum_mode)
+        self.max_surfels, self.width, self.height = max_surfels, width, height
+
+    def close(self):
+        if self._r:
+            lib().orc_recon_destroy(self._r)
+            self._r = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def surfels_size(self):
+        return int(self._r.contents.surfel_count)
+
+    @property
+    def surfel_count(self):
+        return int(self._r.contents.surfel_count - self._r.contents.merge_count)
+
+    @property
+    def merge_count(self):
+        return int(self._r.contents.merge_count)
+
+    def set_counts(self, surfel_count, merge_count):
+        self._r.contents.surfel_count = surfel_count
+        self._r.contents.merge_count = merge_count
+
+    def stats(self):
+        c = self._r.contents
+        return {k: int(getattr(c, "last_" + k)) for k in
+                ("n_visible", "n_new", "n_merged", "n_recent", "n_edges", "n_integrated", "n_replaced",
+                 "n_conflict_hits")}
+
+    def surfels(self):
+        """Writable [25, max_surfels] float32 view of the SoA."""
+        return np.ctypeslib.as_array(self._r.contents.surfels, shape=(ROWS, self.max_surfels))
+
+    def _img(self, name, dtype):
+        a = np.ctypeslib.as_array(getattr(self._r.contents, name), shape=(self.height, self.width))
+        assert a.dtype == dtype, (a.dtype, dtype)
+        return a
+
+    def scratch(self):
+        return {
+            "supporting": self._img("supporting", np.uint32),
+            "support_counts": self._img("support_counts", np.uint32),
+            "depth_sums_q": self._img("depth_sums_q", np.int64),
+            "conflicting": self._img("conflicting", np.uint32),
+            "first_depth": self._img("first_depth", np.float32),
+            "new_flags": self._img("new_flags", np.uint8),
+            "new_indices": self._img("new_indices", np.uint32),
+        }
+
+    def integrate(self, frame_index, depth_scaling, depth, normals, radius, color, global_T_local, params=None):
+        """depth (u16 [H,W]) is mutated in place by blending, as in the reference."""
+        assert depth.dtype == np.uint16 and depth.flags.c_contiguous and depth.flags.writeable
+        params = params or IntegrateParams.defaults()
+        normals = _c(normals, np.float32)
+        radius = _c(radius, np.float32)
+        color = _c(color, np.uint8)
+        T = _c(np.asarray(global_T_local, np.float32).reshape(12), np.float32)
+        lib().orc_recon_integrate(self._r, C.c_uint32(frame_index), C.c_float(depth_scaling), _p(depth),
+                                  _p(normals), _p(radius), _p(color), _p(T), C.byref(params))
+
+    def regularize(self, frame_index, regularizer_weight=10.0, radius_factor=2.0, window=30):
+        lib().orc_recon_regularize(self._r, C.c_uint32(frame_index), C.c_float(regularizer_weight),
+                                   C.c_float(radius_factor), C.c_int(window))
+
+    def transfer_all(self):
+        n = self.surfels_size
+        f = [np.empty(n, np.float32) for _ in range(7)]
+        s = np.empty(n, np.uint32)
+        lib().orc_recon_transfer_all(self._r, *[_p(a) for a in f], _p(s))
+        return {"x": f[0], "y": f[1], "z": f[2], "radius_squared": f[3], "normal_x": f[4], "normal_y": f[5],
+                "normal_z": f[6], "last_update_stamp": s, "surfel_count": n}
+
+    def export_vertices(self):
+        n = self.surfels_size
+        pos = np.empty(3 * n, np.float32)
+        col = np.empty(3 * n, np.uint8)
+        lib().orc_recon_export_vertices(self._r, _p(pos), _p(col))
+        return pos, col
+
+
+# ---- neighbor search -----------------------------------------------------------------------
+def nn_bruteforce(px, py, pz, q, radius_sq, k, state=None, skip_mask=0):
+    px, py, pz = (_c(a, np.float32) for a in (px, py, pz))
+    d2 = np.zeros(k, np.float32)
+    idx = np.zeros(k, np.uint32)
+    st = _p(_c(state, np.uint8)) if state is not None else None
+    n = lib().orc_nn_bruteforce(_p(px), _p(py), _p(pz), C.c_uint32(px.size), C.c_float(q[0]), C.c_float(q[1]),
+                                C.c_float(q[2]), C.c_float(radius_sq), C.c_int(k), st, C.c_uint8(skip_mask),
+                                _p(d2), _p(idx))
+    return n, d2, idx
+
+
+def nn_grid_batch(px, py, pz, cell_size, qx, qy, qz, qr2, k):
+    px, py, pz, qx, qy, qz, qr2 = (_c(a, np.float32) for a in (px, py, pz, qx, qy, qz, qr2))
+    nq = qx.size
+    d2 = np.zeros((nq, k), np.float32)
+    idx = np.zeros((nq, k), np.uint32)
+    cnt = np.zeros(nq, np.int32)
+    lib().orc_nn_grid_batch(_p(px), _p(py), _p(pz), C.c_uint32(px.size), C.c_float(cell_size),
+                            _p(qx), _p(qy), _p(qz), _p(qr2), C.c_uint32(nq), C.c_int(k), _p(d2), _p(idx), _p(cnt))
+    return cnt, d2, idx

@@ -1,0 +1,181 @@
+/*
+ * smx_oracle.h -- CPU ORACLE for the surfel-integration hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke test
+ * in __graft_entry__.py and the `cpu_baseline` leg of bench.py may load it.
+ * Nothing under surfelmeshing_amd/ links, imports or executes it.
+ *
+ * It restates, as plain single-threaded C loops in ascending index order, the
+ * algorithm of puzzlepaint/surfelmeshing's CUDA path (paths relative to the
+ * reference checkout, APP = applications/surfel_meshing/src/surfel_meshing):
+ *   APP/cuda_depth_processing.cu:50-883        depth preprocessing
+ *   APP/cuda_surfel_reconstruction.cc:112-359  Integrate / Regularize / TransferAllToCPU
+ *   APP/cuda_surfel_reconstruction_kernels.cu  every kernel body
+ *   APP/cuda_surfel_reconstruction_kernels.cc  host-side parameter derivation
+ *   APP/octree.cc:313-470 + APP/test/test_octree.cc:116-143  radius-neighbor search
+ *
+ * PARITY PINNING: the reference ships no golden vectors / known-answer tests
+ * for the integration and preprocessing kernels, and it cannot be compiled in
+ * this environment (needs nvcc, CUB, Eigen, Qt).  For those stages this oracle
+ * is therefore "parity unpinned" by reference artefacts: it is pinned only by
+ * hand-derived known answers (tests/test_oracle_known_answers.py).  The
+ * radius-neighbor search IS pinned the way the reference pins it: equality
+ * with brute force (APP/test/test_octree.cc:369-495).
+ *
+ * Deterministic rules adopted where the reference is racy (each is a legal
+ * outcome of the reference's races; see DESIGN.md "Determinism"):
+ *   - supporting surfel of a pixel  = lowest qualifying surfel index
+ *   - conflicting surfel of a pixel = lowest index among the merge-phase
+ *     writers if any, else lowest index among the associate-phase writers
+ *   - merge decisions read a snapshot of the other surfel (two-phase)
+ *   - float atomicAdd sums (depth sums, regulariser gradients) are either
+ *     accumulated EXACTLY in 2^-32 fixed point and rounded once
+ *     (sum_mode = ORC_SUM_EXACT, what the HIP path does) or in float in
+ *     ascending surfel order (sum_mode = ORC_SUM_FLOAT_ASCENDING, the
+ *     reference's arithmetic with one fixed schedule).
+ * Arithmetic: IEEE binary32, no FMA contraction (-ffp-contract=off), exact
+ * division and sqrt, and a self-contained expf (orc_expf) so that the GPU can
+ * match bit for bit.
+ */
+#ifndef SMX_ORACLE_H_
+#define SMX_ORACLE_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_INVALID 0xFFFFFFFFu
+
+/* Surfel SoA rows, APP/cuda_surfel_reconstruction_kernels.cuh:49-78 */
+enum {
+  ORC_X = 0, ORC_Y = 1, ORC_Z = 2,
+  ORC_SMOOTH_X = 3, ORC_SMOOTH_Y = 4, ORC_SMOOTH_Z = 5,
+  ORC_CONFIDENCE = 6, ORC_RADIUS_SQ = 7,
+  ORC_NORMAL_X = 8, ORC_NORMAL_Y = 9, ORC_NORMAL_Z = 10,
+  ORC_GRAD_X = 11, ORC_GRAD_Y = 12, ORC_GRAD_Z = 13,
+  ORC_ACCUM_X = 14, ORC_ACCUM_Y = 15, ORC_ACCUM_Z = 16,
+  ORC_CREATION_STAMP = 17, ORC_LAST_UPDATE_STAMP = 18,
+  ORC_NEIGHBOR0 = 19, /* 20, 21, 22 */
+  ORC_GRAD_COUNT = 23, ORC_COLOR = 24,
+  ORC_ROWS = 25
+};
+
+enum { ORC_SUM_EXACT = 0, ORC_SUM_FLOAT_ASCENDING = 1 };
+
+/* Mirrors the trailing arguments of CUDASurfelReconstruction::Integrate,
+ * APP/cuda_surfel_reconstruction.h:59-77 (defaults: APP/main.cc:323-368). */
+typedef struct {
+  float sensor_noise_factor;                                  /* 0.05 */
+  float max_surfel_confidence;                                /* 5    */
+  float regularizer_weight;                                   /* 10   */
+  int32_t regularization_frame_window_size;                   /* 30   */
+  int32_t do_blending;                                        /* 1    */
+  int32_t measurement_blending_radius;                        /* 12   */
+  int32_t regularization_iterations_per_integration_iteration;/* 1    */
+  float radius_factor_for_regularization_neighbors;           /* 2    */
+  float normal_compatibility_threshold_deg;                   /* 40   */
+  int32_t surfel_integration_active_window_size;              /* INT_MAX */
+} orc_integrate_params;
+
+typedef struct {
+  int32_t width, height;
+  float fx, fy, cx, cy;        /* cx, cy in pixel-CORNER convention */
+  uint32_t max_surfels;
+  uint32_t surfel_count;       /* slots in use (incl. merged zombies) */
+  uint32_t merge_count;
+  int32_t sum_mode;
+  float* surfels;              /* [ORC_ROWS][max_surfels] */
+  int64_t* grad_acc;           /* [max_surfels][4] fixed point (exact mode) */
+  /* per-pixel scratch, APP/cuda_surfel_reconstruction.h:133-147 */
+  uint32_t* supporting;        /* [H][W] */
+  uint32_t* support_counts;
+  float*    depth_sums_f;      /* float-ascending mode */
+  int64_t*  depth_sums_q;      /* exact mode */
+  uint32_t* conflicting;       /* decoded index or ORC_INVALID */
+  uint32_t* conflicting_key;   /* internal: (class<<31)|index */
+  float*    first_depth;
+  uint8_t*  distance_map;
+  uint8_t*  new_distance_map;
+  float*    deltas;
+  float*    new_deltas;
+  uint8_t*  new_flags;         /* [W*H] */
+  uint32_t* new_indices;       /* [W*H] exclusive scan */
+  uint8_t*  merge_decision;    /* [max_surfels] snapshot phase */
+  /* statistics of the last Integrate call (value distributions) */
+  uint32_t last_n_visible, last_n_new, last_n_merged, last_n_recent, last_n_edges;
+  uint32_t last_n_integrated, last_n_replaced, last_n_conflict_hits;
+} orc_recon;
+
+/* ---- deterministic math ---- */
+float orc_expf(float x);
+
+/* ---- depth preprocessing (APP/cuda_depth_processing.cu) ---- */
+void orc_bilateral_filter_and_cutoff(
+    float sigma_xy, float sigma_value_factor, uint16_t value_to_ignore,
+    float radius_factor, uint16_t max_depth, float depth_valid_region_radius,
+    int width, int height, const uint16_t* in, uint16_t* out);
+
+/* required_count < 0  ==> all-must-agree variant (cu:168-227), else the
+ * counting variant (cu:337-397).  other_count in {2,4,6,8} is not enforced. */
+void orc_outlier_depth_map_fusion(
+    int other_count, int required_count, float tolerance,
+    int width, int height, const uint16_t* in,
+    float fx, float fy, float cx, float cy,
+    const uint16_t* const* others, const float* others_TR_reference /* [other_count][12] */,
+    uint16_t* out);
+
+void orc_erode_depth_map(int radius, int width, int height, const uint16_t* in, uint16_t* out);
+void orc_copy_without_border(int width, int height, const uint16_t* in, uint16_t* out);
+
+void orc_compute_normals_and_drop_bad_pixels(
+    float observation_angle_threshold_deg, float depth_scaling,
+    float fx, float fy, float cx, float cy,
+    int width, int height, const uint16_t* in, uint16_t* out, float* out_normals /* [H][W][2] */);
+
+void orc_compute_point_radii_and_remove_isolated_pixels(
+    float point_radius_extension_factor, float point_radius_clamp_factor, float depth_scaling,
+    float fx, float fy, float cx, float cy,
+    int width, int height, const uint16_t* in, float* out_radius, uint16_t* out);
+
+/* ---- reconstruction object ---- */
+orc_recon* orc_recon_create(uint32_t max_surfels, int width, int height,
+                            float fx, float fy, float cx, float cy, int sum_mode);
+void orc_recon_destroy(orc_recon* r);
+
+void orc_recon_integrate(orc_recon* r, uint32_t frame_index, float depth_scaling,
+                         uint16_t* depth /* mutated by blending */, const float* normals,
+                         const float* radius, const uint8_t* color /* [H][W][3] */,
+                         const float global_T_local[12], const orc_integrate_params* p);
+
+void orc_recon_regularize(orc_recon* r, uint32_t frame_index, float regularizer_weight,
+                          float radius_factor_for_regularization_neighbors,
+                          int regularization_frame_window_size);
+
+/* TransferAllToCPU row selection, APP/cuda_surfel_reconstruction.cc:348-358 */
+void orc_recon_transfer_all(const orc_recon* r, float* x, float* y, float* z, float* radius_sq,
+                            float* nx, float* ny, float* nz, uint32_t* last_update_stamp);
+
+/* ExportVerticesCUDAKernel, APP/cuda_surfel_reconstruction_kernels.cu:2412-2433 */
+void orc_recon_export_vertices(const orc_recon* r, float* positions /* 3N */, uint8_t* colors /* 3N */);
+
+/* ---- radius-neighbor search (brute force; APP/test/test_octree.cc:116-143),
+ * results ordered by (dist^2, index); optional state filter: a point whose
+ * state byte has any bit of skip_mask set is skipped (octree.cc:330-335). */
+int orc_nn_bruteforce(const float* px, const float* py, const float* pz, uint32_t n,
+                      float qx, float qy, float qz, float radius_sq, int k,
+                      const uint8_t* state_or_null, uint8_t skip_mask,
+                      float* out_d2, uint32_t* out_idx);
+
+/* Same answer via a uniform grid (CPU baseline for the search at large n). */
+void orc_nn_grid_batch(const float* px, const float* py, const float* pz, uint32_t n,
+                       float cell_size,
+                       const float* qx, const float* qy, const float* qz, const float* qr2,
+                       uint32_t nq, int k, float* out_d2, uint32_t* out_idx, int32_t* out_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,114 @@
+"""Loads surfelmeshing_amd/libsmx.so (the C-ABI of include/smx.h) through ctypes.
+
+There is no CPU fallback: if the HIP library is missing or does not load, every
+entry point of this package raises.  If torch is already imported (bench.py
+imports it first for torch.distributed), the library binds to the HIP runtime
+torch has loaded, so both share one runtime per process.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libsmx.so")
+
+
+class SmxError(RuntimeError):
+    pass
+
+
+class BufferDesc(C.Structure):
+    """smx_buffer_desc == CUDABuffer_<T> (VIS/cuda/cuda_buffer.cuh:44-119)."""
+    _fields_ = [("address", C.c_void_p), ("height", C.c_int32), ("width", C.c_int32), ("pitch", C.c_size_t)]
+
+
+class IntegrateParams(C.Structure):
+    """smx_integrate_params: trailing arguments of CUDASurfelReconstruction::Integrate."""
+    _fields_ = [("sensor_noise_factor", C.c_float),
+                ("max_surfel_confidence", C.c_float),
+                ("regularizer_weight", C.c_float),
+                ("regularization_frame_window_size", C.c_int32),
+                ("do_blending", C.c_int32),
+                ("measurement_blending_radius", C.c_int32),
+                ("regularization_iterations_per_integration_iteration", C.c_int32),
+                ("radius_factor_for_regularization_neighbors", C.c_float),
+                ("normal_compatibility_threshold_deg", C.c_float),
+                ("surfel_integration_active_window_size", C.c_int32)]
+
+    @classmethod
+    def defaults(cls, **kw):
+        p = cls(0.05, 5.0, 10.0, 30, 1, 12, 1, 2.0, 40.0, 2147483647)  # APP/main.cc:323-368
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+
+class SurfelBuffersCPU(C.Structure):
+    """smx_surfel_buffers_cpu == CUDASurfelBuffersCPU (APP/cuda_surfels_cpu.h:40-74)."""
+    _fields_ = [("frame_index", C.c_uint32), ("surfel_count", C.c_size_t),
+                ("surfel_x_buffer", C.c_void_p), ("surfel_y_buffer", C.c_void_p), ("surfel_z_buffer", C.c_void_p),
+                ("surfel_radius_squared_buffer", C.c_void_p),
+                ("surfel_normal_x_buffer", C.c_void_p), ("surfel_normal_y_buffer", C.c_void_p),
+                ("surfel_normal_z_buffer", C.c_void_p), ("surfel_last_update_stamp_buffer", C.c_void_p)]
+
+
+class ReconStats(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in
+                ("surfels_size", "merge_count", "n_visible", "n_new", "n_merged", "n_recent", "n_edges",
+                 "n_integrated", "n_replaced", "n_conflict_hits", "capacity_clamped")]
+
+
+# every symbol include/smx.h declares (tests/test_abi.py checks the .so exports them all)
+EXPORTS = [
+    "smx_last_error", "smx_device_count", "smx_set_device", "smx_device_name",
+    "smx_stream_create", "smx_stream_destroy", "smx_stream_synchronize",
+    "smx_buffer_create", "smx_buffer_destroy", "smx_buffer_get_desc", "smx_buffer_upload", "smx_buffer_download",
+    "smx_buffer_upload_part", "smx_buffer_download_part", "smx_buffer_clear", "smx_buffer_set_to",
+    "smx_bilateral_filtering_and_depth_cutoff", "smx_outlier_depth_map_fusion", "smx_erode_depth_map",
+    "smx_copy_without_border", "smx_compute_normals_and_drop_bad_pixels",
+    "smx_compute_point_radii_and_remove_isolated_pixels",
+    "smx_recon_create", "smx_recon_destroy", "smx_recon_integrate", "smx_recon_regularize",
+    "smx_recon_transfer_all_to_cpu", "smx_recon_export_vertices", "smx_recon_get_timings",
+    "smx_recon_set_timing_enabled", "smx_recon_counts", "smx_recon_get_stats",
+    "smx_recon_debug_download_surfels", "smx_recon_debug_upload_surfels", "smx_recon_debug_download_scratch",
+    "smx_recon_set_scan_mode",
+    "smx_nn_create", "smx_nn_destroy", "smx_nn_build", "smx_nn_query_batch",
+]
+
+_lib = None
+
+
+def load():
+    """Returns the ctypes handle of libsmx.so; raises SmxError if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise SmxError("%s is missing: run `python -m surfelmeshing_amd.build` (hipcc, gfx950). "
+                       "There is no CPU fallback." % SO_PATH)
+    try:
+        L = C.CDLL(SO_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover
+        raise SmxError("cannot load %s: %s" % (SO_PATH, e))
+    L.smx_last_error.restype = C.c_char_p
+    for name in EXPORTS:
+        if name != "smx_last_error":
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().smx_last_error()
+        raise SmxError("libsmx error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def device_count():
+    n = C.c_int(0)
+    check(load().smx_device_count(C.byref(n)))
+    return n.value
+
+
+def require_gpu():
+    if device_count() == 0:
+        raise SmxError("no HIP device visible: the surfel-integration path needs an MI355X (no CPU fallback)")

@@ -1,0 +1,449 @@
+"""Host-side mirror of the reference's interface for the surfel-integration path.
+
+Same names, argument order and meaning as the reference's C++ API, on top of the
+C-ABI of include/smx.h (no torch types anywhere):
+
+  CUDABuffer                     VIS/cuda/cuda_buffer.h:45-129
+  BilateralFilteringAndDepthCutoffCUDA, OutlierDepthMapFusionCUDA, ErodeDepthMapCUDA,
+  CopyWithoutBorderCUDA, ComputeNormalsAndDropBadPixelsCUDA,
+  ComputePointRadiiAndRemoveIsolatedPixelsCUDA
+                                 APP/cuda_depth_processing.cuh:43-122
+  CUDASurfelReconstruction       APP/cuda_surfel_reconstruction.h:44-176
+  CUDASurfelBuffersCPU, CUDASurfelsCPU
+                                 APP/cuda_surfels_cpu.h:40-124
+  SurfelNeighborIndex            batched FindNearestSurfelsWithinRadius, APP/octree.h:470-477
+
+Errors: the reference aborts through LOG(FATAL); here a non-zero C-ABI status
+raises SmxError (there is no CPU fallback).
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib
+from ._lib import BufferDesc, IntegrateParams, SmxError, SurfelBuffersCPU, ReconStats  # noqa: F401
+
+kInvalidSurfelIndex = 0xFFFFFFFF  # APP/surfel.h (Surfel::kInvalidIndex)
+kSurfelAttributeCount = 25        # APP/cuda_surfel_reconstruction_kernels.cuh:76
+
+
+def _stream(s):
+    return C.c_void_p(s) if s else C.c_void_p(0)
+
+
+class Stream:
+    """A HIP stream (cudaStream_t in the reference's signatures)."""
+
+    def __init__(self):
+        self.handle = C.c_void_p()
+        _lib.check(_lib.load().smx_stream_create(C.byref(self.handle)))
+
+    def synchronize(self):
+        _lib.check(_lib.load().smx_stream_synchronize(self.handle))
+
+    def __int__(self):
+        return self.handle.value or 0
+
+    def close(self):
+        if self.handle:
+            _lib.load().smx_stream_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+def _sv(stream):
+    if stream is None:
+        return C.c_void_p(0)
+    if isinstance(stream, Stream):
+        return stream.handle
+    return C.c_void_p(int(stream))
+
+
+def StreamSynchronize(stream=None):
+    _lib.check(_lib.load().smx_stream_synchronize(_sv(stream)))
+
+
+class CUDABuffer:
+    """CUDABuffer<T>(height, width): pitched 2-D device memory.  `dtype` is the numpy scalar type
+    and `channels` the number of scalars per element (float2 -> (np.float32, 2), Vec3u8 -> (np.uint8, 3))."""
+
+    def __init__(self, height, width, dtype, channels=1):
+        self.dtype = np.dtype(dtype)
+        self.channels = int(channels)
+        self.elem_bytes = self.dtype.itemsize * self.channels
+        self._h = C.c_void_p()
+        _lib.check(_lib.load().smx_buffer_create(int(height), int(width), self.elem_bytes, C.byref(self._h)))
+        self._desc = BufferDesc()
+        _lib.check(_lib.load().smx_buffer_get_desc(self._h, C.byref(self._desc)))
+
+    # -- reference accessors
+    def width(self):
+        return self._desc.width
+
+    def height(self):
+        return self._desc.height
+
+    def Size(self):
+        return self._desc.pitch * self._desc.height
+
+    def ToCUDA(self):
+        return self._desc
+
+    def _host_shape(self):
+        return (self.height(), self.width()) + ((self.channels,) if self.channels > 1 else ())
+
+    def UploadAsync(self, stream, data):
+        a = np.ascontiguousarray(data, dtype=self.dtype)
+        assert a.shape == self._host_shape(), (a.shape, self._host_shape())
+        _lib.check(_lib.load().smx_buffer_upload(self._h, _sv(stream), a.ctypes.data_as(C.c_void_p), C.c_size_t(0)))
+        self._keep = a  # keep the host array alive until the caller synchronises
+
+    def UploadPitchedAsync(self, stream, pitch, data):
+        _lib.check(_lib.load().smx_buffer_upload(self._h, _sv(stream), data.ctypes.data_as(C.c_void_p), C.c_size_t(pitch)))
+        self._keep = data
+
+    def UploadPartAsync(self, start, length, stream, data):
+        a = np.ascontiguousarray(data)
+        _lib.check(_lib.load().smx_buffer_upload_part(self._h, _sv(stream), C.c_size_t(start), C.c_size_t(length),
+                                                      a.ctypes.data_as(C.c_void_p)))
+        self._keep = a
+
+    def DownloadAsync(self, stream, out=None):
+        if out is None:
+            out = np.empty(self._host_shape(), self.dtype)
+        assert out.flags.c_contiguous and out.dtype == self.dtype and out.shape == self._host_shape()
+        _lib.check(_lib.load().smx_buffer_download(self._h, _sv(stream), out.ctypes.data_as(C.c_void_p), C.c_size_t(0)))
+        return out
+
+    def DownloadPartAsync(self, start, length, stream, out):
+        _lib.check(_lib.load().smx_buffer_download_part(self._h, _sv(stream), C.c_size_t(start), C.c_size_t(length),
+                                                        out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def Download(self, stream=None):
+        """DebugDownload: blocking convenience."""
+        out = self.DownloadAsync(stream)
+        StreamSynchronize(stream)
+        return out
+
+    def Upload(self, data, stream=None):
+        """DebugUpload: blocking convenience."""
+        self.UploadAsync(stream, data)
+        StreamSynchronize(stream)
+
+    def Clear(self, value, stream=None):
+        pat = np.asarray(value, dtype=self.dtype).reshape(-1)
+        if pat.size == 1 and self.channels > 1:
+            pat = np.repeat(pat, self.channels)
+        assert pat.size == self.channels
+        pat = np.ascontiguousarray(pat)
+        _lib.check(_lib.load().smx_buffer_clear(self._h, _sv(stream), pat.ctypes.data_as(C.c_void_p)))
+
+    def SetTo(self, other, stream=None):
+        _lib.check(_lib.load().smx_buffer_set_to(self._h, other._h, _sv(stream)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().smx_buffer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _d(buf):
+    return C.byref(buf.ToCUDA() if isinstance(buf, CUDABuffer) else buf)
+
+
+# ---- depth preprocessing free functions (APP/cuda_depth_processing.cuh) -----------------------
+def BilateralFilteringAndDepthCutoffCUDA(stream, sigma_xy, sigma_value_factor, value_to_ignore, radius_factor,
+                                         max_depth, depth_valid_region_radius, input_depth, output_depth):
+    _lib.check(_lib.load().smx_bilateral_filtering_and_depth_cutoff(
+        _sv(stream), C.c_float(sigma_xy), C.c_float(sigma_value_factor), C.c_uint16(int(value_to_ignore)),
+        C.c_float(radius_factor), C.c_uint16(int(max_depth)), C.c_float(depth_valid_region_radius),
+        _d(input_depth), _d(output_depth)))
+
+
+def OutlierDepthMapFusionCUDA(stream, tolerance, input_depth, depth_fx, depth_fy, depth_cx, depth_cy, other_depths,
+                              others_TR_reference, output_depth, required_count=-1):
+    """Both overloads of OutlierDepthMapFusionCUDA<count,u16>: count-1 == len(other_depths);
+    required_count=-1 is the all-must-agree overload (APP/main.cc:1061-1112)."""
+    n = len(other_depths)
+    descs = (BufferDesc * n)(*[b.ToCUDA() if isinstance(b, CUDABuffer) else b for b in other_depths])
+    T = np.ascontiguousarray(np.asarray(others_TR_reference, np.float32).reshape(n, 12))
+    _lib.check(_lib.load().smx_outlier_depth_map_fusion(
+        _sv(stream), C.c_int32(n), C.c_int32(required_count), C.c_float(tolerance), _d(input_depth),
+        C.c_float(depth_fx), C.c_float(depth_fy), C.c_float(depth_cx), C.c_float(depth_cy),
+        descs, T.ctypes.data_as(C.c_void_p), _d(output_depth)))
+
+
+def ErodeDepthMapCUDA(stream, radius, input_depth, output_depth):
+    _lib.check(_lib.load().smx_erode_depth_map(_sv(stream), C.c_int32(radius), _d(input_depth), _d(output_depth)))
+
+
+def CopyWithoutBorderCUDA(stream, input_depth, output_depth):
+    _lib.check(_lib.load().smx_copy_without_border(_sv(stream), _d(input_depth), _d(output_depth)))
+
+
+def ComputeNormalsAndDropBadPixelsCUDA(stream, observation_angle_threshold_deg, depth_scaling, depth_fx, depth_fy,
+                                       depth_cx, depth_cy, in_depth, out_depth, out_normals):
+    _lib.check(_lib.load().smx_compute_normals_and_drop_bad_pixels(
+        _sv(stream), C.c_float(observation_angle_threshold_deg), C.c_float(depth_scaling),
+        C.c_float(depth_fx), C.c_float(depth_fy), C.c_float(depth_cx), C.c_float(depth_cy),
+        _d(in_depth), _d(out_depth), _d(out_normals)))
+
+
+def ComputePointRadiiAndRemoveIsolatedPixelsCUDA(stream, point_radius_extension_factor, point_radius_clamp_factor,
+                                                 depth_scaling, depth_fx, depth_fy, depth_cx, depth_cy,
+                                                 depth_buffer, radius_buffer, out_depth):
+    _lib.check(_lib.load().smx_compute_point_radii_and_remove_isolated_pixels(
+        _sv(stream), C.c_float(point_radius_extension_factor), C.c_float(point_radius_clamp_factor),
+        C.c_float(depth_scaling), C.c_float(depth_fx), C.c_float(depth_fy), C.c_float(depth_cx), C.c_float(depth_cy),
+        _d(depth_buffer), _d(radius_buffer), _d(out_depth)))
+
+
+# ---- GPU -> CPU hand-off types (APP/cuda_surfels_cpu.h) ---------------------------------------
+class CUDASurfelBuffersCPU:
+    def __init__(self, max_surfel_count):
+        n = int(max_surfel_count)
+        self.frame_index = 0
+        self.surfel_count = 0
+        self.surfel_x_buffer = np.empty(n, np.float32)
+        self.surfel_y_buffer = np.empty(n, np.float32)
+        self.surfel_z_buffer = np.empty(n, np.float32)
+        self.surfel_radius_squared_buffer = np.empty(n, np.float32)
+        self.surfel_normal_x_buffer = np.empty(n, np.float32)
+        self.surfel_normal_y_buffer = np.empty(n, np.float32)
+        self.surfel_normal_z_buffer = np.empty(n, np.float32)
+        self.surfel_last_update_stamp_buffer = np.empty(n, np.uint32)
+
+    def _pod(self):
+        p = SurfelBuffersCPU()
+        for name, _ in SurfelBuffersCPU._fields_[2:]:
+            setattr(p, name, getattr(self, name).ctypes.data)
+        return p
+
+
+class CUDASurfelsCPU:
+    """Mutex-guarded write/read double buffer, APP/cuda_surfels_cpu.h:83-124."""
+
+    def __init__(self, max_surfel_count):
+        self._write = CUDASurfelBuffersCPU(max_surfel_count)
+        self._read = CUDASurfelBuffersCPU(max_surfel_count)
+        self._lock = threading.Lock()
+        self._debug_wrote_data = False
+
+    def LockWriteBuffers(self):
+        self._lock.acquire()
+
+    def UnlockWriteBuffers(self):
+        self._debug_wrote_data = True
+        self._lock.release()
+
+    def WaitForLockAndSwapBuffers(self):
+        with self._lock:
+            if not self._debug_wrote_data:
+                # LOG(FATAL) in the reference (:109-111)
+                raise SmxError("Trying to swap the CUDASurfelsCPU buffers, but no data was written. "
+                               "Possible multi-threading bug!")
+            self._write, self._read = self._read, self._write
+            self._debug_wrote_data = False
+
+    def write_buffers(self):
+        return self._write
+
+    def read_buffers(self):
+        return self._read
+
+
+# ---- CUDASurfelReconstruction (APP/cuda_surfel_reconstruction.h) ------------------------------
+class PinholeCamera4f:
+    """The accessors of VIS/camera.h's PinholeCamera4f that the hot path uses."""
+
+    def __init__(self, width, height, fx, fy, cx, cy):
+        self._w, self._h = int(width), int(height)
+        self._p = (float(fx), float(fy), float(cx), float(cy))
+
+    def width(self):
+        return self._w
+
+    def height(self):
+        return self._h
+
+    def parameters(self):
+        return self._p
+
+
+class CUDASurfelReconstruction:
+    def __init__(self, max_surfel_count, depth_camera, vertex_buffer_resource=None,
+                 neighbor_index_buffer_resource=None, normal_vertex_buffer_resource=None, render_window=None):
+        _lib.require_gpu()
+        self.max_surfel_count = int(max_surfel_count)
+        self.depth_camera = depth_camera
+        fx, fy, cx, cy = depth_camera.parameters()
+        self._h = C.c_void_p()
+        _lib.check(_lib.load().smx_recon_create(C.c_uint32(self.max_surfel_count), depth_camera.width(),
+                                                depth_camera.height(), C.c_float(fx), C.c_float(fy), C.c_float(cx),
+                                                C.c_float(cy), C.byref(self._h)))
+        self._last_stream = None
+
+    def Integrate(self, stream, frame_index, depth_scaling, depth_buffer, normals_buffer, radius_buffer, color_buffer,
+                  global_T_local, sensor_noise_factor, max_surfel_confidence, regularizer_weight,
+                  regularization_frame_window_size, do_blending, measurement_blending_radius,
+                  regularization_iterations_per_integration_iteration, radius_factor_for_regularization_neighbors,
+                  normal_compatibility_threshold_deg, surfel_integration_active_window_size):
+        p = IntegrateParams(sensor_noise_factor, max_surfel_confidence, regularizer_weight,
+                            regularization_frame_window_size, 1 if do_blending else 0, measurement_blending_radius,
+                            regularization_iterations_per_integration_iteration,
+                            radius_factor_for_regularization_neighbors, normal_compatibility_threshold_deg,
+                            surfel_integration_active_window_size)
+        self.IntegrateP(stream, frame_index, depth_scaling, depth_buffer, normals_buffer, radius_buffer, color_buffer,
+                        global_T_local, p)
+
+    def IntegrateP(self, stream, frame_index, depth_scaling, depth_buffer, normals_buffer, radius_buffer,
+                   color_buffer, global_T_local, params):
+        T = np.ascontiguousarray(np.asarray(global_T_local, np.float32).reshape(12))
+        self._last_stream = stream
+        _lib.check(_lib.load().smx_recon_integrate(
+            self._h, _sv(stream), C.c_uint32(frame_index), C.c_float(depth_scaling), _d(depth_buffer),
+            _d(normals_buffer), _d(radius_buffer), _d(color_buffer), T.ctypes.data_as(C.c_void_p), C.byref(params)))
+
+    def Regularize(self, stream, frame_index, regularizer_weight, radius_factor_for_regularization_neighbors,
+                   regularization_frame_window_size):
+        _lib.check(_lib.load().smx_recon_regularize(self._h, _sv(stream), C.c_uint32(frame_index),
+                                                    C.c_float(regularizer_weight),
+                                                    C.c_float(radius_factor_for_regularization_neighbors),
+                                                    C.c_int32(regularization_frame_window_size)))
+
+    def TransferAllToCPU(self, stream, frame_index, buffers):
+        """Requires the caller to hold buffers.LockWriteBuffers() (APP/main.cc:1261-1264)."""
+        wb = buffers.write_buffers()
+        pod = wb._pod()
+        _lib.check(_lib.load().smx_recon_transfer_all_to_cpu(self._h, _sv(stream), C.c_uint32(frame_index),
+                                                             C.byref(pod)))
+        wb.frame_index = pod.frame_index
+        wb.surfel_count = pod.surfel_count
+
+    def UpdateVisualizationBuffers(self, *args, **kwargs):
+        """Viewer-only in the reference (OpenGL interop); nothing to do without a render window."""
+
+    def ExportVertices(self, stream, position_buffer, color_buffer):
+        _lib.check(_lib.load().smx_recon_export_vertices(self._h, _sv(stream), _d(position_buffer), _d(color_buffer)))
+
+    def GetTimings(self):
+        """(data_association, surfel_merging, measurement_blending, integration, neighbor_update,
+        new_surfel_creation, regularization) in ms."""
+        out = (C.c_float * 7)()
+        _lib.check(_lib.load().smx_recon_get_timings(self._h, out))
+        return tuple(out)
+
+    def _counts(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        _lib.check(_lib.load().smx_recon_counts(self._h, _sv(self._last_stream), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def surfel_count(self):
+        return self._counts()[0]
+
+    def surfels_size(self):
+        return self._counts()[1]
+
+    # -- extras (not in the reference interface)
+    def stats(self):
+        s = ReconStats()
+        _lib.check(_lib.load().smx_recon_get_stats(self._h, _sv(self._last_stream), C.byref(s)))
+        return {n: int(getattr(s, n)) for n, _ in ReconStats._fields_}
+
+    def set_timing_enabled(self, enabled):
+        _lib.check(_lib.load().smx_recon_set_timing_enabled(self._h, C.c_int32(1 if enabled else 0)))
+
+    def set_scan_mode(self, mode):
+        _lib.check(_lib.load().smx_recon_set_scan_mode(self._h, C.c_int32(mode)))
+
+    def debug_download_surfels(self, count=None):
+        n = self.surfels_size() if count is None else int(count)
+        rows = np.zeros((kSurfelAttributeCount, n), np.float32)
+        _lib.check(_lib.load().smx_recon_debug_download_surfels(self._h, _sv(self._last_stream),
+                                                                rows.ctypes.data_as(C.c_void_p), C.c_uint32(n)))
+        return rows
+
+    def debug_upload_surfels(self, rows, merge_count=0):
+        rows = np.ascontiguousarray(rows, np.float32)
+        assert rows.ndim == 2 and rows.shape[0] == kSurfelAttributeCount
+        _lib.check(_lib.load().smx_recon_debug_upload_surfels(self._h, _sv(self._last_stream),
+                                                              rows.ctypes.data_as(C.c_void_p),
+                                                              C.c_uint32(rows.shape[1]), C.c_uint32(merge_count)))
+
+    _SCRATCH = {"supporting": (0, np.uint32), "support_counts": (1, np.uint32), "depth_sums_q": (2, np.int64),
+                "conflicting": (3, np.uint32), "first_depth": (4, np.float32), "new_flags": (5, np.uint8),
+                "new_indices": (6, np.uint32)}
+
+    def debug_download_scratch(self, name):
+        which, dt = self._SCRATCH[name]
+        out = np.empty((self.depth_camera.height(), self.depth_camera.width()), dt)
+        _lib.check(_lib.load().smx_recon_debug_download_scratch(self._h, _sv(self._last_stream), C.c_int32(which),
+                                                                out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().smx_recon_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- radius-neighbor search -------------------------------------------------------------------
+class SurfelNeighborIndex:
+    """Batched replacement of CompressedOctree::FindNearestSurfelsWithinRadius (APP/octree.h:470-477):
+    uniform-grid index rebuilt from the surfel position rows, queried for many positions at once."""
+
+    def __init__(self):
+        _lib.require_gpu()
+        self._h = C.c_void_p()
+        _lib.check(_lib.load().smx_nn_create(C.byref(self._h)))
+
+    def Build(self, x, y, z, cell_size, stream=None):
+        x, y, z = (np.ascontiguousarray(a, np.float32) for a in (x, y, z))
+        self._keep = (x, y, z)
+        _lib.check(_lib.load().smx_nn_build(self._h, _sv(stream), x.ctypes.data_as(C.c_void_p),
+                                            y.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p),
+                                            C.c_uint32(x.size), C.c_float(cell_size), C.c_int32(0)))
+
+    def FindNearestSurfelsWithinRadius(self, positions, radius_squared, max_result_count, state=None, skip_mask=0,
+                                       stream=None):
+        """positions [nq,3]; radius_squared scalar or [nq].  Returns (counts [nq], dist2 [nq,K], indices [nq,K])."""
+        q = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        nq = q.shape[0]
+        qx, qy, qz = (np.ascontiguousarray(q[:, i]) for i in range(3))
+        r2 = np.ascontiguousarray(np.broadcast_to(np.asarray(radius_squared, np.float32), (nq,)))
+        k = int(max_result_count)
+        idx = np.zeros((nq, k), np.uint32)
+        d2 = np.zeros((nq, k), np.float32)
+        cnt = np.zeros(nq, np.int32)
+        st = np.ascontiguousarray(state, np.uint8) if state is not None else None
+        _lib.check(_lib.load().smx_nn_query_batch(
+            self._h, _sv(stream), C.c_uint32(nq), qx.ctypes.data_as(C.c_void_p), qy.ctypes.data_as(C.c_void_p),
+            qz.ctypes.data_as(C.c_void_p), r2.ctypes.data_as(C.c_void_p), C.c_int32(k),
+            st.ctypes.data_as(C.c_void_p) if st is not None else C.c_void_p(0), C.c_uint8(skip_mask), C.c_int32(0),
+            idx.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p),
+            C.c_int32(0)))
+        return cnt, d2, idx
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().smx_nn_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

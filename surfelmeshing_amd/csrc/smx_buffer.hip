@@ -1,0 +1,202 @@
+// smx_buffer.hip -- pitched device buffers and their copies/fills.
+// Replaces the libvis helpers VIS/cuda/cuda_buffer.{h,cuh,cu}, cuda_buffer_inl.h
+// (CUDABuffer<T> / CUDABuffer_<T>) behind the C-ABI of include/smx.h.
+#include <stdarg.h>
+
+#include "smx_common.hpp"
+
+namespace smx {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+}
+
+}  // namespace smx
+
+struct smx_buffer_s {
+  smx_buffer_desc desc;
+  int32_t elem_bytes;
+};
+
+using namespace smx;
+
+// Fill kernel: one thread per 4-byte word where possible.  The reference's
+// CUDABufferClearKernel (VIS/cuda/cuda_buffer.cu:40-59) writes one element per
+// thread of a 32x8 block; here rows are written as 16-byte words (rows are
+// 256-byte aligned, so the tail of the pitch may be overwritten safely).
+template <typename T>
+__global__ void k_fill(T* __restrict__ base, size_t pitch, int width, int height, T value) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x < width && y < height)
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (size_t)y * pitch + (size_t)x * sizeof(T)) = value;
+}
+
+__global__ void k_fill_bytes(char* __restrict__ base, size_t pitch, int row_bytes, int height, int elem,
+                             const char* __restrict__ pattern_dev) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x < row_bytes && y < height) base[(size_t)y * pitch + x] = pattern_dev[x % elem];
+}
+
+extern "C" {
+
+const char* smx_last_error(void) { return g_error; }
+
+int smx_device_count(int* count) {
+  SMX_CHECK_ARG(count != nullptr);
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { n = 0; (void)hipGetLastError(); }
+  *count = n;
+  return SMX_OK;
+}
+
+int smx_set_device(int device) {
+  SMX_HIP(hipSetDevice(device));
+  return SMX_OK;
+}
+
+int smx_device_name(int device, char* name, size_t capacity) {
+  SMX_CHECK_ARG(name != nullptr && capacity > 0);
+  hipDeviceProp_t prop;
+  SMX_HIP(hipGetDeviceProperties(&prop, device));
+  snprintf(name, capacity, "%s (%s)", prop.name, prop.gcnArchName);
+  return SMX_OK;
+}
+
+int smx_stream_create(smx_stream* out) {
+  SMX_CHECK_ARG(out != nullptr);
+  hipStream_t s;
+  SMX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *out = (smx_stream)s;
+  return SMX_OK;
+}
+
+int smx_stream_destroy(smx_stream s) {
+  if (s) SMX_HIP(hipStreamDestroy((hipStream_t)s));
+  return SMX_OK;
+}
+
+int smx_stream_synchronize(smx_stream s) {
+  SMX_HIP(hipStreamSynchronize((hipStream_t)s));
+  return SMX_OK;
+}
+
+int smx_buffer_create(int32_t height, int32_t width, int32_t elem_bytes, smx_buffer* out) {
+  SMX_CHECK_ARG(out != nullptr && height > 0 && width > 0 && elem_bytes > 0);
+  smx_buffer_s* b = new smx_buffer_s;
+  b->elem_bytes = elem_bytes;
+  b->desc.height = height;
+  b->desc.width = width;
+  // 256-byte row alignment: whole rows can be moved with 16-byte lane accesses.
+  const size_t row_bytes = (size_t)width * elem_bytes;
+  b->desc.pitch = (row_bytes + 255) / 256 * 256;
+  b->desc.address = nullptr;
+  hipError_t e = hipMalloc(&b->desc.address, b->desc.pitch * (size_t)height);
+  if (e != hipSuccess) {
+    set_error("hipMalloc(%zu bytes) failed: %s", b->desc.pitch * (size_t)height, hipGetErrorString(e));
+    delete b;
+    return SMX_ERR_HIP;
+  }
+  *out = b;
+  return SMX_OK;
+}
+
+int smx_buffer_destroy(smx_buffer b) {
+  if (!b) return SMX_OK;
+  hipError_t e = hipFree(b->desc.address);
+  delete b;
+  if (e != hipSuccess) { set_error("hipFree failed: %s", hipGetErrorString(e)); return SMX_ERR_HIP; }
+  return SMX_OK;
+}
+
+int smx_buffer_get_desc(smx_buffer b, smx_buffer_desc* out) {
+  SMX_CHECK_ARG(b != nullptr && out != nullptr);
+  *out = b->desc;
+  return SMX_OK;
+}
+
+int smx_buffer_upload(smx_buffer b, smx_stream s, const void* src, size_t src_pitch) {
+  SMX_CHECK_ARG(b != nullptr && src != nullptr);
+  const size_t row_bytes = (size_t)b->desc.width * b->elem_bytes;
+  if (src_pitch == 0) src_pitch = row_bytes;
+  SMX_HIP(hipMemcpy2DAsync(b->desc.address, b->desc.pitch, src, src_pitch, row_bytes, b->desc.height,
+                           hipMemcpyHostToDevice, (hipStream_t)s));
+  return SMX_OK;
+}
+
+int smx_buffer_download(smx_buffer b, smx_stream s, void* dst, size_t dst_pitch) {
+  SMX_CHECK_ARG(b != nullptr && dst != nullptr);
+  const size_t row_bytes = (size_t)b->desc.width * b->elem_bytes;
+  if (dst_pitch == 0) dst_pitch = row_bytes;
+  SMX_HIP(hipMemcpy2DAsync(dst, dst_pitch, b->desc.address, b->desc.pitch, row_bytes, b->desc.height,
+                           hipMemcpyDeviceToHost, (hipStream_t)s));
+  return SMX_OK;
+}
+
+int smx_buffer_upload_part(smx_buffer b, smx_stream s, size_t start, size_t length, const void* src) {
+  SMX_CHECK_ARG(b != nullptr && src != nullptr);
+  SMX_CHECK_ARG(start + length <= b->desc.pitch * (size_t)b->desc.height);
+  SMX_HIP(hipMemcpyAsync(reinterpret_cast<char*>(b->desc.address) + start, src, length, hipMemcpyHostToDevice,
+                         (hipStream_t)s));
+  return SMX_OK;
+}
+
+int smx_buffer_download_part(smx_buffer b, smx_stream s, size_t start, size_t length, void* dst) {
+  SMX_CHECK_ARG(b != nullptr && dst != nullptr);
+  SMX_CHECK_ARG(start + length <= b->desc.pitch * (size_t)b->desc.height);
+  SMX_HIP(hipMemcpyAsync(dst, reinterpret_cast<char*>(b->desc.address) + start, length, hipMemcpyDeviceToHost,
+                         (hipStream_t)s));
+  return SMX_OK;
+}
+
+int smx_buffer_clear(smx_buffer b, smx_stream s, const void* pattern) {
+  SMX_CHECK_ARG(b != nullptr && pattern != nullptr);
+  hipStream_t st = (hipStream_t)s;
+  const int w = b->desc.width, h = b->desc.height;
+  dim3 block(256, 1, 1), grid(div_up(w, 256), h, 1);
+  switch (b->elem_bytes) {
+    case 1: { uint8_t v; memcpy(&v, pattern, 1);
+      hipLaunchKernelGGL(k_fill<uint8_t>, grid, block, 0, st, (uint8_t*)b->desc.address, b->desc.pitch, w, h, v); break; }
+    case 2: { uint16_t v; memcpy(&v, pattern, 2);
+      hipLaunchKernelGGL(k_fill<uint16_t>, grid, block, 0, st, (uint16_t*)b->desc.address, b->desc.pitch, w, h, v); break; }
+    case 4: { uint32_t v; memcpy(&v, pattern, 4);
+      hipLaunchKernelGGL(k_fill<uint32_t>, grid, block, 0, st, (uint32_t*)b->desc.address, b->desc.pitch, w, h, v); break; }
+    case 8: { uint64_t v; memcpy(&v, pattern, 8);
+      hipLaunchKernelGGL(k_fill<uint64_t>, grid, block, 0, st, (uint64_t*)b->desc.address, b->desc.pitch, w, h, v); break; }
+    default: {
+      // odd element sizes (e.g. uchar3): expand the pattern over one row and replicate rows.
+      const size_t row_bytes = (size_t)w * b->elem_bytes;
+      char* host_row = new char[row_bytes];
+      for (size_t i = 0; i < row_bytes; ++i) host_row[i] = ((const char*)pattern)[i % b->elem_bytes];
+      hipError_t e = hipSuccess;
+      for (int y = 0; y < h && e == hipSuccess; ++y)
+        e = hipMemcpyAsync((char*)b->desc.address + (size_t)y * b->desc.pitch, host_row, row_bytes,
+                           hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      delete[] host_row;
+      if (e != hipSuccess) { set_error("clear failed: %s", hipGetErrorString(e)); return SMX_ERR_HIP; }
+      return SMX_OK;
+    }
+  }
+  SMX_LAUNCH_CHECK();
+  return SMX_OK;
+}
+
+int smx_buffer_set_to(smx_buffer dst, smx_buffer src, smx_stream s) {
+  SMX_CHECK_ARG(dst != nullptr && src != nullptr);
+  SMX_CHECK_ARG(dst->desc.width == src->desc.width && dst->desc.height == src->desc.height &&
+                dst->elem_bytes == src->elem_bytes);
+  SMX_HIP(hipMemcpy2DAsync(dst->desc.address, dst->desc.pitch, src->desc.address, src->desc.pitch,
+                           (size_t)src->desc.width * src->elem_bytes, src->desc.height, hipMemcpyDeviceToDevice,
+                           (hipStream_t)s));
+  return SMX_OK;
+}
+
+}  // extern "C"

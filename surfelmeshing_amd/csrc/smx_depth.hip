@@ -1,0 +1,341 @@
+// smx_depth.hip -- depth preprocessing kernels for gfx950.
+// Behaviour restated from APP/cuda_depth_processing.cu of the reference (cited
+// per kernel); the implementation is new: 64-lane-wide row tiles, LDS-staged
+// stencils, coalesced u16 row loads.
+#include <math.h>
+
+#include "smx_common.hpp"
+
+using namespace smx;
+
+namespace {
+
+constexpr int kTileW = 64;   // one wavefront per tile row
+constexpr int kTileH = 16;
+constexpr int kThreads = 256;
+
+// ---------------------------------------------------------------------------------------------
+// Bilateral filter + depth cutoff.  Reference: BilateralFilteringAndDepthCutoffCUDAKernel,
+// cuda_depth_processing.cu:50-118.  A 64x16 pixel tile plus its `radius` halo is staged in LDS
+// (zero outside the image: a zero sample is "value_to_ignore"-like only when value_to_ignore
+// is 0, so out-of-image taps are masked by coordinates instead, exactly like the reference's
+// clamped loop bounds).
+constexpr int kMaxBilateralRadius = 8;
+__global__ void __launch_bounds__(kThreads)
+k_bilateral(float denom_xy, float sigma_value_factor, int radius, int radius_squared,
+            uint16_t value_to_ignore, uint16_t max_depth, float region_r2,
+            Img<const uint16_t> in, Img<uint16_t> out) {
+  __shared__ uint16_t tile[(kTileH + 2 * kMaxBilateralRadius) * (kTileW + 2 * kMaxBilateralRadius)];
+  const int W = out.width, H = out.height;
+  const int tw = kTileW + 2 * radius, th = kTileH + 2 * radius;
+  const int x0 = blockIdx.x * kTileW - radius, y0 = blockIdx.y * kTileH - radius;
+  for (int i = threadIdx.x; i < tw * th; i += kThreads) {
+    const int ty = i / tw, tx = i - ty * tw;
+    const int gx = x0 + tx, gy = y0 + ty;
+    uint16_t v = 0;
+    if (gx >= 0 && gy >= 0 && gx < W && gy < H) v = in(gy, gx);
+    tile[i] = v;
+  }
+  __syncthreads();
+
+  const int lx = threadIdx.x & (kTileW - 1);
+  const int x = blockIdx.x * kTileW + lx;
+  const unsigned half_w = (unsigned)(W / 2), half_h = (unsigned)(H / 2);
+  for (int ly = threadIdx.x / kTileW; ly < kTileH; ly += kThreads / kTileW) {
+    const int y = blockIdx.y * kTileH + ly;
+    if (x >= W || y >= H) continue;
+    const unsigned dxc = (unsigned)x - half_w, dyc = (unsigned)y - half_h;
+    const float center_distance_squared = (float)(dxc * dxc + dyc * dyc);
+    if (center_distance_squared > region_r2) { out(y, x) = value_to_ignore; continue; }
+    const uint16_t center_value = tile[(ly + radius) * tw + (lx + radius)];
+    if (center_value == value_to_ignore || center_value > max_depth) { out(y, x) = value_to_ignore; continue; }
+
+    const float adapted_sigma_value = (float)center_value * sigma_value_factor;
+    const float adapted_denom_value = 2.0f * adapted_sigma_value * adapted_sigma_value;
+    float sum = 0, weight = 0;
+    const int min_dy = max(-radius, -y), max_dy = min(radius, H - 1 - y);
+    const int min_dx = max(-radius, -x), max_dx = min(radius, W - 1 - x);
+    for (int dy = min_dy; dy <= max_dy; ++dy) {
+      const uint16_t* trow = &tile[(ly + radius + dy) * tw + (lx + radius)];
+      for (int dx = min_dx; dx <= max_dx; ++dx) {
+        const int g2 = dx * dx + dy * dy;
+        if (g2 > radius_squared) continue;
+        const uint16_t sample = trow[dx];
+        if (sample == value_to_ignore) continue;
+        float vd = (float)((int)center_value - (int)sample);
+        vd *= vd;
+        const float w = det_expf((float)(-g2) / denom_xy + (-vd) / adapted_denom_value);
+        sum += w * (float)sample;
+        weight += w;
+      }
+    }
+    out(y, x) = (weight == 0) ? value_to_ignore : f2u16(sum / weight + 0.5f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-frame outlier cull.  Reference: OutlierDepthMapFusionCUDAKernel (both overloads),
+// cuda_depth_processing.cu:168-227 and :337-397.  Matrices and image descriptors travel in the
+// kernel-argument segment (SGPR-resident), the 8 scattered u16 probes hit L2 (9 x 600 KB).
+struct OutlierParams {
+  Mat34 T[8];
+  Img<const uint16_t> others[8];
+};
+template <int kOthers>
+__global__ void __launch_bounds__(kThreads)
+k_outlier(int required_count, float max_tol, float min_tol, Img<const uint16_t> in,
+          float fx, float fy, float cx, float cy, Unproj up, OutlierParams p, Img<uint16_t> out) {
+  const int x = blockIdx.x * kTileW + (threadIdx.x & (kTileW - 1));
+  const int y = blockIdx.y * (kThreads / kTileW) + threadIdx.x / kTileW;
+  const int W = out.width, H = out.height;
+  if (x >= W || y >= H) return;
+  const uint16_t d = in(y, x);
+  if (d == 0) { out(y, x) = 0; return; }
+  const float fd = (float)d;
+  Vec3 rp;
+  rp.x = fd * (up.fx_inv * (float)x + up.cx_inv);
+  rp.y = fd * (up.fy_inv * (float)y + up.cy_inv);
+  rp.z = fd;
+  int ok_count = 0;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < kOthers; ++k) {
+    const Vec3 o = mul(p.T[k], rp);
+    bool good = false;
+    if (o.z > 0) {
+      const float u = fx * (o.x / o.z) + cx, v = fy * (o.y / o.z) + cy;
+      if (u > -1.0f && v > -1.0f && u < (float)W && v < (float)H) {
+        const int px = (int)u, py = (int)v;
+        const uint16_t od = p.others[k](py, px);
+        const float fod = (float)od;
+        if (!(od == 0 || fod > max_tol * o.z || fod < min_tol * o.z)) good = true;
+      }
+    }
+    if (good) ++ok_count;
+    else ok = false;
+  }
+  if (required_count < 0) out(y, x) = ok ? d : (uint16_t)0;
+  else out(y, x) = (ok_count >= required_count) ? d : (uint16_t)0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Erosion / border copy.  Reference: ErodeDepthMapCUDAKernel<radius>, cu:514-538;
+// CopyWithoutBorderCUDAKernel, cu:589-607.
+__global__ void __launch_bounds__(kThreads)
+k_erode(int radius, Img<const uint16_t> in, Img<uint16_t> out) {
+  const int x = blockIdx.x * kTileW + (threadIdx.x & (kTileW - 1));
+  const int y = blockIdx.y * (kThreads / kTileW) + threadIdx.x / kTileW;
+  const int W = out.width, H = out.height;
+  if (x >= W || y >= H) return;
+  if (x < radius || y < radius || x >= W - radius || y >= H - radius) { out(y, x) = 0; return; }
+  bool all_valid = true;
+  for (int dy = y - radius; dy <= y + radius; ++dy) {
+    const uint16_t* row = in.row(dy);
+    for (int dx = x - radius; dx <= x + radius; ++dx)
+      if (row[dx] == 0) all_valid = false;
+  }
+  out(y, x) = all_valid ? in(y, x) : (uint16_t)0;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_copy_without_border(Img<const uint16_t> in, Img<uint16_t> out) {
+  const int x = blockIdx.x * kTileW + (threadIdx.x & (kTileW - 1));
+  const int y = blockIdx.y * (kThreads / kTileW) + threadIdx.x / kTileW;
+  const int W = out.width, H = out.height;
+  if (x >= W || y >= H) return;
+  out(y, x) = (x < 1 || y < 1 || x >= W - 1 || y >= H - 1) ? (uint16_t)0 : in(y, x);
+}
+
+__device__ __forceinline__ uint16_t rd0(const Img<const uint16_t>& img, int y, int x) {
+  // out-of-image reads are defined as 0 (the reference relies on a zeroed border, cu:659-662)
+  if (x < 0 || y < 0 || x >= img.width || y >= img.height) return 0;
+  return img(y, x);
+}
+
+__device__ __forceinline__ Vec3 unproject(int x, int y, float depth, const Unproj& up) {
+  Vec3 p;  // APP/cuda_util.cuh:61-69
+  p.x = depth * (up.fx_inv * (float)x + up.cx_inv);
+  p.y = depth * (up.fy_inv * (float)y + up.cy_inv);
+  p.z = depth;
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Normals + grazing-angle drop.  Reference: ComputeNormalsAndDropBadPixelsCUDAKernel, cu:642-718.
+__global__ void __launch_bounds__(kThreads)
+k_normals(float normal_dot_threshold, float inv_depth_scaling, Unproj up,
+          Img<const uint16_t> in, Img<uint16_t> out, Img<float2> out_normals) {
+  const int x = blockIdx.x * kTileW + (threadIdx.x & (kTileW - 1));
+  const int y = blockIdx.y * (kThreads / kTileW) + threadIdx.x / kTileW;
+  const int W = in.width, H = in.height;
+  if (x >= W || y >= H) return;
+  const uint16_t c = in(y, x);
+  const uint16_t right = rd0(in, y, x + 1), left = rd0(in, y, x - 1);
+  const uint16_t bottom = rd0(in, y + 1, x), top = rd0(in, y - 1, x);
+  if (c == 0 || right == 0 || left == 0 || bottom == 0 || top == 0) {
+    out(y, x) = 0;
+    out_normals(y, x) = make_float2(0, 0);
+    return;
+  }
+  const Vec3 lp = unproject(x - 1, y, inv_depth_scaling * (float)left, up);
+  const Vec3 tp = unproject(x, y - 1, inv_depth_scaling * (float)top, up);
+  const Vec3 rp = unproject(x + 1, y, inv_depth_scaling * (float)right, up);
+  const Vec3 bp = unproject(x, y + 1, inv_depth_scaling * (float)bottom, up);
+  const Vec3 a = {rp.x - lp.x, rp.y - lp.y, rp.z - lp.z};
+  const Vec3 b = {tp.x - bp.x, tp.y - bp.y, tp.z - bp.z};
+  Vec3 n = {a.y * b.z - b.y * a.z, b.x * a.z - a.x * b.z, a.x * b.y - b.x * a.y};
+  const float length = sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
+  if (!(length > 1e-6f)) {
+    n.x = 0; n.y = 0; n.z = -1;
+  } else {
+    const float inv_length = ((up.fy_inv < 0) ? -1.0f : 1.0f) / length;
+    n.x *= inv_length; n.y *= inv_length; n.z *= inv_length;
+  }
+  out_normals(y, x) = make_float2(n.x, n.y);
+  Vec3 vd = {up.fx_inv * (float)x + up.cx_inv, up.fy_inv * (float)y + up.cy_inv, 1.0f};
+  const float inv_dir_length = 1.0f / sqrtf(vd.x * vd.x + vd.y * vd.y + vd.z * vd.z);
+  vd.x = inv_dir_length * vd.x; vd.y = inv_dir_length * vd.y; vd.z = inv_dir_length * vd.z;
+  const float dot = vd.x * n.x + vd.y * n.y + vd.z * n.z;
+  out(y, x) = (dot >= normal_dot_threshold) ? (uint16_t)0 : c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Point radii + isolated-pixel removal.  Reference:
+// ComputePointRadiiAndRemoveIsolatedPixelsCUDAKernel, cu:765-837.
+__global__ void __launch_bounds__(kThreads)
+k_radii(float ext2, float clamp_term, float inv_depth_scaling, Unproj up,
+        Img<const uint16_t> in, Img<float> out_radius, Img<uint16_t> out) {
+  const int x = blockIdx.x * kTileW + (threadIdx.x & (kTileW - 1));
+  const int y = blockIdx.y * (kThreads / kTileW) + threadIdx.x / kTileW;
+  const int W = in.width, H = in.height;
+  if (x >= W || y >= H) return;
+  const uint16_t c = in(y, x);
+  if (c == 0) { out(y, x) = 0; return; }
+  const float depth = inv_depth_scaling * (float)c;
+  const Vec3 lp = {depth * (up.fx_inv * (float)x + up.cx_inv), depth * (up.fy_inv * (float)y + up.cy_inv), depth};
+  int neighbor_count = 0;
+  float radius_squared = 0;
+  float min_d2 = __builtin_inff();
+  for (int dy = y - 1; dy < y + 2; ++dy) {
+    for (int dx = x - 1; dx < x + 2; ++dx) {
+      const float dd = inv_depth_scaling * (float)rd0(in, dy, dx);
+      if ((dx == x && dy == y) || dd <= 0) continue;
+      ++neighbor_count;
+      const Vec3 op = {dd * (up.fx_inv * (float)dx + up.cx_inv), dd * (up.fy_inv * (float)dy + up.cy_inv), dd};
+      const Vec3 v = {op.x - lp.x, op.y - lp.y, op.z - lp.z};
+      const float d2 = v.x * v.x + v.y * v.y + v.z * v.z;
+      if (d2 > radius_squared) radius_squared = d2;
+      if (d2 < min_d2) min_d2 = d2;
+    }
+  }
+  radius_squared *= ext2;
+  const float clamp = clamp_term * min_d2;
+  if (radius_squared > clamp) radius_squared = clamp;
+  out_radius(y, x) = radius_squared;
+  out(y, x) = (neighbor_count < 8) ? (uint16_t)0 : c;
+}
+
+inline dim3 grid_rows(int W, int H) { return dim3(div_up(W, kTileW), div_up(H, kThreads / kTileW), 1); }
+
+}  // namespace
+
+extern "C" {
+
+int smx_bilateral_filtering_and_depth_cutoff(
+    smx_stream s, float sigma_xy, float sigma_value_factor, uint16_t value_to_ignore,
+    float radius_factor, uint16_t max_depth, float depth_valid_region_radius,
+    const smx_buffer_desc* input_depth, const smx_buffer_desc* output_depth) {
+  SMX_CHECK_ARG(input_depth && output_depth);
+  SMX_CHECK_ARG(input_depth->width == output_depth->width && input_depth->height == output_depth->height);
+  const int radius = (int)(radius_factor * sigma_xy + 0.5f);                       // cu:135
+  SMX_CHECK_ARG(radius >= 0 && radius <= kMaxBilateralRadius);
+  dim3 grid(div_up(output_depth->width, kTileW), div_up(output_depth->height, kTileH), 1);
+  hipLaunchKernelGGL(k_bilateral, grid, dim3(kThreads), 0, (hipStream_t)s,
+                     2.0f * sigma_xy * sigma_xy, sigma_value_factor, radius, radius * radius, value_to_ignore,
+                     max_depth, depth_valid_region_radius * depth_valid_region_radius,
+                     as_img<const uint16_t>(input_depth), as_img<uint16_t>(output_depth));
+  SMX_LAUNCH_CHECK();
+  return SMX_OK;
+}
+
+int smx_outlier_depth_map_fusion(
+    smx_stream s, int32_t other_count, int32_t required_count, float tolerance,
+    const smx_buffer_desc* input_depth, float fx, float fy, float cx, float cy,
+    const smx_buffer_desc* other_depths, const float* others_TR_reference,
+    const smx_buffer_desc* output_depth) {
+  SMX_CHECK_ARG(input_depth && output_depth && other_depths && others_TR_reference);
+  SMX_CHECK_ARG(other_count == 2 || other_count == 4 || other_count == 6 || other_count == 8);  // main.cc:1076-1086
+  OutlierParams p;
+  memset(&p, 0, sizeof(p));
+  for (int i = 0; i < other_count; ++i) {
+    memcpy(p.T[i].m, others_TR_reference + 12 * i, sizeof(float) * 12);
+    p.others[i] = as_img<const uint16_t>(&other_depths[i]);
+    SMX_CHECK_ARG(other_depths[i].width == output_depth->width && other_depths[i].height == output_depth->height);
+  }
+  const float max_tol = 1 + tolerance, min_tol = 1 - tolerance;                    // cu:255-256
+  const Unproj up = make_unproj(fx, fy, cx, cy);
+  dim3 grid = grid_rows(output_depth->width, output_depth->height);
+  hipStream_t st = (hipStream_t)s;
+#define SMX_OUTLIER(N)                                                                                      \
+  hipLaunchKernelGGL(k_outlier<N>, grid, dim3(kThreads), 0, st, required_count, max_tol, min_tol,          \
+                     as_img<const uint16_t>(input_depth), fx, fy, cx, cy, up, p, as_img<uint16_t>(output_depth))
+  switch (other_count) {
+    case 2: SMX_OUTLIER(2); break;
+    case 4: SMX_OUTLIER(4); break;
+    case 6: SMX_OUTLIER(6); break;
+    default: SMX_OUTLIER(8); break;
+  }
+#undef SMX_OUTLIER
+  SMX_LAUNCH_CHECK();
+  return SMX_OK;
+}
+
+int smx_erode_depth_map(smx_stream s, int32_t radius, const smx_buffer_desc* input_depth,
+                        const smx_buffer_desc* output_depth) {
+  SMX_CHECK_ARG(input_depth && output_depth);
+  if (radius < 1 || radius > 3) {                                                  // cu:572-574
+    set_error("radius value of %d is not supported.", radius);
+    return SMX_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(k_erode, grid_rows(output_depth->width, output_depth->height), dim3(kThreads), 0,
+                     (hipStream_t)s, radius, as_img<const uint16_t>(input_depth), as_img<uint16_t>(output_depth));
+  SMX_LAUNCH_CHECK();
+  return SMX_OK;
+}
+
+int smx_copy_without_border(smx_stream s, const smx_buffer_desc* input_depth, const smx_buffer_desc* output_depth) {
+  SMX_CHECK_ARG(input_depth && output_depth);
+  hipLaunchKernelGGL(k_copy_without_border, grid_rows(output_depth->width, output_depth->height), dim3(kThreads), 0,
+                     (hipStream_t)s, as_img<const uint16_t>(input_depth), as_img<uint16_t>(output_depth));
+  SMX_LAUNCH_CHECK();
+  return SMX_OK;
+}
+
+int smx_compute_normals_and_drop_bad_pixels(
+    smx_stream s, float observation_angle_threshold_deg, float depth_scaling,
+    float fx, float fy, float cx, float cy,
+    const smx_buffer_desc* in_depth, const smx_buffer_desc* out_depth, const smx_buffer_desc* out_normals) {
+  SMX_CHECK_ARG(in_depth && out_depth && out_normals);
+  const float thr = -1 * cosf((float)(M_PI / 180.f * observation_angle_threshold_deg));  // cu:752
+  hipLaunchKernelGGL(k_normals, grid_rows(in_depth->width, in_depth->height), dim3(kThreads), 0, (hipStream_t)s,
+                     thr, 1.0f / depth_scaling, make_unproj(fx, fy, cx, cy), as_img<const uint16_t>(in_depth),
+                     as_img<uint16_t>(out_depth), as_img<float2>(out_normals));
+  SMX_LAUNCH_CHECK();
+  return SMX_OK;
+}
+
+int smx_compute_point_radii_and_remove_isolated_pixels(
+    smx_stream s, float point_radius_extension_factor, float point_radius_clamp_factor,
+    float depth_scaling, float fx, float fy, float cx, float cy,
+    const smx_buffer_desc* depth_buffer, const smx_buffer_desc* radius_buffer, const smx_buffer_desc* out_depth) {
+  SMX_CHECK_ARG(depth_buffer && radius_buffer && out_depth);
+  const float ext2 = point_radius_extension_factor * point_radius_extension_factor;
+  const float clamp_term = point_radius_clamp_factor * point_radius_clamp_factor * sqrtf(2) * sqrtf(2);  // cu:873
+  hipLaunchKernelGGL(k_radii, grid_rows(depth_buffer->width, depth_buffer->height), dim3(kThreads), 0,
+                     (hipStream_t)s, ext2, clamp_term, 1.0f / depth_scaling, make_unproj(fx, fy, cx, cy),
+                     as_img<const uint16_t>(depth_buffer), as_img<float>(radius_buffer), as_img<uint16_t>(out_depth));
+  SMX_LAUNCH_CHECK();
+  return SMX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1215 @@
+// smx_recon.hip -- the surfel reconstruction object and its gfx950 kernels.
+//
+// Behaviour: CUDASurfelReconstruction::Integrate / Regularize / TransferAllToCPU /
+// ExportVertices of the reference (APP/cuda_surfel_reconstruction.{h,cc},
+// APP/cuda_surfel_reconstruction_kernels.{cc,cu}); cited per kernel below.
+//
+// Structure (DESIGN.md "Frame pipeline") -- this is NOT the reference's launch
+// sequence.  The reference scans all N surfel slots in every surfel kernel
+// (~140 B/slot/frame) and blocks the host twice per frame.  Here:
+//   pass A  k_scan_visible     one streaming pass over stamp,X,Y,Z (16 B/slot):
+//                              z-buffer atomics + a compacted list of the
+//                              slots that project into the image;
+//   list kernels               associate / merge-decide / integrate /
+//                              update-neighbors run over that list only;
+//   pass B  k_neighbor_scan    one streaming pass over the 4 neighbour rows
+//                              (16 B/slot): detach + regulariser accumulation
+//                              + compacted list of recently updated slots;
+//   list kernels               regulariser step / update over that list only.
+// The surfel count, merge count and all list lengths live in device memory;
+// no kernel launch needs a host round trip.
+#include <math.h>
+
+#include "smx_common.hpp"
+
+using namespace smx;
+
+namespace {
+
+// Surfel SoA rows, APP/cuda_surfel_reconstruction_kernels.cuh:49-78
+enum : int {
+  kX = 0, kY = 1, kZ = 2, kSmoothX = 3, kSmoothY = 4, kSmoothZ = 5, kConfidence = 6, kRadiusSq = 7,
+  kNormalX = 8, kNormalY = 9, kNormalZ = 10, kGradX = 11, kGradY = 12, kGradZ = 13,
+  kCreationStamp = 17, kLastUpdateStamp = 18, kNeighbor0 = 19, kGradCount = 23, kColor = 24, kRows = 25
+};
+
+struct DevState {
+  uint32_t surfel_count;   // slots in use (incl. merged zombies)
+  uint32_t merge_count;
+  uint32_t vis_count;      // length of the visible list of this frame
+  uint32_t recent_count;   // length of the recent list of this regulariser pass
+  uint32_t create_base;
+  uint32_t new_count;
+  uint32_t capacity_clamped;
+  uint32_t n_visible, n_merged, n_edges, n_integrated, n_replaced, n_conflict_hits;
+  uint32_t pad[3];
+};
+
+struct Surfels {
+  float* base;
+  size_t pitch;  // elements per row
+  __device__ __forceinline__ float& f(int row, uint32_t i) const { return base[(size_t)row * pitch + i]; }
+  __device__ __forceinline__ uint32_t& u(int row, uint32_t i) const {
+    return reinterpret_cast<uint32_t*>(base)[(size_t)row * pitch + i];
+  }
+};
+
+struct FrameCtx {
+  Mat34 L;  // local_T_global
+  Mat34 G;  // global_T_local
+  float fx, fy, cx, cy;
+  Unproj up;
+  float inv_depth_scaling;
+  float sensor_noise_factor;
+  float cos_normal_compat;
+  float rf2;
+  float max_conf;
+  int window;
+  uint32_t frame;
+  int W, H;
+};
+
+struct Scratch {
+  uint32_t* supporting;
+  uint32_t* counts;
+  long long* depth_sums;
+  uint32_t* confl_key;
+  float* first_depth;
+};
+
+struct Proj { Vec3 g, l; float u, v; int px, py; };
+
+// IsSurfelActiveForIntegration, kernels.cu:77-87
+__device__ __forceinline__ bool is_active(uint32_t stamp, uint32_t frame, int window) {
+  const int bound = (int)(frame - (uint32_t)window);
+  return (int)stamp > bound;
+}
+
+// The one projection routine (kernels.cu:1481-1500 == 1722-1741 == 2018-2031 == 1023-1048).
+__device__ __forceinline__ bool project_pos(const Vec3& g, const FrameCtx& c, Proj& o) {
+  o.g = g;
+  o.l = mul(c.L, g);
+  if (!(o.l.z > 0)) return false;
+  o.u = c.fx * (o.l.x / o.l.z) + c.cx;
+  o.v = c.fy * (o.l.y / o.l.z) + c.cy;
+  if (!(o.u >= 0 && o.v >= 0 && o.u < (float)c.W && o.v < (float)c.H)) return false;
+  o.px = (int)o.u; o.py = (int)o.v;
+  return true;
+}
+__device__ __forceinline__ bool project(const Surfels& S, uint32_t i, const FrameCtx& c, Proj& o) {
+  Vec3 g = {S.f(kX, i), S.f(kY, i), S.f(kZ, i)};
+  return project_pos(g, c, o);
+}
+
+// "triangle quadrant" neighbour pixel, kernels.cu:1078-1120 == 1506-1549 == 1752-1795
+__device__ __forceinline__ bool quadrant(const Proj& p, const FrameCtx& c, int& ox, int& oy) {
+  const float xf = p.u - (float)p.px, yf = p.v - (float)p.py;
+  if (xf < yf) {
+    if (xf < 1 - yf) { if (p.px > 1) { ox = p.px - 1; oy = p.py; return true; } return false; }
+    else { if (p.py < c.H - 1) { ox = p.px; oy = p.py + 1; return true; } return false; }
+  } else {
+    if (xf < 1 - yf) { if (p.py > 0) { ox = p.px; oy = p.py - 1; return true; } return false; }
+    else { if (p.px < c.W - 1) { ox = p.px + 1; oy = p.py; return true; } return false; }
+  }
+}
+
+__device__ __forceinline__ float meas_normal_z(float nx, float ny) {
+  const float t = 1 - nx * nx - ny * ny;
+  return -sqrtf(t > 0.f ? t : 0.f);
+}
+
+// Wave64 ballot + prefix append: one atomic per wavefront.
+__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
+  const unsigned long long mask = __ballot(pred);
+  if (mask == 0) return 0;
+  const uint32_t lane = __lane_id();
+  const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  const int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  base = __shfl(base, leader);
+  return base + prefix;
+}
+
+constexpr int kBlock = 256;
+static_assert(sizeof(uchar3) == 3, "uchar3 must be packed like the reference's Vec3u8");
+
+// ---------------------------------------------------------------------------------------------
+// 5 clears in one launch (cuda_surfel_reconstruction.cc:134-138) + per-frame counter reset.
+__global__ void __launch_bounds__(kBlock)
+k_clear_assoc(Scratch sc, int P, DevState* st) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k == 0) {
+    st->vis_count = 0;
+    st->n_visible = 0; st->n_merged = 0; st->n_integrated = 0; st->n_replaced = 0; st->n_conflict_hits = 0;
+  }
+  if (k < P) {
+    sc.supporting[k] = kInvalid;
+    sc.counts[k] = 0;
+    sc.depth_sums[k] = 0;
+    sc.confl_key[k] = kInvalid;
+    sc.first_depth[k] = __builtin_inff();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pass A.  RenderMinDepthCUDAKernel (kernels.cu:1466-1557) fused with the construction of the
+// visible list.  Streams rows 18,0,1,2 with 16-byte lane loads (4 slots per lane).
+__device__ __forceinline__ void min_depth_at(float* first_depth, int W, int x, int y, float z) {
+  atomicMin(reinterpret_cast<int*>(&first_depth[(size_t)y * W + x]), __float_as_int(z));  // :1463
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_scan_visible(Surfels S, FrameCtx c, Scratch sc, uint32_t* __restrict__ vis_list, DevState* st) {
+  const uint32_t N = st->surfel_count;
+  const uint32_t stride = gridDim.x * kBlock * 4;
+  for (uint32_t i0 = (blockIdx.x * kBlock + threadIdx.x) * 4; i0 < N; i0 += stride) {
+    // rows are padded to a multiple of 64 elements, so the 16-byte loads stay inside the row
+    const uint4 stamp4 = *reinterpret_cast<const uint4*>(&S.u(kLastUpdateStamp, i0));
+    const float4 x4 = *reinterpret_cast<const float4*>(&S.f(kX, i0));
+    const float4 y4 = *reinterpret_cast<const float4*>(&S.f(kY, i0));
+    const float4 z4 = *reinterpret_cast<const float4*>(&S.f(kZ, i0));
+    const uint32_t stamps[4] = {stamp4.x, stamp4.y, stamp4.z, stamp4.w};
+    const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+    const float ys[4] = {y4.x, y4.y, y4.z, y4.w};
+    const float zs[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t i = i0 + j;
+      Proj p;
+      const Vec3 g = {xs[j], ys[j], zs[j]};
+      const bool vis = (i < N) && project_pos(g, c, p);
+      const uint32_t slot = wave_append(&st->vis_count, vis);
+      if (vis) {
+        vis_list[slot] = i;
+        if (is_active(stamps[j], c.frame, c.window)) {
+          atomicAdd(&st->n_visible, 1u);
+          min_depth_at(sc.first_depth, c.W, p.px, p.py, p.l.z);
+          int ox, oy;
+          if (quadrant(p, c, ox, oy)) min_depth_at(sc.first_depth, c.W, ox, oy, p.l.z);
+        }
+      }
+    }
+  }
+}
+
+// Index source for the list kernels: the compacted list (default) or every slot (A/B mode).
+template <bool kUseList>
+__device__ __forceinline__ uint32_t work_count(const DevState* st) {
+  return kUseList ? st->vis_count : st->surfel_count;
+}
+
+// ---------------------------------------------------------------------------------------------
+// AssociateSurfelsCUDAKernel / ConsiderSurfelAssociationToPixel, kernels.cu:1586-1808.
+__device__ __forceinline__ void associate_at(const Surfels& S, const FrameCtx& c, const Scratch& sc,
+                                             const Img<const uint16_t>& depth, const Img<const float2>& normals,
+                                             int x, int y, const Proj& p, uint32_t i) {
+  const size_t k = (size_t)y * c.W + x;
+  const float measurement_depth = c.inv_depth_scaling * (float)depth(y, x);
+  if (measurement_depth <= 0) return;
+  const float first = sc.first_depth[k];
+  if (first < (1 - c.sensor_noise_factor) * measurement_depth) {
+    // :1615 racing plain store -> deterministic: associate-phase writers carry class bit 31
+    if (first == p.l.z) atomicMin(&sc.confl_key[k], 0x80000000u | i);
+    return;
+  }
+  const float occlusion_depth = (1 + c.sensor_noise_factor) * measurement_depth;
+  if (p.l.z > occlusion_depth) return;
+  const float surfel_distance = sqrtf(p.l.x * p.l.x + p.l.y * p.l.y + p.l.z * p.l.z);
+  const Vec3 gn = {S.f(kNormalX, i), S.f(kNormalY, i), S.f(kNormalZ, i)};
+  const Vec3 ln = rotate(c.L, gn);
+  const float dot_angle = (1.0f / surfel_distance) * (p.l.x * ln.x + p.l.y * ln.y + p.l.z * ln.z);
+  if (dot_angle > 0) return;
+  if (measurement_depth < p.l.z) {
+    const float2 n = normals(y, x);
+    const float nz = meas_normal_z(n.x, n.y);
+    const float d = ln.x * n.x + ln.y * n.y + ln.z * nz;
+    if (d < c.cos_normal_compat) return;
+  }
+  if (S.f(kRadiusSq, i) <= 0) return;  // :1674
+  atomicMin(&sc.supporting[k], i);      // :1688 first-wins CAS -> lowest index
+  atomicAdd(&sc.counts[k], 1u);
+  atomicAdd(reinterpret_cast<unsigned long long*>(&sc.depth_sums[k]), (unsigned long long)q_from_float(p.l.z));
+}
+
+template <bool kUseList>
+__global__ void __launch_bounds__(kBlock)
+k_associate(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<const float2> normals,
+            const uint32_t* __restrict__ vis_list, const DevState* st) {
+  const uint32_t n = work_count<kUseList>(st);
+  for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < n; e += gridDim.x * kBlock) {
+    const uint32_t i = kUseList ? vis_list[e] : e;
+    if (!is_active(S.u(kLastUpdateStamp, i), c.frame, c.window)) continue;
+    Proj p;
+    if (!project(S, i, c, p)) continue;
+    associate_at(S, c, sc, depth, normals, p.px, p.py, p, i);
+    int ox, oy;
+    if (quadrant(p, c, ox, oy)) associate_at(S, c, sc, depth, normals, ox, oy, p, i);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MergeSurfelsCUDAKernel / ConsiderSurfelMergeAtPixel, kernels.cu:1857-2052.  Snapshot
+// semantics: this kernel only records decisions (merge_flag); the marks (:1987-1989) are applied
+// at the top of k_integrate, after every decision has read pre-merge state.
+__device__ __forceinline__ bool merge_decide(const Surfels& S, const FrameCtx& c, const Scratch& sc,
+                                             const Img<const uint16_t>& depth, const Img<const float2>& normals,
+                                             const Proj& p, uint32_t i, float r2) {
+  const int x = p.px, y = p.py;
+  const size_t k = (size_t)y * c.W + x;
+  const float measurement_depth = c.inv_depth_scaling * (float)depth(y, x);
+  if (measurement_depth <= 0) return false;
+  const float first = sc.first_depth[k];
+  if (first < (1 - c.sensor_noise_factor) * measurement_depth) {
+    // :1887 plain store issued after the associate kernel: merge-phase writers win (class 0)
+    if (first == p.l.z) atomicMin(&sc.confl_key[k], i);
+    return false;
+  }
+  const float occlusion_depth = (1 + c.sensor_noise_factor) * measurement_depth;
+  if (p.l.z > occlusion_depth) return false;
+  const float surfel_distance = sqrtf(p.l.x * p.l.x + p.l.y * p.l.y + p.l.z * p.l.z);
+  const Vec3 gn = {S.f(kNormalX, i), S.f(kNormalY, i), S.f(kNormalZ, i)};
+  const Vec3 ln = rotate(c.L, gn);
+  float dot_angle = (1.0f / surfel_distance) * (p.l.x * ln.x + p.l.y * ln.y + p.l.z * ln.z);
+  if (dot_angle > 0) return false;
+  if (measurement_depth < p.l.z) {
+    const float2 n = normals(y, x);
+    const float nz = meas_normal_z(n.x, n.y);
+    const float d = ln.x * n.x + ln.y * n.y + ln.z * nz;
+    if (d < c.cos_normal_compat) return false;
+  }
+  const uint32_t s = sc.supporting[k];
+  if (s == i || s == kInvalid) return false;  // :1950-1953
+  const float other_r2 = S.f(kRadiusSq, s);
+  const float radius_diff = r2 / other_r2;
+  const float kT = 1.2f * 1.2f;
+  if (radius_diff > kT || radius_diff < 1 / kT) return false;
+  const float dx = p.g.x - S.f(kX, s), dy = p.g.y - S.f(kY, s), dz = p.g.z - S.f(kZ, s);
+  const float d2 = dx * dx + dy * dy + dz * dz;
+  const float kDist = 0.5f * (0.25f * 0.25f);
+  if (d2 > kDist * (r2 + other_r2)) return false;
+  dot_angle = gn.x * S.f(kNormalX, s) + gn.y * S.f(kNormalY, s) + gn.z * S.f(kNormalZ, s);
+  if (dot_angle < 0.93969f) return false;
+  return true;
+}
+
+template <bool kUseList>
+__global__ void __launch_bounds__(kBlock)
+k_merge_decide(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<const float2> normals,
+               const uint32_t* __restrict__ vis_list, uint8_t* __restrict__ merge_flag, const DevState* st) {
+  const uint32_t n = work_count<kUseList>(st);
+  for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < n; e += gridDim.x * kBlock) {
+    const uint32_t i = kUseList ? vis_list[e] : e;
+    const float r2 = S.f(kRadiusSq, i);
+    if (!(r2 >= 0)) continue;  // :2017
+    Proj p;
+    if (!project(S, i, c, p)) continue;
+    if (merge_decide(S, c, sc, depth, normals, p, i, r2)) merge_flag[i] = 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BlendMeasurementsCUDA, kernels.cc:148-205 + kernels.cu:563-708.
+struct BlendBufs {
+  uint8_t* distance_map; uint8_t* new_distance_map; float* deltas; float* new_deltas;
+};
+
+__global__ void __launch_bounds__(kBlock)
+k_blend_clear(BlendBufs b, int P) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k < P) { b.distance_map[k] = 0; b.new_distance_map[k] = 0; }
+}
+
+__device__ __forceinline__ float depth_sum_avg(const Scratch& sc, size_t k) {
+  return q_to_float(sc.depth_sums[k]) / (float)sc.counts[k];
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_blend_start(float ds, Img<uint16_t> depth, Scratch sc, BlendBufs b, int W, int H) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (!(x >= 1 && y >= 1 && x < W - 1 && y < H - 1)) return;
+  const size_t k = (size_t)y * W + x;
+  const uint16_t own = depth(y, x);
+  if (own == 0 || sc.supporting[k] == kInvalid) return;
+  bool measurement_border = false, surfel_border = false;
+  for (int wy = y - 1; wy <= y + 1; ++wy)
+    for (int wx = x - 1; wx <= x + 1; ++wx) {
+      if (depth(wy, wx) == 0) measurement_border = true;
+      else if (sc.supporting[(size_t)wy * W + wx] == kInvalid) surfel_border = true;
+    }
+  if (surfel_border) {
+    b.new_distance_map[k] = 1;
+    const float avg = depth_sum_avg(sc, k);
+    b.new_deltas[k] = avg - (float)own / ds;
+  }
+  if (measurement_border) {
+    b.distance_map[k] = 1;
+    const float avg = depth_sum_avg(sc, k);
+    b.deltas[k] = avg - (float)own / ds;
+    depth(y, x) = f2u16(ds * avg + 0.5f);  // :610
+  } else {
+    b.distance_map[k] = 255;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_blend_iter(int it, float term, float ds, Img<uint16_t> depth, Scratch sc, BlendBufs b, int W, int H) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (!(x >= 1 && y >= 1 && x < W - 1 && y < H - 1)) return;
+  const size_t k = (size_t)y * W + x;
+  if (b.distance_map[k] == 255) {
+    float delta_sum = 0; int count = 0;
+    for (int wy = y - 1; wy <= y + 1; ++wy)
+      for (int wx = x - 1; wx <= x + 1; ++wx) {
+        const size_t kk = (size_t)wy * W + wx;
+        if (b.distance_map[kk] == it - 1) { delta_sum += b.deltas[kk]; ++count; }
+      }
+    if (count > 0) {
+      b.distance_map[k] = (uint8_t)it;
+      const float avg = delta_sum / (float)count;
+      b.deltas[k] = avg;
+      const float f = (float)(it - 1) * term;
+      depth(y, x) = f2u16((float)depth(y, x) + (ds * (1 - f) * avg + 0.5f));  // :681
+    }
+  }
+  if (depth(y, x) != 0 && sc.supporting[k] == kInvalid && b.new_distance_map[k] == 0) {
+    float delta_sum = 0; int count = 0;
+    for (int wy = y - 1; wy <= y + 1; ++wy)
+      for (int wx = x - 1; wx <= x + 1; ++wx) {
+        const size_t kk = (size_t)wy * W + wx;
+        if (b.new_distance_map[kk] == it - 1) { delta_sum += b.new_deltas[kk]; ++count; }
+      }
+    if (count > 0) {
+      b.new_distance_map[k] = (uint8_t)it;
+      const float avg = delta_sum / (float)count;
+      b.new_deltas[k] = avg;
+      const float f = (float)(it - 1) * term;
+      depth(y, x) = f2u16((float)depth(y, x) + (ds * (1 - f) * avg + 0.5f));  // :704
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// IntegrateMeasurementsCUDAKernel / IntegrateOrConflictSurfel, kernels.cu:741-1142.  One lane per
+// visible surfel; no lock, no block-wide votes (both are redundant in the reference: thread i is
+// the only writer of surfel i).
+struct FrameIn {
+  Img<const uint16_t> depth; Img<const float2> normals; Img<const float> radius; Img<const uchar3> color;
+};
+
+__device__ __forceinline__ void integrate_or_conflict(const Surfels& S, const FrameCtx& c, const Scratch& sc,
+                                                      const FrameIn& in, bool integrate, int x, int y,
+                                                      const Vec3& cam, uint32_t i, DevState* st) {
+  if (!integrate) return;
+  const size_t k = (size_t)y * c.W + x;
+  const float measurement_depth = c.inv_depth_scaling * (float)in.depth(y, x);
+  if (measurement_depth <= 0) return;
+  bool conflicting = false;
+  const float first = sc.first_depth[k];
+  if (first < (1 - c.sensor_noise_factor) * measurement_depth) {
+    if (first == cam.z) {
+      const uint32_t key = sc.confl_key[k];
+      if (key != kInvalid && (key & 0x7FFFFFFFu) == i) conflicting = true;
+    }
+    integrate = false;
+  }
+  if (!integrate && !conflicting) return;
+  const float occlusion_depth = (1 + c.sensor_noise_factor) * measurement_depth;
+  if (cam.z > occlusion_depth) integrate = false;
+  if (!integrate && !conflicting) return;
+
+  const float depth = measurement_depth;
+  const Vec3 lp = {depth * (c.up.fx_inv * (float)x + c.up.cx_inv), depth * (c.up.fy_inv * (float)y + c.up.cy_inv), depth};
+  const Vec3 gp = mul(c.G, lp);
+  const float2 nxy = in.normals(y, x);
+  const Vec3 mn = {nxy.x, nxy.y, meas_normal_z(nxy.x, nxy.y)};
+  const Vec3 gn = rotate(c.G, mn);
+  const uchar3 col = in.color(y, x);
+
+  if (conflicting) {  // :816-868
+    atomicAdd(&st->n_conflict_hits, 1u);
+    float confidence = S.f(kConfidence, i);
+    confidence -= 1;
+    if (confidence <= 0) {
+      atomicAdd(&st->n_replaced, 1u);
+      S.f(kX, i) = gp.x; S.f(kY, i) = gp.y; S.f(kZ, i) = gp.z;
+      S.f(kSmoothX, i) = gp.x; S.f(kSmoothY, i) = gp.y; S.f(kSmoothZ, i) = gp.z;
+      S.f(kNormalX, i) = gn.x; S.f(kNormalY, i) = gn.y; S.f(kNormalZ, i) = gn.z;
+      S.u(kColor, i) = (uint32_t)col.x | ((uint32_t)col.y << 8) | ((uint32_t)col.z << 16) | (1u << 24);
+      S.f(kRadiusSq, i) = in.radius(y, x);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) S.u(kNeighbor0 + n, i) = kInvalid;
+      S.f(kConfidence, i) = 1;
+      S.u(kCreationStamp, i) = c.frame;
+      S.u(kLastUpdateStamp, i) = c.frame;
+    } else {
+      S.f(kConfidence, i) = confidence;
+    }
+  }
+  if (!integrate) return;
+
+  const float surfel_distance = sqrtf(cam.x * cam.x + cam.y * cam.y + cam.z * cam.z);
+  const Vec3 sn = {S.f(kNormalX, i), S.f(kNormalY, i), S.f(kNormalZ, i)};
+  const Vec3 ln = rotate(c.L, sn);
+  const float dot_angle = (1.0f / surfel_distance) * (cam.x * ln.x + cam.y * ln.y + cam.z * ln.z);
+  if (dot_angle > 0) return;
+  if (measurement_depth < cam.z) {
+    const float d = sn.x * gn.x + sn.y * gn.y + sn.z * gn.z;  // :898-903
+    if (d < c.cos_normal_compat) integrate = false;
+  }
+  const float old_r2 = S.f(kRadiusSq, i);
+  if (old_r2 < 0) integrate = false;
+  if (!integrate) return;
+
+  uint32_t cnt = sc.counts[k];  // :933
+  if (cnt < 1) cnt = 1;
+  const float weight = 1.0f / (float)cnt;
+  if (S.u(kCreationStamp, i) < c.frame) {  // :940
+    atomicAdd(&st->n_integrated, 1u);
+    const float confidence = S.f(kConfidence, i);
+    S.f(kConfidence, i) = (confidence + weight < c.max_conf) ? (confidence + weight) : c.max_conf;
+    const float nf = 1.0f / (confidence + weight);
+    S.f(kX, i) = (confidence * S.f(kX, i) + weight * gp.x) * nf;
+    S.f(kY, i) = (confidence * S.f(kY, i) + weight * gp.y) * nf;
+    S.f(kZ, i) = (confidence * S.f(kZ, i) + weight * gp.z) * nf;
+    const Vec3 nn = {confidence * sn.x + weight * gn.x, confidence * sn.y + weight * gn.y, confidence * sn.z + weight * gn.z};
+    const float inv = 1.0f / sqrtf(nn.x * nn.x + nn.y * nn.y + nn.z * nn.z);
+    S.f(kNormalX, i) = inv * nn.x; S.f(kNormalY, i) = inv * nn.y; S.f(kNormalZ, i) = inv * nn.z;
+    S.f(kRadiusSq, i) = fminf(old_r2, in.radius(y, x));
+    const uint32_t oc = S.u(kColor, i);
+    const uint32_t c0 = (uint32_t)(uint8_t)(int)((confidence * (float)(oc & 255u) + weight * (float)col.x) * nf + 0.5f);
+    const uint32_t c1 = (uint32_t)(uint8_t)(int)((confidence * (float)((oc >> 8) & 255u) + weight * (float)col.y) * nf + 0.5f);
+    const uint32_t c2 = (uint32_t)(uint8_t)(int)((confidence * (float)((oc >> 16) & 255u) + weight * (float)col.z) * nf + 0.5f);
+    S.u(kColor, i) = c0 | (c1 << 8) | (c2 << 16);
+    S.u(kLastUpdateStamp, i) = c.frame;
+  }
+}
+
+template <bool kUseList>
+__global__ void __launch_bounds__(kBlock)
+k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, const uint32_t* __restrict__ vis_list,
+            uint8_t* __restrict__ merge_flag, DevState* st) {
+  const uint32_t n = work_count<kUseList>(st);
+  for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < n; e += gridDim.x * kBlock) {
+    const uint32_t i = kUseList ? vis_list[e] : e;
+    if (merge_flag[i]) {
+      // apply the merge marks, kernels.cu:1987-1989 (decided in k_merge_decide)
+      merge_flag[i] = 0;
+      S.u(kLastUpdateStamp, i) = 0;
+      S.f(kRadiusSq, i) = -1;
+      S.u(kColor, i) = (S.u(kColor, i) & 0x00FFFFFFu) | 0x01000000u;
+      atomicAdd(&st->merge_count, 1u);
+      atomicAdd(&st->n_merged, 1u);
+      continue;  // r^2 < 0: the integrate kernel does nothing for it (:1050-1052)
+    }
+    if (!is_active(S.u(kLastUpdateStamp, i), c.frame, c.window)) continue;
+    Proj p;
+    if (!project(S, i, c, p)) continue;
+    if (S.f(kRadiusSq, i) < 0) continue;
+    integrate_or_conflict(S, c, sc, in, true, p.px, p.py, p.l, i, st);
+    int ox = 0, oy = 0;
+    const bool second = quadrant(p, c, ox, oy);
+    integrate_or_conflict(S, c, sc, in, second, ox, oy, p.l, i, st);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// UpdateNeighborsCUDAKernel, kernels.cu:1197-1380.
+template <bool kUseList>
+__global__ void __launch_bounds__(kBlock)
+k_update_neighbors(Surfels S, FrameCtx c, Scratch sc, FrameIn in, const uint32_t* __restrict__ vis_list,
+                   const DevState* st) {
+  const int kDX[4] = {-1, 1, 0, 0}, kDY[4] = {0, 0, -1, 1};
+  const uint32_t n = work_count<kUseList>(st);
+  for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < n; e += gridDim.x * kBlock) {
+    const uint32_t i = kUseList ? vis_list[e] : e;
+    if (!is_active(S.u(kLastUpdateStamp, i), c.frame, c.window)) continue;
+    const Vec3 g = {S.f(kX, i), S.f(kY, i), S.f(kZ, i)};
+    const Vec3 cam = mul(c.L, g);
+    if (!(cam.z > 0)) continue;
+    const float u = c.fx * (cam.x / cam.z) + c.cx, v = c.fy * (cam.y / cam.z) + c.cy;
+    if (!(u >= 1.0f && v >= 1.0f && u < (float)(c.W - 1) && v < (float)(c.H - 1))) continue;  // :1232-1240
+    const int x = (int)u, y = (int)v;
+    const float measurement_depth = c.inv_depth_scaling * (float)in.depth(y, x);
+    const float occlusion_depth = (1 + c.sensor_noise_factor) * measurement_depth;
+    if (cam.z > occlusion_depth) continue;
+    const float surfel_distance = sqrtf(cam.x * cam.x + cam.y * cam.y + cam.z * cam.z);
+    const Vec3 gn = {S.f(kNormalX, i), S.f(kNormalY, i), S.f(kNormalZ, i)};
+    const Vec3 ln = rotate(c.L, gn);
+    const float dot_angle = (1.0f / surfel_distance) * (cam.x * ln.x + cam.y * ln.y + cam.z * ln.z);
+    if (dot_angle > 0) continue;
+    const float r2 = S.f(kRadiusSq, i);
+    if (r2 < 0) continue;
+    if (in.radius(y, x) / r2 > 1.5f * 1.5f) continue;  // :1287-1291
+
+    float nd2[4]; uint32_t ni[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ni[q] = S.u(kNeighbor0 + q, i);
+      if (ni[q] == kInvalid) nd2[q] = __builtin_inff();
+      else {
+        const float dx = g.x - S.f(kX, ni[q]), dy = g.y - S.f(kY, ni[q]), dz = g.z - S.f(kZ, ni[q]);
+        nd2[q] = dx * dx + dy * dy + dz * dz;
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t nb = sc.supporting[(size_t)(y + kDY[d]) * c.W + (x + kDX[d])];
+      if (nb == kInvalid || nb == i) continue;
+      const float dx = S.f(kX, nb) - g.x, dy = S.f(kY, nb) - g.y, dz = S.f(kZ, nb) - g.z;
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      if (d2 > c.rf2 * r2) continue;
+      const float nd = gn.x * S.f(kNormalX, nb) + gn.y * S.f(kNormalY, nb) + gn.z * S.f(kNormalZ, nb);
+      if (nd <= 0) continue;
+      int best_n = -1; float best_d2 = -1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (best_n == -2) continue;
+        if (nb == ni[q]) { best_n = -2; }
+        else if (nd2[q] > best_d2) { best_n = q; best_d2 = nd2[q]; }
+      }
+      if (best_n >= 0 && d2 < best_d2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (q == best_n) { ni[q] = nb; nd2[q] = d2; }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) S.u(kNeighbor0 + q, i) = ni[q];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// CreateNewSurfelsCUDA, kernels.cc:37-146.  The u8 flag kernel (kernels.cu:90-111), the CUB
+// exclusive scan (kernels.cu:2506-2520) and the two D2H count reads are replaced by:
+//   k_new_flags_scan  flags + block-local exclusive ranks (wave64 ballot/popcount + LDS),
+//   k_new_finalize    scan of <= a few hundred block totals, advances the device-side count,
+//   k_new_create      the creation kernel (kernels.cu:133-231).
+constexpr int kScanPxPerThread = 4;
+constexpr int kScanPxPerBlock = kBlock * kScanPxPerThread;
+
+__global__ void __launch_bounds__(kBlock)
+k_new_flags_scan(Img<const uint16_t> depth, Scratch sc, int W, int H, uint8_t* __restrict__ flags,
+                 uint32_t* __restrict__ local_rank, uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t wave_tot[kBlock / 64];
+  const int P = W * H;
+  const int k0 = (blockIdx.x * kBlock + threadIdx.x) * kScanPxPerThread;
+  uint32_t f[kScanPxPerThread];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int j = 0; j < kScanPxPerThread; ++j) {
+    const int k = k0 + j;
+    bool fl = false;
+    if (k < P) {
+      const int y = k / W, x = k - y * W;
+      fl = x >= 1 && y >= 1 && x < W - 1 && y < H - 1 && depth(y, x) > 0 &&
+           sc.supporting[k] == kInvalid && sc.confl_key[k] == kInvalid;
+      flags[k] = fl ? 1 : 0;
+    }
+    f[j] = fl ? 1u : 0u;
+    mine += f[j];
+  }
+  // wave-level inclusive scan of per-lane counts
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off);
+    if (lane >= (uint32_t)off) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t wave_off = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    if ((uint32_t)w < wave) wave_off += wave_tot[w];
+    total += wave_tot[w];
+  }
+  uint32_t run = wave_off + incl - mine;
+#pragma unroll
+  for (int j = 0; j < kScanPxPerThread; ++j) {
+    const int k = k0 + j;
+    if (k < P) local_rank[k] = run;
+    run += f[j];
+  }
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(1024)
+k_new_finalize(uint32_t* __restrict__ block_sums, int nblocks, uint32_t max_surfels, DevState* st) {
+  // exclusive scan of the block totals in place (nblocks is a few hundred)
+  __shared__ uint32_t tot[1024];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += 1024) {
+    const int b = base + threadIdx.x;
+    const uint32_t v = (b < nblocks) ? block_sums[b] : 0;
+    tot[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      uint32_t t = 0;
+      if ((int)threadIdx.x >= off) t = tot[threadIdx.x - off];
+      __syncthreads();
+      tot[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (b < nblocks) block_sums[b] = carry + tot[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += tot[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const uint32_t N = st->surfel_count;
+    const uint32_t room = max_surfels - N;
+    const uint32_t created = carry < room ? carry : room;  // cap rule (reference: unchecked, cc:291)
+    st->create_base = N;
+    st->new_count = created;
+    st->capacity_clamped = (carry > room) ? 1u : 0u;
+    st->surfel_count = N + created;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_new_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, const uint8_t* __restrict__ flags,
+             uint32_t* __restrict__ ranks, const uint32_t* __restrict__ block_offsets, const DevState* st) {
+  const int kDX[4] = {-1, 1, 0, 0}, kDY[4] = {0, 0, -1, 1};
+  const int W = c.W, H = c.H, P = W * H;
+  const uint32_t base = st->create_base, created = st->new_count;
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < P; k += gridDim.x * kBlock) {
+    const uint32_t rank = block_offsets[k / kScanPxPerBlock] + ranks[k];
+    // ranks[] keeps the block-local values; global rank = block offset + local rank
+    if (flags[k] != 1 || rank >= created) continue;
+    const int y = k / W, x = k - y * W;
+    const uint32_t i = base + rank;
+    const float depth = c.inv_depth_scaling * (float)in.depth(y, x);
+    const Vec3 lp = {depth * (c.up.fx_inv * (float)x + c.up.cx_inv), depth * (c.up.fy_inv * (float)y + c.up.cy_inv), depth};
+    const Vec3 gp = mul(c.G, lp);
+    S.f(kX, i) = gp.x; S.f(kY, i) = gp.y; S.f(kZ, i) = gp.z;
+    const float2 nxy = in.normals(y, x);
+    const Vec3 mn = {nxy.x, nxy.y, meas_normal_z(nxy.x, nxy.y)};
+    const Vec3 gn = rotate(c.G, mn);
+    S.f(kNormalX, i) = gn.x; S.f(kNormalY, i) = gn.y; S.f(kNormalZ, i) = gn.z;
+    const uchar3 col = in.color(y, x);
+    S.u(kColor, i) = (uint32_t)col.x | ((uint32_t)col.y << 8) | ((uint32_t)col.z << 16);
+    S.f(kConfidence, i) = 1;
+    S.u(kCreationStamp, i) = c.frame;
+    S.u(kLastUpdateStamp, i) = c.frame;
+    const float r2 = in.radius(y, x);
+    S.f(kRadiusSq, i) = r2;
+    Vec3 sum = {0, 0, 0};
+    int count_plus_1 = 1;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int kk = (y + kDY[d]) * W + (x + kDX[d]);
+      uint32_t nb = sc.supporting[kk];
+      if (nb != kInvalid) {
+        const float dx = S.f(kX, nb) - gp.x, dy = S.f(kY, nb) - gp.y, dz = S.f(kZ, nb) - gp.z;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        if (d2 > c.rf2 * r2) nb = kInvalid;
+        else {
+          sum.x = sum.x + S.f(kSmoothX, nb); sum.y = sum.y + S.f(kSmoothY, nb); sum.z = sum.z + S.f(kSmoothZ, nb);
+          ++count_plus_1;
+        }
+      } else if (flags[kk] == 1) {
+        const uint32_t nrank = block_offsets[kk / kScanPxPerBlock] + ranks[kk];
+        if (nrank < created) {
+          const float od = c.inv_depth_scaling * (float)in.depth(y + kDY[d], x + kDX[d]);
+          const float ad2 = (depth - od) * (depth - od);
+          if (ad2 <= c.rf2 * r2) nb = base + nrank;
+        }
+      }
+      S.u(kNeighbor0 + d, i) = nb;
+    }
+    S.f(kSmoothX, i) = (gp.x + sum.x) / (float)count_plus_1;  // :227-229
+    S.f(kSmoothY, i) = (gp.y + sum.y) / (float)count_plus_1;
+    S.f(kSmoothZ, i) = (gp.z + sum.z) / (float)count_plus_1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pass B.  UpdateNeighborsCUDARemoveReplacedNeighborsKernel (kernels.cu:1420-1437) +
+// RegularizeSurfelsCUDAAccumulateNeighborGradientsKernel (kernels.cu:2115-2195) in one streaming
+// pass over the 4 neighbour rows, plus construction of the list of recently updated slots that
+// the step/update kernels run over.  The gradient clear (kernels.cu:2099-2113) is gone: the
+// fixed-point accumulators are zero between calls (k_reg_step zeroes what it consumes).
+__device__ __forceinline__ bool stamp_outside_window(uint32_t stamp, uint32_t frame, int window) {
+  return (int)stamp < (int)(frame - (uint32_t)window);  // :2132
+}
+
+template <bool kDetach, bool kAccumulate>
+__global__ void __launch_bounds__(kBlock)
+k_neighbor_scan(Surfels S, uint32_t frame, int window, float rf2, float weight,
+                long long* __restrict__ grad_acc, uint32_t* __restrict__ recent_list, DevState* st) {
+  const uint32_t N = st->surfel_count;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+    const bool recent = !stamp_outside_window(S.u(kLastUpdateStamp, i), frame, window);
+    const uint32_t slot = wave_append(&st->recent_count, recent);
+    if (recent) recent_list[slot] = i;
+
+    uint32_t ni[4];
+    bool in_window[4];
+    int neighbor_count = 0;
+    uint32_t valid_edges = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ni[q] = S.u(kNeighbor0 + q, i);
+      in_window[q] = false;
+      if (ni[q] == kInvalid) continue;
+      if (kDetach && (S.u(kColor, ni[q]) >> 24) == 1u) {  // :1430-1433
+        ni[q] = kInvalid;
+        S.u(kNeighbor0 + q, i) = kInvalid;
+        continue;
+      }
+      ++valid_edges;
+      if (!kAccumulate) continue;
+      if (stamp_outside_window(S.u(kLastUpdateStamp, ni[q]), frame, window)) continue;
+      in_window[q] = true;
+      ++neighbor_count;
+    }
+    if (kAccumulate && valid_edges) atomicAdd(&st->n_edges, valid_edges);
+    if (!kAccumulate || neighbor_count == 0) continue;
+
+    const Vec3 sp = {S.f(kSmoothX, i), S.f(kSmoothY, i), S.f(kSmoothZ, i)};
+    const Vec3 nrm = {S.f(kNormalX, i), S.f(kNormalY, i), S.f(kNormalZ, i)};
+    const float r2 = S.f(kRadiusSq, i);
+    const float factor = 2 * weight / (float)neighbor_count;  // :2153
+    const float wk = weight / (float)neighbor_count;          // :2182
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!in_window[q]) continue;
+      const uint32_t nb = ni[q];
+      const Vec3 t = {S.f(kSmoothX, nb) - sp.x, S.f(kSmoothY, nb) - sp.y, S.f(kSmoothZ, nb) - sp.z};
+      const float f = factor * (nrm.x * t.x + nrm.y * t.y + nrm.z * t.z);
+      unsigned long long* a = reinterpret_cast<unsigned long long*>(&grad_acc[4 * (size_t)nb]);
+      atomicAdd(&a[0], (unsigned long long)q_from_float(f * nrm.x));
+      atomicAdd(&a[1], (unsigned long long)q_from_float(f * nrm.y));
+      atomicAdd(&a[2], (unsigned long long)q_from_float(f * nrm.z));
+      atomicAdd(&a[3], (unsigned long long)q_from_float(wk));
+      const float d2 = t.x * t.x + t.y * t.y + t.z * t.z;
+      if (d2 > rf2 * r2) S.u(kNeighbor0 + q, i) = kInvalid;  // :2190-2192
+    }
+  }
+}
+
+// RegularizeSurfelsCUDAKernel, kernels.cu:2197-2290, over the recent list.
+__global__ void __launch_bounds__(kBlock)
+k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, const uint32_t* __restrict__ recent_list,
+           const DevState* st) {
+  const uint32_t n = st->recent_count;
+  for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < n; e += gridDim.x * kBlock) {
+    const uint32_t i = recent_list[e];
+    const Vec3 mp = {S.f(kX, i), S.f(kY, i), S.f(kZ, i)};
+    const Vec3 sp = {S.f(kSmoothX, i), S.f(kSmoothY, i), S.f(kSmoothZ, i)};
+    const Vec3 nrm = {S.f(kNormalX, i), S.f(kNormalY, i), S.f(kNormalZ, i)};
+    longlong4* ap = reinterpret_cast<longlong4*>(&grad_acc[4 * (size_t)i]);
+    const longlong4 a = *ap;
+    if (a.x | a.y | a.z | a.w) *ap = make_longlong4(0, 0, 0, 0);  // keep the accumulators zero between calls
+    const float acc[4] = {q_to_float(a.x), q_to_float(a.y), q_to_float(a.z), q_to_float(a.w)};
+    Vec3 grad = {2 * (sp.x - mp.x) + acc[0], 2 * (sp.y - mp.y) + acc[1], 2 * (sp.z - mp.z) + acc[2]};
+    int neighbor_count = 0;
+    Vec3 rg = {0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t nb = S.u(kNeighbor0 + q, i);
+      if (nb == kInvalid) continue;
+      ++neighbor_count;
+      const Vec3 t = {S.f(kSmoothX, nb) - sp.x, S.f(kSmoothY, nb) - sp.y, S.f(kSmoothZ, nb) - sp.z};
+      const float nd = nrm.x * t.x + nrm.y * t.y + nrm.z * t.z;
+      rg.x = rg.x - nd * nrm.x; rg.y = rg.y - nd * nrm.y; rg.z = rg.z - nd * nrm.z;
+    }
+    if (neighbor_count > 0) {
+      const float factor = 2 * weight / (float)neighbor_count;
+      grad.x = grad.x + factor * rg.x; grad.y = grad.y + factor * rg.y; grad.z = grad.z + factor * rg.z;
+    }
+    const float wsum = 1 + weight + acc[3];  // :2267
+    const float kStep = 0.5f / wsum;
+    const float max_step = 1.0f * sqrtf(S.f(kRadiusSq, i));
+    const float step_len = kStep * sqrtf(grad.x * grad.x + grad.y * grad.y + grad.z * grad.z);
+    float step = kStep;
+    if (step_len > max_step) step = max_step / step_len * kStep;
+    S.f(kGradX, i) = sp.x - step * grad.x;  // parked until k_reg_update (:2283-2288)
+    S.f(kGradY, i) = sp.y - step * grad.y;
+    S.f(kGradZ, i) = sp.z - step * grad.z;
+  }
+}
+
+// RegularizeSurfelsCUDAUpdateKernel (:2292-2308) / CopyOnlyKernel (:2310-2327), over the recent list.
+template <bool kCopyRaw>
+__global__ void __launch_bounds__(kBlock)
+k_reg_update(Surfels S, const uint32_t* __restrict__ recent_list, const DevState* st) {
+  const uint32_t n = st->recent_count;
+  for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < n; e += gridDim.x * kBlock) {
+    const uint32_t i = recent_list[e];
+    S.f(kSmoothX, i) = S.f(kCopyRaw ? kX : kGradX, i);
+    S.f(kSmoothY, i) = S.f(kCopyRaw ? kY : kGradY, i);
+    S.f(kSmoothZ, i) = S.f(kCopyRaw ? kZ : kGradZ, i);
+  }
+}
+
+__global__ void k_reset_recent(DevState* st) { st->recent_count = 0; st->n_edges = 0; }
+
+// ExportVerticesCUDAKernel, kernels.cu:2412-2433
+__global__ void __launch_bounds__(kBlock)
+k_export(Surfels S, float* __restrict__ pos, uint8_t* __restrict__ col, const DevState* st) {
+  const uint32_t N = st->surfel_count;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+    const bool merged = S.f(kRadiusSq, i) < 0;
+    const float nanv = __builtin_nanf("");
+    pos[3 * (size_t)i + 0] = merged ? nanv : S.f(kSmoothX, i);
+    pos[3 * (size_t)i + 1] = merged ? nanv : S.f(kSmoothY, i);
+    pos[3 * (size_t)i + 2] = merged ? nanv : S.f(kSmoothZ, i);
+    const uint32_t c = S.u(kColor, i);
+    col[3 * (size_t)i + 0] = (uint8_t)(c & 255u);
+    col[3 * (size_t)i + 1] = (uint8_t)((c >> 8) & 255u);
+    col[3 * (size_t)i + 2] = (uint8_t)((c >> 16) & 255u);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_decode_conflicting(const uint32_t* __restrict__ key, uint32_t* __restrict__ out, int P) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k < P) out[k] = (key[k] == kInvalid) ? kInvalid : (key[k] & 0x7FFFFFFFu);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_global_ranks(const uint32_t* __restrict__ local_rank, const uint32_t* __restrict__ block_offsets,
+               uint32_t* __restrict__ out, int P) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k < P) out[k] = block_offsets[k / kScanPxPerBlock] + local_rank[k];
+}
+
+}  // namespace
+
+// =============================================================================================
+struct smx_recon_s {
+  uint32_t max_surfels;
+  int W, H;
+  float fx, fy, cx, cy;
+  Surfels S;
+  long long* grad_acc;
+  uint32_t* vis_list;
+  uint32_t* recent_list;
+  uint8_t* merge_flag;
+  Scratch sc;
+  BlendBufs bb;
+  uint8_t* new_flags;
+  uint32_t* new_ranks;
+  uint32_t* block_sums;
+  uint32_t* tmp_u32;  // [W*H] debug decode target
+  int n_scan_blocks;
+  DevState* st;
+  int scan_mode;
+  int timing_enabled;
+  bool have_timings;
+  hipEvent_t ev[14];
+  int grid_surfels;  // persistent grid for the all-slot passes
+  int grid_list;
+};
+
+namespace {
+
+int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, float weight, int window,
+                       bool detach, bool copy_only) {
+  hipLaunchKernelGGL(k_reset_recent, dim3(1), dim3(1), 0, st, r->st);
+  const dim3 g(r->grid_surfels), b(kBlock);
+  const float rf2 = rf * rf;
+  if (copy_only) {
+    if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, false>), g, b, 0, st, r->S, frame, window, rf2, weight, r->grad_acc, r->recent_list, r->st);
+    else hipLaunchKernelGGL((k_neighbor_scan<false, false>), g, b, 0, st, r->S, frame, window, rf2, weight, r->grad_acc, r->recent_list, r->st);
+    hipLaunchKernelGGL((k_reg_update<true>), dim3(r->grid_list), b, 0, st, r->S, r->recent_list, r->st);
+  } else {
+    if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, true>), g, b, 0, st, r->S, frame, window, rf2, weight, r->grad_acc, r->recent_list, r->st);
+    else hipLaunchKernelGGL((k_neighbor_scan<false, true>), g, b, 0, st, r->S, frame, window, rf2, weight, r->grad_acc, r->recent_list, r->st);
+    hipLaunchKernelGGL(k_reg_step, dim3(r->grid_list), b, 0, st, r->S, weight, r->grad_acc, r->recent_list, r->st);
+    hipLaunchKernelGGL((k_reg_update<false>), dim3(r->grid_list), b, 0, st, r->S, r->recent_list, r->st);
+  }
+  SMX_LAUNCH_CHECK();
+  return SMX_OK;
+}
+
+template <typename T>
+int dev_alloc(T** p, size_t count, bool zero) {
+  SMX_HIP(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+  if (zero) SMX_HIP(hipMemset(*p, 0, count * sizeof(T)));
+  return SMX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
+                     float fx, float fy, float cx, float cy, smx_recon* out) {
+  SMX_CHECK_ARG(out != nullptr && max_surfel_count > 0 && max_surfel_count < 0x7FFFFFFFu);
+  SMX_CHECK_ARG(width >= 3 && height >= 3);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    (void)hipGetLastError();
+    set_error("no HIP device available");
+    return SMX_ERR_NO_DEVICE;
+  }
+  smx_recon_s* r = new smx_recon_s();
+  memset(r, 0, sizeof(*r));
+  r->max_surfels = max_surfel_count;
+  r->W = width; r->H = height; r->fx = fx; r->fy = fy; r->cx = cx; r->cy = cy;
+  r->S.pitch = ((size_t)max_surfel_count + 63) / 64 * 64;
+  const size_t P = (size_t)width * height;
+  int rc;
+#define SMX_TRY(x) do { rc = (x); if (rc != SMX_OK) return rc; } while (0)
+  // cuda_surfel_reconstruction.cc:59 -- 25 rows x max_surfel_count (zero-filled here so that the
+  // padded tail of every row is defined)
+  SMX_TRY(dev_alloc(&r->S.base, (size_t)kRows * r->S.pitch, true));
+  SMX_TRY(dev_alloc(&r->grad_acc, 4 * r->S.pitch, true));
+  SMX_TRY(dev_alloc(&r->vis_list, r->S.pitch, false));
+  SMX_TRY(dev_alloc(&r->recent_list, r->S.pitch, false));
+  SMX_TRY(dev_alloc(&r->merge_flag, r->S.pitch, true));
+  SMX_TRY(dev_alloc(&r->sc.supporting, P, false));
+  SMX_TRY(dev_alloc(&r->sc.counts, P, false));
+  SMX_TRY(dev_alloc(&r->sc.depth_sums, P, false));
+  SMX_TRY(dev_alloc(&r->sc.confl_key, P, false));
+  SMX_TRY(dev_alloc(&r->sc.first_depth, P, false));
+  SMX_TRY(dev_alloc(&r->bb.distance_map, P, true));
+  SMX_TRY(dev_alloc(&r->bb.new_distance_map, P, true));
+  SMX_TRY(dev_alloc(&r->bb.deltas, P, true));
+  SMX_TRY(dev_alloc(&r->bb.new_deltas, P, true));
+  SMX_TRY(dev_alloc(&r->new_flags, P, true));
+  SMX_TRY(dev_alloc(&r->new_ranks, P, true));
+  SMX_TRY(dev_alloc(&r->tmp_u32, P, true));
+  r->n_scan_blocks = div_up((long long)P, kScanPxPerBlock);
+  SMX_TRY(dev_alloc(&r->block_sums, (size_t)r->n_scan_blocks, true));
+  SMX_TRY(dev_alloc(&r->st, 1, true));
+#undef SMX_TRY
+  for (int i = 0; i < 14; ++i) SMX_HIP(hipEventCreate(&r->ev[i]));
+  r->timing_enabled = 1;
+  hipDeviceProp_t prop;
+  int dev = 0;
+  SMX_HIP(hipGetDevice(&dev));
+  SMX_HIP(hipGetDeviceProperties(&prop, dev));
+  const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  r->grid_surfels = cus * 8;  // 8 x 256-thread workgroups per CU: full occupancy, >> 256 workgroups
+  r->grid_list = cus * 4;
+  *out = r;
+  return SMX_OK;
+}
+
+int smx_recon_destroy(smx_recon r) {
+  if (!r) return SMX_OK;
+  void* ptrs[] = {r->S.base, r->grad_acc, r->vis_list, r->recent_list, r->merge_flag, r->sc.supporting, r->sc.counts,
+                  r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth, r->bb.distance_map, r->bb.new_distance_map,
+                  r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->st};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (int i = 0; i < 14; ++i) if (r->ev[i]) (void)hipEventDestroy(r->ev[i]);
+  delete r;
+  return SMX_OK;
+}
+
+int smx_recon_set_timing_enabled(smx_recon r, int32_t enabled) {
+  SMX_CHECK_ARG(r != nullptr);
+  r->timing_enabled = enabled ? 1 : 0;
+  return SMX_OK;
+}
+
+int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
+  SMX_CHECK_ARG(r != nullptr && (mode == 0 || mode == 1));
+  r->scan_mode = mode;
+  return SMX_OK;
+}
+
+int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float depth_scaling,
+                        const smx_buffer_desc* depth, const smx_buffer_desc* normals,
+                        const smx_buffer_desc* radius, const smx_buffer_desc* color,
+                        const float global_T_local[12], const smx_integrate_params* p) {
+  SMX_CHECK_ARG(r && depth && normals && radius && color && global_T_local && p);
+  SMX_CHECK_ARG(depth->width == r->W && depth->height == r->H && normals->width == r->W && normals->height == r->H);
+  SMX_CHECK_ARG(radius->width == r->W && radius->height == r->H && color->width == r->W && color->height == r->H);
+  SMX_CHECK_ARG(p->measurement_blending_radius >= 2 && p->measurement_blending_radius <= 255);
+  hipStream_t st = (hipStream_t)s;
+  FrameCtx c;
+  memcpy(c.G.m, global_T_local, sizeof(float) * 12);
+  c.L = se3_inverse(global_T_local);  // cc:144
+  c.fx = r->fx; c.fy = r->fy; c.cx = r->cx; c.cy = r->cy;
+  c.up = make_unproj(r->fx, r->fy, r->cx, r->cy);
+  c.inv_depth_scaling = 1.0f / depth_scaling;
+  c.sensor_noise_factor = p->sensor_noise_factor;
+  c.cos_normal_compat = cosf((float)(M_PI / 180.0f * p->normal_compatibility_threshold_deg));  // kernels.cc:261
+  c.rf2 = p->radius_factor_for_regularization_neighbors * p->radius_factor_for_regularization_neighbors;
+  c.max_conf = p->max_surfel_confidence;
+  c.window = p->surfel_integration_active_window_size;
+  c.frame = frame_index;
+  c.W = r->W; c.H = r->H;
+  const int P = r->W * r->H;
+  const dim3 b(kBlock), gpx(div_up(P, kBlock)), gimg(div_up(r->W, 64), div_up(r->H, 4));
+  const dim3 gs(r->grid_surfels), gl(r->scan_mode ? r->grid_surfels : r->grid_list);
+  const bool tm = r->timing_enabled != 0;
+  FrameIn in;
+  in.depth = as_img<const uint16_t>(depth); in.normals = as_img<const float2>(normals);
+  in.radius = as_img<const float>(radius); in.color = as_img<const uchar3>(color);
+  const Img<uint16_t> depth_rw = as_img<uint16_t>(depth);
+
+  if (tm) SMX_HIP(hipEventRecord(r->ev[0], st));
+  hipLaunchKernelGGL(k_clear_assoc, gpx, b, 0, st, r->sc, P, r->st);
+  hipLaunchKernelGGL(k_scan_visible, gs, b, 0, st, r->S, c, r->sc, r->vis_list, r->st);
+  if (r->scan_mode) hipLaunchKernelGGL((k_associate<false>), gl, b, 0, st, r->S, c, r->sc, in.depth, in.normals, r->vis_list, r->st);
+  else hipLaunchKernelGGL((k_associate<true>), gl, b, 0, st, r->S, c, r->sc, in.depth, in.normals, r->vis_list, r->st);
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[1], st)); SMX_HIP(hipEventRecord(r->ev[2], st)); }
+  if (r->scan_mode) hipLaunchKernelGGL((k_merge_decide<false>), gl, b, 0, st, r->S, c, r->sc, in.depth, in.normals, r->vis_list, r->merge_flag, r->st);
+  else hipLaunchKernelGGL((k_merge_decide<true>), gl, b, 0, st, r->S, c, r->sc, in.depth, in.normals, r->vis_list, r->merge_flag, r->st);
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[3], st)); SMX_HIP(hipEventRecord(r->ev[4], st)); }
+  if (p->do_blending) {
+    const float ds = 1.0f / c.inv_depth_scaling;  // kernels.cc:179
+    hipLaunchKernelGGL(k_blend_clear, gpx, b, 0, st, r->bb, P);
+    hipLaunchKernelGGL(k_blend_start, gimg, b, 0, st, ds, depth_rw, r->sc, r->bb, r->W, r->H);
+    const float term = 1.0f / ((float)p->measurement_blending_radius - 1.0f);  // kernels.cc:196
+    for (int it = 2; it < p->measurement_blending_radius; ++it)
+      hipLaunchKernelGGL(k_blend_iter, gimg, b, 0, st, it, term, ds, depth_rw, r->sc, r->bb, r->W, r->H);
+  }
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[5], st)); SMX_HIP(hipEventRecord(r->ev[6], st)); }
+  if (r->scan_mode) hipLaunchKernelGGL((k_integrate<false>), gl, b, 0, st, r->S, c, r->sc, in, r->vis_list, r->merge_flag, r->st);
+  else hipLaunchKernelGGL((k_integrate<true>), gl, b, 0, st, r->S, c, r->sc, in, r->vis_list, r->merge_flag, r->st);
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[7], st)); SMX_HIP(hipEventRecord(r->ev[8], st)); }
+  if (r->scan_mode) hipLaunchKernelGGL((k_update_neighbors<false>), gl, b, 0, st, r->S, c, r->sc, in, r->vis_list, r->st);
+  else hipLaunchKernelGGL((k_update_neighbors<true>), gl, b, 0, st, r->S, c, r->sc, in, r->vis_list, r->st);
+  // (the detach half of UpdateNeighborsCUDA runs fused into pass B below)
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[9], st)); SMX_HIP(hipEventRecord(r->ev[10], st)); }
+  hipLaunchKernelGGL(k_new_flags_scan, dim3(r->n_scan_blocks), b, 0, st, in.depth, r->sc, r->W, r->H, r->new_flags,
+                     r->new_ranks, r->block_sums);
+  hipLaunchKernelGGL(k_new_finalize, dim3(1), dim3(1024), 0, st, r->block_sums, r->n_scan_blocks, r->max_surfels, r->st);
+  hipLaunchKernelGGL(k_new_create, dim3(div_up(P, kBlock)), b, 0, st, r->S, c, r->sc, in, r->new_flags, r->new_ranks,
+                     r->block_sums, r->st);
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[11], st)); SMX_HIP(hipEventRecord(r->ev[12], st)); }
+  SMX_LAUNCH_CHECK();
+  int rc = SMX_OK;
+  const int iters = p->regularization_iterations_per_integration_iteration;
+  if (iters == 0) {
+    rc = enqueue_regularize(r, st, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
+                            p->regularization_frame_window_size, true, true);
+  } else {
+    for (int k = 0; k < iters && rc == SMX_OK; ++k)
+      rc = enqueue_regularize(r, st, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
+                              p->regularization_frame_window_size, k == 0, false);
+  }
+  if (rc != SMX_OK) return rc;
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[13], st)); r->have_timings = true; }
+  return SMX_OK;
+}
+
+int smx_recon_regularize(smx_recon r, smx_stream s, uint32_t frame_index, float regularizer_weight,
+                         float radius_factor_for_regularization_neighbors, int32_t regularization_frame_window_size) {
+  SMX_CHECK_ARG(r != nullptr);
+  return enqueue_regularize(r, (hipStream_t)s, frame_index, radius_factor_for_regularization_neighbors,
+                            regularizer_weight, regularization_frame_window_size, false, false);
+}
+
+int smx_recon_counts(smx_recon r, smx_stream s, uint32_t* surfel_count, uint32_t* surfels_size) {
+  SMX_CHECK_ARG(r != nullptr);
+  DevState h;
+  SMX_HIP(hipMemcpyAsync(&h, r->st, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)s));
+  SMX_HIP(hipStreamSynchronize((hipStream_t)s));
+  if (surfel_count) *surfel_count = h.surfel_count - h.merge_count;  // .h:125-128
+  if (surfels_size) *surfels_size = h.surfel_count;
+  return SMX_OK;
+}
+
+int smx_recon_get_stats(smx_recon r, smx_stream s, smx_recon_stats* out) {
+  SMX_CHECK_ARG(r != nullptr && out != nullptr);
+  DevState h;
+  SMX_HIP(hipMemcpyAsync(&h, r->st, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)s));
+  SMX_HIP(hipStreamSynchronize((hipStream_t)s));
+  out->surfels_size = h.surfel_count; out->merge_count = h.merge_count;
+  out->n_visible = h.n_visible; out->n_new = h.new_count; out->n_merged = h.n_merged;
+  out->n_recent = h.recent_count; out->n_edges = h.n_edges;
+  out->n_integrated = h.n_integrated; out->n_replaced = h.n_replaced; out->n_conflict_hits = h.n_conflict_hits;
+  out->capacity_clamped = h.capacity_clamped;
+  return SMX_OK;
+}
+
+int smx_recon_transfer_all_to_cpu(smx_recon r, smx_stream s, uint32_t frame_index, smx_surfel_buffers_cpu* buf) {
+  SMX_CHECK_ARG(r != nullptr && buf != nullptr);
+  hipStream_t st = (hipStream_t)s;
+  uint32_t n = 0;
+  SMX_HIP(hipMemcpyAsync(&n, &r->st->surfel_count, sizeof(n), hipMemcpyDeviceToHost, st));
+  SMX_HIP(hipStreamSynchronize(st));
+  buf->frame_index = frame_index;  // cc:345-346
+  buf->surfel_count = n;
+  if (n == 0) return SMX_OK;
+  const size_t bytes = (size_t)n * 4;
+  struct { int row; void* dst; } rows[8] = {
+      {kSmoothX, buf->surfel_x_buffer}, {kSmoothY, buf->surfel_y_buffer}, {kSmoothZ, buf->surfel_z_buffer},
+      {kRadiusSq, buf->surfel_radius_squared_buffer},
+      {kNormalX, buf->surfel_normal_x_buffer}, {kNormalY, buf->surfel_normal_y_buffer}, {kNormalZ, buf->surfel_normal_z_buffer},
+      {kLastUpdateStamp, buf->surfel_last_update_stamp_buffer}};  // cc:348-358
+  for (auto& q : rows) {
+    SMX_CHECK_ARG(q.dst != nullptr);
+    SMX_HIP(hipMemcpyAsync(q.dst, r->S.base + (size_t)q.row * r->S.pitch, bytes, hipMemcpyDeviceToHost, st));
+  }
+  return SMX_OK;
+}
+
+int smx_recon_export_vertices(smx_recon r, smx_stream s, const smx_buffer_desc* position_buffer,
+                              const smx_buffer_desc* color_buffer) {
+  SMX_CHECK_ARG(r && position_buffer && color_buffer);
+  hipLaunchKernelGGL(k_export, dim3(r->grid_surfels), dim3(kBlock), 0, (hipStream_t)s, r->S,
+                     (float*)position_buffer->address, (uint8_t*)color_buffer->address, r->st);
+  SMX_LAUNCH_CHECK();
+  return SMX_OK;
+}
+
+int smx_recon_get_timings(smx_recon r, float out_ms[7]) {
+  SMX_CHECK_ARG(r != nullptr && out_ms != nullptr);
+  if (!r->have_timings) { for (int i = 0; i < 7; ++i) out_ms[i] = 0; return SMX_OK; }
+  SMX_HIP(hipEventSynchronize(r->ev[13]));  // cc:420
+  for (int i = 0; i < 7; ++i) SMX_HIP(hipEventElapsedTime(&out_ms[i], r->ev[2 * i], r->ev[2 * i + 1]));
+  return SMX_OK;
+}
+
+int smx_recon_debug_download_surfels(smx_recon r, smx_stream s, float* rows, uint32_t count) {
+  SMX_CHECK_ARG(r != nullptr && rows != nullptr && count <= r->max_surfels);
+  if (count == 0) return SMX_OK;
+  SMX_HIP(hipMemcpy2DAsync(rows, (size_t)count * 4, r->S.base, r->S.pitch * 4, (size_t)count * 4, kRows,
+                           hipMemcpyDeviceToHost, (hipStream_t)s));
+  SMX_HIP(hipStreamSynchronize((hipStream_t)s));
+  return SMX_OK;
+}
+
+int smx_recon_debug_upload_surfels(smx_recon r, smx_stream s, const float* rows, uint32_t count, uint32_t merge_count) {
+  SMX_CHECK_ARG(r != nullptr && count <= r->max_surfels && (rows != nullptr || count == 0));
+  hipStream_t st = (hipStream_t)s;
+  if (count) SMX_HIP(hipMemcpy2DAsync(r->S.base, r->S.pitch * 4, rows, (size_t)count * 4, (size_t)count * 4, kRows,
+                                      hipMemcpyHostToDevice, st));
+  DevState h;
+  memset(&h, 0, sizeof(h));
+  h.surfel_count = count; h.merge_count = merge_count;
+  SMX_HIP(hipMemcpyAsync(r->st, &h, sizeof(h), hipMemcpyHostToDevice, st));
+  SMX_HIP(hipMemsetAsync(r->grad_acc, 0, 4 * r->S.pitch * sizeof(long long), st));
+  SMX_HIP(hipMemsetAsync(r->merge_flag, 0, r->S.pitch, st));
+  SMX_HIP(hipStreamSynchronize(st));
+  return SMX_OK;
+}
+
+int smx_recon_debug_download_scratch(smx_recon r, smx_stream s, int32_t which, void* dst) {
+  SMX_CHECK_ARG(r != nullptr && dst != nullptr);
+  hipStream_t st = (hipStream_t)s;
+  const size_t P = (size_t)r->W * r->H;
+  const void* src = nullptr; size_t bytes = 0;
+  switch (which) {
+    case SMX_SCRATCH_SUPPORTING: src = r->sc.supporting; bytes = P * 4; break;
+    case SMX_SCRATCH_SUPPORT_COUNTS: src = r->sc.counts; bytes = P * 4; break;
+    case SMX_SCRATCH_DEPTH_SUMS: src = r->sc.depth_sums; bytes = P * 8; break;
+    case SMX_SCRATCH_FIRST_DEPTH: src = r->sc.first_depth; bytes = P * 4; break;
+    case SMX_SCRATCH_NEW_FLAGS: src = r->new_flags; bytes = P; break;
+    case SMX_SCRATCH_CONFLICTING:
+      hipLaunchKernelGGL(k_decode_conflicting, dim3(div_up((long long)P, kBlock)), dim3(kBlock), 0, st, r->sc.confl_key, r->tmp_u32, (int)P);
+      src = r->tmp_u32; bytes = P * 4; break;
+    case SMX_SCRATCH_NEW_INDICES:
+      hipLaunchKernelGGL(k_global_ranks, dim3(div_up((long long)P, kBlock)), dim3(kBlock), 0, st, r->new_ranks, r->block_sums, r->tmp_u32, (int)P);
+      src = r->tmp_u32; bytes = P * 4; break;
+    default: set_error("unknown scratch id %d", which); return SMX_ERR_INVALID_ARGUMENT;
+  }
+  SMX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+  SMX_HIP(hipStreamSynchronize(st));
+  return SMX_OK;
+}
+
+}  // extern "C"
