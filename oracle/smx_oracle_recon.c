@@ -632,8 +632,10 @@ static void regularize_once(orc_recon* r, uint32_t frame, float rf, float weight
   const uint32_t N = r->surfel_count;
   if (N == 0) return;
   if (copy_only) {                                                   /* :2310-2327 */
+    r->last_n_recent = 0; r->last_n_edges = 0;
     for (uint32_t i = 0; i < N; ++i) {
       if (stamp_outside_window(r, i, frame, window)) continue;
+      r->last_n_recent++;
       SURF(r, ORC_SMOOTH_X, i) = SURF(r, ORC_X, i);
       SURF(r, ORC_SMOOTH_Y, i) = SURF(r, ORC_Y, i);
       SURF(r, ORC_SMOOTH_Z, i) = SURF(r, ORC_Z, i);

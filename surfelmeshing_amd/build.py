@@ -3,7 +3,7 @@
     python -m surfelmeshing_amd.build [--force]
 
 -ffp-contract=off is part of the arithmetic contract: kernels must
-not fuse a*b+c, so that results are bit-identical to the CPU oracle.
+not fuse a*b+c, so that results are reproducible bit for bit on an IEEE host.
 """
 import os
 import subprocess

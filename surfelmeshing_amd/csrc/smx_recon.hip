@@ -743,6 +743,9 @@ __global__ void __launch_bounds__(kBlock)
 k_neighbor_scan(Surfels S, uint32_t frame, int window, float rf2, float weight,
                 long long* __restrict__ grad_acc, uint32_t* __restrict__ recent_list, DevState* st) {
   const uint32_t N = st->surfel_count;
+  // The reference detaches BEFORE it creates new surfels (kernels.cc:333-339 precedes cc:264-286), so
+  // slots created in this frame keep links to flagged surfels until the next frame.
+  const uint32_t detach_limit = st->create_base;
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
     const bool recent = !stamp_outside_window(S.u(kLastUpdateStamp, i), frame, window);
     const uint32_t slot = wave_append(&st->recent_count, recent);
@@ -757,7 +760,7 @@ k_neighbor_scan(Surfels S, uint32_t frame, int window, float rf2, float weight,
       ni[q] = S.u(kNeighbor0 + q, i);
       in_window[q] = false;
       if (ni[q] == kInvalid) continue;
-      if (kDetach && (S.u(kColor, ni[q]) >> 24) == 1u) {  // :1430-1433
+      if (kDetach && i < detach_limit && (S.u(kColor, ni[q]) >> 24) == 1u) {  // :1430-1433
         ni[q] = kInvalid;
         S.u(kNeighbor0 + q, i) = kInvalid;
         continue;

@@ -26,7 +26,8 @@ def _relief(a, b):
 class SyntheticStream:
     def __init__(self, width=640, height=480, fx=525.0, fy=525.0, cx=320.0, cy=240.0,
                  seed=0x5EED0001, depth_scaling=5000.0, yaw_deg_per_frame=0.5, step_m_per_frame=0.005,
-                 path_radius=1.0, start_yaw_deg=0.0, pitch_deg=0.0, dropout=0.01, noise_sigma=0.001):
+                 path_radius=1.0, start_yaw_deg=0.0, pitch_deg=0.0, dropout=0.01, noise_sigma=0.001,
+                 obstacle_until=-1, obstacle_center=(1.0, 0.1, 1.7), obstacle_radius=0.35):
         self.width, self.height = width, height
         self.fx, self.fy, self.cx, self.cy = float(fx), float(fy), float(cx), float(cy)
         self.seed = int(seed)
@@ -38,6 +39,11 @@ class SyntheticStream:
         self.pitch = np.deg2rad(pitch_deg)
         self.dropout = float(dropout)
         self.noise_sigma = float(noise_sigma)
+        # a sphere that is present for frames < obstacle_until and then vanishes: its surfels end up in
+        # measured free space, which exercises the conflict / replace path of the integration
+        self.obstacle_until = int(obstacle_until)
+        self.obstacle_center = np.asarray(obstacle_center, np.float64)
+        self.obstacle_radius = float(obstacle_radius)
         xs = (np.arange(width, dtype=np.float64) + 0.5 - self.cx) / self.fx
         ys = (np.arange(height, dtype=np.float64) + 0.5 - self.cy) / self.fy
         self._dx, self._dy = np.meshgrid(xs, ys)
@@ -78,6 +84,16 @@ class SyntheticStream:
                         t = (plane - _relief(ha, hb) - 0.03 - sign * o[axis]) / dn
                 t = np.where(valid & (t > 0), t, np.inf)
                 best_t = np.minimum(best_t, t)
+        if f < self.obstacle_until:
+            oc = o - self.obstacle_center
+            a = (d * d).sum(-1)
+            b = 2.0 * (d @ oc)
+            c = oc @ oc - self.obstacle_radius ** 2
+            disc = b * b - 4 * a * c
+            with np.errstate(invalid="ignore"):
+                ts = np.where(disc > 0, (-b - np.sqrt(np.maximum(disc, 0))) / (2 * a), np.inf)
+            ts = np.where(ts > 0, ts, np.inf)
+            best_t = np.minimum(best_t, ts)
         hit = o[None, None, :] + best_t[..., None] * d
         return best_t, hit
 

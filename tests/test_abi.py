@@ -1,0 +1,45 @@
+"""The C-ABI library builds, loads without a GPU and exports every symbol include/smx.h declares."""
+import ctypes
+import os
+import re
+
+from common import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "smx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(smx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    from surfelmeshing_amd import _lib, build
+    build.build(verbose=False)
+    lib = ctypes.CDLL(_lib.SO_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 35
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    # the Python binding lists exactly the header's functions
+    assert sorted(_lib.EXPORTS) == declared
+
+
+def test_integrate_params_layout_matches_oracle_and_header():
+    from surfelmeshing_amd._lib import IntegrateParams, BufferDesc, SurfelBuffersCPU
+    import oracle
+    assert ctypes.sizeof(IntegrateParams) == 40 == ctypes.sizeof(oracle.IntegrateParams)
+    assert [f[0] for f in IntegrateParams._fields_] == [f[0] for f in oracle.IntegrateParams._fields_]
+    assert ctypes.sizeof(BufferDesc) == 24          # CUDABuffer_<T>: T*, int, int, size_t
+    assert ctypes.sizeof(SurfelBuffersCPU) == 16 + 8 * 8
+
+
+def test_no_device_errors_are_loud():
+    """Without a GPU the product path must fail loudly (no CPU fallback)."""
+    from surfelmeshing_amd import _lib, api
+    import pytest
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.SmxError):
+        api.CUDASurfelReconstruction(1000, api.PinholeCamera4f(64, 48, 50.0, 50.0, 32.0, 24.0))
+    with pytest.raises(_lib.SmxError):
+        api.SurfelNeighborIndex()

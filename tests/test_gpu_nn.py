@@ -1,0 +1,64 @@
+"""GPU radius-neighbor search vs the brute-force oracle (the reference's own pinning protocol,
+APP/test/test_octree.cc:369-495: exact equality of indices and float squared distances)."""
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(smx, pts, queries, r2, k, cell, state=None, skip_mask=0):
+    nn = smx.SurfelNeighborIndex()
+    nn.Build(pts[:, 0], pts[:, 1], pts[:, 2], cell)
+    cnt, d2, idx = nn.FindNearestSurfelsWithinRadius(queries, r2, k, state=state, skip_mask=skip_mask)
+    r2a = np.broadcast_to(np.asarray(r2, np.float32), (len(queries),))
+    for q in range(len(queries)):
+        n, od2, oidx = orc.nn_bruteforce(pts[:, 0], pts[:, 1], pts[:, 2], queries[q], float(r2a[q]), k,
+                                         state=state, skip_mask=skip_mask)
+        assert cnt[q] == n, (q, cnt[q], n)
+        assert np.array_equal(idx[q, :n], oidx[:n]), q
+        assert np.array_equal(d2[q, :n].view(np.uint32), od2[:n].view(np.uint32)), q
+    nn.close()
+    return cnt
+
+
+def test_reference_protocol_random_cube(smx):
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        pts = rng.uniform(-10, 10, (100, 3)).astype(np.float32)
+        qs = rng.uniform(-10, 10, (5, 3)).astype(np.float32)
+        _check(smx, pts, qs, 9.0, 10, 3.0)
+
+
+def test_self_queries_k64_on_surface(smx):
+    # the RemeshTrianglesAt pattern (surfel_meshing.cc:819-823): query = a surfel's own position, K = 64
+    rng = np.random.default_rng(1)
+    g = np.stack(np.meshgrid(np.arange(60), np.arange(50)), -1).reshape(-1, 2).astype(np.float32) * 0.01
+    pts = np.concatenate([g + rng.normal(0, 0.002, g.shape).astype(np.float32),
+                          (0.02 * np.sin(5 * g[:, :1])).astype(np.float32)], axis=1).astype(np.float32)
+    sel = rng.choice(len(pts), 300, replace=False)
+    r2 = (rng.uniform(0.015, 0.06, 300) ** 2).astype(np.float32)
+    cnt = _check(smx, pts, pts[sel], r2, 64, 0.03)
+    assert cnt.max() == 64 and cnt.min() >= 1          # some queries truncate at K, every query finds itself
+    state = (rng.random(len(pts)) < 0.4).astype(np.uint8)
+    _check(smx, pts, pts[sel[:100]], r2[:100], 64, 0.03, state=state, skip_mask=1)
+
+
+def test_edge_cases(smx):
+    pts = np.zeros((7, 3), np.float32)                  # all points identical: ties ordered by index
+    q = np.zeros((2, 3), np.float32)
+    q[1] = 5.0
+    cnt = _check(smx, pts, q, 1.0, 4, 0.5)
+    assert list(cnt) == [4, 0]
+    one = np.array([[1.0, 2.0, 3.0]], np.float32)
+    _check(smx, one, one, 0.0, 1, 1.0)                  # radius 0 still returns the point itself (d2 <= r2)
+    rng = np.random.default_rng(2)
+    pts = rng.uniform(-1, 1, (5000, 3)).astype(np.float32)
+    _check(smx, pts, pts[:50], 100.0, 64, 0.05)         # radius covering everything, tiny cells
+    nn = smx.SurfelNeighborIndex()
+    nn.Build(np.zeros(0, np.float32), np.zeros(0, np.float32), np.zeros(0, np.float32), 1.0)
+    cnt, _, _ = nn.FindNearestSurfelsWithinRadius(np.zeros((3, 3), np.float32), 1.0, 8)
+    assert list(cnt) == [0, 0, 0]
+    with pytest.raises(smx.SmxError):
+        nn.FindNearestSurfelsWithinRadius(np.zeros((3, 3), np.float32), 1.0, 65)

@@ -1,0 +1,255 @@
+"""GPU parity tests: the HIP path (through the C-ABI, via surfelmeshing_amd.api) against the CPU oracle on the
+same seeded inputs.  Bar (BASELINE.json): surfel indices / counts bit-exact, per-surfel floats within 1e-4
+relative -- the two sides share one arithmetic contract, so the float rows are in fact required bit-equal."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from common import assert_surfels_match, run_both, small_pre, small_stream
+from oracle_pipeline import OraclePipeline
+
+pytestmark = pytest.mark.gpu
+
+
+def _pipes(smx, s, max_surfels, pre=None, params_kw=None, scan_mode=0):
+    from surfelmeshing_amd.pipeline import FramePipeline
+    from surfelmeshing_amd._lib import IntegrateParams
+    pre = pre or small_pre(s.width)
+    kw = params_kw or {}
+    po = OraclePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, max_surfels, pre, orc.IntegrateParams.defaults(**kw))
+    pg = FramePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, max_surfels, pre, IntegrateParams.defaults(**kw))
+    pg.reconstruction.set_scan_mode(scan_mode)
+    return po, pg
+
+
+def _compare_state(po, pg, check_scratch=True):
+    n = po.recon.surfels_size
+    assert pg.reconstruction.surfels_size() == n
+    assert pg.reconstruction.surfel_count() == po.recon.surfel_count
+    assert_surfels_match(pg.reconstruction.debug_download_surfels(n), po.recon.surfels(), n)
+    if check_scratch:
+        for name, ref in po.recon.scratch().items():
+            got = pg.reconstruction.debug_download_scratch(name)
+            assert np.array_equal(got, ref), name
+        assert np.array_equal(pg.depth_final.Download(), po.depth_final), "blended depth"
+    so, sg = po.recon.stats(), pg.reconstruction.stats()
+    for k, v in so.items():
+        assert sg[k] == v, (k, v, sg[k])
+
+
+# ---- preprocessing stages -------------------------------------------------------------------
+@pytest.mark.parametrize("w,h", [(160, 120), (200, 77), (640, 480)])
+def test_depth_stages_bit_exact(smx, w, h):
+    s = small_stream(w, h)
+    pre = small_pre(w)
+    raw = {f: s.frame(f)[0] for f in range(0, 9)}
+    f = 4
+    stream = None
+    bufs = {g: smx.CUDABuffer(h, w, np.uint16) for g in raw}
+    for g, b in bufs.items():
+        b.UploadAsync(stream, raw[g])
+    A, B = smx.CUDABuffer(h, w, np.uint16), smx.CUDABuffer(h, w, np.uint16)
+    N, R = smx.CUDABuffer(h, w, np.float32, 2), smx.CUDABuffer(h, w, np.float32)
+    R.Clear(0.0)
+    smx.BilateralFilteringAndDepthCutoffCUDA(stream, 3.0, 0.05, 0, 2.0, pre.max_depth_u16(), pre.depth_valid_region_radius, bufs[f], A)
+    o = orc.bilateral_filter_and_cutoff(raw[f], max_depth=pre.max_depth_u16(), depth_valid_region_radius=pre.depth_valid_region_radius)
+    assert np.array_equal(A.Download(), o)
+    for count in (2, 4, 6, 8):
+        for req in (-1, count - 1):
+            others = s.outlier_frames(f, count)
+            T = s.others_TR_reference(f, count)
+            smx.OutlierDepthMapFusionCUDA(stream, 0.02, A, s.fx, s.fy, s.cx, s.cy, [bufs[g] for g in others], T, B, required_count=req)
+            oo = orc.outlier_depth_map_fusion(o, [raw[g] for g in others], T, s.fx, s.fy, s.cx, s.cy, 0.02, req)
+            assert np.array_equal(B.Download(), oo), (count, req)
+    for radius in (0, 1, 2, 3):
+        if radius == 0:
+            smx.CopyWithoutBorderCUDA(stream, B, A)
+        else:
+            smx.ErodeDepthMapCUDA(stream, radius, B, A)
+        oe = orc.erode_depth_map(oo, radius)
+        assert np.array_equal(A.Download(), oe), radius
+    smx.ErodeDepthMapCUDA(stream, 2, B, A)
+    oe = orc.erode_depth_map(oo, 2)
+    smx.ComputeNormalsAndDropBadPixelsCUDA(stream, 85.0, 5000.0, s.fx, s.fy, s.cx, s.cy, A, B, N)
+    on_d, on = orc.compute_normals_and_drop_bad_pixels(oe, s.fx, s.fy, s.cx, s.cy)
+    assert np.array_equal(B.Download(), on_d)
+    assert np.array_equal(N.Download().view(np.uint32), on.view(np.uint32))
+    smx.ComputePointRadiiAndRemoveIsolatedPixelsCUDA(stream, 1.5, float("inf"), 5000.0, s.fx, s.fy, s.cx, s.cy, B, R, A)
+    or_d, orad = orc.compute_point_radii_and_remove_isolated_pixels(on_d, s.fx, s.fy, s.cx, s.cy)
+    assert np.array_equal(A.Download(), or_d)
+    m = on_d > 0                                      # radius is written wherever the input depth is valid
+    assert np.array_equal(R.Download()[m].view(np.uint32), orad[m].view(np.uint32))
+    assert (or_d > 0).sum() > 0.2 * w * h
+
+
+def test_depth_stage_edge_cases(smx):
+    h, w = 37, 131                                    # ragged: not a multiple of the 64x16 tile
+    z = np.zeros((h, w), np.uint16)
+    A, B = smx.CUDABuffer(h, w, np.uint16), smx.CUDABuffer(h, w, np.uint16)
+    N, R = smx.CUDABuffer(h, w, np.float32, 2), smx.CUDABuffer(h, w, np.float32)
+    R.Clear(0.0)
+    for img in (z, np.full((h, w), 65535, np.uint16), np.full((h, w), 1, np.uint16)):
+        A.Upload(img)
+        smx.BilateralFilteringAndDepthCutoffCUDA(None, 3.0, 0.05, 0, 2.0, 65535, 1000.0, A, B)
+        assert np.array_equal(B.Download(), orc.bilateral_filter_and_cutoff(img, max_depth=65535, depth_valid_region_radius=1000.0))
+        smx.ComputeNormalsAndDropBadPixelsCUDA(None, 85.0, 5000.0, 100.0, 100.0, 65.5, 18.5, A, B, N)
+        od, on = orc.compute_normals_and_drop_bad_pixels(img, 100.0, 100.0, 65.5, 18.5)
+        assert np.array_equal(B.Download(), od)
+        assert np.array_equal(N.Download().view(np.uint32), on.view(np.uint32))
+        smx.ComputePointRadiiAndRemoveIsolatedPixelsCUDA(None, 1.5, float("inf"), 5000.0, 100.0, 100.0, 65.5, 18.5, A, R, B)
+        od, _ = orc.compute_point_radii_and_remove_isolated_pixels(img, 100.0, 100.0, 65.5, 18.5)
+        assert np.array_equal(B.Download(), od)
+    rng = np.random.default_rng(3)
+    img = np.where(rng.random((h, w)) < 0.3, 0, rng.integers(400, 30000, (h, w))).astype(np.uint16)
+    A.Upload(img)
+    smx.BilateralFilteringAndDepthCutoffCUDA(None, 2.0, 0.1, 0, 3.0, 20000, 50.0, A, B)
+    assert np.array_equal(B.Download(), orc.bilateral_filter_and_cutoff(img, 2.0, 0.1, 0, 3.0, 20000, 50.0))
+    with pytest.raises(smx.SmxError):
+        smx.ErodeDepthMapCUDA(None, 4, A, B)          # "radius value of 4 is not supported." (cu:572-574)
+    with pytest.raises(smx.SmxError):
+        smx.OutlierDepthMapFusionCUDA(None, 0.02, A, 1, 1, 1, 1, [A] * 3, np.zeros((3, 12), np.float32), B)
+
+
+# ---- CUDABuffer -----------------------------------------------------------------------------
+def test_cuda_buffer_roundtrips(smx):
+    rng = np.random.default_rng(0)
+    for dtype, ch, shape in ((np.uint16, 1, (31, 77)), (np.float32, 2, (9, 130)), (np.uint8, 3, (17, 65)), (np.float32, 1, (25, 1000))):
+        b = smx.CUDABuffer(shape[0], shape[1], dtype, ch)
+        assert b.ToCUDA().pitch % 256 == 0 and b.ToCUDA().pitch >= shape[1] * np.dtype(dtype).itemsize * ch
+        hs = shape + ((ch,) if ch > 1 else ())
+        a = (rng.random(hs) * 200).astype(dtype)
+        b.Upload(a)
+        assert np.array_equal(b.Download(), a)
+        b2 = smx.CUDABuffer(shape[0], shape[1], dtype, ch)
+        b2.SetTo(b)
+        assert np.array_equal(b2.Download(), a)
+        val = np.arange(1, ch + 1).astype(dtype)
+        b.Clear(val if ch > 1 else val[0])
+        assert np.all(b.Download().reshape(-1, ch) == val)
+    # byte-range part transfers on a 1-row buffer (UploadPartAsync / DownloadPartAsync)
+    b = smx.CUDABuffer(1, 1000, np.uint32)
+    b.Clear(0)
+    part = np.arange(10, dtype=np.uint32)
+    b.UploadPartAsync(40, 40, None, part)
+    out = np.zeros(10, np.uint32)
+    b.DownloadPartAsync(40, 40, None, out)
+    smx.StreamSynchronize(None)
+    assert np.array_equal(out, part) and b.Download()[0, 10:20].tolist() == part.tolist() and b.Download()[0, 9] == 0
+
+
+# ---- full pipeline --------------------------------------------------------------------------
+@pytest.mark.parametrize("scan_mode", [0, 1])
+def test_stream_parity_every_frame(smx, scan_mode):
+    s = small_stream(obstacle_until=10)               # vanishing obstacle -> conflicts and replacements
+    po, pg = _pipes(smx, s, 60000, scan_mode=scan_mode)
+    seen = {"replaced": 0, "merged": 0, "conflict": 0}
+
+    def check(f):
+        _compare_state(po, pg)
+        st = po.recon.stats()
+        seen["replaced"] += st["n_replaced"]
+        seen["merged"] += st["n_merged"]
+        seen["conflict"] += st["n_conflict_hits"]
+
+    run_both(po, pg, s, list(range(4, 26)), check)
+    assert seen["replaced"] > 50 and seen["merged"] > 10 and seen["conflict"] > 100, seen
+    assert po.recon.surfels_size > 10000
+
+
+@pytest.mark.parametrize("kw", [
+    dict(do_blending=0),
+    dict(regularization_iterations_per_integration_iteration=0),
+    dict(regularization_iterations_per_integration_iteration=3),
+    dict(surfel_integration_active_window_size=4, regularization_frame_window_size=3),
+    dict(measurement_blending_radius=4, sensor_noise_factor=0.02, max_surfel_confidence=2.5,
+         normal_compatibility_threshold_deg=20.0, radius_factor_for_regularization_neighbors=1.2, regularizer_weight=3.0),
+])
+def test_stream_parity_parameter_variants(smx, kw):
+    s = small_stream(obstacle_until=8)
+    po, pg = _pipes(smx, s, 60000, params_kw=kw)
+    run_both(po, pg, s, list(range(4, 20)), lambda f: _compare_state(po, pg))
+
+
+def test_full_resolution_parity(smx):
+    s = small_stream(640, 480)
+    po, pg = _pipes(smx, s, 1200000)
+    run_both(po, pg, s, list(range(4, 9)), None)
+    _compare_state(po, pg)
+    assert po.recon.surfels_size > 150000
+
+
+def test_regularize_transfer_export(smx):
+    s = small_stream()
+    po, pg = _pipes(smx, s, 60000)
+    run_both(po, pg, s, list(range(4, 12)), None)
+    # extra regulariser iteration, cc:322-337
+    po.recon.regularize(11, 10.0, 2.0, 30)
+    pg.reconstruction.Regularize(None, 11, 10.0, 2.0, 30)
+    _compare_state(po, pg, check_scratch=False)
+    # TransferAllToCPU through the CUDASurfelsCPU double buffer (protocol of test_triangulation.cc:71-99)
+    cpu = smx.CUDASurfelsCPU(60000)
+    with pytest.raises(smx.SmxError):
+        cpu.WaitForLockAndSwapBuffers()               # nothing written yet -> LOG(FATAL) in the reference
+    cpu.LockWriteBuffers()
+    pg.reconstruction.TransferAllToCPU(None, 11, cpu)
+    smx.StreamSynchronize(None)
+    cpu.UnlockWriteBuffers()
+    cpu.WaitForLockAndSwapBuffers()
+    rb = cpu.read_buffers()
+    t = po.recon.transfer_all()
+    n = t["surfel_count"]
+    assert rb.surfel_count == n and rb.frame_index == 11
+    for a, b in (("surfel_x_buffer", "x"), ("surfel_y_buffer", "y"), ("surfel_z_buffer", "z"),
+                 ("surfel_radius_squared_buffer", "radius_squared"), ("surfel_normal_x_buffer", "normal_x"),
+                 ("surfel_normal_y_buffer", "normal_y"), ("surfel_normal_z_buffer", "normal_z"),
+                 ("surfel_last_update_stamp_buffer", "last_update_stamp")):
+        assert np.array_equal(getattr(rb, a)[:n].view(np.uint32), t[b].view(np.uint32)), a
+    # ExportVertices
+    pos, col = smx.CUDABuffer(1, 3 * n, np.float32), smx.CUDABuffer(1, 3 * n, np.uint8)
+    pg.reconstruction.ExportVertices(None, pos, col)
+    opos, ocol = po.recon.export_vertices()
+    assert np.array_equal(pos.Download()[0].view(np.uint32), opos.view(np.uint32))
+    assert np.array_equal(col.Download()[0], ocol)
+    tm = pg.reconstruction.GetTimings()
+    assert len(tm) == 7 and all(x >= 0 for x in tm)
+
+
+def test_capacity_clamp(smx):
+    s = small_stream()
+    cap = 9000                                         # first frame alone wants ~9.4k surfels
+    po, pg = _pipes(smx, s, cap)
+    run_both(po, pg, s, list(range(4, 8)), None)
+    assert po.recon.surfels_size == cap
+    _compare_state(po, pg)
+    assert pg.reconstruction.stats()["capacity_clamped"] in (0, 1)
+
+
+def test_state_injection_roundtrip(smx):
+    s = small_stream()
+    po, pg = _pipes(smx, s, 60000)
+    run_both(po, pg, s, list(range(4, 10)), None)
+    n = po.recon.surfels_size
+    rows = pg.reconstruction.debug_download_surfels(n)
+    from surfelmeshing_amd.pipeline import FramePipeline
+    pg2 = FramePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, 60000, small_pre(s.width))
+    pg2.reconstruction.debug_upload_surfels(rows, po.recon.merge_count)
+    assert pg2.reconstruction.surfels_size() == n and pg2.reconstruction.surfel_count() == po.recon.surfel_count
+    for f in range(6, 15):
+        pg2.upload(f, *s.frame(f))
+        po.upload(f, *s.frame(f))
+    f = 10
+    for p in (po, pg2):
+        p.process(f, s.outlier_frames(f), s.others_TR_reference(f), s.pose(f))
+    _compare_state(po, pg2)
+
+
+def test_invalid_arguments_raise(smx):
+    cam = smx.PinholeCamera4f(64, 48, 50.0, 50.0, 32.0, 24.0)
+    rec = smx.CUDASurfelReconstruction(1000, cam)
+    d = smx.CUDABuffer(48, 64, np.uint16)
+    wrong = smx.CUDABuffer(40, 64, np.uint16)
+    n, r, c = smx.CUDABuffer(48, 64, np.float32, 2), smx.CUDABuffer(48, 64, np.float32), smx.CUDABuffer(48, 64, np.uint8, 3)
+    from surfelmeshing_amd._lib import IntegrateParams
+    with pytest.raises(smx.SmxError):
+        rec.IntegrateP(None, 0, 5000.0, wrong, n, r, c, np.eye(3, 4), IntegrateParams.defaults())
+    assert rec.surfels_size() == 0 and rec.surfel_count() == 0
