@@ -1,0 +1,323 @@
+#!/usr/bin/env python
+"""Benchmark of the surfel-integration hot path (BASELINE.json: RGB-D frames/s integrated @640x480 with
+5 M live surfels; achieved HBM GB/s).
+
+One "step" = one frame of the reference's per-frame call sequence (APP/main.cc:1015-1223): bilateral filter,
+9-frame outlier cull, erosion, normals, radii, CUDASurfelReconstruction::Integrate -- with the raw depth and
+colour frames already resident in HBM.  Workload = config C2 of SURVEY.md 8(d): the synthetic room stream at
+640x480; the map is first grown to >= 5 M surfels by running the real pipeline over a sweeping trajectory
+(untimed), then the timed window re-traverses mapped area (steady state).
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1: launched by torch.distributed.run, one rank per GPU, one independent stream per rank, no data-path
+collective -- weak scaling; value = all frames of all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# Dominant kernel of the frame (profiles/): pass A streams stamp, X, Y, Z of every slot = 16 B per slot.
+DOMINANT_KERNEL = "scan_visible"
+
+
+def DOMINANT_BYTES(st):
+    return 16.0 * st["surfels_size"]
+
+
+def pose64(g, seed_phase=0.0):
+    """Growth / re-traversal trajectory: yaw 2 deg/frame, slow Lissajous pitch, small circle around the room
+    centre.  Returns global_T_frame (R, t) in float64."""
+    yaw = math.radians(2.0 * g) + seed_phase
+    pitch = math.radians(62.0) * math.sin(2.0 * math.pi * g / (180.0 * 2.7))
+    phi = 0.01 * g + seed_phase
+    t = np.array([0.8 * math.cos(phi), 0.25 * math.sin(0.003 * g), 0.8 * math.sin(phi)])
+    cy_, sy_ = math.cos(yaw), math.sin(yaw)
+    Ry = np.array([[cy_, 0, sy_], [0, 1, 0], [-sy_, 0, cy_]])
+    cp, sp = math.cos(pitch), math.sin(pitch)
+    Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+    return Ry @ Rx, t
+
+
+def pose32(g, phase):
+    R, t = pose64(g, phase)
+    return np.concatenate([R, t[:, None]], axis=1).astype(np.float32)
+
+
+def others_tr_reference(g, phase, count, scaling):
+    """(ref_scaled_frame_T_global * global_T_other_scaled)^-1, APP/main.cc:1039-1059."""
+    Rr, tr = pose64(g, phase)
+    half = count // 2
+    frames = [g - (i + 1) for i in range(half)] + [g + (i + 1) for i in range(half)]
+    out = []
+    for o in frames:
+        Ro, to = pose64(o, phase)
+        R = Rr.T @ Ro
+        t = Rr.T @ (to * scaling) - Rr.T @ (tr * scaling)
+        Ri = R.T
+        out.append(np.concatenate([Ri, (-Ri @ t)[:, None]], axis=1))
+    return frames, np.asarray(out, np.float32)
+
+
+class Workload:
+    def __init__(self, api, width, height, target_surfels, cap_surfels, seed, phase):
+        from surfelmeshing_amd.pipeline import FramePipeline, PreprocessParams
+        self.api = api
+        sc = width / 640.0
+        self.w, self.h = width, height
+        self.fx = self.fy = 525.0 * sc
+        self.cx, self.cy = 320.0 * sc, 240.0 * sc
+        self.seed, self.phase = seed, phase
+        self.target = target_surfels
+        self.pre = PreprocessParams(max_depth=10.0, depth_valid_region_radius=333.0 * sc)
+        self.pipe = FramePipeline(width, height, self.fx, self.fy, self.cx, self.cy, cap_surfels, self.pre)
+        self.pipe.reconstruction.set_timing_enabled(0)
+        self.slot = {}  # logical frame -> (depth buffer, colour buffer)
+
+    def render(self, logical, pose_index):
+        """Render logical frame `logical` (noise seed) at trajectory position `pose_index` into new buffers."""
+        api = self.api
+        d = api.CUDABuffer(self.h, self.w, np.uint16)
+        c = api.CUDABuffer(self.h, self.w, np.uint8, 3)
+        api.SynthRenderRoom(None, d, c, self.fx, self.fy, self.cx, self.cy, pose32(pose_index, self.phase),
+                            self.seed, logical)
+        self.pipe.raw_depth[logical] = d
+        self.pipe.color[logical] = c
+
+    def step(self, logical, pose_index):
+        """One frame: preprocessing + Integrate.  Frames logical-4 .. logical+4 must be resident."""
+        frames, T = others_tr_reference(pose_index, self.phase, 8, self.pre.depth_scaling)
+        others = [logical + (f - pose_index) for f in frames]
+        self.pipe.process(logical, others, T, pose32(pose_index, self.phase))
+
+    def prepared_step(self, logical, pose_index):
+        frames, T = others_tr_reference(pose_index, self.phase, 8, self.pre.depth_scaling)
+        return logical, [logical + (f - pose_index) for f in frames], T, pose32(pose_index, self.phase)
+
+    def grow(self, log):
+        """Untimed: run the real pipeline along the trajectory until the map holds >= target surfels."""
+        g = 4
+        for f in range(0, 9):
+            self.render(f, f)
+        n = 0
+        t0 = time.time()
+        while n < self.target and g < 20000:
+            for _ in range(50):
+                self.step(g, g)
+                self.pipe.release(g - 4)
+                self.render(g + 5, g + 5)
+                g += 1
+            n = self.pipe.reconstruction.surfels_size()
+            if log and (g - 4) % 500 == 0:
+                print("# grow: frame %d surfels %d (%.1fs)" % (g, n, time.time() - t0), file=sys.stderr, flush=True)
+        for f in list(self.pipe.raw_depth):
+            self.pipe.release(f)
+        self.api.StreamSynchronize(None)
+        return g, n
+
+
+def algorithmic_bytes(st, P):
+    """SURVEY.md 8(d) byte model of the REFERENCE's per-frame traffic (for comparison only) and this
+    design's own compulsory traffic (DESIGN.md 'Bytes')."""
+    N, E = st["surfels_size"], st["n_edges"]
+    ref = 140 * N + 8 * E + 460 * st["n_visible"] + 360 * st["n_recent"] + 122 * st["n_new"] + 193 * P
+    ours = 32 * N + 8 * E + 460 * st["n_visible"] + 360 * st["n_recent"] + 122 * st["n_new"] + 193 * P
+    return ref, ours
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--surfels", type=int, default=5_000_000, help="live surfels to reach before timing")
+    ap.add_argument("--cap", type=int, default=0, help="max_surfel_count (default: surfels * 1.1)")
+    ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-check", action="store_true", help="skip the full-size GPU-vs-oracle check")
+    ap.add_argument("--quiet", action="store_true")
+    args = ap.parse_args()
+
+    import torch  # first: libsmx then binds to the HIP runtime torch loaded
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from surfelmeshing_amd import _lib, api
+    _lib.require_gpu()
+    _lib.check(_lib.load().smx_set_device(local_rank if world > 1 else 0))
+    log = (rank == 0) and not args.quiet
+
+    cap = args.cap or int(args.surfels * 1.1)
+    wl = Workload(api, args.width, args.height, args.surfels, cap, 0x5EED0001 + rank, 0.37 * rank)
+    t0 = time.time()
+    g_end, n_grown = wl.grow(log)
+    if log:
+        print("# grown to %d surfels in %d frames, %.1fs" % (n_grown, g_end, time.time() - t0), file=sys.stderr)
+
+    # timed window: re-traverse the start of the trajectory (mapped area) with new frame indices
+    K, W = args.steps, args.warmup
+    first = g_end + 10
+    total = W + K
+    for j in range(-4, total + 4):
+        wl.render(first + j, 4 + j)
+    plan = [wl.prepared_step(first + j, 4 + j) for j in range(total)]
+    api.StreamSynchronize(None)
+
+    rec = wl.pipe.reconstruction
+    rec.set_stats_enabled(False)   # the distribution counters are single-address atomics: off while timing
+    for j in range(W):
+        wl.pipe.process(*plan[j])
+    api.StreamSynchronize(None)
+    state0 = rec.debug_download_surfels() if (rank == 0 and args.cpu_frames > 0) else None
+    merge0 = rec.stats()["merge_count"] if state0 is not None else 0
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # HIP events around the dominant kernel only (2 records per frame on the launch stream) stay on during
+    # the timed region; everything else is measured in a separate pass below.
+    rec.profile_begin(DOMINANT_KERNEL, K)
+    sync_all()
+    t_start = time.perf_counter()
+    for j in range(W, W + K):
+        wl.pipe.process(*plan[j])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+    dom_ms, dom_n = rec.profile_end()
+
+    # value distributions of one more frame (counters on)
+    rec.set_stats_enabled(True)
+    for j in range(total, total + 5):
+        wl.render(first + j + 4 - 1, 4 + j + 4 - 1)
+    wl.pipe.process(*wl.prepared_step(first + total, 4 + total))
+    st = rec.stats()
+    rec.set_stats_enabled(False)
+
+    # per-stage and per-kernel device times (separate untimed pass, HIP events on the launch stream)
+    rec.set_timing_enabled(3)
+    reps = 20
+    for j in range(total + 1, total + 1 + reps + 4):
+        if (first + j + 4) not in wl.pipe.raw_depth:
+            wl.render(first + j + 4, 4 + j + 4)
+    stage_ms = np.zeros(7)
+    kernel_ms = np.zeros(len(rec.kernel_time_names()))
+    for j in range(total + 1, total + 1 + reps):
+        wl.pipe.process(*wl.prepared_step(first + j, 4 + j))
+        stage_ms += np.array(rec.GetTimings())
+        kernel_ms += np.array(rec.kernel_times_ms())
+    stage_ms /= reps
+    kernel_ms /= reps
+    rec.set_timing_enabled(0)
+
+    fps = world * K / elapsed
+    ref_bytes, own_bytes = algorithmic_bytes(st, args.width * args.height)
+    result = {
+        "metric": "RGB-D frames/s integrated @640x480, 5M live surfels; achieved HBM GB/s",
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C2: synthetic room stream %dx%d, full preprocessing + Integrate per frame, "
+                               "%d surfel slots (%d live), steady-state re-traversal" %
+                               (args.width, args.height, st["surfels_size"], st["surfels_size"] - st["merge_count"]),
+                   "max_surfel_count": cap, "streams": world, "parallelism": "1 independent stream per GPU"},
+        "distributions": st,
+        "stage_ms": dict(zip(["data_association", "surfel_merging", "measurement_blending", "integration",
+                              "neighbor_update", "new_surfel_creation", "regularization"], [float(x) for x in stage_ms])),
+        "reference_model_bytes_per_frame": ref_bytes,
+        "design_bytes_per_frame": own_bytes,
+        "reference_model_GBs": ref_bytes * (K / elapsed) / 1e9,
+    }
+
+    if rank == 0:
+        result["roofline"] = roofline_block(st, dom_ms, dom_n, dict(zip(rec.kernel_time_names(), [float(x) for x in kernel_ms])))
+        if args.cpu_frames > 0:
+            result["cpu_baseline"] = cpu_baseline(wl, plan, W, args.cpu_frames, state0, merge0, cap, not args.no_check, log)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def roofline_block(st, dom_ms, dom_n, kernel_ms):
+    """Roofline of the dominant kernel: algorithmic bytes per launch (DESIGN.md 'Bytes') / average launch
+    duration measured with HIP events on the launch stream over the timed region."""
+    N = st["surfels_size"]
+    alg = DOMINANT_BYTES(st)
+    achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": DOMINANT_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
+            "avg_launch_ms": dom_ms, "launches_timed": dom_n, "surfel_slots": N,
+            "all_kernels_ms_untimed_pass": kernel_ms}
+
+
+def cpu_baseline(wl, plan, W, frames, state0, merge0, cap, check, log):
+    """The oracle (plain single-threaded C loops) on the first `frames` frames of the timed window, starting
+    from the same surfel state; also used as a full-size parity check of the HIP path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as orc
+    from oracle_pipeline import OraclePipeline
+    api = wl.api
+    po = OraclePipeline(wl.w, wl.h, wl.fx, wl.fy, wl.cx, wl.cy, cap, wl.pre)
+    n0 = state0.shape[1]
+    po.recon.surfels()[:, :n0] = state0
+    po.recon.set_counts(n0, merge0)
+    need = set()
+    for j in range(W, W + frames):
+        need.add(plan[j][0])
+        need.update(plan[j][1])
+    for f in sorted(need):
+        po.upload(f, wl.pipe.raw_depth[f].Download(), wl.pipe.color[f].Download())
+    t0 = time.perf_counter()
+    for j in range(W, W + frames):
+        po.process(*plan[j])
+    dt = time.perf_counter() - t0
+    out = {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d frames of the timed window from the same %d-surfel state (oracle, -O2, 1 thread)" % (frames, n0)}
+    if check:
+        from surfelmeshing_amd.pipeline import FramePipeline
+        pg = FramePipeline(wl.w, wl.h, wl.fx, wl.fy, wl.cx, wl.cy, cap, wl.pre)
+        pg.reconstruction.debug_upload_surfels(state0, merge0)
+        pg.raw_depth, pg.color = wl.pipe.raw_depth, wl.pipe.color
+        for j in range(W, W + frames):
+            pg.process(*plan[j])
+        n = po.recon.surfels_size
+        ok = pg.reconstruction.surfels_size() == n
+        bad_rows = []
+        if ok:
+            G = pg.reconstruction.debug_download_surfels(n)
+            O = po.recon.surfels()[:, :n]
+            for r in range(25):
+                if r in orc.SCRATCH_ROWS:
+                    continue
+                if not np.array_equal(G[r].view(np.uint32), O[r].view(np.uint32)):
+                    bad_rows.append(r)
+        out["parity_check"] = {"frames": frames, "surfels": int(n), "counts_equal": bool(ok),
+                               "rows_not_bit_equal": bad_rows}
+        pg.raw_depth, pg.color = {}, {}
+    return out
+
+
+if __name__ == "__main__":
+    main()

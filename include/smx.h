@@ -173,7 +173,17 @@ int smx_recon_export_vertices(smx_recon r, smx_stream s, const smx_buffer_desc* 
 /* GetTimings, .h:115-122 / .cc:412-429: data association, merging, blending,
  * integration, neighbor update, new surfel creation, regularization (ms). */
 int smx_recon_get_timings(smx_recon r, float out_ms[7]);
+/* enabled: bit 0 = the reference's 14 stage events (default on), bit 1 = events around every kernel */
 int smx_recon_set_timing_enabled(smx_recon r, int32_t enabled);
+/* Per-kernel device times of the last Integrate call (needs timing bit 1); slot names from
+ * smx_recon_kernel_slot_name(0 .. smx_recon_kernel_slot_count()-1). */
+int smx_recon_kernel_slot_count(void);
+const char* smx_recon_kernel_slot_name(int32_t slot);
+int smx_recon_get_kernel_timings(smx_recon r, float* out_ms, int32_t capacity);
+/* HIP-event timing of ONE kernel slot over many Integrate calls (2 event records per frame on the
+ * launch stream): begin, run up to max_frames frames, end -> average launch duration. */
+int smx_recon_profile_begin(smx_recon r, int32_t slot, int32_t max_frames);
+int smx_recon_profile_end(smx_recon r, float* avg_ms, int32_t* frames);
 /* surfel_count() = slots - merged, surfels_size() = slots, .h:125-128.  Synchronises s. */
 int smx_recon_counts(smx_recon r, smx_stream s, uint32_t* surfel_count, uint32_t* surfels_size);
 
@@ -186,6 +196,10 @@ typedef struct {
   uint32_t capacity_clamped;  /* 1 if new-surfel creation hit max_surfel_count */
 } smx_recon_stats;
 int smx_recon_get_stats(smx_recon r, smx_stream s, smx_recon_stats* out);
+/* The n_* counters above are single-address atomics; they are collected only while enabled
+ * (default on; benchmarks switch them off for the timed region).  surfels_size / merge_count are
+ * always exact. */
+int smx_recon_set_stats_enabled(smx_recon r, int32_t enabled);
 
 /* Test / benchmark hooks (not part of the reference interface): raw access to
  * the surfel SoA rows (25 rows as in APP/cuda_surfel_reconstruction_kernels.cuh:49-78,
@@ -224,6 +238,15 @@ int smx_nn_query_batch(smx_nn nn, smx_stream s, uint32_t nq, const float* qx, co
                        uint8_t skip_mask, int32_t queries_on_device,
                        uint32_t* out_idx, float* out_d2, int32_t* out_count,
                        int32_t outputs_on_device);
+
+/* ---- benchmark input generator (not part of the reference's interface) ----
+ * Renders one frame of the synthetic room stream into device buffers:
+ * depth u16 = round(depth_scaling * z) with sigma = noise_sigma * z^2 noise and coherent 8x8
+ * drop-outs, colour uchar3 = hash of the 10 cm world cell.  Pure function of its arguments. */
+int smx_synth_render_room(smx_stream s, const smx_buffer_desc* depth_out, const smx_buffer_desc* color_out,
+                          float fx, float fy, float cx, float cy, const float global_T_frame[12],
+                          uint32_t seed, uint32_t frame_index, float depth_scaling, float noise_sigma,
+                          float dropout);
 
 #ifdef __cplusplus
 }

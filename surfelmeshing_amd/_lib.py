@@ -68,10 +68,13 @@ EXPORTS = [
     "smx_compute_point_radii_and_remove_isolated_pixels",
     "smx_recon_create", "smx_recon_destroy", "smx_recon_integrate", "smx_recon_regularize",
     "smx_recon_transfer_all_to_cpu", "smx_recon_export_vertices", "smx_recon_get_timings",
-    "smx_recon_set_timing_enabled", "smx_recon_counts", "smx_recon_get_stats",
+    "smx_recon_set_timing_enabled", "smx_recon_counts", "smx_recon_get_stats", "smx_recon_set_stats_enabled",
+    "smx_recon_kernel_slot_count", "smx_recon_kernel_slot_name", "smx_recon_get_kernel_timings",
+    "smx_recon_profile_begin", "smx_recon_profile_end",
     "smx_recon_debug_download_surfels", "smx_recon_debug_upload_surfels", "smx_recon_debug_download_scratch",
     "smx_recon_set_scan_mode",
     "smx_nn_create", "smx_nn_destroy", "smx_nn_build", "smx_nn_query_batch",
+    "smx_synth_render_room",
 ]
 
 _lib = None
@@ -90,8 +93,9 @@ def load():
     except OSError as e:  # pragma: no cover
         raise SmxError("cannot load %s: %s" % (SO_PATH, e))
     L.smx_last_error.restype = C.c_char_p
+    L.smx_recon_kernel_slot_name.restype = C.c_char_p
     for name in EXPORTS:
-        if name != "smx_last_error":
+        if name not in ("smx_last_error", "smx_recon_kernel_slot_name"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

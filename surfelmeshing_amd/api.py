@@ -205,6 +205,16 @@ def ComputePointRadiiAndRemoveIsolatedPixelsCUDA(stream, point_radius_extension_
         _d(depth_buffer), _d(radius_buffer), _d(out_depth)))
 
 
+def SynthRenderRoom(stream, depth_out, color_out, fx, fy, cx, cy, global_T_frame, seed, frame_index,
+                    depth_scaling=5000.0, noise_sigma=0.001, dropout=0.01):
+    """Benchmark input generator (smx_synth_render_room): one synthetic room frame into device buffers."""
+    T = np.ascontiguousarray(np.asarray(global_T_frame, np.float32).reshape(12))
+    _lib.check(_lib.load().smx_synth_render_room(
+        _sv(stream), _d(depth_out), _d(color_out), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
+        T.ctypes.data_as(C.c_void_p), C.c_uint32(seed & 0xFFFFFFFF), C.c_uint32(frame_index),
+        C.c_float(depth_scaling), C.c_float(noise_sigma), C.c_float(dropout)))
+
+
 # ---- GPU -> CPU hand-off types (APP/cuda_surfels_cpu.h) ---------------------------------------
 class CUDASurfelBuffersCPU:
     def __init__(self, max_surfel_count):
@@ -358,7 +368,31 @@ class CUDASurfelReconstruction:
         return {n: int(getattr(s, n)) for n, _ in ReconStats._fields_}
 
     def set_timing_enabled(self, enabled):
-        _lib.check(_lib.load().smx_recon_set_timing_enabled(self._h, C.c_int32(1 if enabled else 0)))
+        """False/0 = off, True/1 = the reference's stage events, 3 = stage events + per-kernel events."""
+        _lib.check(_lib.load().smx_recon_set_timing_enabled(self._h, C.c_int32(int(enabled))))
+
+    @staticmethod
+    def kernel_time_names():
+        L = _lib.load()
+        return [L.smx_recon_kernel_slot_name(i).decode() for i in range(L.smx_recon_kernel_slot_count())]
+
+    def kernel_times_ms(self):
+        n = _lib.load().smx_recon_kernel_slot_count()
+        out = (C.c_float * n)()
+        _lib.check(_lib.load().smx_recon_get_kernel_timings(self._h, out, C.c_int32(n)))
+        return list(out)
+
+    def profile_begin(self, kernel_name, max_frames):
+        _lib.check(_lib.load().smx_recon_profile_begin(self._h, C.c_int32(self.kernel_time_names().index(kernel_name)),
+                                                       C.c_int32(max_frames)))
+
+    def profile_end(self):
+        ms, n = C.c_float(), C.c_int32()
+        _lib.check(_lib.load().smx_recon_profile_end(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def set_stats_enabled(self, enabled):
+        _lib.check(_lib.load().smx_recon_set_stats_enabled(self._h, C.c_int32(1 if enabled else 0)))
 
     def set_scan_mode(self, mode):
         _lib.check(_lib.load().smx_recon_set_scan_mode(self._h, C.c_int32(mode)))

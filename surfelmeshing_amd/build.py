@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsmx.so")
-SOURCES = ["smx_buffer.hip", "smx_depth.hip", "smx_recon.hip", "smx_nn.hip"]
+SOURCES = ["smx_buffer.hip", "smx_depth.hip", "smx_recon.hip", "smx_nn.hip", "smx_synth.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
 

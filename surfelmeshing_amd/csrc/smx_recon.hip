@@ -64,9 +64,11 @@ struct FrameCtx {
   float cos_normal_compat;
   float rf2;
   float max_conf;
-  int window;
+  int window;      // surfel_integration_active_window_size
+  int reg_window;  // regularization_frame_window_size (for the flag table)
   uint32_t frame;
   int W, H;
+  int stats;       // collect the value-distribution counters (single-address atomics: off when timing)
 };
 
 struct Scratch {
@@ -118,29 +120,60 @@ __device__ __forceinline__ float meas_normal_z(float nx, float ny) {
   return -sqrtf(t > 0.f ? t : 0.f);
 }
 
-// Wave64 ballot + prefix append: one atomic per wavefront.
-__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
-  const unsigned long long mask = __ballot(pred);
-  if (mask == 0) return 0;
-  const uint32_t lane = __lane_id();
-  const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-  const int leader = __ffsll((long long)mask) - 1;
-  uint32_t base = 0;
-  if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-  base = __shfl(base, leader);
-  return base + prefix;
-}
-
 constexpr int kBlock = 256;
 static_assert(sizeof(uchar3) == 3, "uchar3 must be packed like the reference's Vec3u8");
 
+// Work lists are SEGMENTED: the slots [s*kSeg, (s+1)*kSeg) are scanned by one workgroup, which writes the
+// indices it selects to list[s*kSeg ...] (ascending) and their number to seg[s].  No global counter, no
+// atomics, and the list order is deterministic.
+constexpr int kSeg = 1024;
+struct Lists {
+  uint32_t* vis_list;     // slots that project into the image this frame
+  uint32_t* vis_seg;
+  uint32_t* recent_list;  // slots whose last update stamp lies inside the regulariser window
+  uint32_t* recent_seg;
+  uint8_t* flags8;        // per slot: bit 0 = stamp inside the regulariser window, bit 1 = detach request
+};
+
+__device__ __forceinline__ bool stamp_outside_window(uint32_t stamp, uint32_t frame, int window) {
+  return (int)stamp < (int)(frame - (uint32_t)window);  // kernels.cu:2132
+}
+__device__ __forceinline__ uint8_t make_flags(uint32_t stamp, uint32_t color, uint32_t frame, int reg_window) {
+  return (uint8_t)(((color >> 24) == 1u ? 2u : 0u) | (stamp_outside_window(stamp, frame, reg_window) ? 0u : 1u));
+}
+
+// Exclusive prefix sum of one value per thread over a 256-thread workgroup (wave64 shuffles + LDS).
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t mine, uint32_t* wave_tot /* LDS [4] */, uint32_t& total) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off);
+    if (lane >= (uint32_t)off) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t wave_off = 0;
+  total = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    if ((uint32_t)w < wave) wave_off += wave_tot[w];
+    total += wave_tot[w];
+  }
+  return wave_off + incl - mine;
+}
+
 // ---------------------------------------------------------------------------------------------
-// 5 clears in one launch (cuda_surfel_reconstruction.cc:134-138) + per-frame counter reset.
+// 5 clears (cuda_surfel_reconstruction.cc:134-138) + the 2 clears of BlendMeasurementsCUDA
+// (kernels.cc:165-166) in one launch + per-frame counter reset.
+struct BlendBufs {
+  uint8_t* distance_map; uint8_t* new_distance_map; float* deltas; float* new_deltas;
+};
+
 __global__ void __launch_bounds__(kBlock)
-k_clear_assoc(Scratch sc, int P, DevState* st) {
+k_clear_assoc(Scratch sc, BlendBufs bb, int P, DevState* st) {
   const int k = blockIdx.x * kBlock + threadIdx.x;
   if (k == 0) {
-    st->vis_count = 0;
     st->n_visible = 0; st->n_merged = 0; st->n_integrated = 0; st->n_replaced = 0; st->n_conflict_hits = 0;
   }
   if (k < P) {
@@ -149,54 +182,82 @@ k_clear_assoc(Scratch sc, int P, DevState* st) {
     sc.depth_sums[k] = 0;
     sc.confl_key[k] = kInvalid;
     sc.first_depth[k] = __builtin_inff();
+    bb.distance_map[k] = 0;
+    bb.new_distance_map[k] = 0;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Pass A.  RenderMinDepthCUDAKernel (kernels.cu:1466-1557) fused with the construction of the
-// visible list.  Streams rows 18,0,1,2 with 16-byte lane loads (4 slots per lane).
+// visible list and the refresh of the "recent" bit of the flag table.  One workgroup per segment of
+// kSeg slots; rows 18,0,1,2 are streamed with 16-byte lane loads (4 slots per lane).
 __device__ __forceinline__ void min_depth_at(float* first_depth, int W, int x, int y, float z) {
   atomicMin(reinterpret_cast<int*>(&first_depth[(size_t)y * W + x]), __float_as_int(z));  // :1463
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_scan_visible(Surfels S, FrameCtx c, Scratch sc, uint32_t* __restrict__ vis_list, DevState* st) {
+k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, DevState* st) {
+  __shared__ uint32_t wave_tot[kBlock / 64];
   const uint32_t N = st->surfel_count;
-  const uint32_t stride = gridDim.x * kBlock * 4;
-  for (uint32_t i0 = (blockIdx.x * kBlock + threadIdx.x) * 4; i0 < N; i0 += stride) {
+  const uint32_t base = blockIdx.x * kSeg;
+  if (base >= N) return;  // uniform per workgroup
+  const uint32_t i0 = base + threadIdx.x * 4;
+  uint32_t vis_bits = 0;
+  if (i0 < N) {
     // rows are padded to a multiple of 64 elements, so the 16-byte loads stay inside the row
     const uint4 stamp4 = *reinterpret_cast<const uint4*>(&S.u(kLastUpdateStamp, i0));
     const float4 x4 = *reinterpret_cast<const float4*>(&S.f(kX, i0));
     const float4 y4 = *reinterpret_cast<const float4*>(&S.f(kY, i0));
     const float4 z4 = *reinterpret_cast<const float4*>(&S.f(kZ, i0));
+    const uchar4 of = *reinterpret_cast<const uchar4*>(&L.flags8[i0]);
     const uint32_t stamps[4] = {stamp4.x, stamp4.y, stamp4.z, stamp4.w};
     const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
     const float ys[4] = {y4.x, y4.y, y4.z, y4.w};
     const float zs[4] = {z4.x, z4.y, z4.z, z4.w};
+    const uint8_t old_flags[4] = {of.x, of.y, of.z, of.w};
+    uint8_t new_flags[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint32_t i = i0 + j;
+      new_flags[j] = (uint8_t)((old_flags[j] & 2u) | (stamp_outside_window(stamps[j], c.frame, c.reg_window) ? 0u : 1u));
       Proj p;
       const Vec3 g = {xs[j], ys[j], zs[j]};
-      const bool vis = (i < N) && project_pos(g, c, p);
-      const uint32_t slot = wave_append(&st->vis_count, vis);
-      if (vis) {
-        vis_list[slot] = i;
+      if (i < N && project_pos(g, c, p)) {
+        vis_bits |= 1u << j;
         if (is_active(stamps[j], c.frame, c.window)) {
-          atomicAdd(&st->n_visible, 1u);
+          if (c.stats) atomicAdd(&st->n_visible, 1u);
           min_depth_at(sc.first_depth, c.W, p.px, p.py, p.l.z);
           int ox, oy;
           if (quadrant(p, c, ox, oy)) min_depth_at(sc.first_depth, c.W, ox, oy, p.l.z);
         }
       }
     }
+    *reinterpret_cast<uchar4*>(&L.flags8[i0]) = make_uchar4(new_flags[0], new_flags[1], new_flags[2], new_flags[3]);
   }
+  uint32_t total;
+  uint32_t off = base + block_excl_scan((uint32_t)__popc(vis_bits), wave_tot, total);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (vis_bits & (1u << j)) L.vis_list[off++] = i0 + j;
+  if (threadIdx.x == 0) L.vis_seg[blockIdx.x] = total;
 }
 
-// Index source for the list kernels: the compacted list (default) or every slot (A/B mode).
+// List kernels walk the segmented list in chunks of kBlock entries (one entry per lane), grid-striding
+// over the chunk ids so that the visible slots -- which cluster in a few segments -- still spread over the
+// whole chip.  In the A/B "scan mode" every slot of the chunk is visited instead of the list entries.
+constexpr int kChunksPerSeg = kSeg / kBlock;
 template <bool kUseList>
-__device__ __forceinline__ uint32_t work_count(const DevState* st) {
-  return kUseList ? st->vis_count : st->surfel_count;
+__device__ __forceinline__ bool chunk_entry(const uint32_t* __restrict__ list, const uint32_t* __restrict__ seg,
+                                            uint32_t n_slots, uint32_t chunk, uint32_t& i) {
+  const uint32_t s = chunk / kChunksPerSeg, sub = chunk % kChunksPerSeg;
+  const uint32_t e = sub * kBlock + threadIdx.x;
+  if (kUseList) {
+    if (e >= seg[s]) return false;
+    i = list[s * kSeg + e];
+    return true;
+  }
+  i = s * kSeg + e;
+  return i < n_slots;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -235,10 +296,11 @@ __device__ __forceinline__ void associate_at(const Surfels& S, const FrameCtx& c
 template <bool kUseList>
 __global__ void __launch_bounds__(kBlock)
 k_associate(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<const float2> normals,
-            const uint32_t* __restrict__ vis_list, const DevState* st) {
-  const uint32_t n = work_count<kUseList>(st);
-  for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < n; e += gridDim.x * kBlock) {
-    const uint32_t i = kUseList ? vis_list[e] : e;
+            Lists L, const DevState* st) {
+  const uint32_t n_slots = st->surfel_count, n_chunks = (n_slots + kBlock - 1) / kBlock;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    uint32_t i;
+    if (!chunk_entry<kUseList>(L.vis_list, L.vis_seg, n_slots, chunk, i)) continue;
     if (!is_active(S.u(kLastUpdateStamp, i), c.frame, c.window)) continue;
     Proj p;
     if (!project(S, i, c, p)) continue;
@@ -296,10 +358,11 @@ __device__ __forceinline__ bool merge_decide(const Surfels& S, const FrameCtx& c
 template <bool kUseList>
 __global__ void __launch_bounds__(kBlock)
 k_merge_decide(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<const float2> normals,
-               const uint32_t* __restrict__ vis_list, uint8_t* __restrict__ merge_flag, const DevState* st) {
-  const uint32_t n = work_count<kUseList>(st);
-  for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < n; e += gridDim.x * kBlock) {
-    const uint32_t i = kUseList ? vis_list[e] : e;
+               Lists L, uint8_t* __restrict__ merge_flag, const DevState* st) {
+  const uint32_t n_slots = st->surfel_count, n_chunks = (n_slots + kBlock - 1) / kBlock;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    uint32_t i;
+    if (!chunk_entry<kUseList>(L.vis_list, L.vis_seg, n_slots, chunk, i)) continue;
     const float r2 = S.f(kRadiusSq, i);
     if (!(r2 >= 0)) continue;  // :2017
     Proj p;
@@ -310,16 +373,6 @@ k_merge_decide(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img
 
 // ---------------------------------------------------------------------------------------------
 // BlendMeasurementsCUDA, kernels.cc:148-205 + kernels.cu:563-708.
-struct BlendBufs {
-  uint8_t* distance_map; uint8_t* new_distance_map; float* deltas; float* new_deltas;
-};
-
-__global__ void __launch_bounds__(kBlock)
-k_blend_clear(BlendBufs b, int P) {
-  const int k = blockIdx.x * kBlock + threadIdx.x;
-  if (k < P) { b.distance_map[k] = 0; b.new_distance_map[k] = 0; }
-}
-
 __device__ __forceinline__ float depth_sum_avg(const Scratch& sc, size_t k) {
   return q_to_float(sc.depth_sums[k]) / (float)sc.counts[k];
 }
@@ -429,11 +482,11 @@ __device__ __forceinline__ void integrate_or_conflict(const Surfels& S, const Fr
   const uchar3 col = in.color(y, x);
 
   if (conflicting) {  // :816-868
-    atomicAdd(&st->n_conflict_hits, 1u);
+    if (c.stats) atomicAdd(&st->n_conflict_hits, 1u);
     float confidence = S.f(kConfidence, i);
     confidence -= 1;
     if (confidence <= 0) {
-      atomicAdd(&st->n_replaced, 1u);
+      if (c.stats) atomicAdd(&st->n_replaced, 1u);
       S.f(kX, i) = gp.x; S.f(kY, i) = gp.y; S.f(kZ, i) = gp.z;
       S.f(kSmoothX, i) = gp.x; S.f(kSmoothY, i) = gp.y; S.f(kSmoothZ, i) = gp.z;
       S.f(kNormalX, i) = gn.x; S.f(kNormalY, i) = gn.y; S.f(kNormalZ, i) = gn.z;
@@ -467,7 +520,7 @@ __device__ __forceinline__ void integrate_or_conflict(const Surfels& S, const Fr
   if (cnt < 1) cnt = 1;
   const float weight = 1.0f / (float)cnt;
   if (S.u(kCreationStamp, i) < c.frame) {  // :940
-    atomicAdd(&st->n_integrated, 1u);
+    if (c.stats) atomicAdd(&st->n_integrated, 1u);
     const float confidence = S.f(kConfidence, i);
     S.f(kConfidence, i) = (confidence + weight < c.max_conf) ? (confidence + weight) : c.max_conf;
     const float nf = 1.0f / (confidence + weight);
@@ -489,19 +542,22 @@ __device__ __forceinline__ void integrate_or_conflict(const Surfels& S, const Fr
 
 template <bool kUseList>
 __global__ void __launch_bounds__(kBlock)
-k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, const uint32_t* __restrict__ vis_list,
+k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
             uint8_t* __restrict__ merge_flag, DevState* st) {
-  const uint32_t n = work_count<kUseList>(st);
-  for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < n; e += gridDim.x * kBlock) {
-    const uint32_t i = kUseList ? vis_list[e] : e;
+  const uint32_t n_slots = st->surfel_count, n_chunks = (n_slots + kBlock - 1) / kBlock;
+  uint32_t merged_here = 0;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    uint32_t i;
+    if (!chunk_entry<kUseList>(L.vis_list, L.vis_seg, n_slots, chunk, i)) continue;
     if (merge_flag[i]) {
       // apply the merge marks, kernels.cu:1987-1989 (decided in k_merge_decide)
       merge_flag[i] = 0;
       S.u(kLastUpdateStamp, i) = 0;
       S.f(kRadiusSq, i) = -1;
-      S.u(kColor, i) = (S.u(kColor, i) & 0x00FFFFFFu) | 0x01000000u;
-      atomicAdd(&st->merge_count, 1u);
-      atomicAdd(&st->n_merged, 1u);
+      const uint32_t col = (S.u(kColor, i) & 0x00FFFFFFu) | 0x01000000u;
+      S.u(kColor, i) = col;
+      L.flags8[i] = make_flags(0u, col, c.frame, c.reg_window);
+      ++merged_here;
       continue;  // r^2 < 0: the integrate kernel does nothing for it (:1050-1052)
     }
     if (!is_active(S.u(kLastUpdateStamp, i), c.frame, c.window)) continue;
@@ -512,6 +568,15 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, const uint32_t* __res
     int ox = 0, oy = 0;
     const bool second = quadrant(p, c, ox, oy);
     integrate_or_conflict(S, c, sc, in, second, ox, oy, p.l, i, st);
+    // stamp and detach flag may have changed: refresh the flag table entry
+    L.flags8[i] = make_flags(S.u(kLastUpdateStamp, i), S.u(kColor, i), c.frame, c.reg_window);
+  }
+  // merge counter: one atomic per wavefront that merged something (kernels.cu:2045-2051 block-reduces)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) merged_here += __shfl_xor(merged_here, off);
+  if ((threadIdx.x & 63) == 0 && merged_here) {
+    atomicAdd(&st->merge_count, merged_here);
+    atomicAdd(&st->n_merged, merged_here);
   }
 }
 
@@ -519,12 +584,12 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, const uint32_t* __res
 // UpdateNeighborsCUDAKernel, kernels.cu:1197-1380.
 template <bool kUseList>
 __global__ void __launch_bounds__(kBlock)
-k_update_neighbors(Surfels S, FrameCtx c, Scratch sc, FrameIn in, const uint32_t* __restrict__ vis_list,
-                   const DevState* st) {
+k_update_neighbors(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, const DevState* st) {
   const int kDX[4] = {-1, 1, 0, 0}, kDY[4] = {0, 0, -1, 1};
-  const uint32_t n = work_count<kUseList>(st);
-  for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < n; e += gridDim.x * kBlock) {
-    const uint32_t i = kUseList ? vis_list[e] : e;
+  const uint32_t n_slots = st->surfel_count, n_chunks = (n_slots + kBlock - 1) / kBlock;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    uint32_t i;
+    if (!chunk_entry<kUseList>(L.vis_list, L.vis_seg, n_slots, chunk, i)) continue;
     if (!is_active(S.u(kLastUpdateStamp, i), c.frame, c.window)) continue;
     const Vec3 g = {S.f(kX, i), S.f(kY, i), S.f(kZ, i)};
     const Vec3 cam = mul(c.L, g);
@@ -673,7 +738,8 @@ k_new_finalize(uint32_t* __restrict__ block_sums, int nblocks, uint32_t max_surf
 
 __global__ void __launch_bounds__(kBlock)
 k_new_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, const uint8_t* __restrict__ flags,
-             uint32_t* __restrict__ ranks, const uint32_t* __restrict__ block_offsets, const DevState* st) {
+             uint32_t* __restrict__ ranks, const uint32_t* __restrict__ block_offsets, uint8_t* __restrict__ flags8,
+             const DevState* st) {
   const int kDX[4] = {-1, 1, 0, 0}, kDY[4] = {0, 0, -1, 1};
   const int W = c.W, H = c.H, P = W * H;
   const uint32_t base = st->create_base, created = st->new_count;
@@ -696,6 +762,7 @@ k_new_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, const uint8_t* __res
     S.f(kConfidence, i) = 1;
     S.u(kCreationStamp, i) = c.frame;
     S.u(kLastUpdateStamp, i) = c.frame;
+    flags8[i] = make_flags(c.frame, 0u, c.frame, c.reg_window);
     const float r2 = in.radius(y, x);
     S.f(kRadiusSq, i) = r2;
     Vec3 sum = {0, 0, 0};
@@ -731,85 +798,138 @@ k_new_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, const uint8_t* __res
 // ---------------------------------------------------------------------------------------------
 // Pass B.  UpdateNeighborsCUDARemoveReplacedNeighborsKernel (kernels.cu:1420-1437) +
 // RegularizeSurfelsCUDAAccumulateNeighborGradientsKernel (kernels.cu:2115-2195) in one streaming
-// pass over the 4 neighbour rows, plus construction of the list of recently updated slots that
-// the step/update kernels run over.  The gradient clear (kernels.cu:2099-2113) is gone: the
-// fixed-point accumulators are zero between calls (k_reg_step zeroes what it consumes).
-__device__ __forceinline__ bool stamp_outside_window(uint32_t stamp, uint32_t frame, int window) {
-  return (int)stamp < (int)(frame - (uint32_t)window);  // :2132
-}
-
+// pass over the 4 neighbour rows (16 B/slot, 16-byte lane loads), plus construction of the segmented
+// list of recently updated slots that the step/update kernels run over.  The per-edge gathers of the
+// neighbour's colour word (:1430) and stamp (:2132) are replaced by ONE byte gather from the flag table
+// (L2-resident: 1 B/slot).  The gradient clear (kernels.cu:2099-2113) is gone: the fixed-point
+// accumulators are zero between calls (k_reg_step zeroes what it consumes).
 template <bool kDetach, bool kAccumulate>
 __global__ void __launch_bounds__(kBlock)
-k_neighbor_scan(Surfels S, uint32_t frame, int window, float rf2, float weight,
-                long long* __restrict__ grad_acc, uint32_t* __restrict__ recent_list, DevState* st) {
+k_neighbor_scan(Surfels S, float rf2, float weight, int stats, long long* __restrict__ grad_acc,
+                long long* __restrict__ grad_local, Lists L, DevState* st) {
+  __shared__ uint32_t wave_tot[kBlock / 64];
+  // In-segment contributions (most edges link slots that are close in index) are summed in LDS and stored
+  // once per target without any global atomic; only edges that leave the segment use 64-bit global atomics.
+  __shared__ unsigned long long lacc[kAccumulate ? kSeg * 4 : 4];
   const uint32_t N = st->surfel_count;
+  const uint32_t base = blockIdx.x * kSeg;
+  if (base >= N) return;
+  if (kAccumulate) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lacc[k * kBlock + threadIdx.x] = 0;
+    __syncthreads();
+  }
   // The reference detaches BEFORE it creates new surfels (kernels.cc:333-339 precedes cc:264-286), so
   // slots created in this frame keep links to flagged surfels until the next frame.
   const uint32_t detach_limit = st->create_base;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
-    const bool recent = !stamp_outside_window(S.u(kLastUpdateStamp, i), frame, window);
-    const uint32_t slot = wave_append(&st->recent_count, recent);
-    if (recent) recent_list[slot] = i;
-
-    uint32_t ni[4];
-    bool in_window[4];
-    int neighbor_count = 0;
-    uint32_t valid_edges = 0;
+  const uint32_t i0 = base + threadIdx.x * 4;
+  uint32_t recent_bits = 0;
+  if (i0 < N) {
+    const uchar4 own = *reinterpret_cast<const uchar4*>(&L.flags8[i0]);
+    const uint8_t ownf[4] = {own.x, own.y, own.z, own.w};
+    uint4 nrow[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      ni[q] = S.u(kNeighbor0 + q, i);
-      in_window[q] = false;
-      if (ni[q] == kInvalid) continue;
-      if (kDetach && i < detach_limit && (S.u(kColor, ni[q]) >> 24) == 1u) {  // :1430-1433
-        ni[q] = kInvalid;
-        S.u(kNeighbor0 + q, i) = kInvalid;
-        continue;
+    for (int q = 0; q < 4; ++q) nrow[q] = *reinterpret_cast<const uint4*>(&S.u(kNeighbor0 + q, i0));
+    uint32_t edges = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t i = i0 + j;
+      if (i >= N) continue;
+      if (ownf[j] & 1u) recent_bits |= 1u << j;
+      uint32_t ni[4] = {j == 0 ? nrow[0].x : j == 1 ? nrow[0].y : j == 2 ? nrow[0].z : nrow[0].w,
+                        j == 0 ? nrow[1].x : j == 1 ? nrow[1].y : j == 2 ? nrow[1].z : nrow[1].w,
+                        j == 0 ? nrow[2].x : j == 1 ? nrow[2].y : j == 2 ? nrow[2].z : nrow[2].w,
+                        j == 0 ? nrow[3].x : j == 1 ? nrow[3].y : j == 2 ? nrow[3].z : nrow[3].w};
+      uint32_t in_window = 0;
+      int neighbor_count = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (ni[q] == kInvalid) continue;
+        const uint32_t f = L.flags8[ni[q]];
+        if (kDetach && i < detach_limit && (f & 2u)) {  // :1430-1433
+          ni[q] = kInvalid;
+          S.u(kNeighbor0 + q, i) = kInvalid;
+          continue;
+        }
+        ++edges;
+        if (kAccumulate && (f & 1u)) { in_window |= 1u << q; ++neighbor_count; }
       }
-      ++valid_edges;
-      if (!kAccumulate) continue;
-      if (stamp_outside_window(S.u(kLastUpdateStamp, ni[q]), frame, window)) continue;
-      in_window[q] = true;
-      ++neighbor_count;
-    }
-    if (kAccumulate && valid_edges) atomicAdd(&st->n_edges, valid_edges);
-    if (!kAccumulate || neighbor_count == 0) continue;
-
-    const Vec3 sp = {S.f(kSmoothX, i), S.f(kSmoothY, i), S.f(kSmoothZ, i)};
-    const Vec3 nrm = {S.f(kNormalX, i), S.f(kNormalY, i), S.f(kNormalZ, i)};
-    const float r2 = S.f(kRadiusSq, i);
-    const float factor = 2 * weight / (float)neighbor_count;  // :2153
-    const float wk = weight / (float)neighbor_count;          // :2182
+      if (!kAccumulate || neighbor_count == 0) continue;
+      const Vec3 sp = {S.f(kSmoothX, i), S.f(kSmoothY, i), S.f(kSmoothZ, i)};
+      const Vec3 nrm = {S.f(kNormalX, i), S.f(kNormalY, i), S.f(kNormalZ, i)};
+      const float r2 = S.f(kRadiusSq, i);
+      const float factor = 2 * weight / (float)neighbor_count;  // :2153
+      const float wk = weight / (float)neighbor_count;          // :2182
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (!in_window[q]) continue;
-      const uint32_t nb = ni[q];
-      const Vec3 t = {S.f(kSmoothX, nb) - sp.x, S.f(kSmoothY, nb) - sp.y, S.f(kSmoothZ, nb) - sp.z};
-      const float f = factor * (nrm.x * t.x + nrm.y * t.y + nrm.z * t.z);
-      unsigned long long* a = reinterpret_cast<unsigned long long*>(&grad_acc[4 * (size_t)nb]);
-      atomicAdd(&a[0], (unsigned long long)q_from_float(f * nrm.x));
-      atomicAdd(&a[1], (unsigned long long)q_from_float(f * nrm.y));
-      atomicAdd(&a[2], (unsigned long long)q_from_float(f * nrm.z));
-      atomicAdd(&a[3], (unsigned long long)q_from_float(wk));
-      const float d2 = t.x * t.x + t.y * t.y + t.z * t.z;
-      if (d2 > rf2 * r2) S.u(kNeighbor0 + q, i) = kInvalid;  // :2190-2192
+      for (int q = 0; q < 4; ++q) {
+        if (!(in_window & (1u << q))) continue;
+        const uint32_t nb = ni[q];
+        const Vec3 t = {S.f(kSmoothX, nb) - sp.x, S.f(kSmoothY, nb) - sp.y, S.f(kSmoothZ, nb) - sp.z};
+        const float f = factor * (nrm.x * t.x + nrm.y * t.y + nrm.z * t.z);
+        const uint32_t rel = nb - base;
+        unsigned long long* a = (rel < (uint32_t)kSeg) ? &lacc[4 * rel]
+                                                       : reinterpret_cast<unsigned long long*>(&grad_acc[4 * (size_t)nb]);
+        atomicAdd(&a[0], (unsigned long long)q_from_float(f * nrm.x));
+        atomicAdd(&a[1], (unsigned long long)q_from_float(f * nrm.y));
+        atomicAdd(&a[2], (unsigned long long)q_from_float(f * nrm.z));
+        atomicAdd(&a[3], (unsigned long long)q_from_float(wk));
+        const float d2 = t.x * t.x + t.y * t.y + t.z * t.z;
+        if (d2 > rf2 * r2) S.u(kNeighbor0 + q, i) = kInvalid;  // :2190-2192
+      }
+    }
+    if (stats && kAccumulate && edges) atomicAdd(&st->n_edges, edges);
+  }
+  if (kAccumulate) {
+    __syncthreads();
+    // store the in-segment sums (only this workgroup writes the grad_local entries of its segment)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t rel = threadIdx.x * 4 + j;
+      const unsigned long long v0 = lacc[4 * rel], v1 = lacc[4 * rel + 1], v2 = lacc[4 * rel + 2], v3 = lacc[4 * rel + 3];
+      if (v0 | v1 | v2 | v3)
+        *reinterpret_cast<longlong4*>(&grad_local[4 * (size_t)(base + rel)]) =
+            make_longlong4((long long)v0, (long long)v1, (long long)v2, (long long)v3);
     }
   }
+  uint32_t total;
+  uint32_t off = base + block_excl_scan((uint32_t)__popc(recent_bits), wave_tot, total);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (recent_bits & (1u << j)) L.recent_list[off++] = i0 + j;
+  if (threadIdx.x == 0) {
+    L.recent_seg[blockIdx.x] = total;
+    if (stats && total) atomicAdd(&st->recent_count, total);
+  }
+}
+
+// Rebuilds the flag table for an arbitrary (frame, window): used when Regularize() is called with other
+// parameters than the last Integrate(), and after a state upload.
+__global__ void __launch_bounds__(kBlock)
+k_rebuild_flags(Surfels S, uint32_t frame, int reg_window, uint8_t* __restrict__ flags8, const DevState* st) {
+  const uint32_t N = st->surfel_count;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock)
+    flags8[i] = make_flags(S.u(kLastUpdateStamp, i), S.u(kColor, i), frame, reg_window);
 }
 
 // RegularizeSurfelsCUDAKernel, kernels.cu:2197-2290, over the recent list.
 __global__ void __launch_bounds__(kBlock)
-k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, const uint32_t* __restrict__ recent_list,
+k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long* __restrict__ grad_local, Lists L,
            const DevState* st) {
-  const uint32_t n = st->recent_count;
-  for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < n; e += gridDim.x * kBlock) {
-    const uint32_t i = recent_list[e];
+  const uint32_t n_slots = st->surfel_count, n_chunks = (n_slots + kBlock - 1) / kBlock;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    uint32_t i;
+    if (!chunk_entry<true>(L.recent_list, L.recent_seg, n_slots, chunk, i)) continue;
     const Vec3 mp = {S.f(kX, i), S.f(kY, i), S.f(kZ, i)};
     const Vec3 sp = {S.f(kSmoothX, i), S.f(kSmoothY, i), S.f(kSmoothZ, i)};
     const Vec3 nrm = {S.f(kNormalX, i), S.f(kNormalY, i), S.f(kNormalZ, i)};
+    // exact fixed-point sums: contributions from other segments (global atomics) + from the own segment
+    // (accumulated in LDS by pass B and stored plainly); integer addition, so the split does not matter
     longlong4* ap = reinterpret_cast<longlong4*>(&grad_acc[4 * (size_t)i]);
-    const longlong4 a = *ap;
+    longlong4* lp = reinterpret_cast<longlong4*>(&grad_local[4 * (size_t)i]);
+    const longlong4 a = *ap, l = *lp;
     if (a.x | a.y | a.z | a.w) *ap = make_longlong4(0, 0, 0, 0);  // keep the accumulators zero between calls
-    const float acc[4] = {q_to_float(a.x), q_to_float(a.y), q_to_float(a.z), q_to_float(a.w)};
+    if (l.x | l.y | l.z | l.w) *lp = make_longlong4(0, 0, 0, 0);
+    const float acc[4] = {q_to_float(a.x + l.x), q_to_float(a.y + l.y), q_to_float(a.z + l.z), q_to_float(a.w + l.w)};
     Vec3 grad = {2 * (sp.x - mp.x) + acc[0], 2 * (sp.y - mp.y) + acc[1], 2 * (sp.z - mp.z) + acc[2]};
     int neighbor_count = 0;
     Vec3 rg = {0, 0, 0};
@@ -841,10 +961,11 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, const uint
 // RegularizeSurfelsCUDAUpdateKernel (:2292-2308) / CopyOnlyKernel (:2310-2327), over the recent list.
 template <bool kCopyRaw>
 __global__ void __launch_bounds__(kBlock)
-k_reg_update(Surfels S, const uint32_t* __restrict__ recent_list, const DevState* st) {
-  const uint32_t n = st->recent_count;
-  for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < n; e += gridDim.x * kBlock) {
-    const uint32_t i = recent_list[e];
+k_reg_update(Surfels S, Lists L, const DevState* st) {
+  const uint32_t n_slots = st->surfel_count, n_chunks = (n_slots + kBlock - 1) / kBlock;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    uint32_t i;
+    if (!chunk_entry<true>(L.recent_list, L.recent_seg, n_slots, chunk, i)) continue;
     S.f(kSmoothX, i) = S.f(kCopyRaw ? kX : kGradX, i);
     S.f(kSmoothY, i) = S.f(kCopyRaw ? kY : kGradY, i);
     S.f(kSmoothZ, i) = S.f(kCopyRaw ? kZ : kGradZ, i);
@@ -891,10 +1012,15 @@ struct smx_recon_s {
   int W, H;
   float fx, fy, cx, cy;
   Surfels S;
-  long long* grad_acc;
-  uint32_t* vis_list;
-  uint32_t* recent_list;
+  long long* grad_acc;      // [slots][4] 2^-32 fixed point, cross-segment contributions (atomics)
+  long long* grad_local;    // [slots][4] in-segment contributions (plain stores)
+  Lists L;
+  int nseg;                 // number of kSeg-slot segments (= workgroups of the surfel kernels)
   uint8_t* merge_flag;
+  bool table_valid;         // flag table's "recent" bits correspond to (table_frame, table_window)
+  uint32_t table_frame;
+  int table_window;
+  int stats_enabled;
   Scratch sc;
   BlendBufs bb;
   uint8_t* new_flags;
@@ -907,26 +1033,70 @@ struct smx_recon_s {
   int timing_enabled;
   bool have_timings;
   hipEvent_t ev[14];
-  int grid_surfels;  // persistent grid for the all-slot passes
-  int grid_list;
+  // per-kernel instrumentation (timing_enabled bit 1) and single-kernel profiling over many frames
+  hipEvent_t kev[2 * 16];
+  bool kev_recorded[16];
+  int prof_slot;
+  int prof_cap, prof_n;
+  hipEvent_t* prof_ev;
+  int grid_surfels;  // persistent grid for the grid-stride all-slot kernels
+  int grid_list;     // persistent grid of the chunked list kernels
+};
+
+// kernel slots of one Integrate call (launch order)
+enum : int {
+  kSlotClear = 0, kSlotScanVisible, kSlotAssociate, kSlotMergeDecide, kSlotBlend, kSlotIntegrate,
+  kSlotUpdateNeighbors, kSlotNewFlagsScan, kSlotNewFinalize, kSlotNewCreate, kSlotNeighborScan, kSlotRegStep,
+  kSlotRegUpdate, kSlotCount
+};
+static const char* const kSlotNames[kSlotCount] = {
+  "clear_assoc", "scan_visible", "associate", "merge_decide", "blend", "integrate", "update_neighbors",
+  "new_flags_scan", "new_finalize", "new_create", "neighbor_scan", "reg_step", "reg_update"};
+
+struct SlotTimer {
+  smx_recon r; hipStream_t st; int slot; bool kev, prof;
+  SlotTimer(smx_recon r_, hipStream_t st_, int slot_) : r(r_), st(st_), slot(slot_) {
+    kev = (r->timing_enabled & 2) != 0;
+    prof = (r->prof_slot == slot) && r->prof_ev && r->prof_n < r->prof_cap;
+    if (kev) (void)hipEventRecord(r->kev[2 * slot], st);
+    if (prof) (void)hipEventRecord(r->prof_ev[2 * r->prof_n], st);
+  }
+  ~SlotTimer() {
+    if (kev) { (void)hipEventRecord(r->kev[2 * slot + 1], st); r->kev_recorded[slot] = true; }
+    if (prof) { (void)hipEventRecord(r->prof_ev[2 * r->prof_n + 1], st); r->prof_n++; }
+  }
 };
 
 namespace {
 
 int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, float weight, int window,
                        bool detach, bool copy_only) {
-  hipLaunchKernelGGL(k_reset_recent, dim3(1), dim3(1), 0, st, r->st);
-  const dim3 g(r->grid_surfels), b(kBlock);
+  const dim3 g(r->nseg), gl(r->grid_list), b(kBlock);
   const float rf2 = rf * rf;
+  if (!r->table_valid || r->table_frame != frame || r->table_window != window) {
+    hipLaunchKernelGGL(k_rebuild_flags, dim3(r->grid_surfels), b, 0, st, r->S, frame, window, r->L.flags8, r->st);
+    r->table_valid = true; r->table_frame = frame; r->table_window = window;
+  }
+  const int stats = r->stats_enabled;
+  {
+    SlotTimer t(r, st, kSlotNeighborScan);
+    if (stats) hipLaunchKernelGGL(k_reset_recent, dim3(1), dim3(1), 0, st, r->st);
+    if (copy_only) {
+      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, false>), g, b, 0, st, r->S, rf2, weight, stats, r->grad_acc, r->grad_local, r->L, r->st);
+      else hipLaunchKernelGGL((k_neighbor_scan<false, false>), g, b, 0, st, r->S, rf2, weight, stats, r->grad_acc, r->grad_local, r->L, r->st);
+    } else {
+      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, true>), g, b, 0, st, r->S, rf2, weight, stats, r->grad_acc, r->grad_local, r->L, r->st);
+      else hipLaunchKernelGGL((k_neighbor_scan<false, true>), g, b, 0, st, r->S, rf2, weight, stats, r->grad_acc, r->grad_local, r->L, r->st);
+    }
+  }
   if (copy_only) {
-    if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, false>), g, b, 0, st, r->S, frame, window, rf2, weight, r->grad_acc, r->recent_list, r->st);
-    else hipLaunchKernelGGL((k_neighbor_scan<false, false>), g, b, 0, st, r->S, frame, window, rf2, weight, r->grad_acc, r->recent_list, r->st);
-    hipLaunchKernelGGL((k_reg_update<true>), dim3(r->grid_list), b, 0, st, r->S, r->recent_list, r->st);
+    SlotTimer t(r, st, kSlotRegUpdate);
+    hipLaunchKernelGGL((k_reg_update<true>), gl, b, 0, st, r->S, r->L, r->st);
   } else {
-    if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, true>), g, b, 0, st, r->S, frame, window, rf2, weight, r->grad_acc, r->recent_list, r->st);
-    else hipLaunchKernelGGL((k_neighbor_scan<false, true>), g, b, 0, st, r->S, frame, window, rf2, weight, r->grad_acc, r->recent_list, r->st);
-    hipLaunchKernelGGL(k_reg_step, dim3(r->grid_list), b, 0, st, r->S, weight, r->grad_acc, r->recent_list, r->st);
-    hipLaunchKernelGGL((k_reg_update<false>), dim3(r->grid_list), b, 0, st, r->S, r->recent_list, r->st);
+    { SlotTimer t(r, st, kSlotRegStep);
+      hipLaunchKernelGGL(k_reg_step, gl, b, 0, st, r->S, weight, r->grad_acc, r->grad_local, r->L, r->st); }
+    { SlotTimer t(r, st, kSlotRegUpdate);
+      hipLaunchKernelGGL((k_reg_update<false>), gl, b, 0, st, r->S, r->L, r->st); }
   }
   SMX_LAUNCH_CHECK();
   return SMX_OK;
@@ -964,9 +1134,14 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   // cuda_surfel_reconstruction.cc:59 -- 25 rows x max_surfel_count (zero-filled here so that the
   // padded tail of every row is defined)
   SMX_TRY(dev_alloc(&r->S.base, (size_t)kRows * r->S.pitch, true));
-  SMX_TRY(dev_alloc(&r->grad_acc, 4 * r->S.pitch, true));
-  SMX_TRY(dev_alloc(&r->vis_list, r->S.pitch, false));
-  SMX_TRY(dev_alloc(&r->recent_list, r->S.pitch, false));
+  SMX_TRY(dev_alloc(&r->grad_acc, 4 * ((size_t)r->S.pitch + kSeg), true));
+  SMX_TRY(dev_alloc(&r->grad_local, 4 * ((size_t)r->S.pitch + kSeg), true));
+  r->nseg = div_up((long long)r->S.pitch, kSeg);
+  SMX_TRY(dev_alloc(&r->L.vis_list, (size_t)r->nseg * kSeg, false));
+  SMX_TRY(dev_alloc(&r->L.recent_list, (size_t)r->nseg * kSeg, false));
+  SMX_TRY(dev_alloc(&r->L.vis_seg, (size_t)r->nseg, true));
+  SMX_TRY(dev_alloc(&r->L.recent_seg, (size_t)r->nseg, true));
+  SMX_TRY(dev_alloc(&r->L.flags8, (size_t)r->nseg * kSeg, true));
   SMX_TRY(dev_alloc(&r->merge_flag, r->S.pitch, true));
   SMX_TRY(dev_alloc(&r->sc.supporting, P, false));
   SMX_TRY(dev_alloc(&r->sc.counts, P, false));
@@ -985,6 +1160,8 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->st, 1, true));
 #undef SMX_TRY
   for (int i = 0; i < 14; ++i) SMX_HIP(hipEventCreate(&r->ev[i]));
+  for (int i = 0; i < 2 * 16; ++i) SMX_HIP(hipEventCreate(&r->kev[i]));
+  r->prof_slot = -1;
   r->timing_enabled = 1;
   hipDeviceProp_t prop;
   int dev = 0;
@@ -992,25 +1169,73 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_HIP(hipGetDeviceProperties(&prop, dev));
   const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   r->grid_surfels = cus * 8;  // 8 x 256-thread workgroups per CU: full occupancy, >> 256 workgroups
-  r->grid_list = cus * 4;
+  r->grid_list = cus * 8;
+  r->stats_enabled = 1;
   *out = r;
   return SMX_OK;
 }
 
 int smx_recon_destroy(smx_recon r) {
   if (!r) return SMX_OK;
-  void* ptrs[] = {r->S.base, r->grad_acc, r->vis_list, r->recent_list, r->merge_flag, r->sc.supporting, r->sc.counts,
+  void* ptrs[] = {r->S.base, r->grad_acc, r->grad_local, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.recent_seg, r->L.flags8,
+                  r->merge_flag, r->sc.supporting, r->sc.counts,
                   r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->st};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int i = 0; i < 14; ++i) if (r->ev[i]) (void)hipEventDestroy(r->ev[i]);
+  for (int i = 0; i < 2 * 16; ++i) if (r->kev[i]) (void)hipEventDestroy(r->kev[i]);
+  if (r->prof_ev) { for (int i = 0; i < 2 * r->prof_cap; ++i) (void)hipEventDestroy(r->prof_ev[i]); delete[] r->prof_ev; }
   delete r;
   return SMX_OK;
 }
 
 int smx_recon_set_timing_enabled(smx_recon r, int32_t enabled) {
+  SMX_CHECK_ARG(r != nullptr && enabled >= 0 && enabled <= 3);
+  r->timing_enabled = enabled;
+  return SMX_OK;
+}
+
+int smx_recon_kernel_slot_count(void) { return kSlotCount; }
+const char* smx_recon_kernel_slot_name(int32_t slot) { return (slot >= 0 && slot < kSlotCount) ? kSlotNames[slot] : ""; }
+
+int smx_recon_get_kernel_timings(smx_recon r, float* out_ms, int32_t capacity) {
+  SMX_CHECK_ARG(r != nullptr && out_ms != nullptr && capacity >= kSlotCount);
+  for (int i = 0; i < kSlotCount; ++i) {
+    out_ms[i] = 0;
+    if (!r->kev_recorded[i]) continue;
+    SMX_HIP(hipEventSynchronize(r->kev[2 * i + 1]));
+    SMX_HIP(hipEventElapsedTime(&out_ms[i], r->kev[2 * i], r->kev[2 * i + 1]));
+  }
+  return SMX_OK;
+}
+
+int smx_recon_profile_begin(smx_recon r, int32_t slot, int32_t max_frames) {
+  SMX_CHECK_ARG(r != nullptr && slot >= 0 && slot < kSlotCount && max_frames > 0);
+  if (r->prof_ev) { for (int i = 0; i < 2 * r->prof_cap; ++i) (void)hipEventDestroy(r->prof_ev[i]); delete[] r->prof_ev; }
+  r->prof_ev = new hipEvent_t[2 * max_frames];
+  for (int i = 0; i < 2 * max_frames; ++i) SMX_HIP(hipEventCreate(&r->prof_ev[i]));
+  r->prof_cap = max_frames; r->prof_n = 0; r->prof_slot = slot;
+  return SMX_OK;
+}
+
+int smx_recon_profile_end(smx_recon r, float* avg_ms, int32_t* frames) {
+  SMX_CHECK_ARG(r != nullptr && avg_ms != nullptr && frames != nullptr);
+  double sum = 0;
+  for (int i = 0; i < r->prof_n; ++i) {
+    float ms = 0;
+    SMX_HIP(hipEventSynchronize(r->prof_ev[2 * i + 1]));
+    SMX_HIP(hipEventElapsedTime(&ms, r->prof_ev[2 * i], r->prof_ev[2 * i + 1]));
+    sum += ms;
+  }
+  *frames = r->prof_n;
+  *avg_ms = r->prof_n ? (float)(sum / r->prof_n) : 0.0f;
+  r->prof_slot = -1;
+  return SMX_OK;
+}
+
+int smx_recon_set_stats_enabled(smx_recon r, int32_t enabled) {
   SMX_CHECK_ARG(r != nullptr);
-  r->timing_enabled = enabled ? 1 : 0;
+  r->stats_enabled = enabled ? 1 : 0;
   return SMX_OK;
 }
 
@@ -1040,47 +1265,59 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   c.rf2 = p->radius_factor_for_regularization_neighbors * p->radius_factor_for_regularization_neighbors;
   c.max_conf = p->max_surfel_confidence;
   c.window = p->surfel_integration_active_window_size;
+  c.reg_window = p->regularization_frame_window_size;
   c.frame = frame_index;
   c.W = r->W; c.H = r->H;
+  c.stats = r->stats_enabled;
   const int P = r->W * r->H;
   const dim3 b(kBlock), gpx(div_up(P, kBlock)), gimg(div_up(r->W, 64), div_up(r->H, 4));
-  const dim3 gs(r->grid_surfels), gl(r->scan_mode ? r->grid_surfels : r->grid_list);
-  const bool tm = r->timing_enabled != 0;
+  const dim3 gs(r->nseg), gl(r->grid_list);
+  const bool tm = (r->timing_enabled & 1) != 0;
   FrameIn in;
   in.depth = as_img<const uint16_t>(depth); in.normals = as_img<const float2>(normals);
   in.radius = as_img<const float>(radius); in.color = as_img<const uchar3>(color);
   const Img<uint16_t> depth_rw = as_img<uint16_t>(depth);
 
   if (tm) SMX_HIP(hipEventRecord(r->ev[0], st));
-  hipLaunchKernelGGL(k_clear_assoc, gpx, b, 0, st, r->sc, P, r->st);
-  hipLaunchKernelGGL(k_scan_visible, gs, b, 0, st, r->S, c, r->sc, r->vis_list, r->st);
-  if (r->scan_mode) hipLaunchKernelGGL((k_associate<false>), gl, b, 0, st, r->S, c, r->sc, in.depth, in.normals, r->vis_list, r->st);
-  else hipLaunchKernelGGL((k_associate<true>), gl, b, 0, st, r->S, c, r->sc, in.depth, in.normals, r->vis_list, r->st);
+  { SlotTimer t(r, st, kSlotClear);
+    hipLaunchKernelGGL(k_clear_assoc, gpx, b, 0, st, r->sc, r->bb, P, r->st); }
+  { SlotTimer t(r, st, kSlotScanVisible);
+    hipLaunchKernelGGL(k_scan_visible, gs, b, 0, st, r->S, c, r->sc, r->L, r->st);
+    r->table_valid = true; r->table_frame = frame_index; r->table_window = c.reg_window; }
+  { SlotTimer t(r, st, kSlotAssociate);
+    if (r->scan_mode) hipLaunchKernelGGL((k_associate<false>), gl, b, 0, st, r->S, c, r->sc, in.depth, in.normals, r->L, r->st);
+    else hipLaunchKernelGGL((k_associate<true>), gl, b, 0, st, r->S, c, r->sc, in.depth, in.normals, r->L, r->st); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[1], st)); SMX_HIP(hipEventRecord(r->ev[2], st)); }
-  if (r->scan_mode) hipLaunchKernelGGL((k_merge_decide<false>), gl, b, 0, st, r->S, c, r->sc, in.depth, in.normals, r->vis_list, r->merge_flag, r->st);
-  else hipLaunchKernelGGL((k_merge_decide<true>), gl, b, 0, st, r->S, c, r->sc, in.depth, in.normals, r->vis_list, r->merge_flag, r->st);
+  { SlotTimer t(r, st, kSlotMergeDecide);
+    if (r->scan_mode) hipLaunchKernelGGL((k_merge_decide<false>), gl, b, 0, st, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st);
+    else hipLaunchKernelGGL((k_merge_decide<true>), gl, b, 0, st, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[3], st)); SMX_HIP(hipEventRecord(r->ev[4], st)); }
   if (p->do_blending) {
+    SlotTimer t(r, st, kSlotBlend);
     const float ds = 1.0f / c.inv_depth_scaling;  // kernels.cc:179
-    hipLaunchKernelGGL(k_blend_clear, gpx, b, 0, st, r->bb, P);
     hipLaunchKernelGGL(k_blend_start, gimg, b, 0, st, ds, depth_rw, r->sc, r->bb, r->W, r->H);
     const float term = 1.0f / ((float)p->measurement_blending_radius - 1.0f);  // kernels.cc:196
     for (int it = 2; it < p->measurement_blending_radius; ++it)
       hipLaunchKernelGGL(k_blend_iter, gimg, b, 0, st, it, term, ds, depth_rw, r->sc, r->bb, r->W, r->H);
   }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[5], st)); SMX_HIP(hipEventRecord(r->ev[6], st)); }
-  if (r->scan_mode) hipLaunchKernelGGL((k_integrate<false>), gl, b, 0, st, r->S, c, r->sc, in, r->vis_list, r->merge_flag, r->st);
-  else hipLaunchKernelGGL((k_integrate<true>), gl, b, 0, st, r->S, c, r->sc, in, r->vis_list, r->merge_flag, r->st);
+  { SlotTimer t(r, st, kSlotIntegrate);
+    if (r->scan_mode) hipLaunchKernelGGL((k_integrate<false>), gl, b, 0, st, r->S, c, r->sc, in, r->L, r->merge_flag, r->st);
+    else hipLaunchKernelGGL((k_integrate<true>), gl, b, 0, st, r->S, c, r->sc, in, r->L, r->merge_flag, r->st); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[7], st)); SMX_HIP(hipEventRecord(r->ev[8], st)); }
-  if (r->scan_mode) hipLaunchKernelGGL((k_update_neighbors<false>), gl, b, 0, st, r->S, c, r->sc, in, r->vis_list, r->st);
-  else hipLaunchKernelGGL((k_update_neighbors<true>), gl, b, 0, st, r->S, c, r->sc, in, r->vis_list, r->st);
+  { SlotTimer t(r, st, kSlotUpdateNeighbors);
+    if (r->scan_mode) hipLaunchKernelGGL((k_update_neighbors<false>), gl, b, 0, st, r->S, c, r->sc, in, r->L, r->st);
+    else hipLaunchKernelGGL((k_update_neighbors<true>), gl, b, 0, st, r->S, c, r->sc, in, r->L, r->st); }
   // (the detach half of UpdateNeighborsCUDA runs fused into pass B below)
   if (tm) { SMX_HIP(hipEventRecord(r->ev[9], st)); SMX_HIP(hipEventRecord(r->ev[10], st)); }
-  hipLaunchKernelGGL(k_new_flags_scan, dim3(r->n_scan_blocks), b, 0, st, in.depth, r->sc, r->W, r->H, r->new_flags,
-                     r->new_ranks, r->block_sums);
-  hipLaunchKernelGGL(k_new_finalize, dim3(1), dim3(1024), 0, st, r->block_sums, r->n_scan_blocks, r->max_surfels, r->st);
-  hipLaunchKernelGGL(k_new_create, dim3(div_up(P, kBlock)), b, 0, st, r->S, c, r->sc, in, r->new_flags, r->new_ranks,
-                     r->block_sums, r->st);
+  { SlotTimer t(r, st, kSlotNewFlagsScan);
+    hipLaunchKernelGGL(k_new_flags_scan, dim3(r->n_scan_blocks), b, 0, st, in.depth, r->sc, r->W, r->H, r->new_flags,
+                       r->new_ranks, r->block_sums); }
+  { SlotTimer t(r, st, kSlotNewFinalize);
+    hipLaunchKernelGGL(k_new_finalize, dim3(1), dim3(1024), 0, st, r->block_sums, r->n_scan_blocks, r->max_surfels, r->st); }
+  { SlotTimer t(r, st, kSlotNewCreate);
+    hipLaunchKernelGGL(k_new_create, dim3(div_up(P, kBlock)), b, 0, st, r->S, c, r->sc, in, r->new_flags, r->new_ranks,
+                       r->block_sums, r->L.flags8, r->st); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[11], st)); SMX_HIP(hipEventRecord(r->ev[12], st)); }
   SMX_LAUNCH_CHECK();
   int rc = SMX_OK;
@@ -1186,7 +1423,13 @@ int smx_recon_debug_upload_surfels(smx_recon r, smx_stream s, const float* rows,
   h.surfel_count = count; h.merge_count = merge_count;
   SMX_HIP(hipMemcpyAsync(r->st, &h, sizeof(h), hipMemcpyHostToDevice, st));
   SMX_HIP(hipMemsetAsync(r->grad_acc, 0, 4 * r->S.pitch * sizeof(long long), st));
+  SMX_HIP(hipMemsetAsync(r->grad_local, 0, 4 * r->S.pitch * sizeof(long long), st));
   SMX_HIP(hipMemsetAsync(r->merge_flag, 0, r->S.pitch, st));
+  SMX_HIP(hipMemsetAsync(r->L.vis_seg, 0, (size_t)r->nseg * 4, st));
+  SMX_HIP(hipMemsetAsync(r->L.recent_seg, 0, (size_t)r->nseg * 4, st));
+  // detach bits of the flag table come from the colour words; the recent bits are refreshed per frame
+  hipLaunchKernelGGL(k_rebuild_flags, dim3(r->grid_surfels), dim3(kBlock), 0, st, r->S, 0u, 0x7FFFFFFF, r->L.flags8, r->st);
+  r->table_valid = false;
   SMX_HIP(hipStreamSynchronize(st));
   return SMX_OK;
 }
