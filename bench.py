@@ -68,8 +68,10 @@ def others_tr_reference(g, phase, count, scaling):
 
 
 class Workload:
+    """The synthetic C2 stream driven through the native frame loop (include/smx_driver.h)."""
+
     def __init__(self, api, width, height, target_surfels, cap_surfels, seed, phase):
-        from surfelmeshing_amd.pipeline import FramePipeline, PreprocessParams
+        from surfelmeshing_amd.pipeline import NativeFramePipeline, PreprocessParams
         self.api = api
         sc = width / 640.0
         self.w, self.h = width, height
@@ -78,29 +80,23 @@ class Workload:
         self.seed, self.phase = seed, phase
         self.target = target_surfels
         self.pre = PreprocessParams(max_depth=10.0, depth_valid_region_radius=333.0 * sc)
-        self.pipe = FramePipeline(width, height, self.fx, self.fy, self.cx, self.cy, cap_surfels, self.pre)
+        self.pipe = NativeFramePipeline(width, height, self.fx, self.fy, self.cx, self.cy, cap_surfels, self.pre)
         self.pipe.reconstruction.set_timing_enabled(0)
-        self.slot = {}  # logical frame -> (depth buffer, colour buffer)
 
     def render(self, logical, pose_index):
-        """Render logical frame `logical` (noise seed) at trajectory position `pose_index` into new buffers."""
-        api = self.api
-        d = api.CUDABuffer(self.h, self.w, np.uint16)
-        c = api.CUDABuffer(self.h, self.w, np.uint8, 3)
-        api.SynthRenderRoom(None, d, c, self.fx, self.fy, self.cx, self.cy, pose32(pose_index, self.phase),
-                            self.seed, logical)
-        self.pipe.raw_depth[logical] = d
-        self.pipe.color[logical] = c
+        """Render logical frame `logical` (noise seed) at trajectory position `pose_index` on the GPU."""
+        if logical not in self.pipe.resident:
+            self.pipe.render(logical, pose32(pose_index, self.phase), self.seed)
 
-    def step(self, logical, pose_index):
-        """One frame: preprocessing + Integrate.  Frames logical-4 .. logical+4 must be resident."""
-        frames, T = others_tr_reference(pose_index, self.phase, 8, self.pre.depth_scaling)
-        others = [logical + (f - pose_index) for f in frames]
-        self.pipe.process(logical, others, T, pose32(pose_index, self.phase))
-
-    def prepared_step(self, logical, pose_index):
+    def plan(self, logical, pose_index):
+        """(frame, outlier-cull neighbour frames, their relative poses, camera pose) of one step."""
         frames, T = others_tr_reference(pose_index, self.phase, 8, self.pre.depth_scaling)
         return logical, [logical + (f - pose_index) for f in frames], T, pose32(pose_index, self.phase)
+
+    def steps(self, plans):
+        from surfelmeshing_amd.pipeline import DriverStep
+        arr = (DriverStep * len(plans))(*[self.pipe.make_step(*p) for p in plans])
+        return arr, len(plans)
 
     def grow(self, log):
         """Untimed: run the real pipeline along the trajectory until the map holds >= target surfels."""
@@ -110,15 +106,20 @@ class Workload:
         n = 0
         t0 = time.time()
         while n < self.target and g < 20000:
+            batch = []
             for _ in range(50):
-                self.step(g, g)
-                self.pipe.release(g - 4)
-                self.render(g + 5, g + 5)
+                batch.append(self.plan(g, g))
                 g += 1
+            # frames g-4 .. g+4 of every step of the batch must be resident while it runs
+            for f in range(batch[0][0] - 4, batch[-1][0] + 5):
+                self.render(f, f)
+            self.pipe.run_array(*self.steps(batch))
+            for f in range(batch[0][0] - 4, batch[-1][0] - 3):
+                self.pipe.release(f)
             n = self.pipe.reconstruction.surfels_size()
             if log and (g - 4) % 500 == 0:
                 print("# grow: frame %d surfels %d (%.1fs)" % (g, n, time.time() - t0), file=sys.stderr, flush=True)
-        for f in list(self.pipe.raw_depth):
+        for f in list(self.pipe.resident):
             self.pipe.release(f)
         self.api.StreamSynchronize(None)
         return g, n
@@ -172,18 +173,20 @@ def main():
     K, W = args.steps, args.warmup
     first = g_end + 10
     total = W + K
-    for j in range(-4, total + 4):
+    reps = 20
+    for j in range(-4, total + 1 + reps + 4):
         wl.render(first + j, 4 + j)
-    plan = [wl.prepared_step(first + j, 4 + j) for j in range(total)]
+    plan = [wl.plan(first + j, 4 + j) for j in range(total + 1 + reps)]
+    warm_steps = wl.steps(plan[:W])
+    timed_steps = wl.steps(plan[W:W + K])
     api.StreamSynchronize(None)
 
     rec = wl.pipe.reconstruction
     rec.set_stats_enabled(False)   # the distribution counters are single-address atomics: off while timing
-    for j in range(W):
-        wl.pipe.process(*plan[j])
+    wl.pipe.run_array(*warm_steps)
     api.StreamSynchronize(None)
     state0 = rec.debug_download_surfels() if (rank == 0 and args.cpu_frames > 0) else None
-    merge0 = rec.stats()["merge_count"] if state0 is not None else 0
+    merge0 = (rec.surfels_size() - rec.surfel_count()) if state0 is not None else 0
 
     def sync_all():
         torch.cuda.synchronize()
@@ -194,10 +197,10 @@ def main():
     # HIP events around the dominant kernel only (2 records per frame on the launch stream) stay on during
     # the timed region; everything else is measured in a separate pass below.
     rec.profile_begin(DOMINANT_KERNEL, K)
+    _lib.check(_lib.load().smx_debug_marker(None, 1))   # delimits the timed region in rocprofv3 kernel traces
     sync_all()
     t_start = time.perf_counter()
-    for j in range(W, W + K):
-        wl.pipe.process(*plan[j])
+    wl.pipe.run_array(*timed_steps)          # K frames: preprocessing + Integrate each, enqueued by the C++ loop
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
     if world > 1:
@@ -206,25 +209,20 @@ def main():
         elapsed = float(t.item())
         dist.barrier()
     dom_ms, dom_n = rec.profile_end()
+    _lib.check(_lib.load().smx_debug_marker(None, 2))
 
     # value distributions of one more frame (counters on)
     rec.set_stats_enabled(True)
-    for j in range(total, total + 5):
-        wl.render(first + j + 4 - 1, 4 + j + 4 - 1)
-    wl.pipe.process(*wl.prepared_step(first + total, 4 + total))
+    wl.pipe.run_array(*wl.steps(plan[total:total + 1]))
     st = rec.stats()
     rec.set_stats_enabled(False)
 
     # per-stage and per-kernel device times (separate untimed pass, HIP events on the launch stream)
     rec.set_timing_enabled(3)
-    reps = 20
-    for j in range(total + 1, total + 1 + reps + 4):
-        if (first + j + 4) not in wl.pipe.raw_depth:
-            wl.render(first + j + 4, 4 + j + 4)
     stage_ms = np.zeros(7)
     kernel_ms = np.zeros(len(rec.kernel_time_names()))
     for j in range(total + 1, total + 1 + reps):
-        wl.pipe.process(*wl.prepared_step(first + j, 4 + j))
+        wl.pipe.run_array(*wl.steps(plan[j:j + 1]))
         stage_ms += np.array(rec.GetTimings())
         kernel_ms += np.array(rec.kernel_times_ms())
     stage_ms /= reps
@@ -287,8 +285,9 @@ def cpu_baseline(wl, plan, W, frames, state0, merge0, cap, check, log):
     for j in range(W, W + frames):
         need.add(plan[j][0])
         need.update(plan[j][1])
-    for f in sorted(need):
-        po.upload(f, wl.pipe.raw_depth[f].Download(), wl.pipe.color[f].Download())
+    host_frames = {f: wl.pipe.download_frame(f) for f in sorted(need)}
+    for f, (d, c) in host_frames.items():
+        po.upload(f, d, c)
     t0 = time.perf_counter()
     for j in range(W, W + frames):
         po.process(*plan[j])
@@ -299,7 +298,8 @@ def cpu_baseline(wl, plan, W, frames, state0, merge0, cap, check, log):
         from surfelmeshing_amd.pipeline import FramePipeline
         pg = FramePipeline(wl.w, wl.h, wl.fx, wl.fy, wl.cx, wl.cy, cap, wl.pre)
         pg.reconstruction.debug_upload_surfels(state0, merge0)
-        pg.raw_depth, pg.color = wl.pipe.raw_depth, wl.pipe.color
+        for f, (d, c) in host_frames.items():
+            pg.upload(f, d, c)
         for j in range(W, W + frames):
             pg.process(*plan[j])
         n = po.recon.surfels_size
@@ -315,7 +315,6 @@ def cpu_baseline(wl, plan, W, frames, state0, merge0, cap, check, log):
                     bad_rows.append(r)
         out["parity_check"] = {"frames": frames, "surfels": int(n), "counts_equal": bool(ok),
                                "rows_not_bit_equal": bad_rows}
-        pg.raw_depth, pg.color = {}, {}
     return out
 
 

@@ -67,6 +67,8 @@ int smx_device_name(int device, char* name, size_t capacity);
 int smx_stream_create(smx_stream* out);
 int smx_stream_destroy(smx_stream s);
 int smx_stream_synchronize(smx_stream s);
+/* Launches an empty kernel (k_smx_marker) that delimits regions in kernel traces. */
+int smx_debug_marker(smx_stream s, int32_t id);
 
 /* ---- CUDABuffer<T>  (VIS/cuda/cuda_buffer.h:45-129, cuda_buffer_inl.h:36-172) ---- */
 /* CUDABuffer(int height, int width): cudaMallocPitch */

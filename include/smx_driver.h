@@ -1,0 +1,71 @@
+/*
+ * smx_driver.h -- native per-frame driver: the reference caller's frame loop (APP/main.cc:1015-1223) in C++,
+ * written against the shim classes of smx_shim.hpp (CUDABuffer<T>, CUDASurfelReconstruction, the depth
+ * preprocessing free functions).  It exists so that a stream of frames can be enqueued without a scripting
+ * language between the launches; every frame goes through exactly the C-ABI entry points of smx.h.
+ */
+#ifndef SMX_DRIVER_H_
+#define SMX_DRIVER_H_
+
+#include "smx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smx_driver_s* smx_driver;
+
+/* Defaults: APP/main.cc:279, 415-475 and 323-368. */
+typedef struct {
+  int32_t width, height;
+  float fx, fy, cx, cy;                  /* pixel-corner convention */
+  uint32_t max_surfel_count;
+  float depth_scaling;
+  float max_depth;
+  float depth_valid_region_radius;
+  float observation_angle_threshold_deg;
+  int32_t depth_erosion_radius;
+  int32_t outlier_filtering_required_inliers;   /* -1: all */
+  float bilateral_filter_sigma_xy;
+  float bilateral_filter_radius_factor;
+  float bilateral_filter_sigma_depth_factor;
+  float outlier_filtering_depth_tolerance_factor;
+  float point_radius_extension_factor;
+  float point_radius_clamp_factor;
+  smx_integrate_params integrate;
+} smx_driver_config;
+
+/* One frame of work: which resident frames serve as the outlier-cull neighbours, their relative poses
+ * (APP/main.cc:1039-1059) and the camera pose. */
+typedef struct {
+  uint32_t frame_index;
+  int32_t other_count;                   /* 0, 2, 4, 6 or 8 */
+  uint32_t other_frames[8];
+  float others_TR_reference[8][12];
+  float global_T_frame[12];
+} smx_driver_step;
+
+int smx_driver_create(const smx_driver_config* config, smx_driver* out);
+int smx_driver_destroy(smx_driver d);
+/* The reconstruction object the driver owns (borrowed handle). */
+int smx_driver_recon(smx_driver d, smx_recon* out);
+/* Frame store (raw u16 depth + uchar3 colour, APP/main.cc:905-984): upload from host, or render the synthetic
+ * room (smx_synth_render_room), release when no later frame needs it. */
+int smx_driver_upload_frame(smx_driver d, smx_stream s, uint32_t frame_index, const uint16_t* depth, const uint8_t* color);
+int smx_driver_render_frame(smx_driver d, smx_stream s, uint32_t frame_index, const float global_T_frame[12],
+                            uint32_t seed, float noise_sigma, float dropout);
+int smx_driver_release_frame(smx_driver d, uint32_t frame_index);
+int smx_driver_frame_descs(smx_driver d, uint32_t frame_index, smx_buffer_desc* depth, smx_buffer_desc* color);
+/* Enqueue n frames (preprocessing + Integrate each) on the stream; returns without synchronising. */
+int smx_driver_run(smx_driver d, smx_stream s, const smx_driver_step* steps, int32_t n);
+/* Working buffers after the last frame: final (blended) depth, normals, radius. */
+int smx_driver_work_descs(smx_driver d, smx_buffer_desc* depth, smx_buffer_desc* normals, smx_buffer_desc* radius);
+
+/* Blocking downloads (dense host arrays) of a stored frame / of the working buffers. */
+int smx_driver_download_frame(smx_driver d, smx_stream s, uint32_t frame_index, uint16_t* depth, uint8_t* color);
+int smx_driver_download_work(smx_driver d, smx_stream s, uint16_t* depth, float* normals, float* radius);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,319 @@
+// smx_shim.hpp -- header-only C++ shim that re-creates the reference's class and function names for the
+// surfel-integration path on top of the C-ABI of smx.h, so that reference-style host code (APP/main.cc's
+// frame loop, APP/test/test_triangulation.cc's CUDASurfelsCPU protocol) compiles against libsmx.so after
+// replacing cudaStream_t by hipStream_t (both are opaque pointers; smx_stream is a void*).
+//
+//   vis::CUDABuffer<T>, vis::CUDABuffer_<T>           VIS/cuda/cuda_buffer.h:45-129, cuda_buffer.cuh:44-119
+//   vis::CUDAMatrix3x4                                 VIS/cuda/cuda_matrix.cuh:67-116 (host part)
+//   vis::BilateralFilteringAndDepthCutoffCUDA ...      APP/cuda_depth_processing.cuh:43-122
+//   vis::CUDASurfelReconstruction                      APP/cuda_surfel_reconstruction.h:44-176
+//   vis::CUDASurfelBuffersCPU, vis::CUDASurfelsCPU     APP/cuda_surfels_cpu.h:40-124
+//
+// Error behaviour: the reference aborts through LOG(FATAL) / CUDA_CHECKED_CALL
+// (VIS/cuda/cuda_util.h:35-49); SMX_SHIM_CHECK prints smx_last_error() and aborts likewise.
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <mutex>
+#include <utility>
+
+#include "smx.h"
+
+#define SMX_SHIM_CHECK(call)                                                                     \
+  do {                                                                                           \
+    int smx_rc__ = (call);                                                                       \
+    if (smx_rc__ != 0) {                                                                         \
+      std::fprintf(stderr, "FATAL %s:%d: %s -> %d: %s\n", __FILE__, __LINE__, #call, smx_rc__,  \
+                   smx_last_error());                                                            \
+      std::abort();                                                                              \
+    }                                                                                            \
+  } while (0)
+
+namespace vis {
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef size_t usize;
+typedef smx_stream cudaStream_t;  // a hipStream_t
+
+struct float2_ { float x, y; };
+struct Vec3u8 { u8 v[3]; };
+
+// Row-major 3x4 rigid transform.  The reference builds it from Sophus' SE3f::matrix3x4().
+struct CUDAMatrix3x4 {
+  float m[12];
+  CUDAMatrix3x4() {}
+  explicit CUDAMatrix3x4(const float* row_major_3x4) { for (int i = 0; i < 12; ++i) m[i] = row_major_3x4[i]; }
+};
+typedef CUDAMatrix3x4 SE3f;  // the hot path only ever needs matrix3x4() (and inverse(), done inside libsmx)
+
+// Accessors of VIS/camera.h's PinholeCamera4f that the hot path uses.
+class PinholeCamera4f {
+ public:
+  PinholeCamera4f(int width, int height, const float* fx_fy_cx_cy) : width_(width), height_(height) {
+    for (int i = 0; i < 4; ++i) p_[i] = fx_fy_cx_cy[i];
+  }
+  int width() const { return width_; }
+  int height() const { return height_; }
+  const float* parameters() const { return p_; }  // fx, fy, cx, cy (pixel-corner convention)
+ private:
+  int width_, height_;
+  float p_[4];
+};
+
+// Device-side view, same members/layout as the reference's CUDABuffer_<T>.
+template <typename T>
+struct CUDABuffer_ {
+  T* address_;
+  int height_;
+  int width_;
+  size_t pitch_;
+  T* address() const { return address_; }
+  int width() const { return width_; }
+  int height() const { return height_; }
+  size_t pitch() const { return pitch_; }
+  const smx_buffer_desc* desc() const { return reinterpret_cast<const smx_buffer_desc*>(this); }
+};
+static_assert(sizeof(CUDABuffer_<float>) == sizeof(smx_buffer_desc), "CUDABuffer_ must alias smx_buffer_desc");
+
+template <typename T>
+class CUDABuffer {
+ public:
+  typedef T Type;
+  CUDABuffer(int height, int width) {
+    SMX_SHIM_CHECK(smx_buffer_create(height, width, (int32_t)sizeof(T), &handle_));
+    smx_buffer_desc d;
+    SMX_SHIM_CHECK(smx_buffer_get_desc(handle_, &d));
+    data_.address_ = static_cast<T*>(d.address); data_.height_ = d.height; data_.width_ = d.width; data_.pitch_ = d.pitch;
+  }
+  CUDABuffer(const CUDABuffer<T>&) = delete;
+  ~CUDABuffer() { SMX_SHIM_CHECK(smx_buffer_destroy(handle_)); }
+
+  void UploadAsync(cudaStream_t stream, const T* data) { SMX_SHIM_CHECK(smx_buffer_upload(handle_, stream, data, 0)); }
+  void UploadPitchedAsync(cudaStream_t stream, size_t pitch, const T* data) { SMX_SHIM_CHECK(smx_buffer_upload(handle_, stream, data, pitch)); }
+  void UploadPartAsync(size_t start, size_t length, cudaStream_t stream, const T* data) { SMX_SHIM_CHECK(smx_buffer_upload_part(handle_, stream, start, length, data)); }
+  void DownloadAsync(cudaStream_t stream, T* data) const { SMX_SHIM_CHECK(smx_buffer_download(handle_, stream, data, 0)); }
+  void DownloadPitchedAsync(cudaStream_t stream, size_t pitch, T* data) { SMX_SHIM_CHECK(smx_buffer_download(handle_, stream, data, pitch)); }
+  void DownloadPartAsync(size_t start, size_t length, cudaStream_t stream, T* data) const { SMX_SHIM_CHECK(smx_buffer_download_part(handle_, stream, start, length, data)); }
+  void DebugUpload(const T* data) { UploadAsync(nullptr, data); SMX_SHIM_CHECK(smx_stream_synchronize(nullptr)); }
+  void DebugDownload(T* data) const { DownloadAsync(nullptr, data); SMX_SHIM_CHECK(smx_stream_synchronize(nullptr)); }
+  void Clear(T value, cudaStream_t stream) { SMX_SHIM_CHECK(smx_buffer_clear(handle_, stream, &value)); }
+  void SetTo(const CUDABuffer<T>& other, cudaStream_t stream) { SMX_SHIM_CHECK(smx_buffer_set_to(handle_, other.handle_, stream)); }
+
+  int width() const { return data_.width_; }
+  int height() const { return data_.height_; }
+  int Size() const { return (int)(data_.pitch_ * data_.height_); }
+  const CUDABuffer_<T>& ToCUDA() const { return data_; }
+  CUDABuffer_<T>& ToCUDA() { return data_; }
+
+ private:
+  smx_buffer handle_ = nullptr;
+  CUDABuffer_<T> data_;
+};
+template <typename T> using CUDABufferPtr = std::shared_ptr<CUDABuffer<T>>;
+
+// ---- APP/cuda_depth_processing.cuh ------------------------------------------------------------------
+inline void BilateralFilteringAndDepthCutoffCUDA(cudaStream_t stream, float sigma_xy, float sigma_value_factor,
+                                                 u16 value_to_ignore, float radius_factor, u16 max_depth,
+                                                 float depth_valid_region_radius, const CUDABuffer_<u16>& input_depth,
+                                                 CUDABuffer_<u16>* output_depth) {
+  SMX_SHIM_CHECK(smx_bilateral_filtering_and_depth_cutoff(stream, sigma_xy, sigma_value_factor, value_to_ignore,
+                                                          radius_factor, max_depth, depth_valid_region_radius,
+                                                          input_depth.desc(), output_depth->desc()));
+}
+
+// all-must-agree overload (cuda_depth_processing.cu:229-285)
+template <int count, typename DepthT>
+void OutlierDepthMapFusionCUDA(cudaStream_t stream, float tolerance, const CUDABuffer_<DepthT>& input_depth,
+                               float depth_fx, float depth_fy, float depth_cx, float depth_cy,
+                               const CUDABuffer_<DepthT>** other_depths, const CUDAMatrix3x4* others_TR_reference,
+                               CUDABuffer_<u16>* output_depth) {
+  static_assert(sizeof(DepthT) == 2, "u16 depth only, as instantiated by the reference");
+  smx_buffer_desc others[count - 1];
+  float T[(count - 1) * 12];
+  for (int i = 0; i < count - 1; ++i) {
+    others[i] = *other_depths[i]->desc();
+    for (int k = 0; k < 12; ++k) T[12 * i + k] = others_TR_reference[i].m[k];
+  }
+  SMX_SHIM_CHECK(smx_outlier_depth_map_fusion(stream, count - 1, -1, tolerance, input_depth.desc(), depth_fx, depth_fy,
+                                              depth_cx, depth_cy, others, T, output_depth->desc()));
+}
+// counting overload (cu:399-455)
+template <int count, typename DepthT>
+void OutlierDepthMapFusionCUDA(cudaStream_t stream, int required_count, float tolerance,
+                               const CUDABuffer_<DepthT>& input_depth, float depth_fx, float depth_fy, float depth_cx,
+                               float depth_cy, const CUDABuffer_<DepthT>** other_depths,
+                               const CUDAMatrix3x4* others_TR_reference, CUDABuffer_<u16>* output_depth) {
+  smx_buffer_desc others[count - 1];
+  float T[(count - 1) * 12];
+  for (int i = 0; i < count - 1; ++i) {
+    others[i] = *other_depths[i]->desc();
+    for (int k = 0; k < 12; ++k) T[12 * i + k] = others_TR_reference[i].m[k];
+  }
+  SMX_SHIM_CHECK(smx_outlier_depth_map_fusion(stream, count - 1, required_count, tolerance, input_depth.desc(), depth_fx,
+                                              depth_fy, depth_cx, depth_cy, others, T, output_depth->desc()));
+}
+
+template <typename DepthT>
+void ErodeDepthMapCUDA(cudaStream_t stream, int radius, const CUDABuffer_<DepthT>& input_depth,
+                       CUDABuffer_<DepthT>* output_depth) {
+  SMX_SHIM_CHECK(smx_erode_depth_map(stream, radius, input_depth.desc(), output_depth->desc()));
+}
+template <typename DepthT>
+void CopyWithoutBorderCUDA(cudaStream_t stream, const CUDABuffer_<DepthT>& input_depth, CUDABuffer_<DepthT>* output_depth) {
+  SMX_SHIM_CHECK(smx_copy_without_border(stream, input_depth.desc(), output_depth->desc()));
+}
+inline void ComputeNormalsAndDropBadPixelsCUDA(cudaStream_t stream, float observation_angle_threshold_deg,
+                                               float depth_scaling, float depth_fx, float depth_fy, float depth_cx,
+                                               float depth_cy, const CUDABuffer_<u16>& in_depth,
+                                               CUDABuffer_<u16>* out_depth, CUDABuffer_<float2_>* out_normals) {
+  SMX_SHIM_CHECK(smx_compute_normals_and_drop_bad_pixels(stream, observation_angle_threshold_deg, depth_scaling, depth_fx,
+                                                         depth_fy, depth_cx, depth_cy, in_depth.desc(), out_depth->desc(),
+                                                         out_normals->desc()));
+}
+inline void ComputePointRadiiAndRemoveIsolatedPixelsCUDA(cudaStream_t stream, float point_radius_extension_factor,
+                                                         float point_radius_clamp_factor, float depth_scaling,
+                                                         float depth_fx, float depth_fy, float depth_cx, float depth_cy,
+                                                         const CUDABuffer_<u16>& depth_buffer,
+                                                         CUDABuffer_<float>* radius_buffer, CUDABuffer_<u16>* out_depth) {
+  SMX_SHIM_CHECK(smx_compute_point_radii_and_remove_isolated_pixels(
+      stream, point_radius_extension_factor, point_radius_clamp_factor, depth_scaling, depth_fx, depth_fy, depth_cx,
+      depth_cy, depth_buffer.desc(), radius_buffer->desc(), out_depth->desc()));
+}
+
+// ---- APP/cuda_surfels_cpu.h ---------------------------------------------------------------------------
+struct CUDASurfelBuffersCPU {
+  explicit CUDASurfelBuffersCPU(usize max_surfel_count) {
+    surfel_x_buffer = new float[max_surfel_count];
+    surfel_y_buffer = new float[max_surfel_count];
+    surfel_z_buffer = new float[max_surfel_count];
+    surfel_radius_squared_buffer = new float[max_surfel_count];
+    surfel_normal_x_buffer = new float[max_surfel_count];
+    surfel_normal_y_buffer = new float[max_surfel_count];
+    surfel_normal_z_buffer = new float[max_surfel_count];
+    surfel_last_update_stamp_buffer = new u32[max_surfel_count];
+  }
+  ~CUDASurfelBuffersCPU() {
+    delete[] surfel_x_buffer; delete[] surfel_y_buffer; delete[] surfel_z_buffer;
+    delete[] surfel_radius_squared_buffer; delete[] surfel_normal_x_buffer; delete[] surfel_normal_y_buffer;
+    delete[] surfel_normal_z_buffer; delete[] surfel_last_update_stamp_buffer;
+  }
+  u32 frame_index = 0;
+  usize surfel_count = 0;
+  float* surfel_x_buffer;
+  float* surfel_y_buffer;
+  float* surfel_z_buffer;
+  float* surfel_radius_squared_buffer;
+  float* surfel_normal_x_buffer;
+  float* surfel_normal_y_buffer;
+  float* surfel_normal_z_buffer;
+  u32* surfel_last_update_stamp_buffer;
+};
+
+class CUDASurfelsCPU {
+ public:
+  explicit CUDASurfelsCPU(usize max_surfel_count)
+      : write_buffers_(new CUDASurfelBuffersCPU(max_surfel_count)),
+        read_buffers_(new CUDASurfelBuffersCPU(max_surfel_count)) {}
+  ~CUDASurfelsCPU() { delete write_buffers_; delete read_buffers_; }
+  void LockWriteBuffers() { write_buffers_lock_.lock(); }
+  void UnlockWriteBuffers() { debug_wrote_data_ = true; write_buffers_lock_.unlock(); }
+  void WaitForLockAndSwapBuffers() {
+    std::unique_lock<std::mutex> lock(write_buffers_lock_);
+    if (!debug_wrote_data_) {
+      std::fprintf(stderr, "FATAL: Trying to swap the CUDASurfelsCPU buffers, but no data was written. "
+                           "Possible multi-threading bug!\n");
+      std::abort();
+    }
+    std::swap(write_buffers_, read_buffers_);
+    debug_wrote_data_ = false;
+  }
+  CUDASurfelBuffersCPU* write_buffers() { return write_buffers_; }
+  const CUDASurfelBuffersCPU& read_buffers() const { return *read_buffers_; }
+ private:
+  bool debug_wrote_data_ = false;
+  std::mutex write_buffers_lock_;
+  CUDASurfelBuffersCPU* write_buffers_;
+  CUDASurfelBuffersCPU* read_buffers_;
+};
+
+// ---- APP/cuda_surfel_reconstruction.h -----------------------------------------------------------------
+class CUDASurfelReconstruction {
+ public:
+  // The three cudaGraphicsResource_t arguments and the render window of the reference's constructor are
+  // viewer plumbing (OpenGL interop); pass nullptr.
+  CUDASurfelReconstruction(usize max_surfel_count, const PinholeCamera4f& depth_camera, void* = nullptr,
+                           void* = nullptr, void* = nullptr, void* = nullptr) {
+    const float* p = depth_camera.parameters();
+    SMX_SHIM_CHECK(smx_recon_create((uint32_t)max_surfel_count, depth_camera.width(), depth_camera.height(), p[0], p[1],
+                                    p[2], p[3], &handle_));
+  }
+  CUDASurfelReconstruction(const CUDASurfelReconstruction&) = delete;
+  ~CUDASurfelReconstruction() { SMX_SHIM_CHECK(smx_recon_destroy(handle_)); }
+
+  void Integrate(cudaStream_t stream, u32 frame_index, float depth_scaling, CUDABuffer<u16>* depth_buffer,
+                 const CUDABuffer<float2_>& normals_buffer, const CUDABuffer<float>& radius_buffer,
+                 const CUDABuffer<Vec3u8>& color_buffer, const SE3f& global_T_local, float sensor_noise_factor,
+                 float max_surfel_confidence, float regularizer_weight, int regularization_frame_window_size,
+                 bool do_blending, int measurement_blending_radius,
+                 int regularization_iterations_per_integration_iteration,
+                 float radius_factor_for_regularization_neighbors, float normal_compatibility_threshold_deg,
+                 int surfel_integration_active_window_size) {
+    smx_integrate_params p;
+    p.sensor_noise_factor = sensor_noise_factor;
+    p.max_surfel_confidence = max_surfel_confidence;
+    p.regularizer_weight = regularizer_weight;
+    p.regularization_frame_window_size = regularization_frame_window_size;
+    p.do_blending = do_blending ? 1 : 0;
+    p.measurement_blending_radius = measurement_blending_radius;
+    p.regularization_iterations_per_integration_iteration = regularization_iterations_per_integration_iteration;
+    p.radius_factor_for_regularization_neighbors = radius_factor_for_regularization_neighbors;
+    p.normal_compatibility_threshold_deg = normal_compatibility_threshold_deg;
+    p.surfel_integration_active_window_size = surfel_integration_active_window_size;
+    last_stream_ = stream;
+    SMX_SHIM_CHECK(smx_recon_integrate(handle_, stream, frame_index, depth_scaling, depth_buffer->ToCUDA().desc(),
+                                       normals_buffer.ToCUDA().desc(), radius_buffer.ToCUDA().desc(),
+                                       color_buffer.ToCUDA().desc(), global_T_local.m, &p));
+  }
+  void Regularize(cudaStream_t stream, u32 frame_index, float regularizer_weight,
+                  float radius_factor_for_regularization_neighbors, int regularization_frame_window_size) {
+    SMX_SHIM_CHECK(smx_recon_regularize(handle_, stream, frame_index, regularizer_weight,
+                                        radius_factor_for_regularization_neighbors, regularization_frame_window_size));
+  }
+  // Requires buffers->LockWriteBuffers() to be held (APP/main.cc:1261-1264).
+  void TransferAllToCPU(cudaStream_t stream, u32 frame_index, CUDASurfelsCPU* buffers) {
+    CUDASurfelBuffersCPU* b = buffers->write_buffers();
+    smx_surfel_buffers_cpu pod = {frame_index, 0, b->surfel_x_buffer, b->surfel_y_buffer, b->surfel_z_buffer,
+                                  b->surfel_radius_squared_buffer, b->surfel_normal_x_buffer,
+                                  b->surfel_normal_y_buffer, b->surfel_normal_z_buffer,
+                                  b->surfel_last_update_stamp_buffer};
+    SMX_SHIM_CHECK(smx_recon_transfer_all_to_cpu(handle_, stream, frame_index, &pod));
+    b->frame_index = pod.frame_index;
+    b->surfel_count = pod.surfel_count;
+  }
+  void UpdateVisualizationBuffers(cudaStream_t, u32, u32, u32, int, bool, bool, bool, bool) {}  // viewer only
+  void ExportVertices(cudaStream_t stream, CUDABuffer<float>* position_buffer, CUDABuffer<u8>* color_buffer) {
+    SMX_SHIM_CHECK(smx_recon_export_vertices(handle_, stream, position_buffer->ToCUDA().desc(), color_buffer->ToCUDA().desc()));
+  }
+  void GetTimings(float* data_association, float* surfel_merging, float* measurement_blending, float* integration,
+                  float* neighbor_update, float* new_surfel_creation, float* regularization) {
+    float t[7];
+    SMX_SHIM_CHECK(smx_recon_get_timings(handle_, t));
+    *data_association = t[0]; *surfel_merging = t[1]; *measurement_blending = t[2]; *integration = t[3];
+    *neighbor_update = t[4]; *new_surfel_creation = t[5]; *regularization = t[6];
+  }
+  // Unlike the reference these read the device-side counters (they synchronise the last used stream).
+  u32 surfel_count() const { u32 a = 0, b = 0; SMX_SHIM_CHECK(smx_recon_counts(handle_, last_stream_, &a, &b)); return a; }
+  u32 surfels_size() const { u32 a = 0, b = 0; SMX_SHIM_CHECK(smx_recon_counts(handle_, last_stream_, &a, &b)); return b; }
+  smx_recon handle() const { return handle_; }
+
+ private:
+  smx_recon handle_ = nullptr;
+  cudaStream_t last_stream_ = nullptr;
+};
+
+}  // namespace vis

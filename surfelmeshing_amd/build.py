@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsmx.so")
-SOURCES = ["smx_buffer.hip", "smx_depth.hip", "smx_recon.hip", "smx_nn.hip", "smx_synth.hip"]
+SOURCES = ["smx_buffer.hip", "smx_depth.hip", "smx_recon.hip", "smx_nn.hip", "smx_synth.hip", "smx_driver.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
 
@@ -35,15 +35,15 @@ def _stale(target, deps):
 def build(force=False, verbose=True):
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
-    headers.append(os.path.join(ROOT, "include", "smx.h"))
+    headers += [os.path.join(ROOT, "include", h) for h in ("smx.h", "smx_shim.hpp", "smx_driver.h")]
     objs = []
     procs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))

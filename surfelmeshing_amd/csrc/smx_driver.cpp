@@ -1,0 +1,202 @@
+// smx_driver.cpp -- the reference caller's per-frame sequence (APP/main.cc:1015-1223) as native host code,
+// written against the shim API (include/smx_shim.hpp).  No kernels here.
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "smx_driver.h"
+#include "smx_shim.hpp"
+
+using namespace vis;
+
+struct Frame {
+  CUDABuffer<u16> depth;
+  CUDABuffer<Vec3u8> color;
+  Frame(int h, int w) : depth(h, w), color(h, w) {}
+};
+
+struct smx_driver_s {
+  smx_driver_config cfg;
+  PinholeCamera4f camera;
+  CUDASurfelReconstruction reconstruction;
+  CUDABuffer<u16> filtered_depth_buffer_A, filtered_depth_buffer_B;
+  CUDABuffer<float2_> normals_buffer;
+  CUDABuffer<float> radius_buffer;
+  std::map<u32, std::unique_ptr<Frame>> frames;
+  CUDABuffer<u16>* final_depth;
+
+  explicit smx_driver_s(const smx_driver_config& c, const float* intr)
+      : cfg(c), camera(c.width, c.height, intr), reconstruction(c.max_surfel_count, camera),
+        filtered_depth_buffer_A(c.height, c.width), filtered_depth_buffer_B(c.height, c.width),
+        normals_buffer(c.height, c.width), radius_buffer(c.height, c.width), final_depth(&filtered_depth_buffer_A) {
+    radius_buffer.Clear(0.0f, nullptr);
+  }
+};
+
+namespace smx { void set_error(const char* fmt, ...); }  // libsmx's thread-local error text (smx_last_error)
+static int fail(const char* msg) { smx::set_error("smx_driver: %s", msg); return SMX_ERR_INVALID_ARGUMENT; }
+
+// One iteration of the frame loop, APP/main.cc:1015-1223.
+static int process_frame(smx_driver d, cudaStream_t stream, const smx_driver_step& st) {
+  const smx_driver_config& c = d->cfg;
+  auto it = d->frames.find(st.frame_index);
+  if (it == d->frames.end()) return fail("frame not resident");
+  CUDABuffer<u16>& depth_buffer = it->second->depth;
+  const float* cam = d->camera.parameters();
+
+  // Bilateral filtering and depth cutoff (:1015-1024)
+  BilateralFilteringAndDepthCutoffCUDA(stream, c.bilateral_filter_sigma_xy, c.bilateral_filter_sigma_depth_factor,
+                                       /*value_to_ignore*/ 0, c.bilateral_filter_radius_factor,
+                                       (u16)(c.depth_scaling * c.max_depth > 65535.f ? 65535.f : c.depth_scaling * c.max_depth),
+                                       c.depth_valid_region_radius, depth_buffer.ToCUDA(),
+                                       &d->filtered_depth_buffer_A.ToCUDA());
+  CUDABuffer<u16>* src = &d->filtered_depth_buffer_A;
+  CUDABuffer<u16>* dst = &d->filtered_depth_buffer_B;
+
+  // Depth outlier filtering (:1037-1115)
+  if (st.other_count > 0) {
+    const CUDABuffer_<u16>* other_depths[8];
+    CUDAMatrix3x4 others_TR_reference[8];
+    for (int i = 0; i < st.other_count; ++i) {
+      auto o = d->frames.find(st.other_frames[i]);
+      if (o == d->frames.end()) return fail("outlier-cull neighbour frame not resident");
+      other_depths[i] = &o->second->depth.ToCUDA();
+      others_TR_reference[i] = CUDAMatrix3x4(st.others_TR_reference[i]);
+    }
+    const int req = c.outlier_filtering_required_inliers;
+    const bool all = (req == -1 || req == st.other_count);
+#define SMX_CALL_OUTLIER_FUSION(n)                                                                                     \
+  do {                                                                                                                 \
+    if (all) OutlierDepthMapFusionCUDA<n + 1, u16>(stream, c.outlier_filtering_depth_tolerance_factor, src->ToCUDA(), \
+                                                   cam[0], cam[1], cam[2], cam[3], other_depths, others_TR_reference,  \
+                                                   &dst->ToCUDA());                                                    \
+    else OutlierDepthMapFusionCUDA<n + 1, u16>(stream, req, c.outlier_filtering_depth_tolerance_factor, src->ToCUDA(), \
+                                               cam[0], cam[1], cam[2], cam[3], other_depths, others_TR_reference,      \
+                                               &dst->ToCUDA());                                                        \
+  } while (0)
+    switch (st.other_count) {
+      case 2: SMX_CALL_OUTLIER_FUSION(2); break;
+      case 4: SMX_CALL_OUTLIER_FUSION(4); break;
+      case 6: SMX_CALL_OUTLIER_FUSION(6); break;
+      case 8: SMX_CALL_OUTLIER_FUSION(8); break;
+      default: return fail("Unsupported value for outlier_filtering_frame_count");  // main.cc:1084
+    }
+#undef SMX_CALL_OUTLIER_FUSION
+    std::swap(src, dst);
+  }
+  // Depth map erosion (:1128-1140)
+  if (c.depth_erosion_radius > 0) ErodeDepthMapCUDA(stream, c.depth_erosion_radius, src->ToCUDA(), &dst->ToCUDA());
+  else CopyWithoutBorderCUDA(stream, src->ToCUDA(), &dst->ToCUDA());
+  std::swap(src, dst);
+  // Normals (:1154-1164)
+  ComputeNormalsAndDropBadPixelsCUDA(stream, c.observation_angle_threshold_deg, c.depth_scaling, cam[0], cam[1], cam[2],
+                                     cam[3], src->ToCUDA(), &dst->ToCUDA(), &d->normals_buffer.ToCUDA());
+  std::swap(src, dst);
+  // Radii (:1180-1191)
+  ComputePointRadiiAndRemoveIsolatedPixelsCUDA(stream, c.point_radius_extension_factor, c.point_radius_clamp_factor,
+                                               c.depth_scaling, cam[0], cam[1], cam[2], cam[3], src->ToCUDA(),
+                                               &d->radius_buffer.ToCUDA(), &dst->ToCUDA());
+  std::swap(src, dst);
+  d->final_depth = src;
+
+  // Surfel reconstruction (:1205-1223)
+  const smx_integrate_params& p = c.integrate;
+  d->reconstruction.Integrate(stream, st.frame_index, c.depth_scaling, src, d->normals_buffer, d->radius_buffer,
+                              it->second->color, SE3f(st.global_T_frame), p.sensor_noise_factor,
+                              p.max_surfel_confidence, p.regularizer_weight, p.regularization_frame_window_size,
+                              p.do_blending != 0, p.measurement_blending_radius,
+                              p.regularization_iterations_per_integration_iteration,
+                              p.radius_factor_for_regularization_neighbors, p.normal_compatibility_threshold_deg,
+                              p.surfel_integration_active_window_size);
+  return SMX_OK;
+}
+
+extern "C" {
+
+int smx_driver_create(const smx_driver_config* config, smx_driver* out) {
+  if (!config || !out) return fail("null argument");
+  const float intr[4] = {config->fx, config->fy, config->cx, config->cy};
+  *out = new smx_driver_s(*config, intr);
+  return SMX_OK;
+}
+
+int smx_driver_destroy(smx_driver d) { delete d; return SMX_OK; }
+
+int smx_driver_recon(smx_driver d, smx_recon* out) {
+  if (!d || !out) return fail("null argument");
+  *out = d->reconstruction.handle();
+  return SMX_OK;
+}
+
+static Frame* get_or_make(smx_driver d, uint32_t f) {
+  auto& slot = d->frames[f];
+  if (!slot) slot.reset(new Frame(d->cfg.height, d->cfg.width));
+  return slot.get();
+}
+
+int smx_driver_upload_frame(smx_driver d, smx_stream s, uint32_t frame_index, const uint16_t* depth, const uint8_t* color) {
+  if (!d || !depth || !color) return fail("null argument");
+  Frame* f = get_or_make(d, frame_index);
+  f->depth.UploadAsync(s, depth);
+  f->color.UploadAsync(s, reinterpret_cast<const Vec3u8*>(color));
+  return SMX_OK;
+}
+
+int smx_driver_render_frame(smx_driver d, smx_stream s, uint32_t frame_index, const float global_T_frame[12],
+                            uint32_t seed, float noise_sigma, float dropout) {
+  if (!d || !global_T_frame) return fail("null argument");
+  Frame* f = get_or_make(d, frame_index);
+  return smx_synth_render_room(s, f->depth.ToCUDA().desc(), f->color.ToCUDA().desc(), d->cfg.fx, d->cfg.fy, d->cfg.cx,
+                               d->cfg.cy, global_T_frame, seed, frame_index, d->cfg.depth_scaling, noise_sigma, dropout);
+}
+
+int smx_driver_release_frame(smx_driver d, uint32_t frame_index) {
+  if (!d) return fail("null argument");
+  d->frames.erase(frame_index);
+  return SMX_OK;
+}
+
+int smx_driver_frame_descs(smx_driver d, uint32_t frame_index, smx_buffer_desc* depth, smx_buffer_desc* color) {
+  if (!d) return fail("null argument");
+  auto it = d->frames.find(frame_index);
+  if (it == d->frames.end()) return fail("frame not resident");
+  if (depth) *depth = *it->second->depth.ToCUDA().desc();
+  if (color) *color = *it->second->color.ToCUDA().desc();
+  return SMX_OK;
+}
+
+int smx_driver_run(smx_driver d, smx_stream s, const smx_driver_step* steps, int32_t n) {
+  if (!d || (!steps && n > 0)) return fail("null argument");
+  for (int i = 0; i < n; ++i) {
+    int rc = process_frame(d, s, steps[i]);
+    if (rc != SMX_OK) return rc;
+  }
+  return SMX_OK;
+}
+
+int smx_driver_work_descs(smx_driver d, smx_buffer_desc* depth, smx_buffer_desc* normals, smx_buffer_desc* radius) {
+  if (!d) return fail("null argument");
+  if (depth) *depth = *d->final_depth->ToCUDA().desc();
+  if (normals) *normals = *d->normals_buffer.ToCUDA().desc();
+  if (radius) *radius = *d->radius_buffer.ToCUDA().desc();
+  return SMX_OK;
+}
+
+int smx_driver_download_frame(smx_driver d, smx_stream s, uint32_t frame_index, uint16_t* depth, uint8_t* color) {
+  if (!d) return fail("null argument");
+  auto it = d->frames.find(frame_index);
+  if (it == d->frames.end()) return fail("frame not resident");
+  if (depth) it->second->depth.DownloadAsync(s, depth);
+  if (color) it->second->color.DownloadAsync(s, reinterpret_cast<Vec3u8*>(color));
+  return smx_stream_synchronize(s);
+}
+
+int smx_driver_download_work(smx_driver d, smx_stream s, uint16_t* depth, float* normals, float* radius) {
+  if (!d) return fail("null argument");
+  if (depth) d->final_depth->DownloadAsync(s, depth);
+  if (normals) d->normals_buffer.DownloadAsync(s, reinterpret_cast<float2_*>(normals));
+  if (radius) d->radius_buffer.DownloadAsync(s, radius);
+  return smx_stream_synchronize(s);
+}
+
+}  // extern "C"

@@ -102,3 +102,149 @@ class FramePipeline:
     def process(self, frame_index, other_frames, others_TR_reference, global_T_frame):
         self.preprocess(frame_index, other_frames, others_TR_reference)
         self.integrate(frame_index, global_T_frame)
+
+
+# ---- native driver (include/smx_driver.h): the same per-frame sequence in C++ -----------------------
+import ctypes as _C
+
+from . import _lib as _smxlib
+
+
+class DriverConfig(_C.Structure):
+    _fields_ = [("width", _C.c_int32), ("height", _C.c_int32),
+                ("fx", _C.c_float), ("fy", _C.c_float), ("cx", _C.c_float), ("cy", _C.c_float),
+                ("max_surfel_count", _C.c_uint32),
+                ("depth_scaling", _C.c_float), ("max_depth", _C.c_float), ("depth_valid_region_radius", _C.c_float),
+                ("observation_angle_threshold_deg", _C.c_float), ("depth_erosion_radius", _C.c_int32),
+                ("outlier_filtering_required_inliers", _C.c_int32),
+                ("bilateral_filter_sigma_xy", _C.c_float), ("bilateral_filter_radius_factor", _C.c_float),
+                ("bilateral_filter_sigma_depth_factor", _C.c_float),
+                ("outlier_filtering_depth_tolerance_factor", _C.c_float),
+                ("point_radius_extension_factor", _C.c_float), ("point_radius_clamp_factor", _C.c_float),
+                ("integrate", IntegrateParams)]
+
+
+class DriverStep(_C.Structure):
+    _fields_ = [("frame_index", _C.c_uint32), ("other_count", _C.c_int32), ("other_frames", _C.c_uint32 * 8),
+                ("others_TR_reference", (_C.c_float * 12) * 8), ("global_T_frame", _C.c_float * 12)]
+
+
+DRIVER_EXPORTS = ["smx_driver_create", "smx_driver_destroy", "smx_driver_recon", "smx_driver_upload_frame",
+                  "smx_driver_render_frame", "smx_driver_release_frame", "smx_driver_frame_descs", "smx_driver_run",
+                  "smx_driver_work_descs", "smx_driver_download_frame", "smx_driver_download_work"]
+
+
+class _BorrowedRecon(api.CUDASurfelReconstruction):
+    """CUDASurfelReconstruction view of the object the native driver owns."""
+
+    def __init__(self, handle, camera):  # noqa: super().__init__ would create a new object
+        self._h = handle
+        self.depth_camera = camera
+        self._last_stream = None
+
+    def close(self):
+        self._h = _C.c_void_p()
+
+
+class NativeFramePipeline:
+    """FramePipeline twin whose frame loop runs in C++ (smx_driver_run): one ctypes call enqueues many frames."""
+
+    def __init__(self, width, height, fx, fy, cx, cy, max_surfel_count, pre=None, params=None, stream=None):
+        L = _smxlib.load()
+        _smxlib.require_gpu()
+        for n in DRIVER_EXPORTS:
+            getattr(L, n).restype = _C.c_int
+        self.w, self.h, self.fx, self.fy, self.cx, self.cy = width, height, fx, fy, cx, cy
+        self.pre = pre or PreprocessParams()
+        self.params = params or IntegrateParams.defaults()
+        self.stream = stream
+        p = self.pre
+        cfg = DriverConfig(width, height, fx, fy, cx, cy, max_surfel_count, p.depth_scaling, p.max_depth,
+                           p.depth_valid_region_radius, p.observation_angle_threshold_deg, p.depth_erosion_radius,
+                           p.outlier_filtering_required_inliers, p.bilateral_filter_sigma_xy,
+                           p.bilateral_filter_radius_factor, p.bilateral_filter_sigma_depth_factor,
+                           p.outlier_filtering_depth_tolerance_factor, p.point_radius_extension_factor,
+                           p.point_radius_clamp_factor, self.params)
+        self._d = _C.c_void_p()
+        _smxlib.check(L.smx_driver_create(_C.byref(cfg), _C.byref(self._d)))
+        rh = _C.c_void_p()
+        _smxlib.check(L.smx_driver_recon(self._d, _C.byref(rh)))
+        self.reconstruction = _BorrowedRecon(rh, api.PinholeCamera4f(width, height, fx, fy, cx, cy))
+        self.resident = set()
+
+    def _s(self):
+        return api._sv(self.stream)
+
+    def upload(self, frame_index, depth, color):
+        d = np.ascontiguousarray(depth, np.uint16)
+        c = np.ascontiguousarray(color, np.uint8)
+        _smxlib.check(_smxlib.load().smx_driver_upload_frame(self._d, self._s(), _C.c_uint32(frame_index),
+                                                            d.ctypes.data_as(_C.c_void_p), c.ctypes.data_as(_C.c_void_p)))
+        api.StreamSynchronize(self.stream)
+        self.resident.add(frame_index)
+
+    def render(self, frame_index, global_T_frame, seed, noise_sigma=0.001, dropout=0.01):
+        T = np.ascontiguousarray(np.asarray(global_T_frame, np.float32).reshape(12))
+        _smxlib.check(_smxlib.load().smx_driver_render_frame(self._d, self._s(), _C.c_uint32(frame_index),
+                                                            T.ctypes.data_as(_C.c_void_p), _C.c_uint32(seed & 0xFFFFFFFF),
+                                                            _C.c_float(noise_sigma), _C.c_float(dropout)))
+        self.resident.add(frame_index)
+
+    def release(self, frame_index):
+        if frame_index in self.resident:
+            _smxlib.check(_smxlib.load().smx_driver_release_frame(self._d, _C.c_uint32(frame_index)))
+            self.resident.discard(frame_index)
+
+    @staticmethod
+    def make_step(frame_index, other_frames, others_TR_reference, global_T_frame):
+        st = DriverStep()
+        st.frame_index = frame_index
+        st.other_count = len(other_frames)
+        T = np.asarray(others_TR_reference, np.float32).reshape(len(other_frames), 12) if other_frames else None
+        for i, g in enumerate(other_frames):
+            st.other_frames[i] = g
+            for k in range(12):
+                st.others_TR_reference[i][k] = float(T[i, k])
+        G = np.asarray(global_T_frame, np.float32).reshape(12)
+        for k in range(12):
+            st.global_T_frame[k] = float(G[k])
+        return st
+
+    def run(self, steps):
+        """Enqueue a list of DriverStep (no synchronisation)."""
+        arr = (DriverStep * len(steps))(*steps)
+        _smxlib.check(_smxlib.load().smx_driver_run(self._d, self._s(), arr, _C.c_int32(len(steps))))
+
+    def run_array(self, arr, n):
+        _smxlib.check(_smxlib.load().smx_driver_run(self._d, self._s(), arr, _C.c_int32(n)))
+
+    def process(self, frame_index, other_frames, others_TR_reference, global_T_frame):
+        self.run([self.make_step(frame_index, other_frames, others_TR_reference, global_T_frame)])
+
+    def download_frame(self, frame_index):
+        d = np.empty((self.h, self.w), np.uint16)
+        c = np.empty((self.h, self.w, 3), np.uint8)
+        _smxlib.check(_smxlib.load().smx_driver_download_frame(self._d, self._s(), _C.c_uint32(frame_index),
+                                                              d.ctypes.data_as(_C.c_void_p), c.ctypes.data_as(_C.c_void_p)))
+        return d, c
+
+    def download_work(self):
+        """(final depth, normals, radius) after the last processed frame."""
+        d = np.empty((self.h, self.w), np.uint16)
+        n = np.empty((self.h, self.w, 2), np.float32)
+        r = np.empty((self.h, self.w), np.float32)
+        _smxlib.check(_smxlib.load().smx_driver_download_work(self._d, self._s(), d.ctypes.data_as(_C.c_void_p),
+                                                             n.ctypes.data_as(_C.c_void_p), r.ctypes.data_as(_C.c_void_p)))
+        return d, n, r
+
+    def close(self):
+        if getattr(self, "_d", None):
+            self.reconstruction.close()
+            _smxlib.load().smx_driver_destroy(self._d)
+            self._d = _C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -253,3 +253,36 @@ def test_invalid_arguments_raise(smx):
     with pytest.raises(smx.SmxError):
         rec.IntegrateP(None, 0, 5000.0, wrong, n, r, c, np.eye(3, 4), IntegrateParams.defaults())
     assert rec.surfels_size() == 0 and rec.surfel_count() == 0
+
+
+def test_native_driver_matches_oracle(smx):
+    """The C++ frame loop (include/smx_driver.h, written against the shim classes of smx_shim.hpp) produces the
+    same state as the oracle; many frames are enqueued by one call."""
+    from surfelmeshing_amd.pipeline import NativeFramePipeline
+    from surfelmeshing_amd._lib import IntegrateParams
+    s = small_stream(obstacle_until=8)
+    pre = small_pre(s.width)
+    po = OraclePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, 60000, pre)
+    pn = NativeFramePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, 60000, pre, IntegrateParams.defaults())
+    frames = list(range(4, 20))
+    for f in range(0, 24):
+        d, c = s.frame(f)
+        po.upload(f, d, c)
+        pn.upload(f, d, c)
+    steps = []
+    for f in frames:
+        others, T, pose = s.outlier_frames(f), s.others_TR_reference(f), s.pose(f)
+        po.process(f, others, T, pose)
+        steps.append(pn.make_step(f, others, T, pose))
+    pn.run(steps)
+    n = po.recon.surfels_size
+    assert pn.reconstruction.surfels_size() == n
+    assert_surfels_match(pn.reconstruction.debug_download_surfels(n), po.recon.surfels(), n)
+    d, nrm, rad = pn.download_work()
+    assert np.array_equal(d, po.depth_final)
+    assert np.array_equal(nrm.view(np.uint32), po.normals.view(np.uint32))
+    dd, cc = pn.download_frame(10)
+    assert np.array_equal(dd, s.frame(10)[0]) and np.array_equal(cc, s.frame(10)[1])
+    pn.release(10)
+    with pytest.raises(smx.SmxError):
+        pn.download_frame(10)
