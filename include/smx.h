@@ -219,8 +219,9 @@ enum {
   SMX_SCRATCH_NEW_INDICES = 6      /* u32 [W*H], exclusive ranks */
 };
 int smx_recon_debug_download_scratch(smx_recon r, smx_stream s, int32_t which, void* dst);
-/* 0 = list-driven kernels (default), 1 = every surfel kernel scans all slots
- * like the reference does; results are identical, used for A/B checks. */
+/* A/B switches; results are identical in every mode.  bit 0: every surfel kernel scans all slots like
+ * the reference does instead of the compacted lists; bit 1: measurement blending as the reference's
+ * start + iteration launches instead of the fused LDS kernel. */
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode);
 
 /* ---- radius-neighbor search (replaces CompressedOctree::FindNearestSurfelsWithinRadius,

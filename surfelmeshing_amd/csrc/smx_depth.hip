@@ -10,25 +10,27 @@ using namespace smx;
 
 namespace {
 
-constexpr int kTileW = 64;   // one wavefront per tile row
-constexpr int kTileH = 16;
+constexpr int kTileW = 64;   // one wavefront per image row segment
 constexpr int kThreads = 256;
 
 // ---------------------------------------------------------------------------------------------
 // Bilateral filter + depth cutoff.  Reference: BilateralFilteringAndDepthCutoffCUDAKernel,
-// cuda_depth_processing.cu:50-118.  A 64x16 pixel tile plus its `radius` halo is staged in LDS
-// (zero outside the image: a zero sample is "value_to_ignore"-like only when value_to_ignore
-// is 0, so out-of-image taps are masked by coordinates instead, exactly like the reference's
-// clamped loop bounds).
+// cuda_depth_processing.cu:50-118.  One pixel per lane, 32x8 pixel tiles (1200 workgroups at 640x480, so the
+// 256 CUs stay evenly loaded); the tile plus its `radius` halo is staged in LDS with coalesced u16 row
+// loads; the spatial exponent term -(dx^2+dy^2)/(2 sigma_xy^2) depends only on the tap offset and is
+// tabulated once per workgroup (same IEEE division, so the results are unchanged).  Out-of-image taps are
+// masked by coordinates, exactly like the reference's clamped loop bounds.
 constexpr int kMaxBilateralRadius = 8;
+constexpr int kBilTileW = 32, kBilTileH = 8;
 __global__ void __launch_bounds__(kThreads)
 k_bilateral(float denom_xy, float sigma_value_factor, int radius, int radius_squared,
             uint16_t value_to_ignore, uint16_t max_depth, float region_r2,
             Img<const uint16_t> in, Img<uint16_t> out) {
-  __shared__ uint16_t tile[(kTileH + 2 * kMaxBilateralRadius) * (kTileW + 2 * kMaxBilateralRadius)];
+  __shared__ uint16_t tile[(kBilTileH + 2 * kMaxBilateralRadius) * (kBilTileW + 2 * kMaxBilateralRadius)];
+  __shared__ float spatial[kMaxBilateralRadius * kMaxBilateralRadius + 1];
   const int W = out.width, H = out.height;
-  const int tw = kTileW + 2 * radius, th = kTileH + 2 * radius;
-  const int x0 = blockIdx.x * kTileW - radius, y0 = blockIdx.y * kTileH - radius;
+  const int tw = kBilTileW + 2 * radius, th = kBilTileH + 2 * radius;
+  const int x0 = blockIdx.x * kBilTileW - radius, y0 = blockIdx.y * kBilTileH - radius;
   for (int i = threadIdx.x; i < tw * th; i += kThreads) {
     const int ty = i / tw, tx = i - ty * tw;
     const int gx = x0 + tx, gy = y0 + ty;
@@ -36,41 +38,39 @@ k_bilateral(float denom_xy, float sigma_value_factor, int radius, int radius_squ
     if (gx >= 0 && gy >= 0 && gx < W && gy < H) v = in(gy, gx);
     tile[i] = v;
   }
+  for (int g2 = threadIdx.x; g2 <= radius_squared; g2 += kThreads) spatial[g2] = (float)(-g2) / denom_xy;
   __syncthreads();
 
-  const int lx = threadIdx.x & (kTileW - 1);
-  const int x = blockIdx.x * kTileW + lx;
+  const int lx = threadIdx.x & (kBilTileW - 1), ly = threadIdx.x / kBilTileW;
+  const int x = blockIdx.x * kBilTileW + lx, y = blockIdx.y * kBilTileH + ly;
+  if (x >= W || y >= H) return;
   const unsigned half_w = (unsigned)(W / 2), half_h = (unsigned)(H / 2);
-  for (int ly = threadIdx.x / kTileW; ly < kTileH; ly += kThreads / kTileW) {
-    const int y = blockIdx.y * kTileH + ly;
-    if (x >= W || y >= H) continue;
-    const unsigned dxc = (unsigned)x - half_w, dyc = (unsigned)y - half_h;
-    const float center_distance_squared = (float)(dxc * dxc + dyc * dyc);
-    if (center_distance_squared > region_r2) { out(y, x) = value_to_ignore; continue; }
-    const uint16_t center_value = tile[(ly + radius) * tw + (lx + radius)];
-    if (center_value == value_to_ignore || center_value > max_depth) { out(y, x) = value_to_ignore; continue; }
+  const unsigned dxc = (unsigned)x - half_w, dyc = (unsigned)y - half_h;
+  const float center_distance_squared = (float)(dxc * dxc + dyc * dyc);
+  if (center_distance_squared > region_r2) { out(y, x) = value_to_ignore; return; }
+  const uint16_t center_value = tile[(ly + radius) * tw + (lx + radius)];
+  if (center_value == value_to_ignore || center_value > max_depth) { out(y, x) = value_to_ignore; return; }
 
-    const float adapted_sigma_value = (float)center_value * sigma_value_factor;
-    const float adapted_denom_value = 2.0f * adapted_sigma_value * adapted_sigma_value;
-    float sum = 0, weight = 0;
-    const int min_dy = max(-radius, -y), max_dy = min(radius, H - 1 - y);
-    const int min_dx = max(-radius, -x), max_dx = min(radius, W - 1 - x);
-    for (int dy = min_dy; dy <= max_dy; ++dy) {
-      const uint16_t* trow = &tile[(ly + radius + dy) * tw + (lx + radius)];
-      for (int dx = min_dx; dx <= max_dx; ++dx) {
-        const int g2 = dx * dx + dy * dy;
-        if (g2 > radius_squared) continue;
-        const uint16_t sample = trow[dx];
-        if (sample == value_to_ignore) continue;
-        float vd = (float)((int)center_value - (int)sample);
-        vd *= vd;
-        const float w = det_expf((float)(-g2) / denom_xy + (-vd) / adapted_denom_value);
-        sum += w * (float)sample;
-        weight += w;
-      }
+  const float adapted_sigma_value = (float)center_value * sigma_value_factor;
+  const float adapted_denom_value = 2.0f * adapted_sigma_value * adapted_sigma_value;
+  float sum = 0, weight = 0;
+  const int min_dy = max(-radius, -y), max_dy = min(radius, H - 1 - y);
+  const int min_dx = max(-radius, -x), max_dx = min(radius, W - 1 - x);
+  for (int dy = min_dy; dy <= max_dy; ++dy) {
+    const uint16_t* trow = &tile[(ly + radius + dy) * tw + (lx + radius)];
+    for (int dx = min_dx; dx <= max_dx; ++dx) {
+      const int g2 = dx * dx + dy * dy;
+      if (g2 > radius_squared) continue;
+      const uint16_t sample = trow[dx];
+      if (sample == value_to_ignore) continue;
+      float vd = (float)((int)center_value - (int)sample);
+      vd *= vd;
+      const float w = det_expf(spatial[g2] + (-vd) / adapted_denom_value);
+      sum += w * (float)sample;
+      weight += w;
     }
-    out(y, x) = (weight == 0) ? value_to_ignore : f2u16(sum / weight + 0.5f);
   }
+  out(y, x) = (weight == 0) ? value_to_ignore : f2u16(sum / weight + 0.5f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -249,7 +249,7 @@ int smx_bilateral_filtering_and_depth_cutoff(
   SMX_CHECK_ARG(input_depth->width == output_depth->width && input_depth->height == output_depth->height);
   const int radius = (int)(radius_factor * sigma_xy + 0.5f);                       // cu:135
   SMX_CHECK_ARG(radius >= 0 && radius <= kMaxBilateralRadius);
-  dim3 grid(div_up(output_depth->width, kTileW), div_up(output_depth->height, kTileH), 1);
+  dim3 grid(div_up(output_depth->width, kBilTileW), div_up(output_depth->height, kBilTileH), 1);
   hipLaunchKernelGGL(k_bilateral, grid, dim3(kThreads), 0, (hipStream_t)s,
                      2.0f * sigma_xy * sigma_xy, sigma_value_factor, radius, radius * radius, value_to_ignore,
                      max_depth, depth_valid_region_radius * depth_valid_region_radius,

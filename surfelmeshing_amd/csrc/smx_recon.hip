@@ -127,6 +127,11 @@ static_assert(sizeof(uchar3) == 3, "uchar3 must be packed like the reference's V
 // indices it selects to list[s*kSeg ...] (ascending) and their number to seg[s].  No global counter, no
 // atomics, and the list order is deterministic.
 constexpr int kSeg = 1024;
+// Pass B uses larger segments (kSegB slots, one 1024-thread workgroup each): the in-segment regulariser sums
+// live in 128 KB of LDS, and the larger the segment the fewer edges leave it (image-row neighbours are a few
+// hundred slots apart), i.e. the fewer 64-bit global atomics remain.
+constexpr int kSegB = 1024;
+constexpr int kBlockB = kSegB / 4;
 struct Lists {
   uint32_t* vis_list;     // slots that project into the image this frame
   uint32_t* vis_seg;
@@ -142,8 +147,9 @@ __device__ __forceinline__ uint8_t make_flags(uint32_t stamp, uint32_t color, ui
   return (uint8_t)(((color >> 24) == 1u ? 2u : 0u) | (stamp_outside_window(stamp, frame, reg_window) ? 0u : 1u));
 }
 
-// Exclusive prefix sum of one value per thread over a 256-thread workgroup (wave64 shuffles + LDS).
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t mine, uint32_t* wave_tot /* LDS [4] */, uint32_t& total) {
+// Exclusive prefix sum of one value per thread over a workgroup of kWaves wavefronts (wave64 shuffles + LDS).
+template <int kWaves = kBlock / 64>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t mine, uint32_t* wave_tot /* LDS [kWaves] */, uint32_t& total) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t incl = mine;
 #pragma unroll
@@ -156,7 +162,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t mine, uint32_t* wav
   uint32_t wave_off = 0;
   total = 0;
 #pragma unroll
-  for (int w = 0; w < kBlock / 64; ++w) {
+  for (int w = 0; w < kWaves; ++w) {
     if ((uint32_t)w < wave) wave_off += wave_tot[w];
     total += wave_tot[w];
   }
@@ -245,18 +251,18 @@ k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, DevState* st) {
 // List kernels walk the segmented list in chunks of kBlock entries (one entry per lane), grid-striding
 // over the chunk ids so that the visible slots -- which cluster in a few segments -- still spread over the
 // whole chip.  In the A/B "scan mode" every slot of the chunk is visited instead of the list entries.
-constexpr int kChunksPerSeg = kSeg / kBlock;
-template <bool kUseList>
+template <bool kUseList, int kSegSize = kSeg>
 __device__ __forceinline__ bool chunk_entry(const uint32_t* __restrict__ list, const uint32_t* __restrict__ seg,
                                             uint32_t n_slots, uint32_t chunk, uint32_t& i) {
+  constexpr uint32_t kChunksPerSeg = kSegSize / kBlock;
   const uint32_t s = chunk / kChunksPerSeg, sub = chunk % kChunksPerSeg;
   const uint32_t e = sub * kBlock + threadIdx.x;
   if (kUseList) {
     if (e >= seg[s]) return false;
-    i = list[s * kSeg + e];
+    i = list[s * kSegSize + e];
     return true;
   }
-  i = s * kSeg + e;
+  i = s * kSegSize + e;
   return i < n_slots;
 }
 
@@ -441,6 +447,125 @@ k_blend_iter(int it, float term, float ds, Img<uint16_t> depth, Scratch sc, Blen
       const float f = (float)(it - 1) * term;
       depth(y, x) = f2u16((float)depth(y, x) + (ds * (1 - f) * avg + 0.5f));  // :704
     }
+  }
+}
+
+// Fused form of the whole BlendMeasurementsCUDA sequence (start kernel + radius-2 iteration kernels,
+// 13 launches in the reference incl. the clears): one launch, one workgroup per 32x32 pixel tile.  A ring of
+// BFS distance d depends only on pixels within d+1 of it, so a halo of radius-1 pixels makes the tile
+// interior exact; depth, both distance maps and both delta maps of tile + halo live in LDS, the rings
+// advance with workgroup barriers, and only the interior depths are written back.
+constexpr int kBlendTile = 32;
+constexpr int kBlendThreads = 1024;  // 16 wavefronts advance the rings of one tile
+constexpr int kBlendMaxHalo = 16;    // radius <= 17 uses this kernel (<= 64 KB LDS), larger radii the multi-launch path
+__global__ void __launch_bounds__(kBlendThreads)
+k_blend_fused(int radius, float term, float ds, Img<uint16_t> depth, Scratch sc, int W, int H) {
+  extern __shared__ __align__(16) unsigned char blend_lds[];
+  const int halo = radius - 1;
+  const int rw = kBlendTile + 2 * halo;          // region width == height
+  const int cells = rw * rw;
+  float* delta = reinterpret_cast<float*>(blend_lds);
+  float* ndelta = delta + cells;
+  uint16_t* dep = reinterpret_cast<uint16_t*>(ndelta + cells);
+  uint16_t* newdep = dep + cells;
+  uint8_t* dist = reinterpret_cast<uint8_t*>(newdep + cells);
+  uint8_t* ndist = dist + cells;
+  uint8_t* flag = ndist + cells;                  // bit 0: supporting surfel valid, bit 1: processed pixel
+  const int x0 = blockIdx.x * kBlendTile - halo, y0 = blockIdx.y * kBlendTile - halo;
+  for (int k = threadIdx.x; k < cells; k += kBlendThreads) {
+    const int ry = k / rw, rx = k - ry * rw;
+    const int x = x0 + rx, y = y0 + ry;
+    uint16_t d = 0; uint8_t f = 0;
+    if (x >= 0 && y >= 0 && x < W && y < H) {
+      d = depth(y, x);
+      if (sc.supporting[(size_t)y * W + x] != kInvalid) f |= 1;
+      // kBorder = 1 rule of both kernels (:576-577, :660-661); cells on the region rim cannot be
+      // evaluated (their 3x3 window leaves the region) and are not needed
+      if (x >= 1 && y >= 1 && x < W - 1 && y < H - 1 && rx >= 1 && ry >= 1 && rx < rw - 1 && ry < rw - 1) f |= 2;
+    }
+    dep[k] = d; flag[k] = f; dist[k] = 0; ndist[k] = 0; delta[k] = 0; ndelta[k] = 0;
+  }
+  __syncthreads();
+  // start kernel, :563-615 (decisions read the unmodified depths; the new depths are applied afterwards)
+  int any = 0;
+  for (int k = threadIdx.x; k < cells; k += kBlendThreads) {
+    uint16_t nd = dep[k];
+    if ((flag[k] & 2) && dep[k] != 0 && (flag[k] & 1)) {
+      bool mb = false, sb = false;
+      for (int wy = -1; wy <= 1; ++wy)
+        for (int wx = -1; wx <= 1; ++wx) {
+          const int kk = k + wy * rw + wx;
+          if (dep[kk] == 0) mb = true;
+          else if (!(flag[kk] & 1)) sb = true;
+        }
+      const int ry = k / rw, rx = k - ry * rw;
+      const size_t g = (size_t)(y0 + ry) * W + (x0 + rx);
+      const float own = (float)dep[k];
+      if (sb) { ndist[k] = 1; ndelta[k] = depth_sum_avg(sc, g) - own / ds; any = 1; }
+      if (mb) {
+        dist[k] = 1;
+        const float avg = depth_sum_avg(sc, g);
+        delta[k] = avg - own / ds;
+        nd = f2u16(ds * avg + 0.5f);  // :610
+        any = 1;
+      } else {
+        dist[k] = 255;
+      }
+    }
+    newdep[k] = nd;
+  }
+  // no measurement / surfel border anywhere in tile + halo: the blend changes nothing here
+  if (!__syncthreads_or(any)) return;
+  for (int k = threadIdx.x; k < cells; k += kBlendThreads) dep[k] = newdep[k];
+  __syncthreads();
+  // iteration kernels, :647-708.  Ring `it` is only needed (and only exact) up to halo - it pixels outside
+  // the tile, so the evaluated square shrinks by one pixel per ring.
+  for (int it = 2; it < radius; ++it) {
+    const float f = (float)(it - 1) * term;
+    const int side = kBlendTile + 2 * (halo - it);
+    int changed = 0;
+    for (int q = threadIdx.x; q < side * side; q += kBlendThreads) {
+      const int qy = q / side, qx = q - qy * side;
+      const int k = (qy + it) * rw + (qx + it);
+      if (!(flag[k] & 2)) continue;
+      if (dist[k] == 255) {
+        float delta_sum = 0; int count = 0;
+        for (int wy = -1; wy <= 1; ++wy)
+          for (int wx = -1; wx <= 1; ++wx) {
+            const int kk = k + wy * rw + wx;
+            if (dist[kk] == it - 1) { delta_sum += delta[kk]; ++count; }
+          }
+        if (count > 0) {
+          dist[k] = (uint8_t)it;
+          const float avg = delta_sum / (float)count;
+          delta[k] = avg;
+          dep[k] = f2u16((float)dep[k] + (ds * (1 - f) * avg + 0.5f));  // :681
+          changed = 1;
+        }
+      }
+      if (dep[k] != 0 && !(flag[k] & 1) && ndist[k] == 0) {
+        float delta_sum = 0; int count = 0;
+        for (int wy = -1; wy <= 1; ++wy)
+          for (int wx = -1; wx <= 1; ++wx) {
+            const int kk = k + wy * rw + wx;
+            if (ndist[kk] == it - 1) { delta_sum += ndelta[kk]; ++count; }
+          }
+        if (count > 0) {
+          ndist[k] = (uint8_t)it;
+          const float avg = delta_sum / (float)count;
+          ndelta[k] = avg;
+          dep[k] = f2u16((float)dep[k] + (ds * (1 - f) * avg + 0.5f));  // :704
+          changed = 1;
+        }
+      }
+    }
+    // a ring that assigned nothing leaves no frontier: all later rings are empty too
+    if (!__syncthreads_or(changed)) break;
+  }
+  for (int k = threadIdx.x; k < kBlendTile * kBlendTile; k += kBlendThreads) {
+    const int ty = k / kBlendTile, tx = k - ty * kBlendTile;
+    const int x = blockIdx.x * kBlendTile + tx, y = blockIdx.y * kBlendTile + ty;
+    if (x < W && y < H) depth(y, x) = dep[(ty + halo) * rw + (tx + halo)];
   }
 }
 
@@ -804,101 +929,139 @@ k_new_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, const uint8_t* __res
 // (L2-resident: 1 B/slot).  The gradient clear (kernels.cu:2099-2113) is gone: the fixed-point
 // accumulators are zero between calls (k_reg_step zeroes what it consumes).
 template <bool kDetach, bool kAccumulate>
-__global__ void __launch_bounds__(kBlock)
-k_neighbor_scan(Surfels S, float rf2, float weight, int stats, long long* __restrict__ grad_acc,
-                long long* __restrict__ grad_local, Lists L, DevState* st) {
-  __shared__ uint32_t wave_tot[kBlock / 64];
-  // In-segment contributions (most edges link slots that are close in index) are summed in LDS and stored
-  // once per target without any global atomic; only edges that leave the segment use 64-bit global atomics.
-  __shared__ unsigned long long lacc[kAccumulate ? kSeg * 4 : 4];
+__global__ void __launch_bounds__(kBlockB)
+k_neighbor_scan(Surfels S, int stats, Lists L, uint8_t* __restrict__ inwin8, uint32_t* __restrict__ need_seg,
+                DevState* st) {
+  // B1: pure streaming.  Per slot: detach (:1430-1433), which of its neighbours lie inside the regulariser
+  // window (4-bit mask -> inwin8), membership in the recent list.  No LDS accumulators here, so the
+  // occupancy stays high; the accumulation itself runs in k_reg_accumulate on the few segments that need it.
+  __shared__ uint32_t wave_tot[kBlockB / 64];
   const uint32_t N = st->surfel_count;
-  const uint32_t base = blockIdx.x * kSeg;
+  const uint32_t base = blockIdx.x * kSegB;
   if (base >= N) return;
-  if (kAccumulate) {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) lacc[k * kBlock + threadIdx.x] = 0;
-    __syncthreads();
-  }
   // The reference detaches BEFORE it creates new surfels (kernels.cc:333-339 precedes cc:264-286), so
   // slots created in this frame keep links to flagged surfels until the next frame.
   const uint32_t detach_limit = st->create_base;
   const uint32_t i0 = base + threadIdx.x * 4;
   uint32_t recent_bits = 0;
+  int need = 0;
   if (i0 < N) {
     const uchar4 own = *reinterpret_cast<const uchar4*>(&L.flags8[i0]);
     const uint8_t ownf[4] = {own.x, own.y, own.z, own.w};
     uint4 nrow[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) nrow[q] = *reinterpret_cast<const uint4*>(&S.u(kNeighbor0 + q, i0));
+    uint8_t inw[4] = {0, 0, 0, 0};
     uint32_t edges = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint32_t i = i0 + j;
       if (i >= N) continue;
       if (ownf[j] & 1u) recent_bits |= 1u << j;
-      uint32_t ni[4] = {j == 0 ? nrow[0].x : j == 1 ? nrow[0].y : j == 2 ? nrow[0].z : nrow[0].w,
-                        j == 0 ? nrow[1].x : j == 1 ? nrow[1].y : j == 2 ? nrow[1].z : nrow[1].w,
-                        j == 0 ? nrow[2].x : j == 1 ? nrow[2].y : j == 2 ? nrow[2].z : nrow[2].w,
-                        j == 0 ? nrow[3].x : j == 1 ? nrow[3].y : j == 2 ? nrow[3].z : nrow[3].w};
-      uint32_t in_window = 0;
-      int neighbor_count = 0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if (ni[q] == kInvalid) continue;
-        const uint32_t f = L.flags8[ni[q]];
+        const uint32_t nb = j == 0 ? nrow[q].x : j == 1 ? nrow[q].y : j == 2 ? nrow[q].z : nrow[q].w;
+        if (nb == kInvalid) continue;
+        const uint32_t f = L.flags8[nb];
         if (kDetach && i < detach_limit && (f & 2u)) {  // :1430-1433
-          ni[q] = kInvalid;
           S.u(kNeighbor0 + q, i) = kInvalid;
           continue;
         }
         ++edges;
-        if (kAccumulate && (f & 1u)) { in_window |= 1u << q; ++neighbor_count; }
-      }
-      if (!kAccumulate || neighbor_count == 0) continue;
-      const Vec3 sp = {S.f(kSmoothX, i), S.f(kSmoothY, i), S.f(kSmoothZ, i)};
-      const Vec3 nrm = {S.f(kNormalX, i), S.f(kNormalY, i), S.f(kNormalZ, i)};
-      const float r2 = S.f(kRadiusSq, i);
-      const float factor = 2 * weight / (float)neighbor_count;  // :2153
-      const float wk = weight / (float)neighbor_count;          // :2182
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (!(in_window & (1u << q))) continue;
-        const uint32_t nb = ni[q];
-        const Vec3 t = {S.f(kSmoothX, nb) - sp.x, S.f(kSmoothY, nb) - sp.y, S.f(kSmoothZ, nb) - sp.z};
-        const float f = factor * (nrm.x * t.x + nrm.y * t.y + nrm.z * t.z);
-        const uint32_t rel = nb - base;
-        unsigned long long* a = (rel < (uint32_t)kSeg) ? &lacc[4 * rel]
-                                                       : reinterpret_cast<unsigned long long*>(&grad_acc[4 * (size_t)nb]);
-        atomicAdd(&a[0], (unsigned long long)q_from_float(f * nrm.x));
-        atomicAdd(&a[1], (unsigned long long)q_from_float(f * nrm.y));
-        atomicAdd(&a[2], (unsigned long long)q_from_float(f * nrm.z));
-        atomicAdd(&a[3], (unsigned long long)q_from_float(wk));
-        const float d2 = t.x * t.x + t.y * t.y + t.z * t.z;
-        if (d2 > rf2 * r2) S.u(kNeighbor0 + q, i) = kInvalid;  // :2190-2192
+        if (kAccumulate && (f & 1u)) { inw[j] |= (uint8_t)(1u << q); need = 1; }
       }
     }
+    if (kAccumulate) *reinterpret_cast<uchar4*>(&inwin8[i0]) = make_uchar4(inw[0], inw[1], inw[2], inw[3]);
     if (stats && kAccumulate && edges) atomicAdd(&st->n_edges, edges);
   }
-  if (kAccumulate) {
-    __syncthreads();
-    // store the in-segment sums (only this workgroup writes the grad_local entries of its segment)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t rel = threadIdx.x * 4 + j;
-      const unsigned long long v0 = lacc[4 * rel], v1 = lacc[4 * rel + 1], v2 = lacc[4 * rel + 2], v3 = lacc[4 * rel + 3];
-      if (v0 | v1 | v2 | v3)
-        *reinterpret_cast<longlong4*>(&grad_local[4 * (size_t)(base + rel)]) =
-            make_longlong4((long long)v0, (long long)v1, (long long)v2, (long long)v3);
-    }
-  }
   uint32_t total;
-  uint32_t off = base + block_excl_scan((uint32_t)__popc(recent_bits), wave_tot, total);
+  uint32_t off = base + block_excl_scan<kBlockB / 64>((uint32_t)__popc(recent_bits), wave_tot, total);
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     if (recent_bits & (1u << j)) L.recent_list[off++] = i0 + j;
+  const int any = __syncthreads_or(need);
   if (threadIdx.x == 0) {
     L.recent_seg[blockIdx.x] = total;
+    if (kAccumulate) need_seg[blockIdx.x] = any ? 1u : 0u;
     if (stats && total) atomicAdd(&st->recent_count, total);
+  }
+}
+
+// B2: RegularizeSurfelsCUDAAccumulateNeighborGradientsKernel (kernels.cu:2115-2195) on the segments that have
+// at least one edge into the regulariser window.  One lane per slot (1024-lane workgroups: the heavy regions are
+// contiguous, so this is where the parallelism has to come from).  Contributions to targets inside the segment
+// are summed in LDS and stored plainly; edges that leave the segment use 64-bit global atomics.
+constexpr int kSegAcc = 1024;     // slots per accumulation workgroup (32 KB of LDS sums)
+constexpr int kBlockAcc = 1024;
+static_assert(kSegAcc % kSegB == 0 && kSegAcc % kBlockAcc == 0, "segment sizes must nest");
+__global__ void __launch_bounds__(kBlockAcc)
+k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ grad_acc,
+                 long long* __restrict__ grad_local, const uint8_t* __restrict__ inwin8,
+                 const uint32_t* __restrict__ need_seg, const DevState* st) {
+  __shared__ unsigned long long lacc[kSegAcc * 4];
+  const uint32_t N = st->surfel_count;
+  const uint32_t base = blockIdx.x * kSegAcc;
+  if (base >= N) return;
+  uint32_t need = 0;
+#pragma unroll
+  for (int k = 0; k < kSegAcc / kSegB; ++k) need |= need_seg[blockIdx.x * (kSegAcc / kSegB) + k];
+  if (!need) return;
+#pragma unroll
+  for (int k = 0; k < kSegAcc * 4 / kBlockAcc; ++k) lacc[k * kBlockAcc + threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int sub = 0; sub < kSegAcc / kBlockAcc; ++sub) {
+    const uint32_t i = base + sub * kBlockAcc + threadIdx.x;
+    const uint32_t mask = (i < N) ? inwin8[i] : 0u;
+    if (!mask) continue;
+    const int neighbor_count = __popc(mask);
+    // all loads are issued before the first use (the four neighbour ids, then the twelve position
+    // gathers; unused slots read the slot's own data) -- the work per slot is a chain of 3 memory round
+    // trips instead of 10
+    uint32_t nb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) nb[q] = S.u(kNeighbor0 + q, i);
+    const Vec3 sp = {S.f(kSmoothX, i), S.f(kSmoothY, i), S.f(kSmoothZ, i)};
+    const Vec3 nrm = {S.f(kNormalX, i), S.f(kNormalY, i), S.f(kNormalZ, i)};
+    const float r2 = S.f(kRadiusSq, i);
+    Vec3 np[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t g = (mask & (1u << q)) ? nb[q] : i;
+      np[q].x = S.f(kSmoothX, g); np[q].y = S.f(kSmoothY, g); np[q].z = S.f(kSmoothZ, g);
+    }
+    const float factor = 2 * weight / (float)neighbor_count;  // :2153
+    const float wk = weight / (float)neighbor_count;          // :2182
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!(mask & (1u << q))) continue;
+      const Vec3 t = {np[q].x - sp.x, np[q].y - sp.y, np[q].z - sp.z};
+      const float f = factor * (nrm.x * t.x + nrm.y * t.y + nrm.z * t.z);
+      const uint32_t rel = nb[q] - base;
+      const unsigned long long v[4] = {(unsigned long long)q_from_float(f * nrm.x), (unsigned long long)q_from_float(f * nrm.y),
+                                       (unsigned long long)q_from_float(f * nrm.z), (unsigned long long)q_from_float(wk)};
+      if (rel < (uint32_t)kSegAcc) {
+        // component-major LDS layout: consecutive lanes (consecutive targets) hit consecutive banks
+#pragma unroll
+        for (int c = 0; c < 4; ++c) atomicAdd(&lacc[c * kSegAcc + rel], v[c]);
+      } else {
+        unsigned long long* a = reinterpret_cast<unsigned long long*>(&grad_acc[4 * (size_t)nb[q]]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) atomicAdd(&a[c], v[c]);
+      }
+      const float d2 = t.x * t.x + t.y * t.y + t.z * t.z;
+      if (d2 > rf2 * r2) S.u(kNeighbor0 + q, i) = kInvalid;  // :2190-2192
+    }
+  }
+  __syncthreads();
+  // store the in-segment sums (only this workgroup writes the grad_local entries of its segment)
+#pragma unroll
+  for (int sub = 0; sub < kSegAcc / kBlockAcc; ++sub) {
+    const uint32_t rel = sub * kBlockAcc + threadIdx.x;
+    const unsigned long long v0 = lacc[rel], v1 = lacc[kSegAcc + rel], v2 = lacc[2 * kSegAcc + rel], v3 = lacc[3 * kSegAcc + rel];
+    if (v0 | v1 | v2 | v3)
+      *reinterpret_cast<longlong4*>(&grad_local[4 * (size_t)(base + rel)]) =
+          make_longlong4((long long)v0, (long long)v1, (long long)v2, (long long)v3);
   }
 }
 
@@ -918,7 +1081,7 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long*
   const uint32_t n_slots = st->surfel_count, n_chunks = (n_slots + kBlock - 1) / kBlock;
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     uint32_t i;
-    if (!chunk_entry<true>(L.recent_list, L.recent_seg, n_slots, chunk, i)) continue;
+    if (!chunk_entry<true, kSegB>(L.recent_list, L.recent_seg, n_slots, chunk, i)) continue;
     const Vec3 mp = {S.f(kX, i), S.f(kY, i), S.f(kZ, i)};
     const Vec3 sp = {S.f(kSmoothX, i), S.f(kSmoothY, i), S.f(kSmoothZ, i)};
     const Vec3 nrm = {S.f(kNormalX, i), S.f(kNormalY, i), S.f(kNormalZ, i)};
@@ -933,12 +1096,20 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long*
     Vec3 grad = {2 * (sp.x - mp.x) + acc[0], 2 * (sp.y - mp.y) + acc[1], 2 * (sp.z - mp.z) + acc[2]};
     int neighbor_count = 0;
     Vec3 rg = {0, 0, 0};
+    uint32_t nbs[4];
+    Vec3 np[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) nbs[q] = S.u(kNeighbor0 + q, i);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // all gathers in flight together; invalid slots read the slot itself
+      const uint32_t g = (nbs[q] == kInvalid) ? i : nbs[q];
+      np[q].x = S.f(kSmoothX, g); np[q].y = S.f(kSmoothY, g); np[q].z = S.f(kSmoothZ, g);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const uint32_t nb = S.u(kNeighbor0 + q, i);
-      if (nb == kInvalid) continue;
+      if (nbs[q] == kInvalid) continue;
       ++neighbor_count;
-      const Vec3 t = {S.f(kSmoothX, nb) - sp.x, S.f(kSmoothY, nb) - sp.y, S.f(kSmoothZ, nb) - sp.z};
+      const Vec3 t = {np[q].x - sp.x, np[q].y - sp.y, np[q].z - sp.z};
       const float nd = nrm.x * t.x + nrm.y * t.y + nrm.z * t.z;
       rg.x = rg.x - nd * nrm.x; rg.y = rg.y - nd * nrm.y; rg.z = rg.z - nd * nrm.z;
     }
@@ -965,7 +1136,7 @@ k_reg_update(Surfels S, Lists L, const DevState* st) {
   const uint32_t n_slots = st->surfel_count, n_chunks = (n_slots + kBlock - 1) / kBlock;
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     uint32_t i;
-    if (!chunk_entry<true>(L.recent_list, L.recent_seg, n_slots, chunk, i)) continue;
+    if (!chunk_entry<true, kSegB>(L.recent_list, L.recent_seg, n_slots, chunk, i)) continue;
     S.f(kSmoothX, i) = S.f(kCopyRaw ? kX : kGradX, i);
     S.f(kSmoothY, i) = S.f(kCopyRaw ? kY : kGradY, i);
     S.f(kSmoothZ, i) = S.f(kCopyRaw ? kZ : kGradZ, i);
@@ -1015,12 +1186,16 @@ struct smx_recon_s {
   long long* grad_acc;      // [slots][4] 2^-32 fixed point, cross-segment contributions (atomics)
   long long* grad_local;    // [slots][4] in-segment contributions (plain stores)
   Lists L;
-  int nseg;                 // number of kSeg-slot segments (= workgroups of the surfel kernels)
+  int nseg;                 // number of kSeg-slot segments (= workgroups of pass A)
+  int nsegB;                // number of kSegB-slot segments (= workgroups of pass B)
   uint8_t* merge_flag;
+  uint8_t* inwin8;          // per slot: which of its 4 neighbours lie inside the regulariser window
+  uint32_t* need_seg;       // per pass-B segment: 1 if any slot has such a neighbour
   bool table_valid;         // flag table's "recent" bits correspond to (table_frame, table_window)
   uint32_t table_frame;
   int table_window;
   int stats_enabled;
+  int blend_multi_launch;   // A/B switch: 1 = the reference's start + iteration launches instead of the fused kernel
   Scratch sc;
   BlendBufs bb;
   uint8_t* new_flags;
@@ -1046,12 +1221,13 @@ struct smx_recon_s {
 // kernel slots of one Integrate call (launch order)
 enum : int {
   kSlotClear = 0, kSlotScanVisible, kSlotAssociate, kSlotMergeDecide, kSlotBlend, kSlotIntegrate,
-  kSlotUpdateNeighbors, kSlotNewFlagsScan, kSlotNewFinalize, kSlotNewCreate, kSlotNeighborScan, kSlotRegStep,
+  kSlotUpdateNeighbors, kSlotNewFlagsScan, kSlotNewFinalize, kSlotNewCreate, kSlotNeighborScan,
+  kSlotRegAccumulate, kSlotRegStep,
   kSlotRegUpdate, kSlotCount
 };
 static const char* const kSlotNames[kSlotCount] = {
   "clear_assoc", "scan_visible", "associate", "merge_decide", "blend", "integrate", "update_neighbors",
-  "new_flags_scan", "new_finalize", "new_create", "neighbor_scan", "reg_step", "reg_update"};
+  "new_flags_scan", "new_finalize", "new_create", "neighbor_scan", "reg_accumulate", "reg_step", "reg_update"};
 
 struct SlotTimer {
   smx_recon r; hipStream_t st; int slot; bool kev, prof;
@@ -1071,7 +1247,7 @@ namespace {
 
 int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, float weight, int window,
                        bool detach, bool copy_only) {
-  const dim3 g(r->nseg), gl(r->grid_list), b(kBlock);
+  const dim3 g(r->nsegB), bB(kBlockB), gl(r->grid_list), b(kBlock);
   const float rf2 = rf * rf;
   if (!r->table_valid || r->table_frame != frame || r->table_window != window) {
     hipLaunchKernelGGL(k_rebuild_flags, dim3(r->grid_surfels), b, 0, st, r->S, frame, window, r->L.flags8, r->st);
@@ -1082,12 +1258,17 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
     SlotTimer t(r, st, kSlotNeighborScan);
     if (stats) hipLaunchKernelGGL(k_reset_recent, dim3(1), dim3(1), 0, st, r->st);
     if (copy_only) {
-      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, false>), g, b, 0, st, r->S, rf2, weight, stats, r->grad_acc, r->grad_local, r->L, r->st);
-      else hipLaunchKernelGGL((k_neighbor_scan<false, false>), g, b, 0, st, r->S, rf2, weight, stats, r->grad_acc, r->grad_local, r->L, r->st);
+      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, false>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st);
+      else hipLaunchKernelGGL((k_neighbor_scan<false, false>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st);
     } else {
-      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, true>), g, b, 0, st, r->S, rf2, weight, stats, r->grad_acc, r->grad_local, r->L, r->st);
-      else hipLaunchKernelGGL((k_neighbor_scan<false, true>), g, b, 0, st, r->S, rf2, weight, stats, r->grad_acc, r->grad_local, r->L, r->st);
+      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, true>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st);
+      else hipLaunchKernelGGL((k_neighbor_scan<false, true>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st);
     }
+  }
+  if (!copy_only) {
+    SlotTimer t(r, st, kSlotRegAccumulate);
+    hipLaunchKernelGGL(k_reg_accumulate, dim3(div_up((long long)r->nsegB * kSegB, kSegAcc)), dim3(kBlockAcc), 0, st, r->S, rf2, weight, r->grad_acc, r->grad_local,
+                       r->inwin8, r->need_seg, r->st);
   }
   if (copy_only) {
     SlotTimer t(r, st, kSlotRegUpdate);
@@ -1134,15 +1315,18 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   // cuda_surfel_reconstruction.cc:59 -- 25 rows x max_surfel_count (zero-filled here so that the
   // padded tail of every row is defined)
   SMX_TRY(dev_alloc(&r->S.base, (size_t)kRows * r->S.pitch, true));
-  SMX_TRY(dev_alloc(&r->grad_acc, 4 * ((size_t)r->S.pitch + kSeg), true));
-  SMX_TRY(dev_alloc(&r->grad_local, 4 * ((size_t)r->S.pitch + kSeg), true));
+  SMX_TRY(dev_alloc(&r->grad_acc, 4 * ((size_t)r->S.pitch + kSegAcc), true));
+  SMX_TRY(dev_alloc(&r->grad_local, 4 * ((size_t)r->S.pitch + kSegAcc), true));
   r->nseg = div_up((long long)r->S.pitch, kSeg);
+  r->nsegB = div_up((long long)r->S.pitch, kSegB);
   SMX_TRY(dev_alloc(&r->L.vis_list, (size_t)r->nseg * kSeg, false));
-  SMX_TRY(dev_alloc(&r->L.recent_list, (size_t)r->nseg * kSeg, false));
+  SMX_TRY(dev_alloc(&r->L.recent_list, (size_t)r->nsegB * kSegB, false));
   SMX_TRY(dev_alloc(&r->L.vis_seg, (size_t)r->nseg, true));
-  SMX_TRY(dev_alloc(&r->L.recent_seg, (size_t)r->nseg, true));
-  SMX_TRY(dev_alloc(&r->L.flags8, (size_t)r->nseg * kSeg, true));
+  SMX_TRY(dev_alloc(&r->L.recent_seg, (size_t)r->nsegB, true));
+  SMX_TRY(dev_alloc(&r->L.flags8, (size_t)r->nsegB * kSegB, true));
   SMX_TRY(dev_alloc(&r->merge_flag, r->S.pitch, true));
+  SMX_TRY(dev_alloc(&r->inwin8, (size_t)r->nsegB * kSegB, true));
+  SMX_TRY(dev_alloc(&r->need_seg, (size_t)r->nsegB + kSegAcc / kSegB, true));
   SMX_TRY(dev_alloc(&r->sc.supporting, P, false));
   SMX_TRY(dev_alloc(&r->sc.counts, P, false));
   SMX_TRY(dev_alloc(&r->sc.depth_sums, P, false));
@@ -1178,7 +1362,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
 int smx_recon_destroy(smx_recon r) {
   if (!r) return SMX_OK;
   void* ptrs[] = {r->S.base, r->grad_acc, r->grad_local, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.recent_seg, r->L.flags8,
-                  r->merge_flag, r->sc.supporting, r->sc.counts,
+                  r->merge_flag, r->inwin8, r->need_seg, r->sc.supporting, r->sc.counts,
                   r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->st};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1240,8 +1424,9 @@ int smx_recon_set_stats_enabled(smx_recon r, int32_t enabled) {
 }
 
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
-  SMX_CHECK_ARG(r != nullptr && (mode == 0 || mode == 1));
-  r->scan_mode = mode;
+  SMX_CHECK_ARG(r != nullptr && mode >= 0 && mode <= 3);
+  r->scan_mode = mode & 1;
+  r->blend_multi_launch = (mode >> 1) & 1;
   return SMX_OK;
 }
 
@@ -1295,10 +1480,18 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   if (p->do_blending) {
     SlotTimer t(r, st, kSlotBlend);
     const float ds = 1.0f / c.inv_depth_scaling;  // kernels.cc:179
-    hipLaunchKernelGGL(k_blend_start, gimg, b, 0, st, ds, depth_rw, r->sc, r->bb, r->W, r->H);
     const float term = 1.0f / ((float)p->measurement_blending_radius - 1.0f);  // kernels.cc:196
-    for (int it = 2; it < p->measurement_blending_radius; ++it)
-      hipLaunchKernelGGL(k_blend_iter, gimg, b, 0, st, it, term, ds, depth_rw, r->sc, r->bb, r->W, r->H);
+    const int halo = p->measurement_blending_radius - 1;
+    if (halo <= kBlendMaxHalo && !r->blend_multi_launch) {
+      const int rw = kBlendTile + 2 * halo;
+      const size_t lds = (size_t)rw * rw * 15;
+      hipLaunchKernelGGL(k_blend_fused, dim3(div_up(r->W, kBlendTile), div_up(r->H, kBlendTile)), dim3(kBlendThreads), lds, st,
+                         p->measurement_blending_radius, term, ds, depth_rw, r->sc, r->W, r->H);
+    } else {
+      hipLaunchKernelGGL(k_blend_start, gimg, b, 0, st, ds, depth_rw, r->sc, r->bb, r->W, r->H);
+      for (int it = 2; it < p->measurement_blending_radius; ++it)
+        hipLaunchKernelGGL(k_blend_iter, gimg, b, 0, st, it, term, ds, depth_rw, r->sc, r->bb, r->W, r->H);
+    }
   }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[5], st)); SMX_HIP(hipEventRecord(r->ev[6], st)); }
   { SlotTimer t(r, st, kSlotIntegrate);
@@ -1426,7 +1619,7 @@ int smx_recon_debug_upload_surfels(smx_recon r, smx_stream s, const float* rows,
   SMX_HIP(hipMemsetAsync(r->grad_local, 0, 4 * r->S.pitch * sizeof(long long), st));
   SMX_HIP(hipMemsetAsync(r->merge_flag, 0, r->S.pitch, st));
   SMX_HIP(hipMemsetAsync(r->L.vis_seg, 0, (size_t)r->nseg * 4, st));
-  SMX_HIP(hipMemsetAsync(r->L.recent_seg, 0, (size_t)r->nseg * 4, st));
+  SMX_HIP(hipMemsetAsync(r->L.recent_seg, 0, (size_t)r->nsegB * 4, st));
   // detach bits of the flag table come from the colour words; the recent bits are refreshed per frame
   hipLaunchKernelGGL(k_rebuild_flags, dim3(r->grid_surfels), dim3(kBlock), 0, st, r->S, 0u, 0x7FFFFFFF, r->L.flags8, r->st);
   r->table_valid = false;
