@@ -45,12 +45,40 @@ struct DevState {
   uint32_t pad[3];
 };
 
+// HBM layout of the surfel attributes.  The reference keeps 25 separate rows (SoA, kernels.cuh:49-78); that is
+// ideal for its all-slot scans but makes every per-surfel gather touch one cache line per attribute.  Here
+// the attributes are grouped into six 16-byte records per slot, chosen by which kernels use them together,
+// and each group is its own array (group-major):
+//   P  X, Y, Z, LastUpdateStamp      -- exactly what pass A streams (16 B/slot), and what every projection needs
+//   S  SmoothX, SmoothY, SmoothZ, -   -- what the regulariser gathers per neighbour (one line instead of three)
+//   N  NormalX, NormalY, NormalZ, RadiusSquared
+//   T  Neighbor0..3                  -- what pass B streams (16 B/slot)
+//   C  Confidence, CreationStamp, Color, -
+//   G  GradientX, GradientY, GradientZ, -  (parked next smooth position)
+// The reference's row order only matters at the boundary (TransferAllToCPU, ExportVertices, the debug row
+// accessors); pack/unpack kernels convert there.  Rows 14-16 (Accum*, never used) and 23 (GradientCount,
+// replaced by the fixed-point accumulators) have no storage.
+enum : int { kGroupP = 0, kGroupS, kGroupN, kGroupT, kGroupC, kGroupG, kGroups };
+__host__ __device__ constexpr int row_group(int row) {
+  return row <= 2 ? kGroupP : row <= 5 ? kGroupS : row == 6 ? kGroupC : row == 7 ? kGroupN : row <= 10 ? kGroupN
+       : row <= 13 ? kGroupG : row == 17 ? kGroupC : row == 18 ? kGroupP : row <= 22 ? kGroupT : row == 24 ? kGroupC : -1;
+}
+__host__ __device__ constexpr int row_sub(int row) {
+  return row <= 2 ? row : row <= 5 ? row - 3 : row == 6 ? 0 : row == 7 ? 3 : row <= 10 ? row - 8
+       : row <= 13 ? row - 11 : row == 17 ? 1 : row == 18 ? 3 : row <= 22 ? row - 19 : row == 24 ? 2 : -1;
+}
 struct Surfels {
   float* base;
-  size_t pitch;  // elements per row
-  __device__ __forceinline__ float& f(int row, uint32_t i) const { return base[(size_t)row * pitch + i]; }
+  size_t pitch;  // slots per group array (multiple of 64)
+  __device__ __forceinline__ float& f(int row, uint32_t i) const {
+    return base[((size_t)row_group(row) * pitch + i) * 4 + row_sub(row)];
+  }
   __device__ __forceinline__ uint32_t& u(int row, uint32_t i) const {
-    return reinterpret_cast<uint32_t*>(base)[(size_t)row * pitch + i];
+    return reinterpret_cast<uint32_t*>(base)[((size_t)row_group(row) * pitch + i) * 4 + row_sub(row)];
+  }
+  // whole 16-byte group of slot i
+  __device__ __forceinline__ float4* group(int g, uint32_t i) const {
+    return reinterpret_cast<float4*>(base) + ((size_t)g * pitch + i);
   }
 };
 
@@ -210,16 +238,15 @@ k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, DevState* st) {
   const uint32_t i0 = base + threadIdx.x * 4;
   uint32_t vis_bits = 0;
   if (i0 < N) {
-    // rows are padded to a multiple of 64 elements, so the 16-byte loads stay inside the row
-    const uint4 stamp4 = *reinterpret_cast<const uint4*>(&S.u(kLastUpdateStamp, i0));
-    const float4 x4 = *reinterpret_cast<const float4*>(&S.f(kX, i0));
-    const float4 y4 = *reinterpret_cast<const float4*>(&S.f(kY, i0));
-    const float4 z4 = *reinterpret_cast<const float4*>(&S.f(kZ, i0));
+    // four consecutive P records (X, Y, Z, stamp) = 64 contiguous bytes per lane; the group arrays are
+    // padded to a multiple of 64 slots, so the loads stay inside the array
+    const float4* P = S.group(kGroupP, i0);
+    const float4 p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3];
     const uchar4 of = *reinterpret_cast<const uchar4*>(&L.flags8[i0]);
-    const uint32_t stamps[4] = {stamp4.x, stamp4.y, stamp4.z, stamp4.w};
-    const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
-    const float ys[4] = {y4.x, y4.y, y4.z, y4.w};
-    const float zs[4] = {z4.x, z4.y, z4.z, z4.w};
+    const uint32_t stamps[4] = {__float_as_uint(p0.w), __float_as_uint(p1.w), __float_as_uint(p2.w), __float_as_uint(p3.w)};
+    const float xs[4] = {p0.x, p1.x, p2.x, p3.x};
+    const float ys[4] = {p0.y, p1.y, p2.y, p3.y};
+    const float zs[4] = {p0.z, p1.z, p2.z, p3.z};
     const uint8_t old_flags[4] = {of.x, of.y, of.z, of.w};
     uint8_t new_flags[4];
 #pragma unroll
@@ -948,9 +975,9 @@ k_neighbor_scan(Surfels S, int stats, Lists L, uint8_t* __restrict__ inwin8, uin
   if (i0 < N) {
     const uchar4 own = *reinterpret_cast<const uchar4*>(&L.flags8[i0]);
     const uint8_t ownf[4] = {own.x, own.y, own.z, own.w};
-    uint4 nrow[4];
+    uint4 trec[4];  // the T records (4 neighbour ids) of the lane's 4 slots: 64 contiguous bytes
 #pragma unroll
-    for (int q = 0; q < 4; ++q) nrow[q] = *reinterpret_cast<const uint4*>(&S.u(kNeighbor0 + q, i0));
+    for (int j = 0; j < 4; ++j) trec[j] = *reinterpret_cast<const uint4*>(S.group(kGroupT, i0 + j));
     uint8_t inw[4] = {0, 0, 0, 0};
     uint32_t edges = 0;
 #pragma unroll
@@ -960,7 +987,7 @@ k_neighbor_scan(Surfels S, int stats, Lists L, uint8_t* __restrict__ inwin8, uin
       if (ownf[j] & 1u) recent_bits |= 1u << j;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const uint32_t nb = j == 0 ? nrow[q].x : j == 1 ? nrow[q].y : j == 2 ? nrow[q].z : nrow[q].w;
+        const uint32_t nb = q == 0 ? trec[j].x : q == 1 ? trec[j].y : q == 2 ? trec[j].z : trec[j].w;
         if (nb == kInvalid) continue;
         const uint32_t f = L.flags8[nb];
         if (kDetach && i < detach_limit && (f & 2u)) {  // :1430-1433
@@ -988,16 +1015,22 @@ k_neighbor_scan(Surfels S, int stats, Lists L, uint8_t* __restrict__ inwin8, uin
 }
 
 // B2: RegularizeSurfelsCUDAAccumulateNeighborGradientsKernel (kernels.cu:2115-2195) on the segments that have
-// at least one edge into the regulariser window.  One lane per slot (1024-lane workgroups: the heavy regions are
-// contiguous, so this is where the parallelism has to come from).  Contributions to targets inside the segment
-// are summed in LDS and stored plainly; edges that leave the segment use 64-bit global atomics.
+// at least one edge into the regulariser window; one lane per slot, 1024-lane workgroups.
+//
+// The reference pushes every edge's gradient term to the neighbour with four float atomicAdds.  Device-scope
+// atomics on cold lines are the slowest thing this chip does, so the terms travel three ways, all of which end
+// in the same exact 2^-32 fixed-point sum (integer addition: the split cannot change the result):
+//   1. the target lists the source back at slot k (5 of 6 edges): the four floats are STORED, without any
+//      atomic, into inbox[target][k] -- a slot only this source writes; k_reg_step converts and sums them;
+//   2. otherwise, target inside the workgroup's own segment: summed in LDS, stored once per target (grad_local);
+//   3. otherwise: 64-bit global atomics (grad_acc).
 constexpr int kSegAcc = 1024;     // slots per accumulation workgroup (32 KB of LDS sums)
 constexpr int kBlockAcc = 1024;
 static_assert(kSegAcc % kSegB == 0 && kSegAcc % kBlockAcc == 0, "segment sizes must nest");
 __global__ void __launch_bounds__(kBlockAcc)
 k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ grad_acc,
-                 long long* __restrict__ grad_local, const uint8_t* __restrict__ inwin8,
-                 const uint32_t* __restrict__ need_seg, const DevState* st) {
+                 long long* __restrict__ grad_local, float4* __restrict__ inbox,
+                 const uint8_t* __restrict__ inwin8, const uint32_t* __restrict__ need_seg, const DevState* st) {
   __shared__ unsigned long long lacc[kSegAcc * 4];
   const uint32_t N = st->surfel_count;
   const uint32_t base = blockIdx.x * kSegAcc;
@@ -1015,20 +1048,23 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
     const uint32_t mask = (i < N) ? inwin8[i] : 0u;
     if (!mask) continue;
     const int neighbor_count = __popc(mask);
-    // all loads are issued before the first use (the four neighbour ids, then the twelve position
-    // gathers; unused slots read the slot's own data) -- the work per slot is a chain of 3 memory round
-    // trips instead of 10
-    uint32_t nb[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) nb[q] = S.u(kNeighbor0 + q, i);
-    const Vec3 sp = {S.f(kSmoothX, i), S.f(kSmoothY, i), S.f(kSmoothZ, i)};
-    const Vec3 nrm = {S.f(kNormalX, i), S.f(kNormalY, i), S.f(kNormalZ, i)};
-    const float r2 = S.f(kRadiusSq, i);
+    // all loads are issued before the first use: the slot's own records, then per edge the target's S record
+    // (smooth position) and T record (its neighbour ids); unused slots read the slot's own data
+    const uint4 own_t = *reinterpret_cast<const uint4*>(S.group(kGroupT, i));
+    const uint32_t nb[4] = {own_t.x, own_t.y, own_t.z, own_t.w};
+    const float4 own_s = *S.group(kGroupS, i), own_n = *S.group(kGroupN, i);
+    const Vec3 sp = {own_s.x, own_s.y, own_s.z};
+    const Vec3 nrm = {own_n.x, own_n.y, own_n.z};
+    const float r2 = own_n.w;
     Vec3 np[4];
+    int back_slot[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const uint32_t g = (mask & (1u << q)) ? nb[q] : i;
-      np[q].x = S.f(kSmoothX, g); np[q].y = S.f(kSmoothY, g); np[q].z = S.f(kSmoothZ, g);
+      const float4 ts = *S.group(kGroupS, g);
+      const uint4 tt = *reinterpret_cast<const uint4*>(S.group(kGroupT, g));
+      np[q].x = ts.x; np[q].y = ts.y; np[q].z = ts.z;
+      back_slot[q] = tt.x == i ? 0 : tt.y == i ? 1 : tt.z == i ? 2 : tt.w == i ? 3 : -1;
     }
     const float factor = 2 * weight / (float)neighbor_count;  // :2153
     const float wk = weight / (float)neighbor_count;          // :2182
@@ -1037,17 +1073,26 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
       if (!(mask & (1u << q))) continue;
       const Vec3 t = {np[q].x - sp.x, np[q].y - sp.y, np[q].z - sp.z};
       const float f = factor * (nrm.x * t.x + nrm.y * t.y + nrm.z * t.z);
-      const uint32_t rel = nb[q] - base;
-      const unsigned long long v[4] = {(unsigned long long)q_from_float(f * nrm.x), (unsigned long long)q_from_float(f * nrm.y),
-                                       (unsigned long long)q_from_float(f * nrm.z), (unsigned long long)q_from_float(wk)};
-      if (rel < (uint32_t)kSegAcc) {
-        // component-major LDS layout: consecutive lanes (consecutive targets) hit consecutive banks
+      const float4 term = make_float4(f * nrm.x, f * nrm.y, f * nrm.z, wk);
+      // the exclusive inbox slot is only usable if this source has ONE in-window edge to that target
+      bool once = true;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) atomicAdd(&lacc[c * kSegAcc + rel], v[c]);
+      for (int k = 0; k < 4; ++k) if (k != q && (mask & (1u << k)) && nb[k] == nb[q]) once = false;
+      if (back_slot[q] >= 0 && once && wk != 0.0f) {
+        inbox[4 * (size_t)nb[q] + back_slot[q]] = term;
       } else {
-        unsigned long long* a = reinterpret_cast<unsigned long long*>(&grad_acc[4 * (size_t)nb[q]]);
+        const unsigned long long v[4] = {(unsigned long long)q_from_float(term.x), (unsigned long long)q_from_float(term.y),
+                                         (unsigned long long)q_from_float(term.z), (unsigned long long)q_from_float(term.w)};
+        const uint32_t rel = nb[q] - base;
+        if (rel < (uint32_t)kSegAcc) {
+          // component-major LDS layout: consecutive lanes (consecutive targets) hit consecutive banks
 #pragma unroll
-        for (int c = 0; c < 4; ++c) atomicAdd(&a[c], v[c]);
+          for (int c = 0; c < 4; ++c) atomicAdd(&lacc[c * kSegAcc + rel], v[c]);
+        } else {
+          unsigned long long* a = reinterpret_cast<unsigned long long*>(&grad_acc[4 * (size_t)nb[q]]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) atomicAdd(&a[c], v[c]);
+        }
       }
       const float d2 = t.x * t.x + t.y * t.y + t.z * t.z;
       if (d2 > rf2 * r2) S.u(kNeighbor0 + q, i) = kInvalid;  // :2190-2192
@@ -1076,8 +1121,8 @@ k_rebuild_flags(Surfels S, uint32_t frame, int reg_window, uint8_t* __restrict__
 
 // RegularizeSurfelsCUDAKernel, kernels.cu:2197-2290, over the recent list.
 __global__ void __launch_bounds__(kBlock)
-k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long* __restrict__ grad_local, Lists L,
-           const DevState* st) {
+k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long* __restrict__ grad_local,
+           float4* __restrict__ inbox, Lists L, const DevState* st) {
   const uint32_t n_slots = st->surfel_count, n_chunks = (n_slots + kBlock - 1) / kBlock;
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     uint32_t i;
@@ -1090,9 +1135,21 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long*
     longlong4* ap = reinterpret_cast<longlong4*>(&grad_acc[4 * (size_t)i]);
     longlong4* lp = reinterpret_cast<longlong4*>(&grad_local[4 * (size_t)i]);
     const longlong4 a = *ap, l = *lp;
+    float4* ib = &inbox[4 * (size_t)i];
+    const float4 in0 = ib[0], in1 = ib[1], in2 = ib[2], in3 = ib[3];
     if (a.x | a.y | a.z | a.w) *ap = make_longlong4(0, 0, 0, 0);  // keep the accumulators zero between calls
     if (l.x | l.y | l.z | l.w) *lp = make_longlong4(0, 0, 0, 0);
-    const float acc[4] = {q_to_float(a.x + l.x), q_to_float(a.y + l.y), q_to_float(a.z + l.z), q_to_float(a.w + l.w)};
+    long long sum[4] = {a.x + l.x, a.y + l.y, a.z + l.z, a.w + l.w};
+    // terms delivered through the exclusive inbox slots (a used slot has w = weight / k != 0)
+    const float4 ins[4] = {in0, in1, in2, in3};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (ins[k].w == 0.0f) continue;
+      sum[0] += q_from_float(ins[k].x); sum[1] += q_from_float(ins[k].y);
+      sum[2] += q_from_float(ins[k].z); sum[3] += q_from_float(ins[k].w);
+      ib[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float acc[4] = {q_to_float(sum[0]), q_to_float(sum[1]), q_to_float(sum[2]), q_to_float(sum[3])};
     Vec3 grad = {2 * (sp.x - mp.x) + acc[0], 2 * (sp.y - mp.y) + acc[1], 2 * (sp.z - mp.z) + acc[2]};
     int neighbor_count = 0;
     Vec3 rg = {0, 0, 0};
@@ -1145,6 +1202,26 @@ k_reg_update(Surfels S, Lists L, const DevState* st) {
 
 __global__ void k_reset_recent(DevState* st) { st->recent_count = 0; st->n_edges = 0; }
 
+// Boundary conversion between the grouped records and the reference's row layout: out[k][i] = row rows[k] of
+// slot i (pack) and back (unpack).  Rows without storage read as 0.
+struct RowList { int n; int rows[kRows]; };
+__global__ void __launch_bounds__(kBlock)
+k_pack_rows(Surfels S, RowList rl, float* __restrict__ out, uint32_t count) {
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock)
+    for (int k = 0; k < rl.n; ++k) {
+      const int g = row_group(rl.rows[k]), sub = row_sub(rl.rows[k]);
+      out[(size_t)k * count + i] = g < 0 ? 0.0f : S.base[((size_t)g * S.pitch + i) * 4 + sub];
+    }
+}
+__global__ void __launch_bounds__(kBlock)
+k_unpack_rows(Surfels S, RowList rl, const float* __restrict__ in, uint32_t count) {
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock)
+    for (int k = 0; k < rl.n; ++k) {
+      const int g = row_group(rl.rows[k]), sub = row_sub(rl.rows[k]);
+      if (g >= 0) S.base[((size_t)g * S.pitch + i) * 4 + sub] = in[(size_t)k * count + i];
+    }
+}
+
 // ExportVerticesCUDAKernel, kernels.cu:2412-2433
 __global__ void __launch_bounds__(kBlock)
 k_export(Surfels S, float* __restrict__ pos, uint8_t* __restrict__ col, const DevState* st) {
@@ -1185,6 +1262,7 @@ struct smx_recon_s {
   Surfels S;
   long long* grad_acc;      // [slots][4] 2^-32 fixed point, cross-segment contributions (atomics)
   long long* grad_local;    // [slots][4] in-segment contributions (plain stores)
+  float4* inbox;            // [slots][4] terms stored by the neighbour a slot lists at position k (no atomics)
   Lists L;
   int nseg;                 // number of kSeg-slot segments (= workgroups of pass A)
   int nsegB;                // number of kSegB-slot segments (= workgroups of pass B)
@@ -1214,6 +1292,8 @@ struct smx_recon_s {
   int prof_slot;
   int prof_cap, prof_n;
   hipEvent_t* prof_ev;
+  float* staging;    // row-layout staging for the boundary conversions (TransferAllToCPU, debug rows)
+  size_t staging_floats;
   int grid_surfels;  // persistent grid for the grid-stride all-slot kernels
   int grid_list;     // persistent grid of the chunked list kernels
 };
@@ -1268,18 +1348,26 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
   if (!copy_only) {
     SlotTimer t(r, st, kSlotRegAccumulate);
     hipLaunchKernelGGL(k_reg_accumulate, dim3(div_up((long long)r->nsegB * kSegB, kSegAcc)), dim3(kBlockAcc), 0, st, r->S, rf2, weight, r->grad_acc, r->grad_local,
-                       r->inwin8, r->need_seg, r->st);
+                       r->inbox, r->inwin8, r->need_seg, r->st);
   }
   if (copy_only) {
     SlotTimer t(r, st, kSlotRegUpdate);
     hipLaunchKernelGGL((k_reg_update<true>), gl, b, 0, st, r->S, r->L, r->st);
   } else {
     { SlotTimer t(r, st, kSlotRegStep);
-      hipLaunchKernelGGL(k_reg_step, gl, b, 0, st, r->S, weight, r->grad_acc, r->grad_local, r->L, r->st); }
+      hipLaunchKernelGGL(k_reg_step, gl, b, 0, st, r->S, weight, r->grad_acc, r->grad_local, r->inbox, r->L, r->st); }
     { SlotTimer t(r, st, kSlotRegUpdate);
       hipLaunchKernelGGL((k_reg_update<false>), gl, b, 0, st, r->S, r->L, r->st); }
   }
   SMX_LAUNCH_CHECK();
+  return SMX_OK;
+}
+
+int ensure_staging(smx_recon r, size_t floats) {
+  if (r->staging_floats >= floats) return SMX_OK;
+  if (r->staging) { SMX_HIP(hipDeviceSynchronize()); SMX_HIP(hipFree(r->staging)); r->staging = nullptr; r->staging_floats = 0; }
+  SMX_HIP(hipMalloc(reinterpret_cast<void**>(&r->staging), floats * sizeof(float)));
+  r->staging_floats = floats;
   return SMX_OK;
 }
 
@@ -1314,9 +1402,10 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
 #define SMX_TRY(x) do { rc = (x); if (rc != SMX_OK) return rc; } while (0)
   // cuda_surfel_reconstruction.cc:59 -- 25 rows x max_surfel_count (zero-filled here so that the
   // padded tail of every row is defined)
-  SMX_TRY(dev_alloc(&r->S.base, (size_t)kRows * r->S.pitch, true));
+  SMX_TRY(dev_alloc(&r->S.base, (size_t)kGroups * 4 * r->S.pitch, true));
   SMX_TRY(dev_alloc(&r->grad_acc, 4 * ((size_t)r->S.pitch + kSegAcc), true));
   SMX_TRY(dev_alloc(&r->grad_local, 4 * ((size_t)r->S.pitch + kSegAcc), true));
+  SMX_TRY(dev_alloc(&r->inbox, 4 * ((size_t)r->S.pitch + kSegAcc), true));
   r->nseg = div_up((long long)r->S.pitch, kSeg);
   r->nsegB = div_up((long long)r->S.pitch, kSegB);
   SMX_TRY(dev_alloc(&r->L.vis_list, (size_t)r->nseg * kSeg, false));
@@ -1361,7 +1450,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
 
 int smx_recon_destroy(smx_recon r) {
   if (!r) return SMX_OK;
-  void* ptrs[] = {r->S.base, r->grad_acc, r->grad_local, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.recent_seg, r->L.flags8,
+  void* ptrs[] = {r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.recent_seg, r->L.flags8,
                   r->merge_flag, r->inwin8, r->need_seg, r->sc.supporting, r->sc.counts,
                   r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->st};
@@ -1568,14 +1657,25 @@ int smx_recon_transfer_all_to_cpu(smx_recon r, smx_stream s, uint32_t frame_inde
   buf->surfel_count = n;
   if (n == 0) return SMX_OK;
   const size_t bytes = (size_t)n * 4;
+  // the 8 rows are packed out of the grouped records into a row-layout staging buffer, then copied row by row
+  int rc = ensure_staging(r, (size_t)8 * n);
+  if (rc != SMX_OK) return rc;
+  RowList rl;
+  rl.n = 8;
+  const int want[8] = {kSmoothX, kSmoothY, kSmoothZ, kRadiusSq, kNormalX, kNormalY, kNormalZ, kLastUpdateStamp};
+  for (int k = 0; k < 8; ++k) rl.rows[k] = want[k];
+  hipLaunchKernelGGL(k_pack_rows, dim3(r->grid_surfels), dim3(kBlock), 0, st, r->S, rl, r->staging, n);
+  SMX_LAUNCH_CHECK();
   struct { int row; void* dst; } rows[8] = {
       {kSmoothX, buf->surfel_x_buffer}, {kSmoothY, buf->surfel_y_buffer}, {kSmoothZ, buf->surfel_z_buffer},
       {kRadiusSq, buf->surfel_radius_squared_buffer},
       {kNormalX, buf->surfel_normal_x_buffer}, {kNormalY, buf->surfel_normal_y_buffer}, {kNormalZ, buf->surfel_normal_z_buffer},
       {kLastUpdateStamp, buf->surfel_last_update_stamp_buffer}};  // cc:348-358
+  int k = 0;
   for (auto& q : rows) {
     SMX_CHECK_ARG(q.dst != nullptr);
-    SMX_HIP(hipMemcpyAsync(q.dst, r->S.base + (size_t)q.row * r->S.pitch, bytes, hipMemcpyDeviceToHost, st));
+    SMX_HIP(hipMemcpyAsync(q.dst, r->staging + (size_t)k * n, bytes, hipMemcpyDeviceToHost, st));
+    ++k;
   }
   return SMX_OK;
 }
@@ -1600,8 +1700,13 @@ int smx_recon_get_timings(smx_recon r, float out_ms[7]) {
 int smx_recon_debug_download_surfels(smx_recon r, smx_stream s, float* rows, uint32_t count) {
   SMX_CHECK_ARG(r != nullptr && rows != nullptr && count <= r->max_surfels);
   if (count == 0) return SMX_OK;
-  SMX_HIP(hipMemcpy2DAsync(rows, (size_t)count * 4, r->S.base, r->S.pitch * 4, (size_t)count * 4, kRows,
-                           hipMemcpyDeviceToHost, (hipStream_t)s));
+  int rc = ensure_staging(r, (size_t)kRows * count);
+  if (rc != SMX_OK) return rc;
+  RowList rl;
+  rl.n = kRows;
+  for (int k = 0; k < kRows; ++k) rl.rows[k] = k;
+  hipLaunchKernelGGL(k_pack_rows, dim3(r->grid_surfels), dim3(kBlock), 0, (hipStream_t)s, r->S, rl, r->staging, count);
+  SMX_HIP(hipMemcpyAsync(rows, r->staging, (size_t)kRows * count * 4, hipMemcpyDeviceToHost, (hipStream_t)s));
   SMX_HIP(hipStreamSynchronize((hipStream_t)s));
   return SMX_OK;
 }
@@ -1609,14 +1714,22 @@ int smx_recon_debug_download_surfels(smx_recon r, smx_stream s, float* rows, uin
 int smx_recon_debug_upload_surfels(smx_recon r, smx_stream s, const float* rows, uint32_t count, uint32_t merge_count) {
   SMX_CHECK_ARG(r != nullptr && count <= r->max_surfels && (rows != nullptr || count == 0));
   hipStream_t st = (hipStream_t)s;
-  if (count) SMX_HIP(hipMemcpy2DAsync(r->S.base, r->S.pitch * 4, rows, (size_t)count * 4, (size_t)count * 4, kRows,
-                                      hipMemcpyHostToDevice, st));
+  if (count) {
+    int rc = ensure_staging(r, (size_t)kRows * count);
+    if (rc != SMX_OK) return rc;
+    SMX_HIP(hipMemcpyAsync(r->staging, rows, (size_t)kRows * count * 4, hipMemcpyHostToDevice, st));
+    RowList rl;
+    rl.n = kRows;
+    for (int k = 0; k < kRows; ++k) rl.rows[k] = k;
+    hipLaunchKernelGGL(k_unpack_rows, dim3(r->grid_surfels), dim3(kBlock), 0, st, r->S, rl, r->staging, count);
+  }
   DevState h;
   memset(&h, 0, sizeof(h));
   h.surfel_count = count; h.merge_count = merge_count;
   SMX_HIP(hipMemcpyAsync(r->st, &h, sizeof(h), hipMemcpyHostToDevice, st));
   SMX_HIP(hipMemsetAsync(r->grad_acc, 0, 4 * r->S.pitch * sizeof(long long), st));
   SMX_HIP(hipMemsetAsync(r->grad_local, 0, 4 * r->S.pitch * sizeof(long long), st));
+  SMX_HIP(hipMemsetAsync(r->inbox, 0, 4 * r->S.pitch * sizeof(float4), st));
   SMX_HIP(hipMemsetAsync(r->merge_flag, 0, r->S.pitch, st));
   SMX_HIP(hipMemsetAsync(r->L.vis_seg, 0, (size_t)r->nseg * 4, st));
   SMX_HIP(hipMemsetAsync(r->L.recent_seg, 0, (size_t)r->nsegB * 4, st));
