@@ -25,12 +25,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# Dominant kernel of the frame (profiles/): pass A streams stamp, X, Y, Z of every slot = 16 B per slot.
-DOMINANT_KERNEL = "scan_visible"
 
-
-def DOMINANT_BYTES(st):
-    return 16.0 * st["surfels_size"]
+# ALGORITHMIC bytes per launch of each kernel (DESIGN.md "Kernels and bytes"): every record a kernel has to read
+# or write counted once, cache effects and line granularity excluded.  N = slots, V = visible slots, R = slots
+# inside the regulariser window, C = slots with a link into the window, Ew = such links, E = all links, P = pixels.
+ALG_BYTES = {
+    "scan_visible": lambda st, P: 18.0 * st["surfels_size"] + 24.0 * st["n_visible"],
+    "neighbor_scan": lambda st, P: 18.0 * st["surfels_size"] + 1.0 * st["n_edges"] + 4.0 * st["n_recent"],
+    "reg_accumulate": lambda st, P: 49.0 * st["n_contributors"] + 48.0 * st["n_window_edges"],
+    "reg_step": lambda st, P: 272.0 * st["n_recent"],
+    "reg_update": lambda st, P: 36.0 * st["n_recent"],
+    "associate": lambda st, P: 90.0 * st["n_visible"],
+    "merge_decide": lambda st, P: 60.0 * st["n_visible"],
+    "integrate": lambda st, P: 160.0 * st["n_visible"],
+    "update_neighbors": lambda st, P: 190.0 * st["n_visible"],
+    "blend": lambda st, P: 26.0 * P,
+    "clear_assoc": lambda st, P: 26.0 * P,
+    "new_flags_scan": lambda st, P: 15.0 * P,
+    "new_create": lambda st, P: 6.0 * P + 122.0 * st["n_new"],
+    "new_finalize": lambda st, P: 8.0 * (P / 1024.0),
+}
 
 
 def pose64(g, seed_phase=0.0):
@@ -143,16 +157,15 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--surfels", type=int, default=5_000_000, help="live surfels to reach before timing")
     ap.add_argument("--cap", type=int, default=0, help="max_surfel_count (default: surfels * 1.1)")
-    ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the full-size GPU-vs-oracle check")
     ap.add_argument("--quiet", action="store_true")
     args = ap.parse_args()
 
     import torch  # first: libsmx then binds to the HIP runtime torch loaded
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from surfelmeshing_amd import multistream
+    rank, local_rank, world = multistream.rank_info()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -163,7 +176,8 @@ def main():
     log = (rank == 0) and not args.quiet
 
     cap = args.cap or int(args.surfels * 1.1)
-    wl = Workload(api, args.width, args.height, args.surfels, cap, 0x5EED0001 + rank, 0.37 * rank)
+    assign = multistream.stream_assignment(rank)   # one independent stream per rank, no data-path collective
+    wl = Workload(api, args.width, args.height, args.surfels, cap, assign["seed"], assign["phase"])
     t0 = time.time()
     g_end, n_grown = wl.grow(log)
     if log:
@@ -172,21 +186,29 @@ def main():
     # timed window: re-traverse the start of the trajectory (mapped area) with new frame indices
     K, W = args.steps, args.warmup
     first = g_end + 10
-    total = W + K
-    reps = 20
+    cal, reps = 10, 20
+    total = W + cal + K
     for j in range(-4, total + 1 + reps + 4):
         wl.render(first + j, 4 + j)
     plan = [wl.plan(first + j, 4 + j) for j in range(total + 1 + reps)]
-    warm_steps = wl.steps(plan[:W])
-    timed_steps = wl.steps(plan[W:W + K])
     api.StreamSynchronize(None)
 
     rec = wl.pipe.reconstruction
     rec.set_stats_enabled(False)   # the distribution counters are single-address atomics: off while timing
-    wl.pipe.run_array(*warm_steps)
+    wl.pipe.run_array(*wl.steps(plan[:W]))
+    # short calibration pass with HIP events around every kernel: which kernel dominates the frame?
+    rec.set_timing_enabled(2)
+    names = rec.kernel_time_names()
+    cal_ms = np.zeros(len(names))
+    for j in range(W, W + cal):
+        wl.pipe.run_array(*wl.steps(plan[j:j + 1]))
+        cal_ms += np.array(rec.kernel_times_ms())
+    rec.set_timing_enabled(0)
+    dominant = names[int(np.argmax(cal_ms))]
     api.StreamSynchronize(None)
     state0 = rec.debug_download_surfels() if (rank == 0 and args.cpu_frames > 0) else None
     merge0 = (rec.surfels_size() - rec.surfel_count()) if state0 is not None else 0
+    timed_steps = wl.steps(plan[W + cal:W + cal + K])
 
     def sync_all():
         torch.cuda.synchronize()
@@ -195,18 +217,17 @@ def main():
             torch.cuda.synchronize()
 
     # HIP events around the dominant kernel only (2 records per frame on the launch stream) stay on during
-    # the timed region; everything else is measured in a separate pass below.
-    rec.profile_begin(DOMINANT_KERNEL, K)
+    # the timed region; everything else is measured in separate passes.
+    rec.profile_begin(dominant, K)
     _lib.check(_lib.load().smx_debug_marker(None, 1))   # delimits the timed region in rocprofv3 kernel traces
     sync_all()
     t_start = time.perf_counter()
     wl.pipe.run_array(*timed_steps)          # K frames: preprocessing + Integrate each, enqueued by the C++ loop
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_start
+    elapsed_local = time.perf_counter() - t_start
+    from surfelmeshing_amd import multistream
+    fps, elapsed, _ = multistream.aggregate_throughput(K, elapsed_local, world, dist if world > 1 else None, "cuda")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         dist.barrier()
     dom_ms, dom_n = rec.profile_end()
     _lib.check(_lib.load().smx_debug_marker(None, 2))
@@ -220,7 +241,7 @@ def main():
     # per-stage and per-kernel device times (separate untimed pass, HIP events on the launch stream)
     rec.set_timing_enabled(3)
     stage_ms = np.zeros(7)
-    kernel_ms = np.zeros(len(rec.kernel_time_names()))
+    kernel_ms = np.zeros(len(names))
     for j in range(total + 1, total + 1 + reps):
         wl.pipe.run_array(*wl.steps(plan[j:j + 1]))
         stage_ms += np.array(rec.GetTimings())
@@ -229,7 +250,6 @@ def main():
     kernel_ms /= reps
     rec.set_timing_enabled(0)
 
-    fps = world * K / elapsed
     ref_bytes, own_bytes = algorithmic_bytes(st, args.width * args.height)
     result = {
         "metric": "RGB-D frames/s integrated @640x480, 5M live surfels; achieved HBM GB/s",
@@ -249,25 +269,32 @@ def main():
     }
 
     if rank == 0:
-        result["roofline"] = roofline_block(st, dom_ms, dom_n, dict(zip(rec.kernel_time_names(), [float(x) for x in kernel_ms])))
+        result["roofline"] = roofline_block(st, args.width * args.height, dominant, dom_ms, dom_n,
+                                            dict(zip(names, [float(x) for x in kernel_ms])))
         if args.cpu_frames > 0:
-            result["cpu_baseline"] = cpu_baseline(wl, plan, W, args.cpu_frames, state0, merge0, cap, not args.no_check, log)
+            result["cpu_baseline"] = cpu_baseline(wl, plan, W + cal, args.cpu_frames, state0, merge0, cap,
+                                                  not args.no_check, log)
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def roofline_block(st, dom_ms, dom_n, kernel_ms):
-    """Roofline of the dominant kernel: algorithmic bytes per launch (DESIGN.md 'Bytes') / average launch
+def roofline_block(st, P, dominant, dom_ms, dom_n, kernel_ms):
+    """Roofline of the dominant kernel: algorithmic bytes per launch (ALG_BYTES) / average launch
     duration measured with HIP events on the launch stream over the timed region."""
-    N = st["surfels_size"]
-    alg = DOMINANT_BYTES(st)
+    alg = ALG_BYTES[dominant](st, P)
     achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    return {"bound": "hbm", "kernel": DOMINANT_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    per_kernel = {}
+    for k, ms in kernel_ms.items():
+        if k in ALG_BYTES and ms > 0:
+            b = ALG_BYTES[k](st, P)
+            # the per-kernel pass brackets every launch with two event records (~6 us of overhead per kernel)
+            per_kernel[k] = {"ms_with_event_overhead": ms, "algorithmic_MB": b / 1e6}
+    return {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
-            "avg_launch_ms": dom_ms, "launches_timed": dom_n, "surfel_slots": N,
-            "all_kernels_ms_untimed_pass": kernel_ms}
+            "avg_launch_ms": dom_ms, "launches_timed": dom_n, "surfel_slots": st["surfels_size"],
+            "kernels_untimed_pass": per_kernel}
 
 
 def cpu_baseline(wl, plan, W, frames, state0, merge0, cap, check, log):

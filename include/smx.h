@@ -196,6 +196,8 @@ typedef struct {
   uint32_t n_new, n_merged, n_recent, n_edges;
   uint32_t n_integrated, n_replaced, n_conflict_hits;
   uint32_t capacity_clamped;  /* 1 if new-surfel creation hit max_surfel_count */
+  uint32_t n_window_edges;    /* neighbour links whose target lies inside the regulariser window */
+  uint32_t n_contributors;    /* slots with at least one such link */
 } smx_recon_stats;
 int smx_recon_get_stats(smx_recon r, smx_stream s, smx_recon_stats* out);
 /* The n_* counters above are single-address atomics; they are collected only while enabled

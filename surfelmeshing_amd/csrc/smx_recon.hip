@@ -42,7 +42,8 @@ struct DevState {
   uint32_t new_count;
   uint32_t capacity_clamped;
   uint32_t n_visible, n_merged, n_edges, n_integrated, n_replaced, n_conflict_hits;
-  uint32_t pad[3];
+  uint32_t n_window_edges, n_contributors;
+  uint32_t pad[1];
 };
 
 // HBM layout of the surfel attributes.  The reference keeps 25 separate rows (SoA, kernels.cuh:49-78); that is
@@ -999,7 +1000,11 @@ k_neighbor_scan(Surfels S, int stats, Lists L, uint8_t* __restrict__ inwin8, uin
       }
     }
     if (kAccumulate) *reinterpret_cast<uchar4*>(&inwin8[i0]) = make_uchar4(inw[0], inw[1], inw[2], inw[3]);
-    if (stats && kAccumulate && edges) atomicAdd(&st->n_edges, edges);
+    if (stats && kAccumulate && edges) {
+      atomicAdd(&st->n_edges, edges);
+      const uint32_t we = __popc(inw[0]) + __popc(inw[1]) + __popc(inw[2]) + __popc(inw[3]);
+      if (we) { atomicAdd(&st->n_window_edges, we); atomicAdd(&st->n_contributors, (uint32_t)((inw[0] != 0) + (inw[1] != 0) + (inw[2] != 0) + (inw[3] != 0))); }
+    }
   }
   uint32_t total;
   uint32_t off = base + block_excl_scan<kBlockB / 64>((uint32_t)__popc(recent_bits), wave_tot, total);
@@ -1200,7 +1205,7 @@ k_reg_update(Surfels S, Lists L, const DevState* st) {
   }
 }
 
-__global__ void k_reset_recent(DevState* st) { st->recent_count = 0; st->n_edges = 0; }
+__global__ void k_reset_recent(DevState* st) { st->recent_count = 0; st->n_edges = 0; st->n_window_edges = 0; st->n_contributors = 0; }
 
 // Boundary conversion between the grouped records and the reference's row layout: out[k][i] = row rows[k] of
 // slot i (pack) and back (unpack).  Rows without storage read as 0.
@@ -1644,6 +1649,7 @@ int smx_recon_get_stats(smx_recon r, smx_stream s, smx_recon_stats* out) {
   out->n_recent = h.recent_count; out->n_edges = h.n_edges;
   out->n_integrated = h.n_integrated; out->n_replaced = h.n_replaced; out->n_conflict_hits = h.n_conflict_hits;
   out->capacity_clamped = h.capacity_clamped;
+  out->n_window_edges = h.n_window_edges; out->n_contributors = h.n_contributors;
   return SMX_OK;
 }
 

@@ -1,0 +1,62 @@
+"""The N > 1 path on CPU: two processes over gloo, one independent stream each, no data-path collective; the only
+exchanged values are the barrier and the MAX / SUM reductions of the timing."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from common import small_pre  # noqa: F401  (path setup)
+from surfelmeshing_amd import multistream
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a = multistream.stream_assignment(rank)
+        # every rank integrates its own stream with the oracle-free host-side bookkeeping only (no GPU here):
+        # the "work" is a stand-in whose duration differs per rank
+        frames, seconds = 100, 0.5 + 0.25 * rank
+        dist.barrier()
+        fps, tmax, total = multistream.aggregate_throughput(frames, seconds, world, dist)
+        out.put((rank, a["seed"], a["phase"], fps, tmax, total))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_independent_streams():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    seeds = {r[1] for r in res}
+    assert len(seeds) == world                      # distinct streams
+    for r in res:
+        assert r[5] == 200.0 and abs(r[4] - 0.75) < 1e-9       # SUM of frames, MAX of time
+        assert abs(r[3] - 200.0 / 0.75) < 1e-6                 # identical aggregate on every rank
+
+
+def test_single_rank_passthrough():
+    fps, t, n = multistream.aggregate_throughput(50, 0.25, 1)
+    assert fps == 200.0 and t == 0.25 and n == 50
+    assert multistream.stream_assignment(3)["seed"] == 0x5EED0004
