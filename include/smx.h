@@ -67,6 +67,14 @@ int smx_device_name(int device, char* name, size_t capacity);
 int smx_stream_create(smx_stream* out);
 int smx_stream_destroy(smx_stream s);
 int smx_stream_synchronize(smx_stream s);
+/* Events for cross-stream ordering (hipEvent_t, timing disabled): the frame driver overlaps depth
+ * preprocessing of the next frame with the integration of the current one, as APP/main.cc overlaps uploads
+ * (main.cc:902, 995). */
+typedef void* smx_event;
+int smx_event_create(smx_event* out);
+int smx_event_destroy(smx_event e);
+int smx_event_record(smx_event e, smx_stream s);
+int smx_stream_wait_event(smx_stream s, smx_event e);
 /* Launches an empty kernel (k_smx_marker) that delimits regions in kernel traces. */
 int smx_debug_marker(smx_stream s, int32_t id);
 

@@ -58,6 +58,9 @@ int smx_driver_release_frame(smx_driver d, uint32_t frame_index);
 int smx_driver_frame_descs(smx_driver d, uint32_t frame_index, smx_buffer_desc* depth, smx_buffer_desc* color);
 /* Enqueue n frames (preprocessing + Integrate each) on the stream; returns without synchronising. */
 int smx_driver_run(smx_driver d, smx_stream s, const smx_driver_step* steps, int32_t n);
+/* Overlap of the depth preprocessing of frame f+1 (own stream, second set of work images) with Integrate(f);
+ * default on.  Results are identical either way. */
+int smx_driver_set_overlap(smx_driver d, int32_t enabled);
 /* Working buffers after the last frame: final (blended) depth, normals, radius. */
 int smx_driver_work_descs(smx_driver d, smx_buffer_desc* depth, smx_buffer_desc* normals, smx_buffer_desc* radius);
 

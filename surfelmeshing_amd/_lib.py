@@ -61,6 +61,7 @@ class ReconStats(C.Structure):
 EXPORTS = [
     "smx_last_error", "smx_device_count", "smx_set_device", "smx_device_name",
     "smx_stream_create", "smx_stream_destroy", "smx_stream_synchronize", "smx_debug_marker",
+    "smx_event_create", "smx_event_destroy", "smx_event_record", "smx_stream_wait_event",
     "smx_buffer_create", "smx_buffer_destroy", "smx_buffer_get_desc", "smx_buffer_upload", "smx_buffer_download",
     "smx_buffer_upload_part", "smx_buffer_download_part", "smx_buffer_clear", "smx_buffer_set_to",
     "smx_bilateral_filtering_and_depth_cutoff", "smx_outlier_depth_map_fusion", "smx_erode_depth_map",

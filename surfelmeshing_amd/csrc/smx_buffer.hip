@@ -37,13 +37,6 @@ __global__ void k_fill(T* __restrict__ base, size_t pitch, int width, int height
     *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (size_t)y * pitch + (size_t)x * sizeof(T)) = value;
 }
 
-__global__ void k_fill_bytes(char* __restrict__ base, size_t pitch, int row_bytes, int height, int elem,
-                             const char* __restrict__ pattern_dev) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y;
-  if (x < row_bytes && y < height) base[(size_t)y * pitch + x] = pattern_dev[x % elem];
-}
-
 // Empty kernel whose only purpose is to show up in kernel traces (rocprofv3 --kernel-trace) so that
 // tools/prof_summary.py can cut out the timed region of a benchmark run.
 __global__ void k_smx_marker(int id) { (void)id; }
@@ -95,6 +88,29 @@ int smx_stream_destroy(smx_stream s) {
 
 int smx_stream_synchronize(smx_stream s) {
   SMX_HIP(hipStreamSynchronize((hipStream_t)s));
+  return SMX_OK;
+}
+
+int smx_event_create(smx_event* out) {
+  SMX_CHECK_ARG(out != nullptr);
+  hipEvent_t e;
+  SMX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *out = (smx_event)e;
+  return SMX_OK;
+}
+
+int smx_event_destroy(smx_event e) {
+  if (e) SMX_HIP(hipEventDestroy((hipEvent_t)e));
+  return SMX_OK;
+}
+
+int smx_event_record(smx_event e, smx_stream s) {
+  SMX_HIP(hipEventRecord((hipEvent_t)e, (hipStream_t)s));
+  return SMX_OK;
+}
+
+int smx_stream_wait_event(smx_stream s, smx_event e) {
+  SMX_HIP(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)e, 0));
   return SMX_OK;
 }
 

@@ -15,29 +15,51 @@ struct Frame {
   Frame(int h, int w) : depth(h, w), color(h, w) {}
 };
 
+// The per-frame work images (main.cc:801-812).  Two sets: the preprocessing of frame f+1 runs on its own stream
+// while Integrate(f) still reads the other set.
+struct WorkSet {
+  CUDABuffer<u16> filtered_depth_buffer_A, filtered_depth_buffer_B;
+  CUDABuffer<float2_> normals_buffer;
+  CUDABuffer<float> radius_buffer;
+  CUDABuffer<u16>* final_depth;
+  smx_event preprocessed = nullptr, integrated = nullptr;
+  bool used = false;
+  WorkSet(int h, int w) : filtered_depth_buffer_A(h, w), filtered_depth_buffer_B(h, w), normals_buffer(h, w),
+                          radius_buffer(h, w), final_depth(&filtered_depth_buffer_A) {
+    radius_buffer.Clear(0.0f, nullptr);
+    SMX_SHIM_CHECK(smx_event_create(&preprocessed));
+    SMX_SHIM_CHECK(smx_event_create(&integrated));
+  }
+  ~WorkSet() { smx_event_destroy(preprocessed); smx_event_destroy(integrated); }
+};
+
 struct smx_driver_s {
   smx_driver_config cfg;
   PinholeCamera4f camera;
   CUDASurfelReconstruction reconstruction;
-  CUDABuffer<u16> filtered_depth_buffer_A, filtered_depth_buffer_B;
-  CUDABuffer<float2_> normals_buffer;
-  CUDABuffer<float> radius_buffer;
+  WorkSet work0, work1;
+  WorkSet* last;
   std::map<u32, std::unique_ptr<Frame>> frames;
-  CUDABuffer<u16>* final_depth;
+  cudaStream_t pre_stream = nullptr;   // depth preprocessing of the next frame
+  smx_event run_start = nullptr;
+  bool overlap = true;
+  unsigned long long frame_counter = 0;
 
   explicit smx_driver_s(const smx_driver_config& c, const float* intr)
       : cfg(c), camera(c.width, c.height, intr), reconstruction(c.max_surfel_count, camera),
-        filtered_depth_buffer_A(c.height, c.width), filtered_depth_buffer_B(c.height, c.width),
-        normals_buffer(c.height, c.width), radius_buffer(c.height, c.width), final_depth(&filtered_depth_buffer_A) {
-    radius_buffer.Clear(0.0f, nullptr);
+        work0(c.height, c.width), work1(c.height, c.width), last(&work0) {
+    SMX_SHIM_CHECK(smx_stream_create(&pre_stream));
+    SMX_SHIM_CHECK(smx_event_create(&run_start));
+    SMX_SHIM_CHECK(smx_stream_synchronize(nullptr));
   }
+  ~smx_driver_s() { smx_stream_synchronize(pre_stream); smx_stream_destroy(pre_stream); smx_event_destroy(run_start); }
 };
 
 namespace smx { void set_error(const char* fmt, ...); }  // libsmx's thread-local error text (smx_last_error)
 static int fail(const char* msg) { smx::set_error("smx_driver: %s", msg); return SMX_ERR_INVALID_ARGUMENT; }
 
-// One iteration of the frame loop, APP/main.cc:1015-1223.
-static int process_frame(smx_driver d, cudaStream_t stream, const smx_driver_step& st) {
+// Depth preprocessing of one frame, APP/main.cc:1015-1191.
+static int preprocess_frame(smx_driver d, cudaStream_t stream, const smx_driver_step& st, WorkSet* ws) {
   const smx_driver_config& c = d->cfg;
   auto it = d->frames.find(st.frame_index);
   if (it == d->frames.end()) return fail("frame not resident");
@@ -49,9 +71,9 @@ static int process_frame(smx_driver d, cudaStream_t stream, const smx_driver_ste
                                        /*value_to_ignore*/ 0, c.bilateral_filter_radius_factor,
                                        (u16)(c.depth_scaling * c.max_depth > 65535.f ? 65535.f : c.depth_scaling * c.max_depth),
                                        c.depth_valid_region_radius, depth_buffer.ToCUDA(),
-                                       &d->filtered_depth_buffer_A.ToCUDA());
-  CUDABuffer<u16>* src = &d->filtered_depth_buffer_A;
-  CUDABuffer<u16>* dst = &d->filtered_depth_buffer_B;
+                                       &ws->filtered_depth_buffer_A.ToCUDA());
+  CUDABuffer<u16>* src = &ws->filtered_depth_buffer_A;
+  CUDABuffer<u16>* dst = &ws->filtered_depth_buffer_B;
 
   // Depth outlier filtering (:1037-1115)
   if (st.other_count > 0) {
@@ -90,18 +112,26 @@ static int process_frame(smx_driver d, cudaStream_t stream, const smx_driver_ste
   std::swap(src, dst);
   // Normals (:1154-1164)
   ComputeNormalsAndDropBadPixelsCUDA(stream, c.observation_angle_threshold_deg, c.depth_scaling, cam[0], cam[1], cam[2],
-                                     cam[3], src->ToCUDA(), &dst->ToCUDA(), &d->normals_buffer.ToCUDA());
+                                     cam[3], src->ToCUDA(), &dst->ToCUDA(), &ws->normals_buffer.ToCUDA());
   std::swap(src, dst);
   // Radii (:1180-1191)
   ComputePointRadiiAndRemoveIsolatedPixelsCUDA(stream, c.point_radius_extension_factor, c.point_radius_clamp_factor,
                                                c.depth_scaling, cam[0], cam[1], cam[2], cam[3], src->ToCUDA(),
-                                               &d->radius_buffer.ToCUDA(), &dst->ToCUDA());
+                                               &ws->radius_buffer.ToCUDA(), &dst->ToCUDA());
   std::swap(src, dst);
-  d->final_depth = src;
+  ws->final_depth = src;
+  return SMX_OK;
+}
+
+// Surfel reconstruction of one preprocessed frame, APP/main.cc:1205-1223.
+static int integrate_frame(smx_driver d, cudaStream_t stream, const smx_driver_step& st, WorkSet* ws) {
+  const smx_driver_config& c = d->cfg;
+  auto it = d->frames.find(st.frame_index);
+  if (it == d->frames.end()) return fail("frame not resident");
 
   // Surfel reconstruction (:1205-1223)
   const smx_integrate_params& p = c.integrate;
-  d->reconstruction.Integrate(stream, st.frame_index, c.depth_scaling, src, d->normals_buffer, d->radius_buffer,
+  d->reconstruction.Integrate(stream, st.frame_index, c.depth_scaling, ws->final_depth, ws->normals_buffer, ws->radius_buffer,
                               it->second->color, SE3f(st.global_T_frame), p.sensor_noise_factor,
                               p.max_surfel_confidence, p.regularizer_weight, p.regularization_frame_window_size,
                               p.do_blending != 0, p.measurement_blending_radius,
@@ -167,18 +197,46 @@ int smx_driver_frame_descs(smx_driver d, uint32_t frame_index, smx_buffer_desc* 
 
 int smx_driver_run(smx_driver d, smx_stream s, const smx_driver_step* steps, int32_t n) {
   if (!d || (!steps && n > 0)) return fail("null argument");
-  for (int i = 0; i < n; ++i) {
-    int rc = process_frame(d, s, steps[i]);
-    if (rc != SMX_OK) return rc;
+  // Everything already enqueued on s (frame uploads / renders, earlier runs) precedes the first preprocessing.
+  if (d->overlap) {
+    SMX_SHIM_CHECK(smx_event_record(d->run_start, s));
+    SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, d->run_start));
   }
+  for (int i = 0; i < n; ++i) {
+    WorkSet* ws = (d->frame_counter++ & 1) ? &d->work1 : &d->work0;
+    int rc;
+    if (d->overlap) {
+      // preprocessing(f) on its own stream: it may start as soon as Integrate(f-2) has released this work set,
+      // i.e. it overlaps Integrate(f-1); Integrate(f) then waits for it.
+      if (ws->used) SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, ws->integrated));
+      rc = preprocess_frame(d, d->pre_stream, steps[i], ws);
+      if (rc != SMX_OK) return rc;
+      SMX_SHIM_CHECK(smx_event_record(ws->preprocessed, d->pre_stream));
+      SMX_SHIM_CHECK(smx_stream_wait_event(s, ws->preprocessed));
+    } else {
+      rc = preprocess_frame(d, s, steps[i], ws);
+      if (rc != SMX_OK) return rc;
+    }
+    rc = integrate_frame(d, s, steps[i], ws);
+    if (rc != SMX_OK) return rc;
+    if (d->overlap) SMX_SHIM_CHECK(smx_event_record(ws->integrated, s));
+    ws->used = true;
+    d->last = ws;
+  }
+  return SMX_OK;
+}
+
+int smx_driver_set_overlap(smx_driver d, int32_t enabled) {
+  if (!d) return fail("null argument");
+  d->overlap = enabled != 0;
   return SMX_OK;
 }
 
 int smx_driver_work_descs(smx_driver d, smx_buffer_desc* depth, smx_buffer_desc* normals, smx_buffer_desc* radius) {
   if (!d) return fail("null argument");
-  if (depth) *depth = *d->final_depth->ToCUDA().desc();
-  if (normals) *normals = *d->normals_buffer.ToCUDA().desc();
-  if (radius) *radius = *d->radius_buffer.ToCUDA().desc();
+  if (depth) *depth = *d->last->final_depth->ToCUDA().desc();
+  if (normals) *normals = *d->last->normals_buffer.ToCUDA().desc();
+  if (radius) *radius = *d->last->radius_buffer.ToCUDA().desc();
   return SMX_OK;
 }
 
@@ -193,9 +251,9 @@ int smx_driver_download_frame(smx_driver d, smx_stream s, uint32_t frame_index, 
 
 int smx_driver_download_work(smx_driver d, smx_stream s, uint16_t* depth, float* normals, float* radius) {
   if (!d) return fail("null argument");
-  if (depth) d->final_depth->DownloadAsync(s, depth);
-  if (normals) d->normals_buffer.DownloadAsync(s, reinterpret_cast<float2_*>(normals));
-  if (radius) d->radius_buffer.DownloadAsync(s, radius);
+  if (depth) d->last->final_depth->DownloadAsync(s, depth);
+  if (normals) d->last->normals_buffer.DownloadAsync(s, reinterpret_cast<float2_*>(normals));
+  if (radius) d->last->radius_buffer.DownloadAsync(s, radius);
   return smx_stream_synchronize(s);
 }
 

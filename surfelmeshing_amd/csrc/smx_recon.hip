@@ -296,9 +296,9 @@ __device__ __forceinline__ bool chunk_entry(const uint32_t* __restrict__ list, c
 
 // ---------------------------------------------------------------------------------------------
 // AssociateSurfelsCUDAKernel / ConsiderSurfelAssociationToPixel, kernels.cu:1586-1808.
-__device__ __forceinline__ void associate_at(const Surfels& S, const FrameCtx& c, const Scratch& sc,
+__device__ __forceinline__ void associate_at(const FrameCtx& c, const Scratch& sc,
                                              const Img<const uint16_t>& depth, const Img<const float2>& normals,
-                                             int x, int y, const Proj& p, uint32_t i) {
+                                             int x, int y, const Proj& p, uint32_t i, const Vec3& gn, float r2) {
   const size_t k = (size_t)y * c.W + x;
   const float measurement_depth = c.inv_depth_scaling * (float)depth(y, x);
   if (measurement_depth <= 0) return;
@@ -311,7 +311,6 @@ __device__ __forceinline__ void associate_at(const Surfels& S, const FrameCtx& c
   const float occlusion_depth = (1 + c.sensor_noise_factor) * measurement_depth;
   if (p.l.z > occlusion_depth) return;
   const float surfel_distance = sqrtf(p.l.x * p.l.x + p.l.y * p.l.y + p.l.z * p.l.z);
-  const Vec3 gn = {S.f(kNormalX, i), S.f(kNormalY, i), S.f(kNormalZ, i)};
   const Vec3 ln = rotate(c.L, gn);
   const float dot_angle = (1.0f / surfel_distance) * (p.l.x * ln.x + p.l.y * ln.y + p.l.z * ln.z);
   if (dot_angle > 0) return;
@@ -321,7 +320,7 @@ __device__ __forceinline__ void associate_at(const Surfels& S, const FrameCtx& c
     const float d = ln.x * n.x + ln.y * n.y + ln.z * nz;
     if (d < c.cos_normal_compat) return;
   }
-  if (S.f(kRadiusSq, i) <= 0) return;  // :1674
+  if (r2 <= 0) return;  // :1674
   atomicMin(&sc.supporting[k], i);      // :1688 first-wins CAS -> lowest index
   atomicAdd(&sc.counts[k], 1u);
   atomicAdd(reinterpret_cast<unsigned long long*>(&sc.depth_sums[k]), (unsigned long long)q_from_float(p.l.z));
@@ -335,12 +334,15 @@ k_associate(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<co
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     uint32_t i;
     if (!chunk_entry<kUseList>(L.vis_list, L.vis_seg, n_slots, chunk, i)) continue;
-    if (!is_active(S.u(kLastUpdateStamp, i), c.frame, c.window)) continue;
+    const float4 p4 = *S.group(kGroupP, i), n4 = *S.group(kGroupN, i);  // both records in flight together
+    if (!is_active(__float_as_uint(p4.w), c.frame, c.window)) continue;
     Proj p;
-    if (!project(S, i, c, p)) continue;
-    associate_at(S, c, sc, depth, normals, p.px, p.py, p, i);
+    const Vec3 g = {p4.x, p4.y, p4.z};
+    if (!project_pos(g, c, p)) continue;
+    const Vec3 gn = {n4.x, n4.y, n4.z};
+    associate_at(c, sc, depth, normals, p.px, p.py, p, i, gn, n4.w);
     int ox, oy;
-    if (quadrant(p, c, ox, oy)) associate_at(S, c, sc, depth, normals, ox, oy, p, i);
+    if (quadrant(p, c, ox, oy)) associate_at(c, sc, depth, normals, ox, oy, p, i, gn, n4.w);
   }
 }
 
@@ -350,7 +352,7 @@ k_associate(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<co
 // at the top of k_integrate, after every decision has read pre-merge state.
 __device__ __forceinline__ bool merge_decide(const Surfels& S, const FrameCtx& c, const Scratch& sc,
                                              const Img<const uint16_t>& depth, const Img<const float2>& normals,
-                                             const Proj& p, uint32_t i, float r2) {
+                                             const Proj& p, uint32_t i, const Vec3& gn, float r2) {
   const int x = p.px, y = p.py;
   const size_t k = (size_t)y * c.W + x;
   const float measurement_depth = c.inv_depth_scaling * (float)depth(y, x);
@@ -364,7 +366,6 @@ __device__ __forceinline__ bool merge_decide(const Surfels& S, const FrameCtx& c
   const float occlusion_depth = (1 + c.sensor_noise_factor) * measurement_depth;
   if (p.l.z > occlusion_depth) return false;
   const float surfel_distance = sqrtf(p.l.x * p.l.x + p.l.y * p.l.y + p.l.z * p.l.z);
-  const Vec3 gn = {S.f(kNormalX, i), S.f(kNormalY, i), S.f(kNormalZ, i)};
   const Vec3 ln = rotate(c.L, gn);
   float dot_angle = (1.0f / surfel_distance) * (p.l.x * ln.x + p.l.y * ln.y + p.l.z * ln.z);
   if (dot_angle > 0) return false;
@@ -376,15 +377,16 @@ __device__ __forceinline__ bool merge_decide(const Surfels& S, const FrameCtx& c
   }
   const uint32_t s = sc.supporting[k];
   if (s == i || s == kInvalid) return false;  // :1950-1953
-  const float other_r2 = S.f(kRadiusSq, s);
+  const float4 sp4 = *S.group(kGroupP, s), sn4 = *S.group(kGroupN, s);  // the supported surfel's two records
+  const float other_r2 = sn4.w;
   const float radius_diff = r2 / other_r2;
   const float kT = 1.2f * 1.2f;
   if (radius_diff > kT || radius_diff < 1 / kT) return false;
-  const float dx = p.g.x - S.f(kX, s), dy = p.g.y - S.f(kY, s), dz = p.g.z - S.f(kZ, s);
+  const float dx = p.g.x - sp4.x, dy = p.g.y - sp4.y, dz = p.g.z - sp4.z;
   const float d2 = dx * dx + dy * dy + dz * dz;
   const float kDist = 0.5f * (0.25f * 0.25f);
   if (d2 > kDist * (r2 + other_r2)) return false;
-  dot_angle = gn.x * S.f(kNormalX, s) + gn.y * S.f(kNormalY, s) + gn.z * S.f(kNormalZ, s);
+  dot_angle = gn.x * sn4.x + gn.y * sn4.y + gn.z * sn4.z;
   if (dot_angle < 0.93969f) return false;
   return true;
 }
@@ -397,11 +399,14 @@ k_merge_decide(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     uint32_t i;
     if (!chunk_entry<kUseList>(L.vis_list, L.vis_seg, n_slots, chunk, i)) continue;
-    const float r2 = S.f(kRadiusSq, i);
+    const float4 p4 = *S.group(kGroupP, i), n4 = *S.group(kGroupN, i);
+    const float r2 = n4.w;
     if (!(r2 >= 0)) continue;  // :2017
     Proj p;
-    if (!project(S, i, c, p)) continue;
-    if (merge_decide(S, c, sc, depth, normals, p, i, r2)) merge_flag[i] = 1;
+    const Vec3 g = {p4.x, p4.y, p4.z};
+    if (!project_pos(g, c, p)) continue;
+    const Vec3 gn = {n4.x, n4.y, n4.z};
+    if (merge_decide(S, c, sc, depth, normals, p, i, gn, r2)) merge_flag[i] = 1;
   }
 }
 
@@ -713,10 +718,14 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
       ++merged_here;
       continue;  // r^2 < 0: the integrate kernel does nothing for it (:1050-1052)
     }
-    if (!is_active(S.u(kLastUpdateStamp, i), c.frame, c.window)) continue;
+    // P and N records requested together; integrate_or_conflict re-reads individual fields afterwards (the
+    // second pixel must see what the first one wrote), by then from cache
+    const float4 p4 = *S.group(kGroupP, i), n4 = *S.group(kGroupN, i);
+    if (!is_active(__float_as_uint(p4.w), c.frame, c.window)) continue;
     Proj p;
-    if (!project(S, i, c, p)) continue;
-    if (S.f(kRadiusSq, i) < 0) continue;
+    const Vec3 g = {p4.x, p4.y, p4.z};
+    if (!project_pos(g, c, p)) continue;
+    if (n4.w < 0) continue;
     integrate_or_conflict(S, c, sc, in, true, p.px, p.py, p.l, i, st);
     int ox = 0, oy = 0;
     const bool second = quadrant(p, c, ox, oy);
@@ -743,43 +752,62 @@ k_update_neighbors(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, const
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     uint32_t i;
     if (!chunk_entry<kUseList>(L.vis_list, L.vis_seg, n_slots, chunk, i)) continue;
-    if (!is_active(S.u(kLastUpdateStamp, i), c.frame, c.window)) continue;
-    const Vec3 g = {S.f(kX, i), S.f(kY, i), S.f(kZ, i)};
+    // the slot's three records in flight together (P: position + stamp, N: normal + r^2, T: neighbour ids)
+    const float4 p4 = *S.group(kGroupP, i), n4 = *S.group(kGroupN, i);
+    const uint4 t4 = *reinterpret_cast<const uint4*>(S.group(kGroupT, i));
+    if (!is_active(__float_as_uint(p4.w), c.frame, c.window)) continue;
+    const Vec3 g = {p4.x, p4.y, p4.z};
     const Vec3 cam = mul(c.L, g);
     if (!(cam.z > 0)) continue;
     const float u = c.fx * (cam.x / cam.z) + c.cx, v = c.fy * (cam.y / cam.z) + c.cy;
     if (!(u >= 1.0f && v >= 1.0f && u < (float)(c.W - 1) && v < (float)(c.H - 1))) continue;  // :1232-1240
     const int x = (int)u, y = (int)v;
+    // the pixel-side reads that do not depend on each other
     const float measurement_depth = c.inv_depth_scaling * (float)in.depth(y, x);
+    const float obs_r2 = in.radius(y, x);
+    uint32_t cand[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) cand[d] = sc.supporting[(size_t)(y + kDY[d]) * c.W + (x + kDX[d])];
     const float occlusion_depth = (1 + c.sensor_noise_factor) * measurement_depth;
     if (cam.z > occlusion_depth) continue;
     const float surfel_distance = sqrtf(cam.x * cam.x + cam.y * cam.y + cam.z * cam.z);
-    const Vec3 gn = {S.f(kNormalX, i), S.f(kNormalY, i), S.f(kNormalZ, i)};
+    const Vec3 gn = {n4.x, n4.y, n4.z};
     const Vec3 ln = rotate(c.L, gn);
     const float dot_angle = (1.0f / surfel_distance) * (cam.x * ln.x + cam.y * ln.y + cam.z * ln.z);
     if (dot_angle > 0) continue;
-    const float r2 = S.f(kRadiusSq, i);
+    const float r2 = n4.w;
     if (r2 < 0) continue;
-    if (in.radius(y, x) / r2 > 1.5f * 1.5f) continue;  // :1287-1291
+    if (obs_r2 / r2 > 1.5f * 1.5f) continue;  // :1287-1291
 
-    float nd2[4]; uint32_t ni[4];
+    // gathers of the 4 current neighbours (P) and the 4 candidates (P, N), all issued before the first use;
+    // empty slots read the slot's own records
+    uint32_t ni[4] = {t4.x, t4.y, t4.z, t4.w};
+    float4 np4[4], cp4[4], cn4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) np4[q] = *S.group(kGroupP, ni[q] == kInvalid ? i : ni[q]);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t gidx = (cand[d] == kInvalid) ? i : cand[d];
+      cp4[d] = *S.group(kGroupP, gidx);
+      cn4[d] = *S.group(kGroupN, gidx);
+    }
+    float nd2[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      ni[q] = S.u(kNeighbor0 + q, i);
       if (ni[q] == kInvalid) nd2[q] = __builtin_inff();
       else {
-        const float dx = g.x - S.f(kX, ni[q]), dy = g.y - S.f(kY, ni[q]), dz = g.z - S.f(kZ, ni[q]);
+        const float dx = g.x - np4[q].x, dy = g.y - np4[q].y, dz = g.z - np4[q].z;
         nd2[q] = dx * dx + dy * dy + dz * dz;
       }
     }
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      const uint32_t nb = sc.supporting[(size_t)(y + kDY[d]) * c.W + (x + kDX[d])];
+      const uint32_t nb = cand[d];
       if (nb == kInvalid || nb == i) continue;
-      const float dx = S.f(kX, nb) - g.x, dy = S.f(kY, nb) - g.y, dz = S.f(kZ, nb) - g.z;
+      const float dx = cp4[d].x - g.x, dy = cp4[d].y - g.y, dz = cp4[d].z - g.z;
       const float d2 = dx * dx + dy * dy + dz * dz;
       if (d2 > c.rf2 * r2) continue;
-      const float nd = gn.x * S.f(kNormalX, nb) + gn.y * S.f(kNormalY, nb) + gn.z * S.f(kNormalZ, nb);
+      const float nd = gn.x * cn4[d].x + gn.y * cn4[d].y + gn.z * cn4[d].z;
       if (nd <= 0) continue;
       int best_n = -1; float best_d2 = -1;
 #pragma unroll
@@ -793,8 +821,8 @@ k_update_neighbors(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, const
         for (int q = 0; q < 4; ++q) if (q == best_n) { ni[q] = nb; nd2[q] = d2; }
       }
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) S.u(kNeighbor0 + q, i) = ni[q];
+    if (ni[0] != t4.x || ni[1] != t4.y || ni[2] != t4.z || ni[3] != t4.w)
+      *reinterpret_cast<uint4*>(S.group(kGroupT, i)) = make_uint4(ni[0], ni[1], ni[2], ni[3]);
   }
 }
 

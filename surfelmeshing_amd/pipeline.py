@@ -131,7 +131,7 @@ class DriverStep(_C.Structure):
 
 DRIVER_EXPORTS = ["smx_driver_create", "smx_driver_destroy", "smx_driver_recon", "smx_driver_upload_frame",
                   "smx_driver_render_frame", "smx_driver_release_frame", "smx_driver_frame_descs", "smx_driver_run",
-                  "smx_driver_work_descs", "smx_driver_download_frame", "smx_driver_download_work"]
+                  "smx_driver_work_descs", "smx_driver_download_frame", "smx_driver_download_work", "smx_driver_set_overlap"]
 
 
 class _BorrowedRecon(api.CUDASurfelReconstruction):
@@ -171,6 +171,9 @@ class NativeFramePipeline:
         _smxlib.check(L.smx_driver_recon(self._d, _C.byref(rh)))
         self.reconstruction = _BorrowedRecon(rh, api.PinholeCamera4f(width, height, fx, fy, cx, cy))
         self.resident = set()
+
+    def set_overlap(self, enabled):
+        _smxlib.check(_smxlib.load().smx_driver_set_overlap(self._d, _C.c_int32(1 if enabled else 0)))
 
     def _s(self):
         return api._sv(self.stream)
