@@ -296,13 +296,19 @@ __device__ __forceinline__ bool chunk_entry(const uint32_t* __restrict__ list, c
 
 // ---------------------------------------------------------------------------------------------
 // AssociateSurfelsCUDAKernel / ConsiderSurfelAssociationToPixel, kernels.cu:1586-1808.
-__device__ __forceinline__ void associate_at(const FrameCtx& c, const Scratch& sc,
-                                             const Img<const uint16_t>& depth, const Img<const float2>& normals,
+struct AssocPixel { uint16_t depth; float first; float2 nxy; };
+__device__ __forceinline__ AssocPixel load_assoc_pixel(const FrameCtx& c, const Scratch& sc, const Img<const uint16_t>& depth,
+                                                       const Img<const float2>& normals, int x, int y) {
+  AssocPixel a;
+  a.depth = depth(y, x); a.first = sc.first_depth[(size_t)y * c.W + x]; a.nxy = normals(y, x);
+  return a;
+}
+__device__ __forceinline__ void associate_at(const FrameCtx& c, const Scratch& sc, const AssocPixel& px,
                                              int x, int y, const Proj& p, uint32_t i, const Vec3& gn, float r2) {
   const size_t k = (size_t)y * c.W + x;
-  const float measurement_depth = c.inv_depth_scaling * (float)depth(y, x);
+  const float measurement_depth = c.inv_depth_scaling * (float)px.depth;
   if (measurement_depth <= 0) return;
-  const float first = sc.first_depth[k];
+  const float first = px.first;
   if (first < (1 - c.sensor_noise_factor) * measurement_depth) {
     // :1615 racing plain store -> deterministic: associate-phase writers carry class bit 31
     if (first == p.l.z) atomicMin(&sc.confl_key[k], 0x80000000u | i);
@@ -315,7 +321,7 @@ __device__ __forceinline__ void associate_at(const FrameCtx& c, const Scratch& s
   const float dot_angle = (1.0f / surfel_distance) * (p.l.x * ln.x + p.l.y * ln.y + p.l.z * ln.z);
   if (dot_angle > 0) return;
   if (measurement_depth < p.l.z) {
-    const float2 n = normals(y, x);
+    const float2 n = px.nxy;
     const float nz = meas_normal_z(n.x, n.y);
     const float d = ln.x * n.x + ln.y * n.y + ln.z * nz;
     if (d < c.cos_normal_compat) return;
@@ -340,9 +346,12 @@ k_associate(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<co
     const Vec3 g = {p4.x, p4.y, p4.z};
     if (!project_pos(g, c, p)) continue;
     const Vec3 gn = {n4.x, n4.y, n4.z};
-    associate_at(c, sc, depth, normals, p.px, p.py, p, i, gn, n4.w);
-    int ox, oy;
-    if (quadrant(p, c, ox, oy)) associate_at(c, sc, depth, normals, ox, oy, p, i, gn, n4.w);
+    int ox = p.px, oy = p.py;
+    const bool second = quadrant(p, c, ox, oy);
+    const AssocPixel a0 = load_assoc_pixel(c, sc, depth, normals, p.px, p.py);
+    const AssocPixel a1 = load_assoc_pixel(c, sc, depth, normals, ox, oy);  // both pixels' reads in flight together
+    associate_at(c, sc, a0, p.px, p.py, p, i, gn, n4.w);
+    if (second) associate_at(c, sc, a1, ox, oy, p, i, gn, n4.w);
   }
 }
 
@@ -610,18 +619,30 @@ struct FrameIn {
   Img<const uint16_t> depth; Img<const float2> normals; Img<const float> radius; Img<const uchar3> color;
 };
 
-__device__ __forceinline__ void integrate_or_conflict(const Surfels& S, const FrameCtx& c, const Scratch& sc,
-                                                      const FrameIn& in, bool integrate, int x, int y,
+// Everything the integration reads at one pixel, requested in one go (7 independent loads) before any of it
+// is used -- for both pixels of a surfel at once, see k_integrate.
+struct PixelIn {
+  uint16_t depth; float first; uint32_t key; uint32_t count; float2 nxy; uchar3 col; float radius;
+};
+__device__ __forceinline__ PixelIn load_pixel(const FrameCtx& c, const Scratch& sc, const FrameIn& in, int x, int y) {
+  const size_t k = (size_t)y * c.W + x;
+  PixelIn p;
+  p.depth = in.depth(y, x); p.first = sc.first_depth[k]; p.key = sc.confl_key[k]; p.count = sc.counts[k];
+  p.nxy = in.normals(y, x); p.col = in.color(y, x); p.radius = in.radius(y, x);
+  return p;
+}
+
+__device__ __forceinline__ void integrate_or_conflict(const Surfels& S, const FrameCtx& c, const PixelIn& px,
+                                                      bool integrate, int x, int y,
                                                       const Vec3& cam, uint32_t i, DevState* st) {
   if (!integrate) return;
-  const size_t k = (size_t)y * c.W + x;
-  const float measurement_depth = c.inv_depth_scaling * (float)in.depth(y, x);
+  const float measurement_depth = c.inv_depth_scaling * (float)px.depth;
   if (measurement_depth <= 0) return;
   bool conflicting = false;
-  const float first = sc.first_depth[k];
+  const float first = px.first;
   if (first < (1 - c.sensor_noise_factor) * measurement_depth) {
     if (first == cam.z) {
-      const uint32_t key = sc.confl_key[k];
+      const uint32_t key = px.key;
       if (key != kInvalid && (key & 0x7FFFFFFFu) == i) conflicting = true;
     }
     integrate = false;
@@ -634,10 +655,10 @@ __device__ __forceinline__ void integrate_or_conflict(const Surfels& S, const Fr
   const float depth = measurement_depth;
   const Vec3 lp = {depth * (c.up.fx_inv * (float)x + c.up.cx_inv), depth * (c.up.fy_inv * (float)y + c.up.cy_inv), depth};
   const Vec3 gp = mul(c.G, lp);
-  const float2 nxy = in.normals(y, x);
+  const float2 nxy = px.nxy;
   const Vec3 mn = {nxy.x, nxy.y, meas_normal_z(nxy.x, nxy.y)};
   const Vec3 gn = rotate(c.G, mn);
-  const uchar3 col = in.color(y, x);
+  const uchar3 col = px.col;
 
   if (conflicting) {  // :816-868
     if (c.stats) atomicAdd(&st->n_conflict_hits, 1u);
@@ -649,7 +670,7 @@ __device__ __forceinline__ void integrate_or_conflict(const Surfels& S, const Fr
       S.f(kSmoothX, i) = gp.x; S.f(kSmoothY, i) = gp.y; S.f(kSmoothZ, i) = gp.z;
       S.f(kNormalX, i) = gn.x; S.f(kNormalY, i) = gn.y; S.f(kNormalZ, i) = gn.z;
       S.u(kColor, i) = (uint32_t)col.x | ((uint32_t)col.y << 8) | ((uint32_t)col.z << 16) | (1u << 24);
-      S.f(kRadiusSq, i) = in.radius(y, x);
+      S.f(kRadiusSq, i) = px.radius;
 #pragma unroll
       for (int n = 0; n < 4; ++n) S.u(kNeighbor0 + n, i) = kInvalid;
       S.f(kConfidence, i) = 1;
@@ -674,7 +695,7 @@ __device__ __forceinline__ void integrate_or_conflict(const Surfels& S, const Fr
   if (old_r2 < 0) integrate = false;
   if (!integrate) return;
 
-  uint32_t cnt = sc.counts[k];  // :933
+  uint32_t cnt = px.count;  // :933
   if (cnt < 1) cnt = 1;
   const float weight = 1.0f / (float)cnt;
   if (S.u(kCreationStamp, i) < c.frame) {  // :940
@@ -688,7 +709,7 @@ __device__ __forceinline__ void integrate_or_conflict(const Surfels& S, const Fr
     const Vec3 nn = {confidence * sn.x + weight * gn.x, confidence * sn.y + weight * gn.y, confidence * sn.z + weight * gn.z};
     const float inv = 1.0f / sqrtf(nn.x * nn.x + nn.y * nn.y + nn.z * nn.z);
     S.f(kNormalX, i) = inv * nn.x; S.f(kNormalY, i) = inv * nn.y; S.f(kNormalZ, i) = inv * nn.z;
-    S.f(kRadiusSq, i) = fminf(old_r2, in.radius(y, x));
+    S.f(kRadiusSq, i) = fminf(old_r2, px.radius);
     const uint32_t oc = S.u(kColor, i);
     const uint32_t c0 = (uint32_t)(uint8_t)(int)((confidence * (float)(oc & 255u) + weight * (float)col.x) * nf + 0.5f);
     const uint32_t c1 = (uint32_t)(uint8_t)(int)((confidence * (float)((oc >> 8) & 255u) + weight * (float)col.y) * nf + 0.5f);
@@ -726,10 +747,12 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
     const Vec3 g = {p4.x, p4.y, p4.z};
     if (!project_pos(g, c, p)) continue;
     if (n4.w < 0) continue;
-    integrate_or_conflict(S, c, sc, in, true, p.px, p.py, p.l, i, st);
-    int ox = 0, oy = 0;
+    int ox = p.px, oy = p.py;
     const bool second = quadrant(p, c, ox, oy);
-    integrate_or_conflict(S, c, sc, in, second, ox, oy, p.l, i, st);
+    const PixelIn px0 = load_pixel(c, sc, in, p.px, p.py);
+    const PixelIn px1 = load_pixel(c, sc, in, ox, oy);  // (the main pixel again if there is no second one)
+    integrate_or_conflict(S, c, px0, true, p.px, p.py, p.l, i, st);
+    integrate_or_conflict(S, c, px1, second, ox, oy, p.l, i, st);
     // stamp and detach flag may have changed: refresh the flag table entry
     L.flags8[i] = make_flags(S.u(kLastUpdateStamp, i), S.u(kColor, i), c.frame, c.reg_window);
   }
