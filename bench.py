@@ -256,9 +256,10 @@ def main():
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "C2: synthetic room stream %dx%d, full preprocessing + Integrate per frame, "
+        "config": {"workload": "%s: synthetic room stream %dx%d, full preprocessing + Integrate per frame, "
                                "%d surfel slots (%d live), steady-state re-traversal" %
-                               (args.width, args.height, st["surfels_size"], st["surfels_size"] - st["merge_count"]),
+                               ("C2" if args.width == 640 else "C3" if args.width == 1280 else "custom", args.width,
+                                args.height, st["surfels_size"], st["surfels_size"] - st["merge_count"]),
                    "max_surfel_count": cap, "streams": world, "parallelism": "1 independent stream per GPU"},
         "distributions": st,
         "stage_ms": dict(zip(["data_association", "surfel_merging", "measurement_blending", "integration",

@@ -34,6 +34,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = _hipcc()
+    extra = os.environ.get("SMX_EXTRA_FLAGS", "").split()   # experiments only (e.g. -DSMX_EXP=1)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers += [os.path.join(ROOT, "include", h) for h in ("smx.h", "smx_shim.hpp", "smx_driver.h")]
     objs = []
@@ -43,7 +44,7 @@ def build(force=False, verbose=True):
         o = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + extra + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))

@@ -62,3 +62,25 @@ def test_edge_cases(smx):
     assert list(cnt) == [0, 0, 0]
     with pytest.raises(smx.SmxError):
         nn.FindNearestSurfelsWithinRadius(np.zeros((3, 3), np.float32), 1.0, 65)
+
+
+def test_medium_cloud_against_oracle_grid(smx):
+    """200k points on a curved surface, 3000 self-queries: the GPU grid search equals the oracle's grid search
+    (itself equal to brute force, tests/test_nn_oracle.py) -- indices, squared distances and counts."""
+    rng = np.random.default_rng(5)
+    n = 200_000
+    u = rng.uniform(-3, 3, n).astype(np.float32)
+    v = rng.uniform(-1.5, 1.5, n).astype(np.float32)
+    w = (3.0 + 0.02 * np.sin(5 * u) * np.sin(5 * v)).astype(np.float32)
+    pts = np.stack([u, v, w], 1)
+    sel = rng.choice(n, 3000, replace=False)
+    r2 = (rng.uniform(0.01, 0.05, 3000) ** 2).astype(np.float32)
+    nn = smx.SurfelNeighborIndex()
+    nn.Build(pts[:, 0], pts[:, 1], pts[:, 2], 0.05)
+    cnt, d2, idx = nn.FindNearestSurfelsWithinRadius(pts[sel], r2, 64)
+    ocnt, od2, oidx = orc.nn_grid_batch(pts[:, 0], pts[:, 1], pts[:, 2], 0.05, pts[sel, 0], pts[sel, 1], pts[sel, 2], r2, 64)
+    assert np.array_equal(cnt, ocnt)
+    for q in range(len(sel)):
+        k = cnt[q]
+        assert np.array_equal(idx[q, :k], oidx[q, :k]) and np.array_equal(d2[q, :k].view(np.uint32), od2[q, :k].view(np.uint32))
+    assert cnt.max() == 64 and cnt.min() >= 1
