@@ -12,10 +12,12 @@
 //                              slots that project into the image;
 //   list kernels               associate / merge-decide / integrate /
 //                              update-neighbors run over that list only;
-//   pass B  k_neighbor_scan    one streaming pass over the 4 neighbour rows
-//                              (16 B/slot): detach + regulariser accumulation
-//                              + compacted list of recently updated slots;
-//   list kernels               regulariser step / update over that list only.
+//   pass B  k_neighbor_scan    one streaming pass over the neighbour records
+//                              (16 B/slot): detach, which links point into the
+//                              regulariser window, list of recently updated slots;
+//   k_reg_accumulate           gradient terms of those links (inbox stores / LDS
+//                              sums / global atomics), needy segments only;
+//   list kernels               regulariser step / update over the recent list only.
 // The surfel count, merge count and all list lengths live in device memory;
 // no kernel launch needs a host round trip.
 #include <math.h>
@@ -26,7 +28,8 @@ using namespace smx;
 
 namespace {
 
-// Surfel SoA rows, APP/cuda_surfel_reconstruction_kernels.cuh:49-78
+// Attribute ids = the reference's SoA row numbers, APP/cuda_surfel_reconstruction_kernels.cuh:49-78 (the
+// storage itself is grouped differently, see Surfels below)
 enum : int {
   kX = 0, kY = 1, kZ = 2, kSmoothX = 3, kSmoothY = 4, kSmoothZ = 5, kConfidence = 6, kRadiusSq = 7,
   kNormalX = 8, kNormalY = 9, kNormalZ = 10, kGradX = 11, kGradY = 12, kGradZ = 13,
@@ -36,8 +39,8 @@ enum : int {
 struct DevState {
   uint32_t surfel_count;   // slots in use (incl. merged zombies)
   uint32_t merge_count;
-  uint32_t vis_count;      // length of the visible list of this frame
-  uint32_t recent_count;   // length of the recent list of this regulariser pass
+  uint32_t vis_count;      // (unused: the lists are segmented, see Lists)
+  uint32_t recent_count;   // statistics: slots inside the regulariser window
   uint32_t create_base;
   uint32_t new_count;
   uint32_t capacity_clamped;
