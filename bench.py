@@ -32,8 +32,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_BYTES = {
     "scan_visible": lambda st, P: 18.0 * st["surfels_size"] + 24.0 * st["n_visible"],
     "neighbor_scan": lambda st, P: 18.0 * st["surfels_size"] + 1.0 * st["n_edges"] + 4.0 * st["n_recent"],
-    "reg_accumulate": lambda st, P: 49.0 * st["n_contributors"] + 48.0 * st["n_window_edges"],
-    "reg_step": lambda st, P: 272.0 * st["n_recent"],
+    # slots served: contributors and recent slots (mostly the same slots): 50 B own records each; 48 B per link into
+    # the window (target S + T records, 16 B inbox/accumulator store); 16 B own-term record per recent slot
+    "reg_accumulate": lambda st, P: 50.0 * max(st["n_contributors"], st["n_recent"]) + 48.0 * st["n_window_edges"]
+                                    + 16.0 * st["n_recent"],
+    # P, S, r^2, own-term record, three accumulator channels (32 + 32 + 64 B), S store, inbox re-zeroing
+    "reg_step": lambda st, P: 224.0 * st["n_recent"],
     "reg_update": lambda st, P: 36.0 * st["n_recent"],
     "associate": lambda st, P: 90.0 * st["n_visible"],
     "merge_decide": lambda st, P: 60.0 * st["n_visible"],
@@ -206,7 +210,8 @@ def main():
     rec.set_timing_enabled(0)
     dominant = names[int(np.argmax(cal_ms))]
     api.StreamSynchronize(None)
-    state0 = rec.debug_download_surfels() if (rank == 0 and args.cpu_frames > 0) else None
+    do_cpu = rank == 0 and world == 1 and args.cpu_frames > 0   # CPU baseline: rank 0 at N = 1 only
+    state0 = rec.debug_download_surfels() if do_cpu else None
     merge0 = (rec.surfels_size() - rec.surfel_count()) if state0 is not None else 0
     timed_steps = wl.steps(plan[W + cal:W + cal + K])
 
@@ -272,7 +277,7 @@ def main():
     if rank == 0:
         result["roofline"] = roofline_block(st, args.width * args.height, dominant, dom_ms, dom_n,
                                             dict(zip(names, [float(x) for x in kernel_ms])))
-        if args.cpu_frames > 0:
+        if do_cpu:
             result["cpu_baseline"] = cpu_baseline(wl, plan, W + cal, args.cpu_frames, state0, merge0, cap,
                                                   not args.no_check, log)
         print(json.dumps(result))

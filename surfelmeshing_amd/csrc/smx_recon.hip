@@ -1022,11 +1022,12 @@ k_new_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, const uint8_t* __res
 template <bool kDetach, bool kAccumulate>
 __global__ void __launch_bounds__(kBlockB)
 k_neighbor_scan(Surfels S, int stats, Lists L, uint8_t* __restrict__ inwin8, uint32_t* __restrict__ need_seg,
-                DevState* st) {
+                DevState* st, int exp = 0) {
   // B1: pure streaming.  Per slot: detach (:1430-1433), which of its neighbours lie inside the regulariser
   // window (4-bit mask -> inwin8), membership in the recent list.  No LDS accumulators here, so the
   // occupancy stays high; the accumulation itself runs in k_reg_accumulate on the few segments that need it.
   __shared__ uint32_t wave_tot[kBlockB / 64];
+  __shared__ __attribute__((aligned(4))) uint8_t lflags[kSegB];  // the segment's own flag bytes
   const uint32_t N = st->surfel_count;
   const uint32_t base = blockIdx.x * kSegB;
   if (base >= N) return;
@@ -1036,12 +1037,17 @@ k_neighbor_scan(Surfels S, int stats, Lists L, uint8_t* __restrict__ inwin8, uin
   const uint32_t i0 = base + threadIdx.x * 4;
   uint32_t recent_bits = 0;
   int need = 0;
+  uchar4 own = make_uchar4(0, 0, 0, 0);
+  uint4 trec[4];  // the T records (4 neighbour ids) of the lane's 4 slots: 64 contiguous bytes
   if (i0 < N) {
-    const uchar4 own = *reinterpret_cast<const uchar4*>(&L.flags8[i0]);
-    const uint8_t ownf[4] = {own.x, own.y, own.z, own.w};
-    uint4 trec[4];  // the T records (4 neighbour ids) of the lane's 4 slots: 64 contiguous bytes
+    own = *reinterpret_cast<const uchar4*>(&L.flags8[i0]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) trec[j] = *reinterpret_cast<const uint4*>(S.group(kGroupT, i0 + j));
+  }
+  *reinterpret_cast<uchar4*>(&lflags[threadIdx.x * 4]) = own;
+  __syncthreads();
+  if (i0 < N) {
+    const uint8_t ownf[4] = {own.x, own.y, own.z, own.w};
     uint8_t inw[4] = {0, 0, 0, 0};
     uint32_t edges = 0;
 #pragma unroll
@@ -1053,7 +1059,9 @@ k_neighbor_scan(Surfels S, int stats, Lists L, uint8_t* __restrict__ inwin8, uin
       for (int q = 0; q < 4; ++q) {
         const uint32_t nb = q == 0 ? trec[j].x : q == 1 ? trec[j].y : q == 2 ? trec[j].z : trec[j].w;
         if (nb == kInvalid) continue;
-        const uint32_t f = L.flags8[nb];
+        // three of four links stay inside the segment: those flags come from the LDS copy
+        const uint32_t rel = nb - base;
+        const uint32_t f = (rel < (uint32_t)kSegB) ? lflags[rel] : L.flags8[nb];
         if (kDetach && i < detach_limit && (f & 2u)) {  // :1430-1433
           S.u(kNeighbor0 + q, i) = kInvalid;
           continue;
@@ -1077,7 +1085,7 @@ k_neighbor_scan(Surfels S, int stats, Lists L, uint8_t* __restrict__ inwin8, uin
   const int any = __syncthreads_or(need);
   if (threadIdx.x == 0) {
     L.recent_seg[blockIdx.x] = total;
-    if (kAccumulate) need_seg[blockIdx.x] = any ? 1u : 0u;
+    if (kAccumulate) need_seg[blockIdx.x] = (any || total) ? 1u : 0u;  // k_reg_accumulate also serves recent slots
     if (stats && total) atomicAdd(&st->recent_count, total);
   }
 }
@@ -1098,7 +1106,8 @@ static_assert(kSegAcc % kSegB == 0 && kSegAcc % kBlockAcc == 0, "segment sizes m
 __global__ void __launch_bounds__(kBlockAcc)
 k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ grad_acc,
                  long long* __restrict__ grad_local, float4* __restrict__ inbox,
-                 const uint8_t* __restrict__ inwin8, const uint32_t* __restrict__ need_seg, const DevState* st) {
+                 const uint8_t* __restrict__ inwin8, const uint8_t* __restrict__ flags8,
+                 const uint32_t* __restrict__ need_seg, const DevState* st, int exp) {
   __shared__ unsigned long long lacc[kSegAcc * 4];
   const uint32_t N = st->surfel_count;
   const uint32_t base = blockIdx.x * kSegAcc;
@@ -1114,57 +1123,78 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
   for (int sub = 0; sub < kSegAcc / kBlockAcc; ++sub) {
     const uint32_t i = base + sub * kBlockAcc + threadIdx.x;
     const uint32_t mask = (i < N) ? inwin8[i] : 0u;
-    if (!mask) continue;
-    const int neighbor_count = __popc(mask);
+    const bool rec = (i < N) && (flags8[i] & 1u);
+    if (!mask && !rec) continue;
     // all loads are issued before the first use: the slot's own records, then per edge the target's S record
-    // (smooth position) and T record (its neighbour ids); unused slots read the slot's own data
+    // (smooth position) and, for edges into the window, its T record (its neighbour ids); unused slots read
+    // the slot's own data
     const uint4 own_t = *reinterpret_cast<const uint4*>(S.group(kGroupT, i));
     const uint32_t nb[4] = {own_t.x, own_t.y, own_t.z, own_t.w};
     const float4 own_s = *S.group(kGroupS, i), own_n = *S.group(kGroupN, i);
     const Vec3 sp = {own_s.x, own_s.y, own_s.z};
     const Vec3 nrm = {own_n.x, own_n.y, own_n.z};
     const float r2 = own_n.w;
+    // a recent slot needs every valid neighbour (its own step term, :2238-2256), any other slot only the
+    // neighbours inside the window (the terms it pushes)
+    uint32_t gmask = mask;
+    if (rec) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (nb[q] != kInvalid) gmask |= 1u << q;
+    }
     Vec3 np[4];
     int back_slot[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const uint32_t g = (mask & (1u << q)) ? nb[q] : i;
-      const float4 ts = *S.group(kGroupS, g);
-      const uint4 tt = *reinterpret_cast<const uint4*>(S.group(kGroupT, g));
+      const float4 ts = *S.group(kGroupS, (gmask & (1u << q)) ? nb[q] : i);
+      const uint4 tt = *reinterpret_cast<const uint4*>(S.group(kGroupT, ((mask & (1u << q)) && exp != 4) ? nb[q] : i));
       np[q].x = ts.x; np[q].y = ts.y; np[q].z = ts.z;
       back_slot[q] = tt.x == i ? 0 : tt.y == i ? 1 : tt.z == i ? 2 : tt.w == i ? 3 : -1;
     }
+    const int neighbor_count = mask ? __popc(mask) : 1;
     const float factor = 2 * weight / (float)neighbor_count;  // :2153
     const float wk = weight / (float)neighbor_count;          // :2182
+    int own_count = 0;
+    Vec3 rg = {0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (!(mask & (1u << q))) continue;
+      if (!(gmask & (1u << q))) continue;
       const Vec3 t = {np[q].x - sp.x, np[q].y - sp.y, np[q].z - sp.z};
-      const float f = factor * (nrm.x * t.x + nrm.y * t.y + nrm.z * t.z);
-      const float4 term = make_float4(f * nrm.x, f * nrm.y, f * nrm.z, wk);
-      // the exclusive inbox slot is only usable if this source has ONE in-window edge to that target
-      bool once = true;
+      const float nd = nrm.x * t.x + nrm.y * t.y + nrm.z * t.z;
+      bool pruned = false;
+      if (mask & (1u << q)) {
+        const float f = factor * nd;
+        const float4 term = make_float4(f * nrm.x, f * nrm.y, f * nrm.z, wk);
+        // the exclusive inbox slot is only usable if this source has ONE in-window edge to that target
+        bool once = true;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) if (k != q && (mask & (1u << k)) && nb[k] == nb[q]) once = false;
-      if (back_slot[q] >= 0 && once && wk != 0.0f) {
-        inbox[4 * (size_t)nb[q] + back_slot[q]] = term;
-      } else {
-        const unsigned long long v[4] = {(unsigned long long)q_from_float(term.x), (unsigned long long)q_from_float(term.y),
-                                         (unsigned long long)q_from_float(term.z), (unsigned long long)q_from_float(term.w)};
-        const uint32_t rel = nb[q] - base;
-        if (rel < (uint32_t)kSegAcc) {
-          // component-major LDS layout: consecutive lanes (consecutive targets) hit consecutive banks
-#pragma unroll
-          for (int c = 0; c < 4; ++c) atomicAdd(&lacc[c * kSegAcc + rel], v[c]);
+        for (int k = 0; k < 4; ++k) if (k != q && (mask & (1u << k)) && nb[k] == nb[q]) once = false;
+        if (back_slot[q] >= 0 && once && wk != 0.0f) {
+          if (exp != 3) inbox[4 * (size_t)nb[q] + back_slot[q]] = term;
         } else {
-          unsigned long long* a = reinterpret_cast<unsigned long long*>(&grad_acc[4 * (size_t)nb[q]]);
+          const unsigned long long v[4] = {(unsigned long long)q_from_float(term.x), (unsigned long long)q_from_float(term.y),
+                                           (unsigned long long)q_from_float(term.z), (unsigned long long)q_from_float(term.w)};
+          const uint32_t rel = nb[q] - base;
+          if (rel < (uint32_t)kSegAcc) {
+            // component-major LDS layout: consecutive lanes (consecutive targets) hit consecutive banks
 #pragma unroll
-          for (int c = 0; c < 4; ++c) atomicAdd(&a[c], v[c]);
+            for (int c = 0; c < 4; ++c) atomicAdd(&lacc[c * kSegAcc + rel], v[c]);
+          } else if (exp != 2 && exp != 4) {
+            unsigned long long* a = reinterpret_cast<unsigned long long*>(&grad_acc[4 * (size_t)nb[q]]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) atomicAdd(&a[c], v[c]);
+          }
         }
+        const float d2 = t.x * t.x + t.y * t.y + t.z * t.z;
+        if (d2 > rf2 * r2) { S.u(kNeighbor0 + q, i) = kInvalid; pruned = true; }  // :2190-2192
       }
-      const float d2 = t.x * t.x + t.y * t.y + t.z * t.z;
-      if (d2 > rf2 * r2) S.u(kNeighbor0 + q, i) = kInvalid;  // :2190-2192
+      // the slot's own regulariser term (RegularizeSurfelsCUDAKernel :2238-2256 sees the row after the pruning
+      // above): same neighbour positions, same n.t product, so it is formed here and k_reg_step gathers nothing
+      if (rec && !pruned) {
+        ++own_count;
+        rg.x = rg.x - nd * nrm.x; rg.y = rg.y - nd * nrm.y; rg.z = rg.z - nd * nrm.z;
+      }
     }
+    if (rec) *S.group(kGroupG, i) = make_float4(rg.x, rg.y, rg.z, __int_as_float(own_count));
   }
   __syncthreads();
   // store the in-segment sums (only this workgroup writes the grad_local entries of its segment)
@@ -1197,7 +1227,6 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long*
     if (!chunk_entry<true, kSegB>(L.recent_list, L.recent_seg, n_slots, chunk, i)) continue;
     const Vec3 mp = {S.f(kX, i), S.f(kY, i), S.f(kZ, i)};
     const Vec3 sp = {S.f(kSmoothX, i), S.f(kSmoothY, i), S.f(kSmoothZ, i)};
-    const Vec3 nrm = {S.f(kNormalX, i), S.f(kNormalY, i), S.f(kNormalZ, i)};
     // exact fixed-point sums: contributions from other segments (global atomics) + from the own segment
     // (accumulated in LDS by pass B and stored plainly); integer addition, so the split does not matter
     longlong4* ap = reinterpret_cast<longlong4*>(&grad_acc[4 * (size_t)i]);
@@ -1219,25 +1248,10 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long*
     }
     const float acc[4] = {q_to_float(sum[0]), q_to_float(sum[1]), q_to_float(sum[2]), q_to_float(sum[3])};
     Vec3 grad = {2 * (sp.x - mp.x) + acc[0], 2 * (sp.y - mp.y) + acc[1], 2 * (sp.z - mp.z) + acc[2]};
-    int neighbor_count = 0;
-    Vec3 rg = {0, 0, 0};
-    uint32_t nbs[4];
-    Vec3 np[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) nbs[q] = S.u(kNeighbor0 + q, i);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {  // all gathers in flight together; invalid slots read the slot itself
-      const uint32_t g = (nbs[q] == kInvalid) ? i : nbs[q];
-      np[q].x = S.f(kSmoothX, g); np[q].y = S.f(kSmoothY, g); np[q].z = S.f(kSmoothZ, g);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (nbs[q] == kInvalid) continue;
-      ++neighbor_count;
-      const Vec3 t = {np[q].x - sp.x, np[q].y - sp.y, np[q].z - sp.z};
-      const float nd = nrm.x * t.x + nrm.y * t.y + nrm.z * t.z;
-      rg.x = rg.x - nd * nrm.x; rg.y = rg.y - nd * nrm.y; rg.z = rg.z - nd * nrm.z;
-    }
+    // own term and neighbour count: formed by k_reg_accumulate from the pre-step smooth positions
+    const float4 own_g = *S.group(kGroupG, i);
+    const Vec3 rg = {own_g.x, own_g.y, own_g.z};
+    const int neighbor_count = __float_as_int(own_g.w);
     if (neighbor_count > 0) {
       const float factor = 2 * weight / (float)neighbor_count;
       grad.x = grad.x + factor * rg.x; grad.y = grad.y + factor * rg.y; grad.z = grad.z + factor * rg.z;
@@ -1248,23 +1262,24 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long*
     const float step_len = kStep * sqrtf(grad.x * grad.x + grad.y * grad.y + grad.z * grad.z);
     float step = kStep;
     if (step_len > max_step) step = max_step / step_len * kStep;
-    S.f(kGradX, i) = sp.x - step * grad.x;  // parked until k_reg_update (:2283-2288)
-    S.f(kGradY, i) = sp.y - step * grad.y;
-    S.f(kGradZ, i) = sp.z - step * grad.z;
+    // No kernel reads another slot's smooth position after k_reg_accumulate, so the result goes straight to the
+    // S record: the reference's parking rows and RegularizeSurfelsCUDAUpdateKernel (:2283-2308) are not needed.
+    S.f(kSmoothX, i) = sp.x - step * grad.x;
+    S.f(kSmoothY, i) = sp.y - step * grad.y;
+    S.f(kSmoothZ, i) = sp.z - step * grad.z;
   }
 }
 
-// RegularizeSurfelsCUDAUpdateKernel (:2292-2308) / CopyOnlyKernel (:2310-2327), over the recent list.
-template <bool kCopyRaw>
+// RegularizeSurfelsCUDACopyOnlyKernel (:2310-2327), over the recent list.
 __global__ void __launch_bounds__(kBlock)
-k_reg_update(Surfels S, Lists L, const DevState* st) {
+k_reg_copy_raw(Surfels S, Lists L, const DevState* st) {
   const uint32_t n_slots = st->surfel_count, n_chunks = (n_slots + kBlock - 1) / kBlock;
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     uint32_t i;
     if (!chunk_entry<true, kSegB>(L.recent_list, L.recent_seg, n_slots, chunk, i)) continue;
-    S.f(kSmoothX, i) = S.f(kCopyRaw ? kX : kGradX, i);
-    S.f(kSmoothY, i) = S.f(kCopyRaw ? kY : kGradY, i);
-    S.f(kSmoothZ, i) = S.f(kCopyRaw ? kZ : kGradZ, i);
+    S.f(kSmoothX, i) = S.f(kX, i);
+    S.f(kSmoothY, i) = S.f(kY, i);
+    S.f(kSmoothZ, i) = S.f(kZ, i);
   }
 }
 
@@ -1364,6 +1379,7 @@ struct smx_recon_s {
   size_t staging_floats;
   int grid_surfels;  // persistent grid for the grid-stride all-slot kernels
   int grid_list;     // persistent grid of the chunked list kernels
+  int exp = 0;
 };
 
 // kernel slots of one Integrate call (launch order)
@@ -1409,23 +1425,21 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
       if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, false>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st);
       else hipLaunchKernelGGL((k_neighbor_scan<false, false>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st);
     } else {
-      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, true>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st);
+      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, true>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st, r->exp);
       else hipLaunchKernelGGL((k_neighbor_scan<false, true>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st);
     }
   }
   if (!copy_only) {
     SlotTimer t(r, st, kSlotRegAccumulate);
     hipLaunchKernelGGL(k_reg_accumulate, dim3(div_up((long long)r->nsegB * kSegB, kSegAcc)), dim3(kBlockAcc), 0, st, r->S, rf2, weight, r->grad_acc, r->grad_local,
-                       r->inbox, r->inwin8, r->need_seg, r->st);
+                       r->inbox, r->inwin8, r->L.flags8, r->need_seg, r->st, r->exp);
   }
   if (copy_only) {
     SlotTimer t(r, st, kSlotRegUpdate);
-    hipLaunchKernelGGL((k_reg_update<true>), gl, b, 0, st, r->S, r->L, r->st);
+    hipLaunchKernelGGL(k_reg_copy_raw, gl, b, 0, st, r->S, r->L, r->st);
   } else {
-    { SlotTimer t(r, st, kSlotRegStep);
-      hipLaunchKernelGGL(k_reg_step, gl, b, 0, st, r->S, weight, r->grad_acc, r->grad_local, r->inbox, r->L, r->st); }
-    { SlotTimer t(r, st, kSlotRegUpdate);
-      hipLaunchKernelGGL((k_reg_update<false>), gl, b, 0, st, r->S, r->L, r->st); }
+    SlotTimer t(r, st, kSlotRegStep);
+    hipLaunchKernelGGL(k_reg_step, gl, b, 0, st, r->S, weight, r->grad_acc, r->grad_local, r->inbox, r->L, r->st);
   }
   SMX_LAUNCH_CHECK();
   return SMX_OK;
@@ -1510,7 +1524,9 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_HIP(hipGetDeviceProperties(&prop, dev));
   const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   r->grid_surfels = cus * 8;  // 8 x 256-thread workgroups per CU: full occupancy, >> 256 workgroups
-  r->grid_list = cus * 8;
+  r->grid_list = cus * 32;  // the lists are sparse: most chunks are empty, so more, shorter walks
+  if (const char* e = getenv("SMX_EXP")) r->exp = atoi(e);
+  if (const char* e = getenv("SMX_GRID_LIST")) r->grid_list = atoi(e) > 0 ? atoi(e) : r->grid_list;
   r->stats_enabled = 1;
   *out = r;
   return SMX_OK;

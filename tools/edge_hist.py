@@ -36,3 +36,12 @@ for q in range(4):
 print('symmetric fraction of edges into recent targets: %.4f (asymmetric edges: %d)' % (sym.mean(), (~sym).sum()))
 far = np.abs(tgt - src) > 1024
 print('far edges: %d, symmetric among far: %.4f; near asym: %d' % (far.sum(), sym[far].mean(), (~sym & ~far).sum()))
+da = np.abs(tgt - src)[~sym]
+print('asymmetric edges: distance distribution')
+for h in (64, 256, 512, 1024, 2048, 3072, 4096, 8192, 65536, 1<<20):
+    print('  dist <= %7d: %.4f' % (h, (da <= h).mean()))
+seg_same = ((tgt // 1024) == (src // 1024))[~sym]
+print('asym same 1024-segment: %.4f' % seg_same.mean())
+# in-degree from asymmetric edges
+cnt = np.bincount(tgt[~sym], minlength=n)
+print('targets with asym in-edges: %d, max in-degree %d, mean %.3f' % ((cnt > 0).sum(), cnt.max(), cnt[cnt > 0].mean()))
