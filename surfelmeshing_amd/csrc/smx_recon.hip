@@ -1107,7 +1107,7 @@ __global__ void __launch_bounds__(kBlockAcc)
 k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ grad_acc,
                  long long* __restrict__ grad_local, float4* __restrict__ inbox,
                  const uint8_t* __restrict__ inwin8, const uint8_t* __restrict__ flags8,
-                 const uint32_t* __restrict__ need_seg, const DevState* st, int exp) {
+                 const uint32_t* __restrict__ need_seg, const DevState* st, uint32_t epoch, int exp) {
   __shared__ unsigned long long lacc[kSegAcc * 4];
   const uint32_t N = st->surfel_count;
   const uint32_t base = blockIdx.x * kSegAcc;
@@ -1168,8 +1168,12 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
         bool once = true;
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (k != q && (mask & (1u << k)) && nb[k] == nb[q]) once = false;
-        if (back_slot[q] >= 0 && once && wk != 0.0f) {
-          if (exp != 3) inbox[4 * (size_t)nb[q] + back_slot[q]] = term;
+        if (back_slot[q] >= 0 && once) {
+          // w carries (call epoch, neighbour count) instead of weight / count: the reader recomputes the quotient
+          // and ignores slots of older calls, so nobody has to clear the inbox
+          if (exp != 3)
+            inbox[4 * (size_t)nb[q] + back_slot[q]] =
+                make_float4(term.x, term.y, term.z, __uint_as_float((epoch << 3) | (uint32_t)neighbor_count));
         } else {
           const unsigned long long v[4] = {(unsigned long long)q_from_float(term.x), (unsigned long long)q_from_float(term.y),
                                            (unsigned long long)q_from_float(term.z), (unsigned long long)q_from_float(term.w)};
@@ -1220,7 +1224,7 @@ k_rebuild_flags(Surfels S, uint32_t frame, int reg_window, uint8_t* __restrict__
 // RegularizeSurfelsCUDAKernel, kernels.cu:2197-2290, over the recent list.
 __global__ void __launch_bounds__(kBlock)
 k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long* __restrict__ grad_local,
-           float4* __restrict__ inbox, Lists L, const DevState* st) {
+           const float4* __restrict__ inbox, Lists L, const DevState* st, uint32_t epoch) {
   const uint32_t n_slots = st->surfel_count, n_chunks = (n_slots + kBlock - 1) / kBlock;
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     uint32_t i;
@@ -1232,19 +1236,20 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long*
     longlong4* ap = reinterpret_cast<longlong4*>(&grad_acc[4 * (size_t)i]);
     longlong4* lp = reinterpret_cast<longlong4*>(&grad_local[4 * (size_t)i]);
     const longlong4 a = *ap, l = *lp;
-    float4* ib = &inbox[4 * (size_t)i];
+    const float4* ib = &inbox[4 * (size_t)i];
     const float4 in0 = ib[0], in1 = ib[1], in2 = ib[2], in3 = ib[3];
     if (a.x | a.y | a.z | a.w) *ap = make_longlong4(0, 0, 0, 0);  // keep the accumulators zero between calls
     if (l.x | l.y | l.z | l.w) *lp = make_longlong4(0, 0, 0, 0);
     long long sum[4] = {a.x + l.x, a.y + l.y, a.z + l.z, a.w + l.w};
-    // terms delivered through the exclusive inbox slots (a used slot has w = weight / k != 0)
+    // terms delivered through the exclusive inbox slots: valid if stamped by this call's k_reg_accumulate
     const float4 ins[4] = {in0, in1, in2, in3};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (ins[k].w == 0.0f) continue;
+      const uint32_t code = __float_as_uint(ins[k].w);
+      if ((code >> 3) != epoch) continue;
+      const float wk = weight / (float)(code & 7u);  // :2182, the sender's neighbour count
       sum[0] += q_from_float(ins[k].x); sum[1] += q_from_float(ins[k].y);
-      sum[2] += q_from_float(ins[k].z); sum[3] += q_from_float(ins[k].w);
-      ib[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      sum[2] += q_from_float(ins[k].z); sum[3] += q_from_float(wk);
     }
     const float acc[4] = {q_to_float(sum[0]), q_to_float(sum[1]), q_to_float(sum[2]), q_to_float(sum[3])};
     Vec3 grad = {2 * (sp.x - mp.x) + acc[0], 2 * (sp.y - mp.y) + acc[1], 2 * (sp.z - mp.z) + acc[2]};
@@ -1380,6 +1385,7 @@ struct smx_recon_s {
   int grid_surfels;  // persistent grid for the grid-stride all-slot kernels
   int grid_list;     // persistent grid of the chunked list kernels
   int exp = 0;
+  uint32_t reg_epoch = 0;  // regulariser calls so far (stamps the inbox slots)
 };
 
 // kernel slots of one Integrate call (launch order)
@@ -1430,16 +1436,21 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
     }
   }
   if (!copy_only) {
+    // inbox slots are stamped with the call's epoch (29 bits); on wrap-around the old stamps are wiped
+    if (++r->reg_epoch >= (1u << 29)) {
+      SMX_HIP(hipMemsetAsync(r->inbox, 0, 4 * ((size_t)r->S.pitch + kSegAcc) * sizeof(float4), st));
+      r->reg_epoch = 1;
+    }
     SlotTimer t(r, st, kSlotRegAccumulate);
     hipLaunchKernelGGL(k_reg_accumulate, dim3(div_up((long long)r->nsegB * kSegB, kSegAcc)), dim3(kBlockAcc), 0, st, r->S, rf2, weight, r->grad_acc, r->grad_local,
-                       r->inbox, r->inwin8, r->L.flags8, r->need_seg, r->st, r->exp);
+                       r->inbox, r->inwin8, r->L.flags8, r->need_seg, r->st, r->reg_epoch, r->exp);
   }
   if (copy_only) {
     SlotTimer t(r, st, kSlotRegUpdate);
     hipLaunchKernelGGL(k_reg_copy_raw, gl, b, 0, st, r->S, r->L, r->st);
   } else {
     SlotTimer t(r, st, kSlotRegStep);
-    hipLaunchKernelGGL(k_reg_step, gl, b, 0, st, r->S, weight, r->grad_acc, r->grad_local, r->inbox, r->L, r->st);
+    hipLaunchKernelGGL(k_reg_step, gl, b, 0, st, r->S, weight, r->grad_acc, r->grad_local, r->inbox, r->L, r->st, r->reg_epoch);
   }
   SMX_LAUNCH_CHECK();
   return SMX_OK;

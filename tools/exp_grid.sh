@@ -1,4 +1,4 @@
-for g in 0 5; do
+for g in 0; do
   SMX_EXP=$g timeout 200 python bench.py --steps 300 --warmup 20 --cpu-frames 0 --quiet > gpurun_out/e$g.log 2>&1
   python - <<PY
 import json
