@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--cap", type=int, default=0, help="max_surfel_count (default: surfels * 1.1)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the full-size GPU-vs-oracle check")
+    ap.add_argument("--no-overlap", action="store_true", help="A/B: no frame pipelining inside Integrate")
     ap.add_argument("--quiet", action="store_true")
     args = ap.parse_args()
 
@@ -201,6 +202,8 @@ def main():
     rec.set_stats_enabled(False)   # the distribution counters are single-address atomics: off while timing
     wl.pipe.run_array(*wl.steps(plan[:W]))
     # short calibration pass with HIP events around every kernel: which kernel dominates the frame?
+    # (frame pipelining off here and in the per-kernel pass below, so that kernels are timed one at a time)
+    rec.set_overlap(False)
     rec.set_timing_enabled(2)
     names = rec.kernel_time_names()
     cal_ms = np.zeros(len(names))
@@ -208,6 +211,7 @@ def main():
         wl.pipe.run_array(*wl.steps(plan[j:j + 1]))
         cal_ms += np.array(rec.kernel_times_ms())
     rec.set_timing_enabled(0)
+    rec.set_overlap(not args.no_overlap)
     dominant = names[int(np.argmax(cal_ms))]
     api.StreamSynchronize(None)
     do_cpu = rank == 0 and world == 1 and args.cpu_frames > 0   # CPU baseline: rank 0 at N = 1 only
@@ -238,6 +242,7 @@ def main():
     _lib.check(_lib.load().smx_debug_marker(None, 2))
 
     # value distributions of one more frame (counters on)
+    rec.set_overlap(False)
     rec.set_stats_enabled(True)
     wl.pipe.run_array(*wl.steps(plan[total:total + 1]))
     st = rec.stats()

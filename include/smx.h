@@ -65,6 +65,8 @@ int smx_device_count(int* count);
 int smx_set_device(int device);
 int smx_device_name(int device, char* name, size_t capacity);
 int smx_stream_create(smx_stream* out);
+/* priority_class: -1 = lowest, 0 = default, +1 = highest priority the device offers (cudaStreamCreateWithPriority) */
+int smx_stream_create_with_priority(smx_stream* out, int32_t priority_class);
 int smx_stream_destroy(smx_stream s);
 int smx_stream_synchronize(smx_stream s);
 /* Events for cross-stream ordering (hipEvent_t, timing disabled): the frame driver overlaps depth
@@ -233,6 +235,11 @@ int smx_recon_debug_download_scratch(smx_recon r, smx_stream s, int32_t which, v
  * the reference does instead of the compacted lists; bit 1: measurement blending as the reference's
  * start + iteration launches instead of the fused LDS kernel. */
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode);
+/* Frame pipelining (default on): the regulariser of a frame runs on an internal stream beside the first
+ * kernels of the next smx_recon_integrate call (which only read what the regulariser does not write).
+ * Every entry point that takes a stream first orders that stream after the pending regulariser, so the
+ * one-stream semantics of CUDASurfelReconstruction are kept; results are identical on and off. */
+int smx_recon_set_overlap(smx_recon r, int32_t enabled);
 
 /* ---- radius-neighbor search (replaces CompressedOctree::FindNearestSurfelsWithinRadius,
  * APP/octree.h:470-477, APP/octree.cc:313-470, for batched queries) ---- */

@@ -397,6 +397,10 @@ class CUDASurfelReconstruction:
     def set_scan_mode(self, mode):
         _lib.check(_lib.load().smx_recon_set_scan_mode(self._h, C.c_int32(mode)))
 
+    def set_overlap(self, enabled):
+        """Frame pipelining on/off (regulariser of frame f beside the first kernels of frame f+1)."""
+        _lib.check(_lib.load().smx_recon_set_overlap(self._h, C.c_int32(1 if enabled else 0)))
+
     def debug_download_surfels(self, count=None):
         n = self.surfels_size() if count is None else int(count)
         rows = np.zeros((kSurfelAttributeCount, n), np.float32)

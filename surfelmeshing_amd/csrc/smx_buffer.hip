@@ -81,6 +81,17 @@ int smx_stream_create(smx_stream* out) {
   return SMX_OK;
 }
 
+int smx_stream_create_with_priority(smx_stream* out, int32_t priority_class) {
+  SMX_CHECK_ARG(out != nullptr && priority_class >= -1 && priority_class <= 1);
+  int least = 0, greatest = 0;
+  SMX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));  // numerically: greatest <= 0 <= least
+  const int prio = priority_class > 0 ? greatest : priority_class < 0 ? least : 0;
+  hipStream_t s;
+  SMX_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
+  *out = (smx_stream)s;
+  return SMX_OK;
+}
+
 int smx_stream_destroy(smx_stream s) {
   if (s) SMX_HIP(hipStreamDestroy((hipStream_t)s));
   return SMX_OK;

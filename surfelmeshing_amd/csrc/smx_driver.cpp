@@ -1,5 +1,6 @@
 // smx_driver.cpp -- the reference caller's per-frame sequence (APP/main.cc:1015-1223) as native host code,
 // written against the shim API (include/smx_shim.hpp).  No kernels here.
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <vector>
@@ -48,7 +49,8 @@ struct smx_driver_s {
   explicit smx_driver_s(const smx_driver_config& c, const float* intr)
       : cfg(c), camera(c.width, c.height, intr), reconstruction(c.max_surfel_count, camera),
         work0(c.height, c.width), work1(c.height, c.width), last(&work0) {
-    SMX_SHIM_CHECK(smx_stream_create(&pre_stream));
+    // preprocessing runs ahead of the frame loop: it only has to keep up, so it yields to the surfel kernels
+    SMX_SHIM_CHECK(smx_stream_create_with_priority(&pre_stream, getenv("SMX_PRE_NORMAL") ? 0 : -1));
     SMX_SHIM_CHECK(smx_event_create(&run_start));
     SMX_SHIM_CHECK(smx_stream_synchronize(nullptr));
   }

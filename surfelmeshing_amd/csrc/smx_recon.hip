@@ -243,7 +243,7 @@ __device__ __forceinline__ void min_depth_at(float* first_depth, int W, int x, i
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, DevState* st) {
+k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, const uint8_t* __restrict__ flags_prev, DevState* st) {
   __shared__ uint32_t wave_tot[kBlock / 64];
   const uint32_t N = st->surfel_count;
   const uint32_t base = blockIdx.x * kSeg;
@@ -255,7 +255,7 @@ k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, DevState* st) {
     // padded to a multiple of 64 slots, so the loads stay inside the array
     const float4* P = S.group(kGroupP, i0);
     const float4 p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3];
-    const uchar4 of = *reinterpret_cast<const uchar4*>(&L.flags8[i0]);
+    const uchar4 of = *reinterpret_cast<const uchar4*>(&flags_prev[i0]);  // (detach bits carry over)
     const uint32_t stamps[4] = {__float_as_uint(p0.w), __float_as_uint(p1.w), __float_as_uint(p2.w), __float_as_uint(p3.w)};
     const float xs[4] = {p0.x, p1.x, p2.x, p3.x};
     const float ys[4] = {p0.y, p1.y, p2.y, p3.y};
@@ -1101,7 +1101,7 @@ k_neighbor_scan(Surfels S, int stats, Lists L, uint8_t* __restrict__ inwin8, uin
 //   2. otherwise, target inside the workgroup's own segment: summed in LDS, stored once per target (grad_local);
 //   3. otherwise: 64-bit global atomics (grad_acc).
 constexpr int kSegAcc = 1024;     // slots per accumulation workgroup (32 KB of LDS sums)
-constexpr int kBlockAcc = 1024;
+constexpr int kBlockAcc = 512;
 static_assert(kSegAcc % kSegB == 0 && kSegAcc % kBlockAcc == 0, "segment sizes must nest");
 __global__ void __launch_bounds__(kBlockAcc)
 k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ grad_acc,
@@ -1386,6 +1386,15 @@ struct smx_recon_s {
   int grid_list;     // persistent grid of the chunked list kernels
   int exp = 0;
   uint32_t reg_epoch = 0;  // regulariser calls so far (stamps the inbox slots)
+  // Frame pipelining: the regulariser of frame f runs on an internal stream while the caller's stream already
+  // executes clear / pass A / associate / merge / blend of frame f+1 (those read only P and N records, which the
+  // regulariser does not write, and a second copy of the flag table).  Every entry point first orders the
+  // caller's stream after the pending regulariser, so the API keeps its one-stream semantics.
+  int overlap_enabled;
+  hipStream_t reg_stream;
+  hipEvent_t ev_mid, ev_reg;
+  bool reg_pending;
+  uint8_t* flags_buf[2];    // the flag table is double-buffered by frame (L.flags8 = the current frame's)
 };
 
 // kernel slots of one Integrate call (launch order)
@@ -1414,6 +1423,15 @@ struct SlotTimer {
 };
 
 namespace {
+
+// Orders stream st after the regulariser that may still run on the internal stream.
+int join_regularizer(smx_recon r, hipStream_t st) {
+  if (r->reg_pending) {
+    SMX_HIP(hipStreamWaitEvent(st, r->ev_reg, 0));
+    r->reg_pending = false;
+  }
+  return SMX_OK;
+}
 
 int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, float weight, int window,
                        bool detach, bool copy_only) {
@@ -1505,7 +1523,9 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->L.recent_list, (size_t)r->nsegB * kSegB, false));
   SMX_TRY(dev_alloc(&r->L.vis_seg, (size_t)r->nseg, true));
   SMX_TRY(dev_alloc(&r->L.recent_seg, (size_t)r->nsegB, true));
-  SMX_TRY(dev_alloc(&r->L.flags8, (size_t)r->nsegB * kSegB, true));
+  SMX_TRY(dev_alloc(&r->flags_buf[0], (size_t)r->nsegB * kSegB, true));
+  SMX_TRY(dev_alloc(&r->flags_buf[1], (size_t)r->nsegB * kSegB, true));
+  r->L.flags8 = r->flags_buf[0];
   SMX_TRY(dev_alloc(&r->merge_flag, r->S.pitch, true));
   SMX_TRY(dev_alloc(&r->inwin8, (size_t)r->nsegB * kSegB, true));
   SMX_TRY(dev_alloc(&r->need_seg, (size_t)r->nsegB + kSegAcc / kSegB, true));
@@ -1527,6 +1547,15 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
 #undef SMX_TRY
   for (int i = 0; i < 14; ++i) SMX_HIP(hipEventCreate(&r->ev[i]));
   for (int i = 0; i < 2 * 16; ++i) SMX_HIP(hipEventCreate(&r->kev[i]));
+  {
+    // the regulariser is on the frame-to-frame critical path, the work it overlaps with is not
+    int lo = 0, hi = 0;
+    SMX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    SMX_HIP(hipStreamCreateWithPriority(&r->reg_stream, hipStreamNonBlocking, getenv("SMX_NOPRIO") ? lo : hi));
+  }
+  SMX_HIP(hipEventCreateWithFlags(&r->ev_mid, hipEventDisableTiming));
+  SMX_HIP(hipEventCreateWithFlags(&r->ev_reg, hipEventDisableTiming));
+  r->overlap_enabled = 1;
   r->prof_slot = -1;
   r->timing_enabled = 1;
   hipDeviceProp_t prop;
@@ -1545,10 +1574,13 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
 
 int smx_recon_destroy(smx_recon r) {
   if (!r) return SMX_OK;
-  void* ptrs[] = {r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.recent_seg, r->L.flags8,
+  void* ptrs[] = {r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.recent_seg, r->flags_buf[0], r->flags_buf[1],
                   r->merge_flag, r->inwin8, r->need_seg, r->sc.supporting, r->sc.counts,
                   r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->st};
+  if (r->reg_stream) { (void)hipStreamSynchronize(r->reg_stream); (void)hipStreamDestroy(r->reg_stream); }
+  if (r->ev_mid) (void)hipEventDestroy(r->ev_mid);
+  if (r->ev_reg) (void)hipEventDestroy(r->ev_reg);
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int i = 0; i < 14; ++i) if (r->ev[i]) (void)hipEventDestroy(r->ev[i]);
   for (int i = 0; i < 2 * 16; ++i) if (r->kev[i]) (void)hipEventDestroy(r->kev[i]);
@@ -1607,6 +1639,13 @@ int smx_recon_set_stats_enabled(smx_recon r, int32_t enabled) {
   return SMX_OK;
 }
 
+int smx_recon_set_overlap(smx_recon r, int32_t enabled) {
+  SMX_CHECK_ARG(r != nullptr && (enabled == 0 || enabled == 1));
+  if (r->reg_pending) { SMX_HIP(hipStreamSynchronize(r->reg_stream)); r->reg_pending = false; }
+  r->overlap_enabled = enabled;
+  return SMX_OK;
+}
+
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
   SMX_CHECK_ARG(r != nullptr && mode >= 0 && mode <= 3);
   r->scan_mode = mode & 1;
@@ -1647,11 +1686,14 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   in.radius = as_img<const float>(radius); in.color = as_img<const uchar3>(color);
   const Img<uint16_t> depth_rw = as_img<uint16_t>(depth);
 
+  // the flag table of the previous frame stays readable for the regulariser that may still be running
+  const uint8_t* flags_prev = r->L.flags8;
+  r->L.flags8 = (r->L.flags8 == r->flags_buf[0]) ? r->flags_buf[1] : r->flags_buf[0];
   if (tm) SMX_HIP(hipEventRecord(r->ev[0], st));
   { SlotTimer t(r, st, kSlotClear);
     hipLaunchKernelGGL(k_clear_assoc, gpx, b, 0, st, r->sc, r->bb, P, r->st); }
   { SlotTimer t(r, st, kSlotScanVisible);
-    hipLaunchKernelGGL(k_scan_visible, gs, b, 0, st, r->S, c, r->sc, r->L, r->st);
+    hipLaunchKernelGGL(k_scan_visible, gs, b, 0, st, r->S, c, r->sc, r->L, flags_prev, r->st);
     r->table_valid = true; r->table_frame = frame_index; r->table_window = c.reg_window; }
   { SlotTimer t(r, st, kSlotAssociate);
     if (r->scan_mode) hipLaunchKernelGGL((k_associate<false>), gl, b, 0, st, r->S, c, r->sc, in.depth, in.normals, r->L, r->st);
@@ -1678,6 +1720,9 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     }
   }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[5], st)); SMX_HIP(hipEventRecord(r->ev[6], st)); }
+  // Everything up to here only read P and N records; from here on they (and T, S) are written, so the previous
+  // frame's regulariser has to be done.
+  { const int rcj = join_regularizer(r, st); if (rcj != SMX_OK) return rcj; }
   { SlotTimer t(r, st, kSlotIntegrate);
     if (r->scan_mode) hipLaunchKernelGGL((k_integrate<false>), gl, b, 0, st, r->S, c, r->sc, in, r->L, r->merge_flag, r->st);
     else hipLaunchKernelGGL((k_integrate<true>), gl, b, 0, st, r->S, c, r->sc, in, r->L, r->merge_flag, r->st); }
@@ -1699,28 +1744,40 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   SMX_LAUNCH_CHECK();
   int rc = SMX_OK;
   const int iters = p->regularization_iterations_per_integration_iteration;
+  hipStream_t rs = st;
+  if (r->overlap_enabled) {
+    SMX_HIP(hipEventRecord(r->ev_mid, st));
+    SMX_HIP(hipStreamWaitEvent(r->reg_stream, r->ev_mid, 0));
+    rs = r->reg_stream;
+  }
   if (iters == 0) {
-    rc = enqueue_regularize(r, st, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
+    rc = enqueue_regularize(r, rs, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
                             p->regularization_frame_window_size, true, true);
   } else {
     for (int k = 0; k < iters && rc == SMX_OK; ++k)
-      rc = enqueue_regularize(r, st, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
+      rc = enqueue_regularize(r, rs, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
                               p->regularization_frame_window_size, k == 0, false);
   }
   if (rc != SMX_OK) return rc;
-  if (tm) { SMX_HIP(hipEventRecord(r->ev[13], st)); r->have_timings = true; }
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[13], rs)); r->have_timings = true; }
+  if (r->overlap_enabled) {
+    SMX_HIP(hipEventRecord(r->ev_reg, r->reg_stream));
+    r->reg_pending = true;
+  }
   return SMX_OK;
 }
 
 int smx_recon_regularize(smx_recon r, smx_stream s, uint32_t frame_index, float regularizer_weight,
                          float radius_factor_for_regularization_neighbors, int32_t regularization_frame_window_size) {
   SMX_CHECK_ARG(r != nullptr);
+  { const int rcj = join_regularizer(r, (hipStream_t)s); if (rcj != SMX_OK) return rcj; }
   return enqueue_regularize(r, (hipStream_t)s, frame_index, radius_factor_for_regularization_neighbors,
                             regularizer_weight, regularization_frame_window_size, false, false);
 }
 
 int smx_recon_counts(smx_recon r, smx_stream s, uint32_t* surfel_count, uint32_t* surfels_size) {
   SMX_CHECK_ARG(r != nullptr);
+  { const int rcj = join_regularizer(r, (hipStream_t)s); if (rcj != SMX_OK) return rcj; }
   DevState h;
   SMX_HIP(hipMemcpyAsync(&h, r->st, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)s));
   SMX_HIP(hipStreamSynchronize((hipStream_t)s));
@@ -1731,6 +1788,7 @@ int smx_recon_counts(smx_recon r, smx_stream s, uint32_t* surfel_count, uint32_t
 
 int smx_recon_get_stats(smx_recon r, smx_stream s, smx_recon_stats* out) {
   SMX_CHECK_ARG(r != nullptr && out != nullptr);
+  { const int rcj = join_regularizer(r, (hipStream_t)s); if (rcj != SMX_OK) return rcj; }
   DevState h;
   SMX_HIP(hipMemcpyAsync(&h, r->st, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)s));
   SMX_HIP(hipStreamSynchronize((hipStream_t)s));
@@ -1745,6 +1803,7 @@ int smx_recon_get_stats(smx_recon r, smx_stream s, smx_recon_stats* out) {
 
 int smx_recon_transfer_all_to_cpu(smx_recon r, smx_stream s, uint32_t frame_index, smx_surfel_buffers_cpu* buf) {
   SMX_CHECK_ARG(r != nullptr && buf != nullptr);
+  { const int rcj = join_regularizer(r, (hipStream_t)s); if (rcj != SMX_OK) return rcj; }
   hipStream_t st = (hipStream_t)s;
   uint32_t n = 0;
   SMX_HIP(hipMemcpyAsync(&n, &r->st->surfel_count, sizeof(n), hipMemcpyDeviceToHost, st));
@@ -1779,6 +1838,7 @@ int smx_recon_transfer_all_to_cpu(smx_recon r, smx_stream s, uint32_t frame_inde
 int smx_recon_export_vertices(smx_recon r, smx_stream s, const smx_buffer_desc* position_buffer,
                               const smx_buffer_desc* color_buffer) {
   SMX_CHECK_ARG(r && position_buffer && color_buffer);
+  { const int rcj = join_regularizer(r, (hipStream_t)s); if (rcj != SMX_OK) return rcj; }
   hipLaunchKernelGGL(k_export, dim3(r->grid_surfels), dim3(kBlock), 0, (hipStream_t)s, r->S,
                      (float*)position_buffer->address, (uint8_t*)color_buffer->address, r->st);
   SMX_LAUNCH_CHECK();
@@ -1796,6 +1856,7 @@ int smx_recon_get_timings(smx_recon r, float out_ms[7]) {
 int smx_recon_debug_download_surfels(smx_recon r, smx_stream s, float* rows, uint32_t count) {
   SMX_CHECK_ARG(r != nullptr && rows != nullptr && count <= r->max_surfels);
   if (count == 0) return SMX_OK;
+  { const int rcj = join_regularizer(r, (hipStream_t)s); if (rcj != SMX_OK) return rcj; }
   int rc = ensure_staging(r, (size_t)kRows * count);
   if (rc != SMX_OK) return rc;
   RowList rl;
@@ -1809,6 +1870,7 @@ int smx_recon_debug_download_surfels(smx_recon r, smx_stream s, float* rows, uin
 
 int smx_recon_debug_upload_surfels(smx_recon r, smx_stream s, const float* rows, uint32_t count, uint32_t merge_count) {
   SMX_CHECK_ARG(r != nullptr && count <= r->max_surfels && (rows != nullptr || count == 0));
+  { const int rcj = join_regularizer(r, (hipStream_t)s); if (rcj != SMX_OK) return rcj; }
   hipStream_t st = (hipStream_t)s;
   if (count) {
     int rc = ensure_staging(r, (size_t)kRows * count);
@@ -1838,6 +1900,7 @@ int smx_recon_debug_upload_surfels(smx_recon r, smx_stream s, const float* rows,
 
 int smx_recon_debug_download_scratch(smx_recon r, smx_stream s, int32_t which, void* dst) {
   SMX_CHECK_ARG(r != nullptr && dst != nullptr);
+  { const int rcj = join_regularizer(r, (hipStream_t)s); if (rcj != SMX_OK) return rcj; }
   hipStream_t st = (hipStream_t)s;
   const size_t P = (size_t)r->W * r->H;
   const void* src = nullptr; size_t bytes = 0;

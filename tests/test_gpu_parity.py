@@ -170,6 +170,22 @@ def test_stream_parity_parameter_variants(smx, kw):
     run_both(po, pg, s, list(range(4, 20)), lambda f: _compare_state(po, pg))
 
 
+@pytest.mark.parametrize("overlap", [True, False])
+def test_pipelined_frames_parity(smx, overlap):
+    """No download between frames: with pipelining on, the regulariser of frame f really runs beside the first
+    kernels of frame f+1 (a per-frame state download would order them).  Same final state either way."""
+    s = small_stream(obstacle_until=10)
+    po, pg = _pipes(smx, s, 60000)
+    pg.reconstruction.set_overlap(overlap)
+    run_both(po, pg, s, list(range(4, 30)), None)
+    _compare_state(po, pg)
+    # an extra Regularize() and a second run of frames on top of the pending regulariser
+    po.recon.regularize(29, 10.0, 2.0, 30)
+    pg.reconstruction.Regularize(None, 29, 10.0, 2.0, 30)
+    run_both(po, pg, s, list(range(30, 36)), None)
+    _compare_state(po, pg)
+
+
 def test_full_resolution_parity(smx):
     s = small_stream(640, 480)
     po, pg = _pipes(smx, s, 1200000)
