@@ -3,6 +3,7 @@
 // (CUDABuffer<T> / CUDABuffer_<T>) behind the C-ABI of include/smx.h.
 #include <stdarg.h>
 
+#include <stdlib.h>
 #include "smx_common.hpp"
 
 namespace smx {

@@ -1391,8 +1391,8 @@ struct smx_recon_s {
   // regulariser does not write, and a second copy of the flag table).  Every entry point first orders the
   // caller's stream after the pending regulariser, so the API keeps its one-stream semantics.
   int overlap_enabled;
-  hipStream_t reg_stream;
-  hipEvent_t ev_mid, ev_reg;
+  hipStream_t reg_stream;     // high priority: the frame-to-frame critical path
+  hipEvent_t ev_mid, ev_reg, ev_front;
   bool reg_pending;
   uint8_t* flags_buf[2];    // the flag table is double-buffered by frame (L.flags8 = the current frame's)
 };
@@ -1551,8 +1551,9 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
     // the regulariser is on the frame-to-frame critical path, the work it overlaps with is not
     int lo = 0, hi = 0;
     SMX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    SMX_HIP(hipStreamCreateWithPriority(&r->reg_stream, hipStreamNonBlocking, getenv("SMX_NOPRIO") ? lo : hi));
+    SMX_HIP(hipStreamCreateWithPriority(&r->reg_stream, hipStreamNonBlocking, hi));
   }
+  SMX_HIP(hipEventCreateWithFlags(&r->ev_front, hipEventDisableTiming));
   SMX_HIP(hipEventCreateWithFlags(&r->ev_mid, hipEventDisableTiming));
   SMX_HIP(hipEventCreateWithFlags(&r->ev_reg, hipEventDisableTiming));
   r->overlap_enabled = 1;
@@ -1579,6 +1580,7 @@ int smx_recon_destroy(smx_recon r) {
                   r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->st};
   if (r->reg_stream) { (void)hipStreamSynchronize(r->reg_stream); (void)hipStreamDestroy(r->reg_stream); }
+  if (r->ev_front) (void)hipEventDestroy(r->ev_front);
   if (r->ev_mid) (void)hipEventDestroy(r->ev_mid);
   if (r->ev_reg) (void)hipEventDestroy(r->ev_reg);
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1689,66 +1691,81 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   // the flag table of the previous frame stays readable for the regulariser that may still be running
   const uint8_t* flags_prev = r->L.flags8;
   r->L.flags8 = (r->L.flags8 == r->flags_buf[0]) ? r->flags_buf[1] : r->flags_buf[0];
-  if (tm) SMX_HIP(hipEventRecord(r->ev[0], st));
-  { SlotTimer t(r, st, kSlotClear);
-    hipLaunchKernelGGL(k_clear_assoc, gpx, b, 0, st, r->sc, r->bb, P, r->st); }
-  { SlotTimer t(r, st, kSlotScanVisible);
-    hipLaunchKernelGGL(k_scan_visible, gs, b, 0, st, r->S, c, r->sc, r->L, flags_prev, r->st);
+  // Streams.  Pipelined: the kernels that only read surfel state (clear .. blend) stay on the caller's stream,
+  // everything on the frame-to-frame critical path (integrate .. regulariser) goes to the internal high-priority
+  // stream sH, where frame f+1 simply queues behind frame f.  The caller's stream is released once the frame has
+  // created its surfels (ev_mid), so the next call's first kernels run beside this frame's regulariser.
+  const bool pipelined = r->overlap_enabled != 0;
+  const hipStream_t sF = st;
+  const hipStream_t sH = pipelined ? r->reg_stream : st;
+  if (!pipelined) {
+    const int rcj = join_regularizer(r, st);
+    if (rcj != SMX_OK) return rcj;
+  }
+  if (tm) SMX_HIP(hipEventRecord(r->ev[0], sF));
+  { SlotTimer t(r, sF, kSlotClear);
+    hipLaunchKernelGGL(k_clear_assoc, gpx, b, 0, sF, r->sc, r->bb, P, r->st); }
+  { SlotTimer t(r, sF, kSlotScanVisible);
+    hipLaunchKernelGGL(k_scan_visible, gs, b, 0, sF, r->S, c, r->sc, r->L, flags_prev, r->st);
     r->table_valid = true; r->table_frame = frame_index; r->table_window = c.reg_window; }
-  { SlotTimer t(r, st, kSlotAssociate);
-    if (r->scan_mode) hipLaunchKernelGGL((k_associate<false>), gl, b, 0, st, r->S, c, r->sc, in.depth, in.normals, r->L, r->st);
-    else hipLaunchKernelGGL((k_associate<true>), gl, b, 0, st, r->S, c, r->sc, in.depth, in.normals, r->L, r->st); }
-  if (tm) { SMX_HIP(hipEventRecord(r->ev[1], st)); SMX_HIP(hipEventRecord(r->ev[2], st)); }
-  { SlotTimer t(r, st, kSlotMergeDecide);
-    if (r->scan_mode) hipLaunchKernelGGL((k_merge_decide<false>), gl, b, 0, st, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st);
-    else hipLaunchKernelGGL((k_merge_decide<true>), gl, b, 0, st, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st); }
-  if (tm) { SMX_HIP(hipEventRecord(r->ev[3], st)); SMX_HIP(hipEventRecord(r->ev[4], st)); }
+  { SlotTimer t(r, sF, kSlotAssociate);
+    if (r->scan_mode) hipLaunchKernelGGL((k_associate<false>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->st);
+    else hipLaunchKernelGGL((k_associate<true>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->st); }
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[1], sF)); SMX_HIP(hipEventRecord(r->ev[2], sF)); }
+  { SlotTimer t(r, sF, kSlotMergeDecide);
+    if (r->scan_mode) hipLaunchKernelGGL((k_merge_decide<false>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st);
+    else hipLaunchKernelGGL((k_merge_decide<true>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st); }
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[3], sF)); SMX_HIP(hipEventRecord(r->ev[4], sF)); }
   if (p->do_blending) {
-    SlotTimer t(r, st, kSlotBlend);
+    SlotTimer t(r, sF, kSlotBlend);
     const float ds = 1.0f / c.inv_depth_scaling;  // kernels.cc:179
     const float term = 1.0f / ((float)p->measurement_blending_radius - 1.0f);  // kernels.cc:196
     const int halo = p->measurement_blending_radius - 1;
     if (halo <= kBlendMaxHalo && !r->blend_multi_launch) {
       const int rw = kBlendTile + 2 * halo;
       const size_t lds = (size_t)rw * rw * 15;
-      hipLaunchKernelGGL(k_blend_fused, dim3(div_up(r->W, kBlendTile), div_up(r->H, kBlendTile)), dim3(kBlendThreads), lds, st,
+      hipLaunchKernelGGL(k_blend_fused, dim3(div_up(r->W, kBlendTile), div_up(r->H, kBlendTile)), dim3(kBlendThreads), lds, sF,
                          p->measurement_blending_radius, term, ds, depth_rw, r->sc, r->W, r->H);
     } else {
-      hipLaunchKernelGGL(k_blend_start, gimg, b, 0, st, ds, depth_rw, r->sc, r->bb, r->W, r->H);
+      hipLaunchKernelGGL(k_blend_start, gimg, b, 0, sF, ds, depth_rw, r->sc, r->bb, r->W, r->H);
       for (int it = 2; it < p->measurement_blending_radius; ++it)
-        hipLaunchKernelGGL(k_blend_iter, gimg, b, 0, st, it, term, ds, depth_rw, r->sc, r->bb, r->W, r->H);
+        hipLaunchKernelGGL(k_blend_iter, gimg, b, 0, sF, it, term, ds, depth_rw, r->sc, r->bb, r->W, r->H);
     }
   }
-  if (tm) { SMX_HIP(hipEventRecord(r->ev[5], st)); SMX_HIP(hipEventRecord(r->ev[6], st)); }
+  if (tm) SMX_HIP(hipEventRecord(r->ev[5], sF));
+  if (pipelined) {
+    SMX_HIP(hipEventRecord(r->ev_front, sF));
+    SMX_HIP(hipStreamWaitEvent(sH, r->ev_front, 0));
+  }
+  if (tm) SMX_HIP(hipEventRecord(r->ev[6], sH));
   // Everything up to here only read P and N records; from here on they (and T, S) are written, so the previous
-  // frame's regulariser has to be done.
-  { const int rcj = join_regularizer(r, st); if (rcj != SMX_OK) return rcj; }
-  { SlotTimer t(r, st, kSlotIntegrate);
-    if (r->scan_mode) hipLaunchKernelGGL((k_integrate<false>), gl, b, 0, st, r->S, c, r->sc, in, r->L, r->merge_flag, r->st);
-    else hipLaunchKernelGGL((k_integrate<true>), gl, b, 0, st, r->S, c, r->sc, in, r->L, r->merge_flag, r->st); }
-  if (tm) { SMX_HIP(hipEventRecord(r->ev[7], st)); SMX_HIP(hipEventRecord(r->ev[8], st)); }
-  { SlotTimer t(r, st, kSlotUpdateNeighbors);
-    if (r->scan_mode) hipLaunchKernelGGL((k_update_neighbors<false>), gl, b, 0, st, r->S, c, r->sc, in, r->L, r->st);
-    else hipLaunchKernelGGL((k_update_neighbors<true>), gl, b, 0, st, r->S, c, r->sc, in, r->L, r->st); }
+  // frame's regulariser has to be done: it precedes these kernels in the critical stream's own order.
+  { SlotTimer t(r, sH, kSlotIntegrate);
+    if (r->scan_mode) hipLaunchKernelGGL((k_integrate<false>), gl, b, 0, sH, r->S, c, r->sc, in, r->L, r->merge_flag, r->st);
+    else hipLaunchKernelGGL((k_integrate<true>), gl, b, 0, sH, r->S, c, r->sc, in, r->L, r->merge_flag, r->st); }
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[7], sH)); SMX_HIP(hipEventRecord(r->ev[8], sH)); }
+  { SlotTimer t(r, sH, kSlotUpdateNeighbors);
+    if (r->scan_mode) hipLaunchKernelGGL((k_update_neighbors<false>), gl, b, 0, sH, r->S, c, r->sc, in, r->L, r->st);
+    else hipLaunchKernelGGL((k_update_neighbors<true>), gl, b, 0, sH, r->S, c, r->sc, in, r->L, r->st); }
   // (the detach half of UpdateNeighborsCUDA runs fused into pass B below)
-  if (tm) { SMX_HIP(hipEventRecord(r->ev[9], st)); SMX_HIP(hipEventRecord(r->ev[10], st)); }
-  { SlotTimer t(r, st, kSlotNewFlagsScan);
-    hipLaunchKernelGGL(k_new_flags_scan, dim3(r->n_scan_blocks), b, 0, st, in.depth, r->sc, r->W, r->H, r->new_flags,
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[9], sH)); SMX_HIP(hipEventRecord(r->ev[10], sH)); }
+  { SlotTimer t(r, sH, kSlotNewFlagsScan);
+    hipLaunchKernelGGL(k_new_flags_scan, dim3(r->n_scan_blocks), b, 0, sH, in.depth, r->sc, r->W, r->H, r->new_flags,
                        r->new_ranks, r->block_sums); }
-  { SlotTimer t(r, st, kSlotNewFinalize);
-    hipLaunchKernelGGL(k_new_finalize, dim3(1), dim3(1024), 0, st, r->block_sums, r->n_scan_blocks, r->max_surfels, r->st); }
-  { SlotTimer t(r, st, kSlotNewCreate);
-    hipLaunchKernelGGL(k_new_create, dim3(div_up(P, kBlock)), b, 0, st, r->S, c, r->sc, in, r->new_flags, r->new_ranks,
+  { SlotTimer t(r, sH, kSlotNewFinalize);
+    hipLaunchKernelGGL(k_new_finalize, dim3(1), dim3(1024), 0, sH, r->block_sums, r->n_scan_blocks, r->max_surfels, r->st); }
+  { SlotTimer t(r, sH, kSlotNewCreate);
+    hipLaunchKernelGGL(k_new_create, dim3(div_up(P, kBlock)), b, 0, sH, r->S, c, r->sc, in, r->new_flags, r->new_ranks,
                        r->block_sums, r->L.flags8, r->st); }
-  if (tm) { SMX_HIP(hipEventRecord(r->ev[11], st)); SMX_HIP(hipEventRecord(r->ev[12], st)); }
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[11], sH)); SMX_HIP(hipEventRecord(r->ev[12], sH)); }
   SMX_LAUNCH_CHECK();
   int rc = SMX_OK;
   const int iters = p->regularization_iterations_per_integration_iteration;
-  hipStream_t rs = st;
-  if (r->overlap_enabled) {
-    SMX_HIP(hipEventRecord(r->ev_mid, st));
-    SMX_HIP(hipStreamWaitEvent(r->reg_stream, r->ev_mid, 0));
-    rs = r->reg_stream;
+  hipStream_t rs = sH;
+  if (pipelined) {
+    // the caller's buffers are free from here on, and the next frame's read-only kernels may start
+    SMX_HIP(hipEventRecord(r->ev_mid, sH));
+    SMX_HIP(hipStreamWaitEvent(st, r->ev_mid, 0));
   }
   if (iters == 0) {
     rc = enqueue_regularize(r, rs, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
@@ -1760,8 +1777,8 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   }
   if (rc != SMX_OK) return rc;
   if (tm) { SMX_HIP(hipEventRecord(r->ev[13], rs)); r->have_timings = true; }
-  if (r->overlap_enabled) {
-    SMX_HIP(hipEventRecord(r->ev_reg, r->reg_stream));
+  if (pipelined) {
+    SMX_HIP(hipEventRecord(r->ev_reg, sH));
     r->reg_pending = true;
   }
   return SMX_OK;
