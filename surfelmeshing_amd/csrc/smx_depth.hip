@@ -20,17 +20,33 @@ constexpr int kThreads = 256;
 // loads; the spatial exponent term -(dx^2+dy^2)/(2 sigma_xy^2) depends only on the tap offset and is
 // tabulated once per workgroup (same IEEE division, so the results are unchanged).  Out-of-image taps are
 // masked by coordinates, exactly like the reference's clamped loop bounds.
+static int device_cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 256;
+  }
+  return cus;
+}
+
 constexpr int kMaxBilateralRadius = 8;
 constexpr int kBilTileW = 32, kBilTileH = 8;
 __global__ void __launch_bounds__(kThreads)
 k_bilateral(float denom_xy, float sigma_value_factor, int radius, int radius_squared,
             uint16_t value_to_ignore, uint16_t max_depth, float region_r2,
-            Img<const uint16_t> in, Img<uint16_t> out) {
+            Img<const uint16_t> in, Img<uint16_t> out, int tiles_x, int n_tiles) {
   __shared__ uint16_t tile[(kBilTileH + 2 * kMaxBilateralRadius) * (kBilTileW + 2 * kMaxBilateralRadius)];
   __shared__ float spatial[kMaxBilateralRadius * kMaxBilateralRadius + 1];
   const int W = out.width, H = out.height;
   const int tw = kBilTileW + 2 * radius, th = kBilTileH + 2 * radius;
-  const int x0 = blockIdx.x * kBilTileW - radius, y0 = blockIdx.y * kBilTileH - radius;
+  for (int g2 = threadIdx.x; g2 <= radius_squared; g2 += kThreads) spatial[g2] = (float)(-g2) / denom_xy;
+  // the workgroups walk the tiles: the launch can be sized to leave room for concurrent kernels
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+  const int bx = t % tiles_x, by = t / tiles_x;
+  __syncthreads();  // (the previous tile's readers are done)
+  const int x0 = bx * kBilTileW - radius, y0 = by * kBilTileH - radius;
   for (int i = threadIdx.x; i < tw * th; i += kThreads) {
     const int ty = i / tw, tx = i - ty * tw;
     const int gx = x0 + tx, gy = y0 + ty;
@@ -38,18 +54,17 @@ k_bilateral(float denom_xy, float sigma_value_factor, int radius, int radius_squ
     if (gx >= 0 && gy >= 0 && gx < W && gy < H) v = in(gy, gx);
     tile[i] = v;
   }
-  for (int g2 = threadIdx.x; g2 <= radius_squared; g2 += kThreads) spatial[g2] = (float)(-g2) / denom_xy;
   __syncthreads();
 
   const int lx = threadIdx.x & (kBilTileW - 1), ly = threadIdx.x / kBilTileW;
-  const int x = blockIdx.x * kBilTileW + lx, y = blockIdx.y * kBilTileH + ly;
-  if (x >= W || y >= H) return;
+  const int x = bx * kBilTileW + lx, y = by * kBilTileH + ly;
+  if (x >= W || y >= H) continue;
   const unsigned half_w = (unsigned)(W / 2), half_h = (unsigned)(H / 2);
   const unsigned dxc = (unsigned)x - half_w, dyc = (unsigned)y - half_h;
   const float center_distance_squared = (float)(dxc * dxc + dyc * dyc);
-  if (center_distance_squared > region_r2) { out(y, x) = value_to_ignore; return; }
+  if (center_distance_squared > region_r2) { out(y, x) = value_to_ignore; continue; }
   const uint16_t center_value = tile[(ly + radius) * tw + (lx + radius)];
-  if (center_value == value_to_ignore || center_value > max_depth) { out(y, x) = value_to_ignore; return; }
+  if (center_value == value_to_ignore || center_value > max_depth) { out(y, x) = value_to_ignore; continue; }
 
   const float adapted_sigma_value = (float)center_value * sigma_value_factor;
   const float adapted_denom_value = 2.0f * adapted_sigma_value * adapted_sigma_value;
@@ -71,6 +86,7 @@ k_bilateral(float denom_xy, float sigma_value_factor, int radius, int radius_squ
     }
   }
   out(y, x) = (weight == 0) ? value_to_ignore : f2u16(sum / weight + 0.5f);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -249,11 +265,14 @@ int smx_bilateral_filtering_and_depth_cutoff(
   SMX_CHECK_ARG(input_depth->width == output_depth->width && input_depth->height == output_depth->height);
   const int radius = (int)(radius_factor * sigma_xy + 0.5f);                       // cu:135
   SMX_CHECK_ARG(radius >= 0 && radius <= kMaxBilateralRadius);
-  dim3 grid(div_up(output_depth->width, kBilTileW), div_up(output_depth->height, kBilTileH), 1);
-  hipLaunchKernelGGL(k_bilateral, grid, dim3(kThreads), 0, (hipStream_t)s,
+  const int tiles_x = div_up(output_depth->width, kBilTileW), n_tiles = tiles_x * div_up(output_depth->height, kBilTileH);
+  // Two workgroups per CU: the filter is ALU-bound and runs beside the surfel kernels (preprocessing of the next
+  // frame overlaps Integrate); a launch that floods every CU slows those down more than it gains here.
+  static const int max_blocks = 2 * device_cu_count();
+  hipLaunchKernelGGL(k_bilateral, dim3(n_tiles < max_blocks ? n_tiles : max_blocks), dim3(kThreads), 0, (hipStream_t)s,
                      2.0f * sigma_xy * sigma_xy, sigma_value_factor, radius, radius * radius, value_to_ignore,
                      max_depth, depth_valid_region_radius * depth_valid_region_radius,
-                     as_img<const uint16_t>(input_depth), as_img<uint16_t>(output_depth));
+                     as_img<const uint16_t>(input_depth), as_img<uint16_t>(output_depth), tiles_x, n_tiles);
   SMX_LAUNCH_CHECK();
   return SMX_OK;
 }

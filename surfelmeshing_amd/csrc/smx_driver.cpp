@@ -43,7 +43,7 @@ struct smx_driver_s {
   std::map<u32, std::unique_ptr<Frame>> frames;
   cudaStream_t pre_stream = nullptr;   // depth preprocessing of the next frame
   smx_event run_start = nullptr;
-  bool overlap = true;
+  bool overlap = getenv("SMX_DRV_SERIAL") == nullptr;
   unsigned long long frame_counter = 0;
 
   explicit smx_driver_s(const smx_driver_config& c, const float* intr)

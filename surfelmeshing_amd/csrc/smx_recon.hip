@@ -872,7 +872,7 @@ constexpr int kScanPxPerBlock = kBlock * kScanPxPerThread;
 
 __global__ void __launch_bounds__(kBlock)
 k_new_flags_scan(Img<const uint16_t> depth, Scratch sc, int W, int H, uint8_t* __restrict__ flags,
-                 uint32_t* __restrict__ local_rank, uint32_t* __restrict__ block_sums) {
+                 uint32_t* __restrict__ local_rank, uint32_t* __restrict__ block_sums, DevState* st) {
   __shared__ uint32_t wave_tot[kBlock / 64];
   const int P = W * H;
   const int k0 = (blockIdx.x * kBlock + threadIdx.x) * kScanPxPerThread;
@@ -914,51 +914,46 @@ k_new_flags_scan(Img<const uint16_t> depth, Scratch sc, int W, int H, uint8_t* _
     if (k < P) local_rank[k] = run;
     run += f[j];
   }
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-}
-
-__global__ void __launch_bounds__(1024)
-k_new_finalize(uint32_t* __restrict__ block_sums, int nblocks, uint32_t max_surfels, DevState* st) {
-  // exclusive scan of the block totals in place (nblocks is a few hundred)
-  __shared__ uint32_t tot[1024];
-  __shared__ uint32_t carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < nblocks; base += 1024) {
-    const int b = base + threadIdx.x;
-    const uint32_t v = (b < nblocks) ? block_sums[b] : 0;
-    tot[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      uint32_t t = 0;
-      if ((int)threadIdx.x >= off) t = tot[threadIdx.x - off];
-      __syncthreads();
-      tot[threadIdx.x] += t;
-      __syncthreads();
-    }
-    if (b < nblocks) block_sums[b] = carry + tot[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry += tot[1023];
-    __syncthreads();
-  }
   if (threadIdx.x == 0) {
-    const uint32_t N = st->surfel_count;
-    const uint32_t room = max_surfels - N;
-    const uint32_t created = carry < room ? carry : room;  // cap rule (reference: unchecked, cc:291)
-    st->create_base = N;
-    st->new_count = created;
-    st->capacity_clamped = (carry > room) ? 1u : 0u;
-    st->surfel_count = N + created;
+    block_sums[blockIdx.x] = total;
+    if (blockIdx.x == 0) st->create_base = st->surfel_count;  // stable until k_new_create's workgroup 0 adds the new slots
   }
 }
 
 __global__ void __launch_bounds__(kBlock)
 k_new_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, const uint8_t* __restrict__ flags,
-             uint32_t* __restrict__ ranks, const uint32_t* __restrict__ block_offsets, uint8_t* __restrict__ flags8,
-             const DevState* st) {
+             uint32_t* __restrict__ ranks, const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_offsets_out,
+             int n_scan_blocks, uint32_t max_surfels, uint8_t* __restrict__ flags8, DevState* st) {
+  // Every workgroup scans the few hundred block totals of k_new_flags_scan itself (cheaper than a launch of its
+  // own for one workgroup); workgroup 0 publishes the counts (cc:291) and the offsets (debug decode).
+  extern __shared__ uint32_t block_offsets[];  // [n_scan_blocks] exclusive
+  __shared__ uint32_t wave_tot[kBlock / 64];
+  const int per = (n_scan_blocks + kBlock - 1) / kBlock;
+  uint32_t mine = 0;
+  for (int j = 0; j < per; ++j) {
+    const int bidx = threadIdx.x * per + j;
+    if (bidx < n_scan_blocks) mine += block_sums[bidx];
+  }
+  uint32_t total;
+  uint32_t run = block_excl_scan(mine, wave_tot, total);
+  for (int j = 0; j < per; ++j) {
+    const int bidx = threadIdx.x * per + j;
+    if (bidx < n_scan_blocks) { block_offsets[bidx] = run; run += block_sums[bidx]; }
+  }
+  __syncthreads();
+  const uint32_t base = st->create_base;
+  const uint32_t room = max_surfels - base;
+  const uint32_t created = total < room ? total : room;  // cap rule (reference: unchecked, cc:291)
+  if (blockIdx.x == 0) {
+    for (int bidx = threadIdx.x; bidx < n_scan_blocks; bidx += kBlock) block_offsets_out[bidx] = block_offsets[bidx];
+    if (threadIdx.x == 0) {
+      st->new_count = created;
+      st->capacity_clamped = (total > room) ? 1u : 0u;
+      st->surfel_count = base + created;
+    }
+  }
   const int kDX[4] = {-1, 1, 0, 0}, kDY[4] = {0, 0, -1, 1};
   const int W = c.W, H = c.H, P = W * H;
-  const uint32_t base = st->create_base, created = st->new_count;
   for (int k = blockIdx.x * kBlock + threadIdx.x; k < P; k += gridDim.x * kBlock) {
     const uint32_t rank = block_offsets[k / kScanPxPerBlock] + ranks[k];
     // ranks[] keeps the block-local values; global rank = block offset + local rank
@@ -1366,7 +1361,8 @@ struct smx_recon_s {
   BlendBufs bb;
   uint8_t* new_flags;
   uint32_t* new_ranks;
-  uint32_t* block_sums;
+  uint32_t* block_sums;     // per k_new_flags_scan workgroup: flagged pixels
+  uint32_t* block_offsets;  // exclusive scan of block_sums (written by k_new_create's workgroup 0)
   uint32_t* tmp_u32;  // [W*H] debug decode target
   int n_scan_blocks;
   DevState* st;
@@ -1400,13 +1396,13 @@ struct smx_recon_s {
 // kernel slots of one Integrate call (launch order)
 enum : int {
   kSlotClear = 0, kSlotScanVisible, kSlotAssociate, kSlotMergeDecide, kSlotBlend, kSlotIntegrate,
-  kSlotUpdateNeighbors, kSlotNewFlagsScan, kSlotNewFinalize, kSlotNewCreate, kSlotNeighborScan,
+  kSlotUpdateNeighbors, kSlotNewFlagsScan, kSlotNewCreate, kSlotNeighborScan,
   kSlotRegAccumulate, kSlotRegStep,
   kSlotRegUpdate, kSlotCount
 };
 static const char* const kSlotNames[kSlotCount] = {
   "clear_assoc", "scan_visible", "associate", "merge_decide", "blend", "integrate", "update_neighbors",
-  "new_flags_scan", "new_finalize", "new_create", "neighbor_scan", "reg_accumulate", "reg_step", "reg_update"};
+  "new_flags_scan", "new_create", "neighbor_scan", "reg_accumulate", "reg_step", "reg_update"};
 
 struct SlotTimer {
   smx_recon r; hipStream_t st; int slot; bool kev, prof;
@@ -1543,6 +1539,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->tmp_u32, P, true));
   r->n_scan_blocks = div_up((long long)P, kScanPxPerBlock);
   SMX_TRY(dev_alloc(&r->block_sums, (size_t)r->n_scan_blocks, true));
+  SMX_TRY(dev_alloc(&r->block_offsets, (size_t)r->n_scan_blocks, true));
   SMX_TRY(dev_alloc(&r->st, 1, true));
 #undef SMX_TRY
   for (int i = 0; i < 14; ++i) SMX_HIP(hipEventCreate(&r->ev[i]));
@@ -1578,7 +1575,7 @@ int smx_recon_destroy(smx_recon r) {
   void* ptrs[] = {r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.recent_seg, r->flags_buf[0], r->flags_buf[1],
                   r->merge_flag, r->inwin8, r->need_seg, r->sc.supporting, r->sc.counts,
                   r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth, r->bb.distance_map, r->bb.new_distance_map,
-                  r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->st};
+                  r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->block_offsets, r->st};
   if (r->reg_stream) { (void)hipStreamSynchronize(r->reg_stream); (void)hipStreamDestroy(r->reg_stream); }
   if (r->ev_front) (void)hipEventDestroy(r->ev_front);
   if (r->ev_mid) (void)hipEventDestroy(r->ev_mid);
@@ -1751,12 +1748,11 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   if (tm) { SMX_HIP(hipEventRecord(r->ev[9], sH)); SMX_HIP(hipEventRecord(r->ev[10], sH)); }
   { SlotTimer t(r, sH, kSlotNewFlagsScan);
     hipLaunchKernelGGL(k_new_flags_scan, dim3(r->n_scan_blocks), b, 0, sH, in.depth, r->sc, r->W, r->H, r->new_flags,
-                       r->new_ranks, r->block_sums); }
-  { SlotTimer t(r, sH, kSlotNewFinalize);
-    hipLaunchKernelGGL(k_new_finalize, dim3(1), dim3(1024), 0, sH, r->block_sums, r->n_scan_blocks, r->max_surfels, r->st); }
+                       r->new_ranks, r->block_sums, r->st); }
   { SlotTimer t(r, sH, kSlotNewCreate);
-    hipLaunchKernelGGL(k_new_create, dim3(div_up(P, kBlock)), b, 0, sH, r->S, c, r->sc, in, r->new_flags, r->new_ranks,
-                       r->block_sums, r->L.flags8, r->st); }
+    hipLaunchKernelGGL(k_new_create, dim3(div_up(P, kBlock)), b, (size_t)r->n_scan_blocks * sizeof(uint32_t), sH, r->S, c, r->sc, in,
+                       r->new_flags, r->new_ranks, r->block_sums, r->block_offsets, r->n_scan_blocks, r->max_surfels,
+                       r->L.flags8, r->st); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[11], sH)); SMX_HIP(hipEventRecord(r->ev[12], sH)); }
   SMX_LAUNCH_CHECK();
   int rc = SMX_OK;
@@ -1931,7 +1927,7 @@ int smx_recon_debug_download_scratch(smx_recon r, smx_stream s, int32_t which, v
       hipLaunchKernelGGL(k_decode_conflicting, dim3(div_up((long long)P, kBlock)), dim3(kBlock), 0, st, r->sc.confl_key, r->tmp_u32, (int)P);
       src = r->tmp_u32; bytes = P * 4; break;
     case SMX_SCRATCH_NEW_INDICES:
-      hipLaunchKernelGGL(k_global_ranks, dim3(div_up((long long)P, kBlock)), dim3(kBlock), 0, st, r->new_ranks, r->block_sums, r->tmp_u32, (int)P);
+      hipLaunchKernelGGL(k_global_ranks, dim3(div_up((long long)P, kBlock)), dim3(kBlock), 0, st, r->new_ranks, r->block_offsets, r->tmp_u32, (int)P);
       src = r->tmp_u32; bytes = P * 4; break;
     default: set_error("unknown scratch id %d", which); return SMX_ERR_INVALID_ARGUMENT;
   }
