@@ -29,10 +29,12 @@
  *     writers if any, else lowest index among the associate-phase writers
  *   - merge decisions read a snapshot of the other surfel (two-phase)
  *   - float atomicAdd sums (depth sums, regulariser gradients) are either
- *     accumulated EXACTLY in 2^-32 fixed point and rounded once
- *     (sum_mode = ORC_SUM_EXACT, what the HIP path does) or in float in
- *     ascending surfel order (sum_mode = ORC_SUM_FLOAT_ASCENDING, the
- *     reference's arithmetic with one fixed schedule).
+ *     accumulated EXACTLY in fixed point and rounded once (sum_mode =
+ *     ORC_SUM_EXACT, what the HIP path does: 2^-32 for the depth sums and
+ *     the regulariser weights, 2^-22 m with a +-16 clamp per term for the
+ *     regulariser gradient terms) or in float in ascending surfel order
+ *     (sum_mode = ORC_SUM_FLOAT_ASCENDING, the reference's arithmetic with
+ *     one fixed schedule).
  * Arithmetic: IEEE binary32, no FMA contraction (-ffp-contract=off), exact
  * division and sqrt, and a self-contained expf (orc_expf) so that the GPU can
  * match bit for bit.

@@ -27,6 +27,15 @@ static inline uint16_t f2u16(float v) {
 /* 2^-32 fixed point: exact for every float >= 2^-8 in magnitude. */
 static inline int64_t q_from_float(float v) { return (int64_t)((double)v * 4294967296.0); }
 static inline float q_to_float(int64_t s) { return (float)((double)s * (1.0 / 4294967296.0)); }
+/* Regulariser gradient terms: 2^-22 fixed point (0.24 um), clamped to +-16 (NaN -> lower bound), so that the
+ * HIP side can keep two of them in one 64-bit accumulator word; the sums are exact integer sums either way. */
+static inline int32_t q22_from_float(float v) {
+  double d = (double)v * 4194304.0;
+  if (!(d > -67108864.0)) d = -67108864.0;
+  if (d > 67108864.0) d = 67108864.0;
+  return (int32_t)d;
+}
+static inline float q22_to_float(int64_t s) { return (float)((double)s * (1.0 / 4194304.0)); }
 
 /* CUDAMatrix3x4::operator*, VIS/cuda/cuda_matrix.cuh:88-94 (left-to-right adds) */
 static inline void mat_point(const float* m, const float* p, float* o) {
@@ -675,7 +684,7 @@ static void regularize_once(orc_recon* r, uint32_t frame, float rf, float weight
       const float gt[3] = {f * nrm[0], f * nrm[1], f * nrm[2]};
       if (exact) {
         int64_t* a = &r->grad_acc[4 * (size_t)nb];
-        a[0] += q_from_float(gt[0]); a[1] += q_from_float(gt[1]); a[2] += q_from_float(gt[2]); a[3] += q_from_float(wk);
+        a[0] += q22_from_float(gt[0]); a[1] += q22_from_float(gt[1]); a[2] += q22_from_float(gt[2]); a[3] += q_from_float(wk);
       } else {
         SURF(r, ORC_GRAD_X, nb) += gt[0]; SURF(r, ORC_GRAD_Y, nb) += gt[1]; SURF(r, ORC_GRAD_Z, nb) += gt[2];
         SURF(r, ORC_GRAD_COUNT, nb) += wk;
@@ -694,7 +703,7 @@ static void regularize_once(orc_recon* r, uint32_t frame, float rf, float weight
     const float sp[3] = {SURF(r, ORC_SMOOTH_X, i), SURF(r, ORC_SMOOTH_Y, i), SURF(r, ORC_SMOOTH_Z, i)};
     const float nrm[3] = {SURF(r, ORC_NORMAL_X, i), SURF(r, ORC_NORMAL_Y, i), SURF(r, ORC_NORMAL_Z, i)};
     float acc[4];
-    if (exact) { for (int q = 0; q < 4; ++q) acc[q] = q_to_float(r->grad_acc[4 * (size_t)i + q]); }
+    if (exact) { for (int q = 0; q < 3; ++q) acc[q] = q22_to_float(r->grad_acc[4 * (size_t)i + q]); acc[3] = q_to_float(r->grad_acc[4 * (size_t)i + 3]); }
     else { acc[0] = SURF(r, ORC_GRAD_X, i); acc[1] = SURF(r, ORC_GRAD_Y, i); acc[2] = SURF(r, ORC_GRAD_Z, i); acc[3] = SURF(r, ORC_GRAD_COUNT, i); }
     float grad[3] = {2 * (sp[0] - mp[0]) + acc[0], 2 * (sp[1] - mp[1]) + acc[1], 2 * (sp[2] - mp[2]) + acc[2]};
     int neighbor_count = 0;

@@ -108,6 +108,27 @@ __device__ __forceinline__ float q_to_float(long long s) {
   return (float)((double)s * (1.0 / 4294967296.0));
 }
 
+// Regulariser gradient terms: 2^-22 fixed point (0.24 um), clamped to +-16 so that two of them share one 64-bit
+// accumulator word and the sum of up to 31 terms cannot leave its 32-bit half (NaN maps to the lower bound).
+__device__ __forceinline__ int q22_from_float(float v) {
+  double d = (double)v * 4194304.0;
+  if (!(d > -67108864.0)) d = -67108864.0;
+  if (d > 67108864.0) d = 67108864.0;
+  return (int)d;
+}
+__device__ __forceinline__ float q22_to_float(long long s) {
+  return (float)((double)s * (1.0 / 4194304.0));
+}
+// word = hi * 2^32 + lo with signed halves: integer sums of such words stay decodable while both half sums fit
+// in 32 bits (the borrow of a negative lo is undone by decoding lo first)
+__device__ __forceinline__ unsigned long long pack_pair(int hi, int lo) {
+  return (unsigned long long)(((long long)hi << 32) + (long long)lo);
+}
+__device__ __forceinline__ void unpack_pair(long long w, long long& hi, int& lo) {
+  lo = (int)(unsigned int)(unsigned long long)w;
+  hi = (w - (long long)lo) >> 32;
+}
+
 // Deterministic expf (Cody-Waite + degree-6 polynomial with explicit FMAs).
 __device__ __forceinline__ float det_expf(float x) {
   if (x < -86.0f) return 0.0f;

@@ -1086,16 +1086,20 @@ k_neighbor_scan(Surfels S, int stats, Lists L, uint8_t* __restrict__ inwin8, uin
 }
 
 // B2: RegularizeSurfelsCUDAAccumulateNeighborGradientsKernel (kernels.cu:2115-2195) on the segments that have
-// at least one edge into the regulariser window; one lane per slot, 1024-lane workgroups.
+// a recent slot or an edge into the regulariser window; 512-lane workgroups, two slots per lane.  It also forms the
+// slot's OWN smoothness term (the neighbour loop of RegularizeSurfelsCUDAKernel, :2238-2256) from the same
+// gathered neighbour positions and parks it in the G record, so that k_reg_step gathers nothing.
 //
 // The reference pushes every edge's gradient term to the neighbour with four float atomicAdds.  Device-scope
-// atomics on cold lines are the slowest thing this chip does, so the terms travel three ways, all of which end
-// in the same exact 2^-32 fixed-point sum (integer addition: the split cannot change the result):
-//   1. the target lists the source back at slot k (5 of 6 edges): the four floats are STORED, without any
-//      atomic, into inbox[target][k] -- a slot only this source writes; k_reg_step converts and sums them;
+// atomics are the slowest thing this chip does, so the terms travel three ways, all of which end in the same
+// exact integer sum (the three gradient components quantised to 2^-22 m, the weights counted per sender class and
+// multiplied out in 2^-32 fixed point by the reader -- integer addition: the split cannot change the result):
+//   1. the target lists the source back at slot k (5 of 6 edges): the term is STORED, without any atomic, into
+//      inbox[target][k] -- a slot only this source writes, stamped with the call's epoch; k_reg_step converts it;
 //   2. otherwise, target inside the workgroup's own segment: summed in LDS, stored once per target (grad_local);
-//   3. otherwise: 64-bit global atomics (grad_acc).
-constexpr int kSegAcc = 1024;     // slots per accumulation workgroup (32 KB of LDS sums)
+//   3. otherwise: TWO 64-bit global atomics per term (grad_acc): the words hold (gx | gy) and (gz | sender
+//      class counts) as signed 32-bit halves (pack_pair in smx_common.hpp).
+constexpr int kSegAcc = 1024;     // slots per accumulation workgroup (16 KB of LDS sums)
 constexpr int kBlockAcc = 512;
 static_assert(kSegAcc % kSegB == 0 && kSegAcc % kBlockAcc == 0, "segment sizes must nest");
 __global__ void __launch_bounds__(kBlockAcc)
@@ -1103,7 +1107,7 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
                  long long* __restrict__ grad_local, float4* __restrict__ inbox,
                  const uint8_t* __restrict__ inwin8, const uint8_t* __restrict__ flags8,
                  const uint32_t* __restrict__ need_seg, const DevState* st, uint32_t epoch, int exp) {
-  __shared__ unsigned long long lacc[kSegAcc * 4];
+  __shared__ unsigned long long lacc[kSegAcc * 2];  // per target: (gx | gy), (gz | sender classes)
   const uint32_t N = st->surfel_count;
   const uint32_t base = blockIdx.x * kSegAcc;
   if (base >= N) return;
@@ -1112,7 +1116,7 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
   for (int k = 0; k < kSegAcc / kSegB; ++k) need |= need_seg[blockIdx.x * (kSegAcc / kSegB) + k];
   if (!need) return;
 #pragma unroll
-  for (int k = 0; k < kSegAcc * 4 / kBlockAcc; ++k) lacc[k * kBlockAcc + threadIdx.x] = 0;
+  for (int k = 0; k < kSegAcc * 2 / kBlockAcc; ++k) lacc[k * kBlockAcc + threadIdx.x] = 0;
   __syncthreads();
 #pragma unroll
   for (int sub = 0; sub < kSegAcc / kBlockAcc; ++sub) {
@@ -1170,17 +1174,18 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
             inbox[4 * (size_t)nb[q] + back_slot[q]] =
                 make_float4(term.x, term.y, term.z, __uint_as_float((epoch << 3) | (uint32_t)neighbor_count));
         } else {
-          const unsigned long long v[4] = {(unsigned long long)q_from_float(term.x), (unsigned long long)q_from_float(term.y),
-                                           (unsigned long long)q_from_float(term.z), (unsigned long long)q_from_float(term.w)};
+          // two packed words per term: (gx | gy) and (gz | one count in the byte of the sender's class)
+          const unsigned long long w0 = pack_pair(q22_from_float(term.x), q22_from_float(term.y));
+          const unsigned long long w1 = pack_pair(q22_from_float(term.z), 1 << (8 * (neighbor_count - 1)));
           const uint32_t rel = nb[q] - base;
           if (rel < (uint32_t)kSegAcc) {
             // component-major LDS layout: consecutive lanes (consecutive targets) hit consecutive banks
-#pragma unroll
-            for (int c = 0; c < 4; ++c) atomicAdd(&lacc[c * kSegAcc + rel], v[c]);
+            atomicAdd(&lacc[rel], w0);
+            atomicAdd(&lacc[kSegAcc + rel], w1);
           } else if (exp != 2 && exp != 4) {
-            unsigned long long* a = reinterpret_cast<unsigned long long*>(&grad_acc[4 * (size_t)nb[q]]);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) atomicAdd(&a[c], v[c]);
+            unsigned long long* a = reinterpret_cast<unsigned long long*>(&grad_acc[2 * (size_t)nb[q]]);
+            atomicAdd(&a[0], w0);
+            atomicAdd(&a[1], w1);
           }
         }
         const float d2 = t.x * t.x + t.y * t.y + t.z * t.z;
@@ -1200,10 +1205,9 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
 #pragma unroll
   for (int sub = 0; sub < kSegAcc / kBlockAcc; ++sub) {
     const uint32_t rel = sub * kBlockAcc + threadIdx.x;
-    const unsigned long long v0 = lacc[rel], v1 = lacc[kSegAcc + rel], v2 = lacc[2 * kSegAcc + rel], v3 = lacc[3 * kSegAcc + rel];
-    if (v0 | v1 | v2 | v3)
-      *reinterpret_cast<longlong4*>(&grad_local[4 * (size_t)(base + rel)]) =
-          make_longlong4((long long)v0, (long long)v1, (long long)v2, (long long)v3);
+    const unsigned long long v0 = lacc[rel], v1 = lacc[kSegAcc + rel];
+    if (v0 | v1)
+      *reinterpret_cast<ulonglong2*>(&grad_local[2 * (size_t)(base + rel)]) = make_ulonglong2(v0, v1);
   }
 }
 
@@ -1228,25 +1232,34 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long*
     const Vec3 sp = {S.f(kSmoothX, i), S.f(kSmoothY, i), S.f(kSmoothZ, i)};
     // exact fixed-point sums: contributions from other segments (global atomics) + from the own segment
     // (accumulated in LDS by pass B and stored plainly); integer addition, so the split does not matter
-    longlong4* ap = reinterpret_cast<longlong4*>(&grad_acc[4 * (size_t)i]);
-    longlong4* lp = reinterpret_cast<longlong4*>(&grad_local[4 * (size_t)i]);
-    const longlong4 a = *ap, l = *lp;
+    ulonglong2* ap = reinterpret_cast<ulonglong2*>(&grad_acc[2 * (size_t)i]);
+    ulonglong2* lp = reinterpret_cast<ulonglong2*>(&grad_local[2 * (size_t)i]);
+    const ulonglong2 a = *ap, l = *lp;
     const float4* ib = &inbox[4 * (size_t)i];
     const float4 in0 = ib[0], in1 = ib[1], in2 = ib[2], in3 = ib[3];
-    if (a.x | a.y | a.z | a.w) *ap = make_longlong4(0, 0, 0, 0);  // keep the accumulators zero between calls
-    if (l.x | l.y | l.z | l.w) *lp = make_longlong4(0, 0, 0, 0);
-    long long sum[4] = {a.x + l.x, a.y + l.y, a.z + l.z, a.w + l.w};
+    if (a.x | a.y) *ap = make_ulonglong2(0, 0);  // keep the accumulators zero between calls
+    if (l.x | l.y) *lp = make_ulonglong2(0, 0);
+    long long sum[3];
+    int ylo, cls;
+    unpack_pair((long long)(a.x + l.x), sum[0], ylo);
+    unpack_pair((long long)(a.y + l.y), sum[2], cls);
+    sum[1] = ylo;
+    uint32_t senders[4] = {(uint32_t)cls & 255u, ((uint32_t)cls >> 8) & 255u, ((uint32_t)cls >> 16) & 255u, (uint32_t)cls >> 24};
     // terms delivered through the exclusive inbox slots: valid if stamped by this call's k_reg_accumulate
     const float4 ins[4] = {in0, in1, in2, in3};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const uint32_t code = __float_as_uint(ins[k].w);
       if ((code >> 3) != epoch) continue;
-      const float wk = weight / (float)(code & 7u);  // :2182, the sender's neighbour count
-      sum[0] += q_from_float(ins[k].x); sum[1] += q_from_float(ins[k].y);
-      sum[2] += q_from_float(ins[k].z); sum[3] += q_from_float(wk);
+      sum[0] += q22_from_float(ins[k].x); sum[1] += q22_from_float(ins[k].y); sum[2] += q22_from_float(ins[k].z);
+      senders[((code & 7u) - 1u) & 3u] += 1u;
     }
-    const float acc[4] = {q_to_float(sum[0]), q_to_float(sum[1]), q_to_float(sum[2]), q_to_float(sum[3])};
+    // sum over the senders of weight / (sender's neighbour count) (:2182), exact: per class, count x 2^-32 quotient
+    long long wsum_q = 0;
+#pragma unroll
+    for (int cnt = 1; cnt <= 4; ++cnt)
+      if (senders[cnt - 1]) wsum_q += (long long)senders[cnt - 1] * q_from_float(weight / (float)cnt);
+    const float acc[4] = {q22_to_float(sum[0]), q22_to_float(sum[1]), q22_to_float(sum[2]), q_to_float(wsum_q)};
     Vec3 grad = {2 * (sp.x - mp.x) + acc[0], 2 * (sp.y - mp.y) + acc[1], 2 * (sp.z - mp.z) + acc[2]};
     // own term and neighbour count: formed by k_reg_accumulate from the pre-step smooth positions
     const float4 own_g = *S.group(kGroupG, i);
@@ -1343,8 +1356,8 @@ struct smx_recon_s {
   int W, H;
   float fx, fy, cx, cy;
   Surfels S;
-  long long* grad_acc;      // [slots][4] 2^-32 fixed point, cross-segment contributions (atomics)
-  long long* grad_local;    // [slots][4] in-segment contributions (plain stores)
+  long long* grad_acc;      // [slots][2] packed fixed point (see pack_pair), cross-segment contributions (atomics)
+  long long* grad_local;    // [slots][2] in-segment contributions (plain stores)
   float4* inbox;            // [slots][4] terms stored by the neighbour a slot lists at position k (no atomics)
   Lists L;
   int nseg;                 // number of kSeg-slot segments (= workgroups of pass A)
@@ -1380,6 +1393,7 @@ struct smx_recon_s {
   size_t staging_floats;
   int grid_surfels;  // persistent grid for the grid-stride all-slot kernels
   int grid_list;     // persistent grid of the chunked list kernels
+  int grid_front;    // ... of the two list kernels that run beside the previous frame's regulariser
   int exp = 0;
   uint32_t reg_epoch = 0;  // regulariser calls so far (stamps the inbox slots)
   // Frame pipelining: the regulariser of frame f runs on an internal stream while the caller's stream already
@@ -1510,8 +1524,8 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   // cuda_surfel_reconstruction.cc:59 -- 25 rows x max_surfel_count (zero-filled here so that the
   // padded tail of every row is defined)
   SMX_TRY(dev_alloc(&r->S.base, (size_t)kGroups * 4 * r->S.pitch, true));
-  SMX_TRY(dev_alloc(&r->grad_acc, 4 * ((size_t)r->S.pitch + kSegAcc), true));
-  SMX_TRY(dev_alloc(&r->grad_local, 4 * ((size_t)r->S.pitch + kSegAcc), true));
+  SMX_TRY(dev_alloc(&r->grad_acc, 2 * ((size_t)r->S.pitch + kSegAcc), true));
+  SMX_TRY(dev_alloc(&r->grad_local, 2 * ((size_t)r->S.pitch + kSegAcc), true));
   SMX_TRY(dev_alloc(&r->inbox, 4 * ((size_t)r->S.pitch + kSegAcc), true));
   r->nseg = div_up((long long)r->S.pitch, kSeg);
   r->nsegB = div_up((long long)r->S.pitch, kSegB);
@@ -1565,6 +1579,8 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   r->grid_list = cus * 32;  // the lists are sparse: most chunks are empty, so more, shorter walks
   if (const char* e = getenv("SMX_EXP")) r->exp = atoi(e);
   if (const char* e = getenv("SMX_GRID_LIST")) r->grid_list = atoi(e) > 0 ? atoi(e) : r->grid_list;
+  r->grid_front = r->grid_list;
+  if (const char* e = getenv("SMX_GRID_FRONT")) r->grid_front = atoi(e) > 0 ? atoi(e) : r->grid_front;
   r->stats_enabled = 1;
   *out = r;
   return SMX_OK;
@@ -1678,7 +1694,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   c.stats = r->stats_enabled;
   const int P = r->W * r->H;
   const dim3 b(kBlock), gpx(div_up(P, kBlock)), gimg(div_up(r->W, 64), div_up(r->H, 4));
-  const dim3 gs(r->nseg), gl(r->grid_list);
+  const dim3 gs(r->nseg), gl(r->grid_list), glf(r->grid_front);
   const bool tm = (r->timing_enabled & 1) != 0;
   FrameIn in;
   in.depth = as_img<const uint16_t>(depth); in.normals = as_img<const float2>(normals);
@@ -1706,12 +1722,12 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     hipLaunchKernelGGL(k_scan_visible, gs, b, 0, sF, r->S, c, r->sc, r->L, flags_prev, r->st);
     r->table_valid = true; r->table_frame = frame_index; r->table_window = c.reg_window; }
   { SlotTimer t(r, sF, kSlotAssociate);
-    if (r->scan_mode) hipLaunchKernelGGL((k_associate<false>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->st);
-    else hipLaunchKernelGGL((k_associate<true>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->st); }
+    if (r->scan_mode) hipLaunchKernelGGL((k_associate<false>), glf, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->st);
+    else hipLaunchKernelGGL((k_associate<true>), glf, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->st); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[1], sF)); SMX_HIP(hipEventRecord(r->ev[2], sF)); }
   { SlotTimer t(r, sF, kSlotMergeDecide);
-    if (r->scan_mode) hipLaunchKernelGGL((k_merge_decide<false>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st);
-    else hipLaunchKernelGGL((k_merge_decide<true>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st); }
+    if (r->scan_mode) hipLaunchKernelGGL((k_merge_decide<false>), glf, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st);
+    else hipLaunchKernelGGL((k_merge_decide<true>), glf, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[3], sF)); SMX_HIP(hipEventRecord(r->ev[4], sF)); }
   if (p->do_blending) {
     SlotTimer t(r, sF, kSlotBlend);
@@ -1898,8 +1914,8 @@ int smx_recon_debug_upload_surfels(smx_recon r, smx_stream s, const float* rows,
   memset(&h, 0, sizeof(h));
   h.surfel_count = count; h.merge_count = merge_count;
   SMX_HIP(hipMemcpyAsync(r->st, &h, sizeof(h), hipMemcpyHostToDevice, st));
-  SMX_HIP(hipMemsetAsync(r->grad_acc, 0, 4 * r->S.pitch * sizeof(long long), st));
-  SMX_HIP(hipMemsetAsync(r->grad_local, 0, 4 * r->S.pitch * sizeof(long long), st));
+  SMX_HIP(hipMemsetAsync(r->grad_acc, 0, 2 * r->S.pitch * sizeof(long long), st));
+  SMX_HIP(hipMemsetAsync(r->grad_local, 0, 2 * r->S.pitch * sizeof(long long), st));
   SMX_HIP(hipMemsetAsync(r->inbox, 0, 4 * r->S.pitch * sizeof(float4), st));
   SMX_HIP(hipMemsetAsync(r->merge_flag, 0, r->S.pitch, st));
   SMX_HIP(hipMemsetAsync(r->L.vis_seg, 0, (size_t)r->nseg * 4, st));

@@ -1,4 +1,4 @@
-for g in "X=1" "X=2"; do
+for g in "SMX_GRID_FRONT=4096" "SMX_GRID_FRONT=2048" "SMX_GRID_FRONT=1024" "SMX_GRID_FRONT=512"; do
   env $g timeout 200 python bench.py --steps 300 --warmup 20 --cpu-frames 0 --quiet > gpurun_out/e.log 2>&1
   python - <<PY
 import json
