@@ -644,7 +644,19 @@ __device__ __forceinline__ PixelIn load_pixel(const FrameCtx& c, const Scratch& 
   return p;
 }
 
-__device__ __forceinline__ void integrate_or_conflict(const Surfels& S, const FrameCtx& c, const PixelIn& px,
+// Register copy of the records of one surfel that the integration may touch.  Thread i is the only reader and
+// writer of surfel i in this kernel, so both pixel visits work on the copy (the second one sees what the first
+// one changed, as in the reference) and the changed records are written back once, 16 bytes at a time.
+struct SurfelRegs {
+  float4 P;   // X, Y, Z, LastUpdateStamp
+  float4 N;   // normal, RadiusSquared
+  float4 C;   // Confidence, CreationStamp, Color, -
+  bool dirty;      // P, N or C changed
+  bool replaced;   // S and T have to be reset as well (:816-868)
+  Vec3 new_smooth;
+};
+
+__device__ __forceinline__ void integrate_or_conflict(SurfelRegs& R, const FrameCtx& c, const PixelIn& px,
                                                       bool integrate, int x, int y,
                                                       const Vec3& cam, uint32_t i, DevState* st) {
   if (!integrate) return;
@@ -674,28 +686,25 @@ __device__ __forceinline__ void integrate_or_conflict(const Surfels& S, const Fr
 
   if (conflicting) {  // :816-868
     if (c.stats) atomicAdd(&st->n_conflict_hits, 1u);
-    float confidence = S.f(kConfidence, i);
+    float confidence = R.C.x;
     confidence -= 1;
+    R.dirty = true;
     if (confidence <= 0) {
       if (c.stats) atomicAdd(&st->n_replaced, 1u);
-      S.f(kX, i) = gp.x; S.f(kY, i) = gp.y; S.f(kZ, i) = gp.z;
-      S.f(kSmoothX, i) = gp.x; S.f(kSmoothY, i) = gp.y; S.f(kSmoothZ, i) = gp.z;
-      S.f(kNormalX, i) = gn.x; S.f(kNormalY, i) = gn.y; S.f(kNormalZ, i) = gn.z;
-      S.u(kColor, i) = (uint32_t)col.x | ((uint32_t)col.y << 8) | ((uint32_t)col.z << 16) | (1u << 24);
-      S.f(kRadiusSq, i) = px.radius;
-#pragma unroll
-      for (int n = 0; n < 4; ++n) S.u(kNeighbor0 + n, i) = kInvalid;
-      S.f(kConfidence, i) = 1;
-      S.u(kCreationStamp, i) = c.frame;
-      S.u(kLastUpdateStamp, i) = c.frame;
+      R.P = make_float4(gp.x, gp.y, gp.z, __uint_as_float(c.frame));
+      R.new_smooth = gp;
+      R.replaced = true;  // smooth position := position, neighbours := none
+      R.N = make_float4(gn.x, gn.y, gn.z, px.radius);
+      R.C = make_float4(1.0f, __uint_as_float(c.frame),
+                        __uint_as_float((uint32_t)col.x | ((uint32_t)col.y << 8) | ((uint32_t)col.z << 16) | (1u << 24)), R.C.w);
     } else {
-      S.f(kConfidence, i) = confidence;
+      R.C.x = confidence;
     }
   }
   if (!integrate) return;
 
   const float surfel_distance = sqrtf(cam.x * cam.x + cam.y * cam.y + cam.z * cam.z);
-  const Vec3 sn = {S.f(kNormalX, i), S.f(kNormalY, i), S.f(kNormalZ, i)};
+  const Vec3 sn = {R.N.x, R.N.y, R.N.z};
   const Vec3 ln = rotate(c.L, sn);
   const float dot_angle = (1.0f / surfel_distance) * (cam.x * ln.x + cam.y * ln.y + cam.z * ln.z);
   if (dot_angle > 0) return;
@@ -703,31 +712,31 @@ __device__ __forceinline__ void integrate_or_conflict(const Surfels& S, const Fr
     const float d = sn.x * gn.x + sn.y * gn.y + sn.z * gn.z;  // :898-903
     if (d < c.cos_normal_compat) integrate = false;
   }
-  const float old_r2 = S.f(kRadiusSq, i);
+  const float old_r2 = R.N.w;
   if (old_r2 < 0) integrate = false;
   if (!integrate) return;
 
   uint32_t cnt = px.count;  // :933
   if (cnt < 1) cnt = 1;
   const float weight = 1.0f / (float)cnt;
-  if (S.u(kCreationStamp, i) < c.frame) {  // :940
+  if (__float_as_uint(R.C.y) < c.frame) {  // :940
     if (c.stats) atomicAdd(&st->n_integrated, 1u);
-    const float confidence = S.f(kConfidence, i);
-    S.f(kConfidence, i) = (confidence + weight < c.max_conf) ? (confidence + weight) : c.max_conf;
+    const float confidence = R.C.x;
+    R.C.x = (confidence + weight < c.max_conf) ? (confidence + weight) : c.max_conf;
     const float nf = 1.0f / (confidence + weight);
-    S.f(kX, i) = (confidence * S.f(kX, i) + weight * gp.x) * nf;
-    S.f(kY, i) = (confidence * S.f(kY, i) + weight * gp.y) * nf;
-    S.f(kZ, i) = (confidence * S.f(kZ, i) + weight * gp.z) * nf;
+    R.P.x = (confidence * R.P.x + weight * gp.x) * nf;
+    R.P.y = (confidence * R.P.y + weight * gp.y) * nf;
+    R.P.z = (confidence * R.P.z + weight * gp.z) * nf;
     const Vec3 nn = {confidence * sn.x + weight * gn.x, confidence * sn.y + weight * gn.y, confidence * sn.z + weight * gn.z};
     const float inv = 1.0f / sqrtf(nn.x * nn.x + nn.y * nn.y + nn.z * nn.z);
-    S.f(kNormalX, i) = inv * nn.x; S.f(kNormalY, i) = inv * nn.y; S.f(kNormalZ, i) = inv * nn.z;
-    S.f(kRadiusSq, i) = fminf(old_r2, px.radius);
-    const uint32_t oc = S.u(kColor, i);
+    R.N = make_float4(inv * nn.x, inv * nn.y, inv * nn.z, fminf(old_r2, px.radius));
+    const uint32_t oc = __float_as_uint(R.C.z);
     const uint32_t c0 = (uint32_t)(uint8_t)(int)((confidence * (float)(oc & 255u) + weight * (float)col.x) * nf + 0.5f);
     const uint32_t c1 = (uint32_t)(uint8_t)(int)((confidence * (float)((oc >> 8) & 255u) + weight * (float)col.y) * nf + 0.5f);
     const uint32_t c2 = (uint32_t)(uint8_t)(int)((confidence * (float)((oc >> 16) & 255u) + weight * (float)col.z) * nf + 0.5f);
-    S.u(kColor, i) = c0 | (c1 << 8) | (c2 << 16);
-    S.u(kLastUpdateStamp, i) = c.frame;
+    R.C.z = __uint_as_float(c0 | (c1 << 8) | (c2 << 16));
+    R.P.w = __uint_as_float(c.frame);
+    R.dirty = true;
   }
 }
 
@@ -751,9 +760,11 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
       ++merged_here;
       continue;  // r^2 < 0: the integrate kernel does nothing for it (:1050-1052)
     }
-    // P and N records requested together; integrate_or_conflict re-reads individual fields afterwards (the
-    // second pixel must see what the first one wrote), by then from cache
-    const float4 p4 = *S.group(kGroupP, i), n4 = *S.group(kGroupN, i);
+    // the three records the integration works on, requested together
+    SurfelRegs R;
+    R.P = *S.group(kGroupP, i); R.N = *S.group(kGroupN, i); R.C = *S.group(kGroupC, i);
+    R.dirty = false; R.replaced = false;
+    const float4 p4 = R.P, n4 = R.N;
     if (!is_active(__float_as_uint(p4.w), c.frame, c.window)) continue;
     Proj p;
     const Vec3 g = {p4.x, p4.y, p4.z};
@@ -763,10 +774,17 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
     const bool second = quadrant(p, c, ox, oy);
     const PixelIn px0 = load_pixel(c, sc, in, p.px, p.py);
     const PixelIn px1 = load_pixel(c, sc, in, ox, oy);  // (the main pixel again if there is no second one)
-    integrate_or_conflict(S, c, px0, true, p.px, p.py, p.l, i, st);
-    integrate_or_conflict(S, c, px1, second, ox, oy, p.l, i, st);
+    integrate_or_conflict(R, c, px0, true, p.px, p.py, p.l, i, st);
+    integrate_or_conflict(R, c, px1, second, ox, oy, p.l, i, st);
+    if (R.dirty) {
+      *S.group(kGroupP, i) = R.P; *S.group(kGroupN, i) = R.N; *S.group(kGroupC, i) = R.C;
+      if (R.replaced) {
+        S.f(kSmoothX, i) = R.new_smooth.x; S.f(kSmoothY, i) = R.new_smooth.y; S.f(kSmoothZ, i) = R.new_smooth.z;
+        *reinterpret_cast<uint4*>(S.group(kGroupT, i)) = make_uint4(kInvalid, kInvalid, kInvalid, kInvalid);
+      }
+    }
     // stamp and detach flag may have changed: refresh the flag table entry
-    L.flags8[i] = make_flags(S.u(kLastUpdateStamp, i), S.u(kColor, i), c.frame, c.reg_window);
+    L.flags8[i] = make_flags(__float_as_uint(R.P.w), __float_as_uint(R.C.z), c.frame, c.reg_window);
   }
   // merge counter: one atomic per wavefront that merged something (kernels.cu:2045-2051 block-reduces)
 #pragma unroll
