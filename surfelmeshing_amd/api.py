@@ -35,9 +35,14 @@ def _stream(s):
 class Stream:
     """A HIP stream (cudaStream_t in the reference's signatures)."""
 
-    def __init__(self):
+    def __init__(self, priority_class=None):
+        """priority_class: None = plain stream; -1 / 0 / +1 = lowest / default / highest device priority
+        (cudaStreamCreateWithPriority)."""
         self.handle = C.c_void_p()
-        _lib.check(_lib.load().smx_stream_create(C.byref(self.handle)))
+        if priority_class is None:
+            _lib.check(_lib.load().smx_stream_create(C.byref(self.handle)))
+        else:
+            _lib.check(_lib.load().smx_stream_create_with_priority(C.byref(self.handle), C.c_int32(priority_class)))
 
     def synchronize(self):
         _lib.check(_lib.load().smx_stream_synchronize(self.handle))

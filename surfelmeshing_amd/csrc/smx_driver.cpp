@@ -43,14 +43,14 @@ struct smx_driver_s {
   std::map<u32, std::unique_ptr<Frame>> frames;
   cudaStream_t pre_stream = nullptr;   // depth preprocessing of the next frame
   smx_event run_start = nullptr;
-  bool overlap = getenv("SMX_DRV_SERIAL") == nullptr;
+  bool overlap = true;
   unsigned long long frame_counter = 0;
 
   explicit smx_driver_s(const smx_driver_config& c, const float* intr)
       : cfg(c), camera(c.width, c.height, intr), reconstruction(c.max_surfel_count, camera),
         work0(c.height, c.width), work1(c.height, c.width), last(&work0) {
     // preprocessing runs ahead of the frame loop: it only has to keep up, so it yields to the surfel kernels
-    SMX_SHIM_CHECK(smx_stream_create_with_priority(&pre_stream, getenv("SMX_PRE_NORMAL") ? 0 : -1));
+    SMX_SHIM_CHECK(smx_stream_create_with_priority(&pre_stream, -1));
     SMX_SHIM_CHECK(smx_event_create(&run_start));
     SMX_SHIM_CHECK(smx_stream_synchronize(nullptr));
   }

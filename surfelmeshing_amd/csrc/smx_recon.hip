@@ -883,8 +883,8 @@ k_update_neighbors(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, const
 // CreateNewSurfelsCUDA, kernels.cc:37-146.  The u8 flag kernel (kernels.cu:90-111), the CUB
 // exclusive scan (kernels.cu:2506-2520) and the two D2H count reads are replaced by:
 //   k_new_flags_scan  flags + block-local exclusive ranks (wave64 ballot/popcount + LDS),
-//   k_new_finalize    scan of <= a few hundred block totals, advances the device-side count,
-//   k_new_create      the creation kernel (kernels.cu:133-231).
+//   k_new_create      scan of the <= a few hundred block totals (redundantly per workgroup; workgroup 0 advances
+//                     the device-side count) + the creation kernel (kernels.cu:133-231).
 constexpr int kScanPxPerThread = 4;
 constexpr int kScanPxPerBlock = kBlock * kScanPxPerThread;
 
@@ -1035,7 +1035,7 @@ k_new_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, const uint8_t* __res
 template <bool kDetach, bool kAccumulate>
 __global__ void __launch_bounds__(kBlockB)
 k_neighbor_scan(Surfels S, int stats, Lists L, uint8_t* __restrict__ inwin8, uint32_t* __restrict__ need_seg,
-                DevState* st, int exp = 0) {
+                DevState* st) {
   // B1: pure streaming.  Per slot: detach (:1430-1433), which of its neighbours lie inside the regulariser
   // window (4-bit mask -> inwin8), membership in the recent list.  No LDS accumulators here, so the
   // occupancy stays high; the accumulation itself runs in k_reg_accumulate on the few segments that need it.
@@ -1124,7 +1124,7 @@ __global__ void __launch_bounds__(kBlockAcc)
 k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ grad_acc,
                  long long* __restrict__ grad_local, float4* __restrict__ inbox,
                  const uint8_t* __restrict__ inwin8, const uint8_t* __restrict__ flags8,
-                 const uint32_t* __restrict__ need_seg, const DevState* st, uint32_t epoch, int exp) {
+                 const uint32_t* __restrict__ need_seg, const DevState* st, uint32_t epoch) {
   __shared__ unsigned long long lacc[kSegAcc * 2];  // per target: (gx | gy), (gz | sender classes)
   const uint32_t N = st->surfel_count;
   const uint32_t base = blockIdx.x * kSegAcc;
@@ -1163,7 +1163,7 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float4 ts = *S.group(kGroupS, (gmask & (1u << q)) ? nb[q] : i);
-      const uint4 tt = *reinterpret_cast<const uint4*>(S.group(kGroupT, ((mask & (1u << q)) && exp != 4) ? nb[q] : i));
+      const uint4 tt = *reinterpret_cast<const uint4*>(S.group(kGroupT, (mask & (1u << q)) ? nb[q] : i));
       np[q].x = ts.x; np[q].y = ts.y; np[q].z = ts.z;
       back_slot[q] = tt.x == i ? 0 : tt.y == i ? 1 : tt.z == i ? 2 : tt.w == i ? 3 : -1;
     }
@@ -1188,9 +1188,8 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
         if (back_slot[q] >= 0 && once) {
           // w carries (call epoch, neighbour count) instead of weight / count: the reader recomputes the quotient
           // and ignores slots of older calls, so nobody has to clear the inbox
-          if (exp != 3)
-            inbox[4 * (size_t)nb[q] + back_slot[q]] =
-                make_float4(term.x, term.y, term.z, __uint_as_float((epoch << 3) | (uint32_t)neighbor_count));
+          inbox[4 * (size_t)nb[q] + back_slot[q]] =
+              make_float4(term.x, term.y, term.z, __uint_as_float((epoch << 3) | (uint32_t)neighbor_count));
         } else {
           // two packed words per term: (gx | gy) and (gz | one count in the byte of the sender's class)
           const unsigned long long w0 = pack_pair(q22_from_float(term.x), q22_from_float(term.y));
@@ -1200,7 +1199,7 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
             // component-major LDS layout: consecutive lanes (consecutive targets) hit consecutive banks
             atomicAdd(&lacc[rel], w0);
             atomicAdd(&lacc[kSegAcc + rel], w1);
-          } else if (exp != 2 && exp != 4) {
+          } else {
             unsigned long long* a = reinterpret_cast<unsigned long long*>(&grad_acc[2 * (size_t)nb[q]]);
             atomicAdd(&a[0], w0);
             atomicAdd(&a[1], w1);
@@ -1411,8 +1410,6 @@ struct smx_recon_s {
   size_t staging_floats;
   int grid_surfels;  // persistent grid for the grid-stride all-slot kernels
   int grid_list;     // persistent grid of the chunked list kernels
-  int grid_front;    // ... of the two list kernels that run beside the previous frame's regulariser
-  int exp = 0;
   uint32_t reg_epoch = 0;  // regulariser calls so far (stamps the inbox slots)
   // Frame pipelining: the regulariser of frame f runs on an internal stream while the caller's stream already
   // executes clear / pass A / associate / merge / blend of frame f+1 (those read only P and N records, which the
@@ -1477,7 +1474,7 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
       if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, false>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st);
       else hipLaunchKernelGGL((k_neighbor_scan<false, false>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st);
     } else {
-      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, true>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st, r->exp);
+      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, true>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st);
       else hipLaunchKernelGGL((k_neighbor_scan<false, true>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st);
     }
   }
@@ -1489,7 +1486,7 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
     }
     SlotTimer t(r, st, kSlotRegAccumulate);
     hipLaunchKernelGGL(k_reg_accumulate, dim3(div_up((long long)r->nsegB * kSegB, kSegAcc)), dim3(kBlockAcc), 0, st, r->S, rf2, weight, r->grad_acc, r->grad_local,
-                       r->inbox, r->inwin8, r->L.flags8, r->need_seg, r->st, r->reg_epoch, r->exp);
+                       r->inbox, r->inwin8, r->L.flags8, r->need_seg, r->st, r->reg_epoch);
   }
   if (copy_only) {
     SlotTimer t(r, st, kSlotRegUpdate);
@@ -1595,10 +1592,6 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   r->grid_surfels = cus * 8;  // 8 x 256-thread workgroups per CU: full occupancy, >> 256 workgroups
   r->grid_list = cus * 32;  // the lists are sparse: most chunks are empty, so more, shorter walks
-  if (const char* e = getenv("SMX_EXP")) r->exp = atoi(e);
-  if (const char* e = getenv("SMX_GRID_LIST")) r->grid_list = atoi(e) > 0 ? atoi(e) : r->grid_list;
-  r->grid_front = r->grid_list;
-  if (const char* e = getenv("SMX_GRID_FRONT")) r->grid_front = atoi(e) > 0 ? atoi(e) : r->grid_front;
   r->stats_enabled = 1;
   *out = r;
   return SMX_OK;
@@ -1712,7 +1705,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   c.stats = r->stats_enabled;
   const int P = r->W * r->H;
   const dim3 b(kBlock), gpx(div_up(P, kBlock)), gimg(div_up(r->W, 64), div_up(r->H, 4));
-  const dim3 gs(r->nseg), gl(r->grid_list), glf(r->grid_front);
+  const dim3 gs(r->nseg), gl(r->grid_list);
   const bool tm = (r->timing_enabled & 1) != 0;
   FrameIn in;
   in.depth = as_img<const uint16_t>(depth); in.normals = as_img<const float2>(normals);
@@ -1740,12 +1733,12 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     hipLaunchKernelGGL(k_scan_visible, gs, b, 0, sF, r->S, c, r->sc, r->L, flags_prev, r->st);
     r->table_valid = true; r->table_frame = frame_index; r->table_window = c.reg_window; }
   { SlotTimer t(r, sF, kSlotAssociate);
-    if (r->scan_mode) hipLaunchKernelGGL((k_associate<false>), glf, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->st);
-    else hipLaunchKernelGGL((k_associate<true>), glf, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->st); }
+    if (r->scan_mode) hipLaunchKernelGGL((k_associate<false>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->st);
+    else hipLaunchKernelGGL((k_associate<true>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->st); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[1], sF)); SMX_HIP(hipEventRecord(r->ev[2], sF)); }
   { SlotTimer t(r, sF, kSlotMergeDecide);
-    if (r->scan_mode) hipLaunchKernelGGL((k_merge_decide<false>), glf, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st);
-    else hipLaunchKernelGGL((k_merge_decide<true>), glf, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st); }
+    if (r->scan_mode) hipLaunchKernelGGL((k_merge_decide<false>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st);
+    else hipLaunchKernelGGL((k_merge_decide<true>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[3], sF)); SMX_HIP(hipEventRecord(r->ev[4], sF)); }
   if (p->do_blending) {
     SlotTimer t(r, sF, kSlotBlend);

@@ -271,6 +271,22 @@ def test_invalid_arguments_raise(smx):
     assert rec.surfels_size() == 0 and rec.surfel_count() == 0
 
 
+def test_streams_with_priority_and_explicit_stream(smx):
+    """Integrate on an explicit (non-default) caller stream, with pipelining: same result as the oracle; stream
+    creation with a priority class validates its argument."""
+    with pytest.raises(smx.SmxError):
+        smx.Stream(priority_class=5)
+    st = smx.Stream(priority_class=1)
+    s = small_stream(obstacle_until=8)
+    po, pg = _pipes(smx, s, 60000)
+    smx.StreamSynchronize(None)                        # (construction used the default stream)
+    pg.stream = st
+    run_both(po, pg, s, list(range(4, 16)), None)
+    st.synchronize()
+    _compare_state(po, pg)
+    st.close()
+
+
 def test_native_driver_matches_oracle(smx):
     """The C++ frame loop (include/smx_driver.h, written against the shim classes of smx_shim.hpp) produces the
     same state as the oracle; many frames are enqueued by one call."""
