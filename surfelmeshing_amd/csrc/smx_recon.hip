@@ -39,7 +39,7 @@ enum : int {
 struct DevState {
   uint32_t surfel_count;   // slots in use (incl. merged zombies)
   uint32_t merge_count;
-  uint32_t vis_count;      // (unused: the lists are segmented, see Lists)
+  uint32_t create_base_next;  // slot count seen by k_new_flags_scan (which may run beside the previous frame's pass B)
   uint32_t recent_count;   // statistics: slots inside the regulariser window
   uint32_t create_base;
   uint32_t new_count;
@@ -934,7 +934,8 @@ k_new_flags_scan(Img<const uint16_t> depth, Scratch sc, int W, int H, uint8_t* _
   }
   if (threadIdx.x == 0) {
     block_sums[blockIdx.x] = total;
-    if (blockIdx.x == 0) st->create_base = st->surfel_count;  // stable until k_new_create's workgroup 0 adds the new slots
+    // (not create_base itself: the previous frame's pass B may still be reading that one)
+    if (blockIdx.x == 0) st->create_base_next = st->surfel_count;  // stable until k_new_create's workgroup 0 adds the new slots
   }
 }
 
@@ -959,12 +960,13 @@ k_new_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, const uint8_t* __res
     if (bidx < n_scan_blocks) { block_offsets[bidx] = run; run += block_sums[bidx]; }
   }
   __syncthreads();
-  const uint32_t base = st->create_base;
+  const uint32_t base = st->create_base_next;
   const uint32_t room = max_surfels - base;
   const uint32_t created = total < room ? total : room;  // cap rule (reference: unchecked, cc:291)
   if (blockIdx.x == 0) {
     for (int bidx = threadIdx.x; bidx < n_scan_blocks; bidx += kBlock) block_offsets_out[bidx] = block_offsets[bidx];
     if (threadIdx.x == 0) {
+      st->create_base = base;
       st->new_count = created;
       st->capacity_clamped = (total > room) ? 1u : 0u;
       st->surfel_count = base + created;
@@ -1757,6 +1759,11 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     }
   }
   if (tm) SMX_HIP(hipEventRecord(r->ev[5], sF));
+  // Which pixels spawn a surfel depends only on the association images and the blended depth: the flag + rank
+  // kernel of CreateNewSurfelsCUDA runs here, off the frame-to-frame critical path.
+  { SlotTimer t(r, sF, kSlotNewFlagsScan);
+    hipLaunchKernelGGL(k_new_flags_scan, dim3(r->n_scan_blocks), b, 0, sF, in.depth, r->sc, r->W, r->H, r->new_flags,
+                       r->new_ranks, r->block_sums, r->st); }
   if (pipelined) {
     SMX_HIP(hipEventRecord(r->ev_front, sF));
     SMX_HIP(hipStreamWaitEvent(sH, r->ev_front, 0));
@@ -1773,9 +1780,6 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     else hipLaunchKernelGGL((k_update_neighbors<true>), gl, b, 0, sH, r->S, c, r->sc, in, r->L, r->st); }
   // (the detach half of UpdateNeighborsCUDA runs fused into pass B below)
   if (tm) { SMX_HIP(hipEventRecord(r->ev[9], sH)); SMX_HIP(hipEventRecord(r->ev[10], sH)); }
-  { SlotTimer t(r, sH, kSlotNewFlagsScan);
-    hipLaunchKernelGGL(k_new_flags_scan, dim3(r->n_scan_blocks), b, 0, sH, in.depth, r->sc, r->W, r->H, r->new_flags,
-                       r->new_ranks, r->block_sums, r->st); }
   { SlotTimer t(r, sH, kSlotNewCreate);
     hipLaunchKernelGGL(k_new_create, dim3(div_up(P, kBlock)), b, (size_t)r->n_scan_blocks * sizeof(uint32_t), sH, r->S, c, r->sc, in,
                        r->new_flags, r->new_ranks, r->block_sums, r->block_offsets, r->n_scan_blocks, r->max_surfels,
