@@ -42,12 +42,10 @@ ALG_BYTES = {
     "associate": lambda st, P: 90.0 * st["n_visible"],
     "merge_decide": lambda st, P: 60.0 * st["n_visible"],
     "integrate": lambda st, P: 160.0 * st["n_visible"],
-    "update_neighbors": lambda st, P: 190.0 * st["n_visible"],
+    "update_neighbors+create": lambda st, P: 190.0 * st["n_visible"] + 6.0 * P + 122.0 * st["n_new"],
     "blend": lambda st, P: 26.0 * P,
     "clear_assoc": lambda st, P: 26.0 * P,
     "new_flags_scan": lambda st, P: 15.0 * P,
-    "new_create": lambda st, P: 6.0 * P + 122.0 * st["n_new"],
-    "new_finalize": lambda st, P: 8.0 * (P / 1024.0),
 }
 
 

@@ -798,11 +798,12 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
 // ---------------------------------------------------------------------------------------------
 // UpdateNeighborsCUDAKernel, kernels.cu:1197-1380.
 template <bool kUseList>
-__global__ void __launch_bounds__(kBlock)
-k_update_neighbors(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, const DevState* st) {
+__device__ __forceinline__ void update_neighbors_body(const Surfels& S, const FrameCtx& c, const Scratch& sc, const FrameIn& in,
+                                                      const Lists& L, const DevState* st, uint32_t block, uint32_t n_blocks) {
   const int kDX[4] = {-1, 1, 0, 0}, kDY[4] = {0, 0, -1, 1};
-  const uint32_t n_slots = st->surfel_count, n_chunks = (n_slots + kBlock - 1) / kBlock;
-  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  // (the slot count BEFORE this frame's creation: the creating workgroups of the same launch advance surfel_count)
+  const uint32_t n_slots = st->create_base_next, n_chunks = (n_slots + kBlock - 1) / kBlock;
+  for (uint32_t chunk = block; chunk < n_chunks; chunk += n_blocks) {
     uint32_t i;
     if (!chunk_entry<kUseList>(L.vis_list, L.vis_seg, n_slots, chunk, i)) continue;
     // the slot's three records in flight together (P: position + stamp, N: normal + r^2, T: neighbour ids)
@@ -939,10 +940,19 @@ k_new_flags_scan(Img<const uint16_t> depth, Scratch sc, int W, int H, uint8_t* _
   }
 }
 
-__global__ void __launch_bounds__(kBlock)
-k_new_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, const uint8_t* __restrict__ flags,
-             uint32_t* __restrict__ ranks, const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_offsets_out,
-             int n_scan_blocks, uint32_t max_surfels, uint8_t* __restrict__ flags8, DevState* st) {
+struct CreateArgs {
+  const uint8_t* flags; const uint32_t* ranks; const uint32_t* block_sums; uint32_t* block_offsets_out;
+  int n_scan_blocks; uint32_t max_surfels; uint8_t* flags8;
+};
+__device__ __forceinline__ void new_create_body(const Surfels& S, const FrameCtx& c, const Scratch& sc, const FrameIn& in,
+                                                const CreateArgs& a, DevState* st, uint32_t block, uint32_t n_blocks) {
+  const uint8_t* __restrict__ flags = a.flags;
+  const uint32_t* __restrict__ ranks = a.ranks;
+  const uint32_t* __restrict__ block_sums = a.block_sums;
+  uint32_t* __restrict__ block_offsets_out = a.block_offsets_out;
+  const int n_scan_blocks = a.n_scan_blocks;
+  const uint32_t max_surfels = a.max_surfels;
+  uint8_t* __restrict__ flags8 = a.flags8;
   // Every workgroup scans the few hundred block totals of k_new_flags_scan itself (cheaper than a launch of its
   // own for one workgroup); workgroup 0 publishes the counts (cc:291) and the offsets (debug decode).
   extern __shared__ uint32_t block_offsets[];  // [n_scan_blocks] exclusive
@@ -963,7 +973,7 @@ k_new_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, const uint8_t* __res
   const uint32_t base = st->create_base_next;
   const uint32_t room = max_surfels - base;
   const uint32_t created = total < room ? total : room;  // cap rule (reference: unchecked, cc:291)
-  if (blockIdx.x == 0) {
+  if (block == 0) {
     for (int bidx = threadIdx.x; bidx < n_scan_blocks; bidx += kBlock) block_offsets_out[bidx] = block_offsets[bidx];
     if (threadIdx.x == 0) {
       st->create_base = base;
@@ -974,7 +984,7 @@ k_new_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, const uint8_t* __res
   }
   const int kDX[4] = {-1, 1, 0, 0}, kDY[4] = {0, 0, -1, 1};
   const int W = c.W, H = c.H, P = W * H;
-  for (int k = blockIdx.x * kBlock + threadIdx.x; k < P; k += gridDim.x * kBlock) {
+  for (int k = block * kBlock + threadIdx.x; k < P; k += n_blocks * kBlock) {
     const uint32_t rank = block_offsets[k / kScanPxPerBlock] + ranks[k];
     // ranks[] keeps the block-local values; global rank = block offset + local rank
     if (flags[k] != 1 || rank >= created) continue;
@@ -1024,6 +1034,17 @@ k_new_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, const uint8_t* __res
     S.f(kSmoothY, i) = (gp.y + sum.y) / (float)count_plus_1;
     S.f(kSmoothZ, i) = (gp.z + sum.z) / (float)count_plus_1;
   }
+}
+
+// UpdateNeighborsCUDAKernel and the creation kernel in ONE launch: both only need the integrated surfels, they
+// write disjoint slots (visible old ones / new ones), and every launch boundary on the frame-to-frame critical
+// path costs a cache write-back across the eight XCDs.  The first n_create_blocks workgroups create.
+template <bool kUseList>
+__global__ void __launch_bounds__(kBlock)
+k_update_and_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, CreateArgs a, uint32_t n_create_blocks,
+                    DevState* st) {
+  if (blockIdx.x < n_create_blocks) new_create_body(S, c, sc, in, a, st, blockIdx.x, n_create_blocks);
+  else update_neighbors_body<kUseList>(S, c, sc, in, L, st, blockIdx.x - n_create_blocks, gridDim.x - n_create_blocks);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1427,13 +1448,13 @@ struct smx_recon_s {
 // kernel slots of one Integrate call (launch order)
 enum : int {
   kSlotClear = 0, kSlotScanVisible, kSlotAssociate, kSlotMergeDecide, kSlotBlend, kSlotIntegrate,
-  kSlotUpdateNeighbors, kSlotNewFlagsScan, kSlotNewCreate, kSlotNeighborScan,
+  kSlotUpdateNeighbors, kSlotNewFlagsScan, kSlotNeighborScan,
   kSlotRegAccumulate, kSlotRegStep,
   kSlotRegUpdate, kSlotCount
 };
 static const char* const kSlotNames[kSlotCount] = {
-  "clear_assoc", "scan_visible", "associate", "merge_decide", "blend", "integrate", "update_neighbors",
-  "new_flags_scan", "new_create", "neighbor_scan", "reg_accumulate", "reg_step", "reg_update"};
+  "clear_assoc", "scan_visible", "associate", "merge_decide", "blend", "integrate", "update_neighbors+create",
+  "new_flags_scan", "neighbor_scan", "reg_accumulate", "reg_step", "reg_update"};
 
 struct SlotTimer {
   smx_recon r; hipStream_t st; int slot; bool kev, prof;
@@ -1776,14 +1797,16 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     else hipLaunchKernelGGL((k_integrate<true>), gl, b, 0, sH, r->S, c, r->sc, in, r->L, r->merge_flag, r->st); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[7], sH)); SMX_HIP(hipEventRecord(r->ev[8], sH)); }
   { SlotTimer t(r, sH, kSlotUpdateNeighbors);
-    if (r->scan_mode) hipLaunchKernelGGL((k_update_neighbors<false>), gl, b, 0, sH, r->S, c, r->sc, in, r->L, r->st);
-    else hipLaunchKernelGGL((k_update_neighbors<true>), gl, b, 0, sH, r->S, c, r->sc, in, r->L, r->st); }
+    CreateArgs ca;
+    ca.flags = r->new_flags; ca.ranks = r->new_ranks; ca.block_sums = r->block_sums; ca.block_offsets_out = r->block_offsets;
+    ca.n_scan_blocks = r->n_scan_blocks; ca.max_surfels = r->max_surfels; ca.flags8 = r->L.flags8;
+    const uint32_t ncb = (uint32_t)div_up(P, kBlock);
+    const dim3 guc(ncb + (uint32_t)r->grid_list);
+    const size_t lds = (size_t)r->n_scan_blocks * sizeof(uint32_t);
+    if (r->scan_mode) hipLaunchKernelGGL((k_update_and_create<false>), guc, b, lds, sH, r->S, c, r->sc, in, r->L, ca, ncb, r->st);
+    else hipLaunchKernelGGL((k_update_and_create<true>), guc, b, lds, sH, r->S, c, r->sc, in, r->L, ca, ncb, r->st); }
   // (the detach half of UpdateNeighborsCUDA runs fused into pass B below)
   if (tm) { SMX_HIP(hipEventRecord(r->ev[9], sH)); SMX_HIP(hipEventRecord(r->ev[10], sH)); }
-  { SlotTimer t(r, sH, kSlotNewCreate);
-    hipLaunchKernelGGL(k_new_create, dim3(div_up(P, kBlock)), b, (size_t)r->n_scan_blocks * sizeof(uint32_t), sH, r->S, c, r->sc, in,
-                       r->new_flags, r->new_ranks, r->block_sums, r->block_offsets, r->n_scan_blocks, r->max_surfels,
-                       r->L.flags8, r->st); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[11], sH)); SMX_HIP(hipEventRecord(r->ev[12], sH)); }
   SMX_LAUNCH_CHECK();
   int rc = SMX_OK;
