@@ -79,6 +79,9 @@ void orc_bilateral_filter_and_cutoff(
       }
       const float adapted_sigma_value = (float)center_value * sigma_value_factor;
       const float adapted_denom_value = 2.0f * adapted_sigma_value * adapted_sigma_value;
+      /* the reference is built with -use_fast_math (a / b == a * rcp(b)); here: one correctly rounded
+       * reciprocal per pixel, one multiplication per tap -- same on the CPU and on the GPU */
+      const float inv_denom_value = 1.0f / adapted_denom_value;
 
       float sum = 0, weight = 0;
       const int min_y = (y - radius) > 0 ? (y - radius) : 0;
@@ -95,7 +98,7 @@ void orc_bilateral_filter_and_cutoff(
           if (sample == value_to_ignore) continue;
           float vd = (float)((int)center_value - (int)sample);
           vd *= vd;
-          float w = orc_expf((float)(-g2) / denom_xy + (-vd) / adapted_denom_value);  /* :110 */
+          float w = orc_expf((float)(-g2) / denom_xy + (-vd) * inv_denom_value);  /* :110 */
           sum += w * (float)sample;
           weight += w;
         }

@@ -68,6 +68,7 @@ k_bilateral(float denom_xy, float sigma_value_factor, int radius, int radius_squ
 
   const float adapted_sigma_value = (float)center_value * sigma_value_factor;
   const float adapted_denom_value = 2.0f * adapted_sigma_value * adapted_sigma_value;
+  const float inv_denom_value = 1.0f / adapted_denom_value;  // one division per pixel, not per tap (arithmetic contract)
   float sum = 0, weight = 0;
   const int min_dy = max(-radius, -y), max_dy = min(radius, H - 1 - y);
   const int min_dx = max(-radius, -x), max_dx = min(radius, W - 1 - x);
@@ -80,7 +81,7 @@ k_bilateral(float denom_xy, float sigma_value_factor, int radius, int radius_squ
       if (sample == value_to_ignore) continue;
       float vd = (float)((int)center_value - (int)sample);
       vd *= vd;
-      const float w = det_expf(spatial[g2] + (-vd) / adapted_denom_value);
+      const float w = det_expf(spatial[g2] + (-vd) * inv_denom_value);
       sum += w * (float)sample;
       weight += w;
     }
