@@ -289,6 +289,30 @@ def main():
         dist.destroy_process_group()
 
 
+# kernel-slot name -> kernel name in rocprofv3 output
+SLOT_KERNEL = {"reg_accumulate": "k_reg_accumulate", "reg_step": "k_reg_step", "neighbor_scan": "k_neighbor_scan<true, true>",
+               "scan_visible": "k_scan_visible", "associate": "k_associate<true>", "merge_decide": "k_merge_decide<true>",
+               "integrate": "k_integrate<true>", "update_neighbors+create": "k_update_and_create<true>",
+               "blend": "k_blend_fused", "clear_assoc": "k_clear_assoc", "new_flags_scan": "k_new_flags_scan"}
+
+
+def pmc_traffic(dominant):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/pmc_traffic.json, written by tools/pmc_summary.py; FETCH_SIZE and WRITE_SIZE are in KB and need
+    separate passes).  Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE
+    reports half of the bytes read, so it is doubled; WRITE_SIZE is taken as is.  None if there is no such file."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    try:
+        k = json.load(open(path)).get(SLOT_KERNEL.get(dominant, ""), {})
+        if "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
+            return None, None
+        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0, {"FETCH_SIZE_KB": k["FETCH_SIZE"], "WRITE_SIZE_KB": k["WRITE_SIZE"]}
+    except (ValueError, OSError):
+        return None, None
+
+
 def roofline_block(st, P, dominant, dom_ms, dom_n, kernel_ms):
     """Roofline of the dominant kernel: algorithmic bytes per launch (ALG_BYTES) / average launch
     duration measured with HIP events on the launch stream over the timed region."""
@@ -300,8 +324,10 @@ def roofline_block(st, P, dominant, dom_ms, dom_n, kernel_ms):
             b = ALG_BYTES[k](st, P)
             # the per-kernel pass brackets every launch with two event records (~6 us of overhead per kernel)
             per_kernel[k] = {"ms_with_event_overhead": ms, "algorithmic_MB": b / 1e6}
+    traffic, raw = pmc_traffic(dominant)
     return {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_pmc_raw": raw,
+            "algorithmic_bytes_per_launch": alg,
             "avg_launch_ms": dom_ms, "launches_timed": dom_n, "surfel_slots": st["surfels_size"],
             "kernels_untimed_pass": per_kernel}
 

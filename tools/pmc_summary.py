@@ -1,8 +1,13 @@
 #!/usr/bin/env python
 """Per-kernel averages of rocprofv3 --pmc counters inside the timed region of a bench.py run (between the two
-k_smx_marker dispatches).  Usage: python tools/pmc_summary.py <rocprofv3 output dir> [out.md]"""
+k_smx_marker dispatches).  Usage: python tools/pmc_summary.py <rocprofv3 output dir> [out.md] [merge.json]
+
+With a third argument the averages are merged into that JSON file ({kernel: {counter: average per launch}}), so
+that separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit into one) end up in one place;
+profiles/pmc_traffic.json is what bench.py reads for roofline.traffic."""
 import csv
 import glob
+import json
 import os
 import re
 import sys
@@ -40,6 +45,12 @@ def main():
     out = "\n".join(lines) + "\n"
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(out)
+    if len(sys.argv) > 3:
+        merged = json.load(open(sys.argv[3])) if os.path.exists(sys.argv[3]) else {}
+        for k in agg:
+            merged.setdefault(k, {}).update({c: agg[k][c] / len(cnt[k]) for c in agg[k]})
+            merged[k]["launches"] = len(cnt[k])
+        json.dump(merged, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     print(out)
 
 
