@@ -309,6 +309,8 @@ class CUDASurfelReconstruction {
   // Unlike the reference these read the device-side counters (they synchronise the last used stream).
   u32 surfel_count() const { u32 a = 0, b = 0; SMX_SHIM_CHECK(smx_recon_counts(handle_, last_stream_, &a, &b)); return a; }
   u32 surfels_size() const { u32 a = 0, b = 0; SMX_SHIM_CHECK(smx_recon_counts(handle_, last_stream_, &a, &b)); return b; }
+  // Not in the reference: frame pipelining inside Integrate (on by default, see smx.h smx_recon_set_overlap).
+  void SetFramePipelining(bool enabled) { SMX_SHIM_CHECK(smx_recon_set_overlap(handle_, enabled ? 1 : 0)); }
   smx_recon handle() const { return handle_; }
 
  private:
