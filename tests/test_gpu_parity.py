@@ -186,6 +186,94 @@ def test_pipelined_frames_parity(smx, overlap):
     _compare_state(po, pg)
 
 
+class _EditedStream:
+    """A synthetic stream whose frames are edited before they reach both pipelines."""
+
+    def __init__(self, base, edit):
+        self._b, self._edit = base, edit
+        for k in ("width", "height", "fx", "fy", "cx", "cy"):
+            setattr(self, k, getattr(base, k))
+
+    def frame(self, f):
+        d, c = self._b.frame(f)
+        return self._edit(f, d.copy(), c)
+
+    def __getattr__(self, name):
+        return getattr(self._b, name)
+
+
+def test_empty_and_degenerate_frames(smx):
+    """Empty inputs in the middle of a run: frames without a single valid depth pixel (also as outlier-cull
+    partners), a frame where only one isolated 8x8 patch is valid, then normal frames again.  Empty map first."""
+    base = small_stream(obstacle_until=8)
+
+    def edit(f, d, c):
+        if f in (2, 3, 9, 10, 11):
+            d[:] = 0                                   # nothing measured
+        if f == 14:
+            keep = d[40:48, 60:68].copy()
+            d[:] = 0
+            d[40:48, 60:68] = keep                      # one patch: everything else must be carved / unsupported
+        return d, c
+
+    s = _EditedStream(base, edit)
+    po, pg = _pipes(smx, s, 60000)
+    seen_empty = []
+
+    def check(f):
+        _compare_state(po, pg)
+        if f in (9, 10, 11):
+            seen_empty.append(po.recon.stats()["n_new"])
+
+    # frame 4 integrates into an EMPTY map whose outlier-cull partners include the empty frames 2 and 3
+    run_both(po, pg, s, list(range(4, 20)), check)
+    assert seen_empty == [0, 0, 0]
+    assert po.recon.surfels_size > 5000
+    # Regularize / TransferAllToCPU / ExportVertices on an object that never integrated anything
+    cam = smx.PinholeCamera4f(64, 48, 50.0, 50.0, 32.0, 24.0)
+    rec = smx.CUDASurfelReconstruction(1000, cam)
+    rec.Regularize(None, 0, 10.0, 2.0, 30)
+    cpu = smx.CUDASurfelsCPU(1000)
+    cpu.LockWriteBuffers()
+    rec.TransferAllToCPU(None, 0, cpu)
+    smx.StreamSynchronize(None)
+    cpu.UnlockWriteBuffers()
+    cpu.WaitForLockAndSwapBuffers()
+    assert cpu.read_buffers().surfel_count == 0 and rec.surfels_size() == 0 and rec.surfel_count() == 0
+
+
+def test_large_blending_radius_uses_multi_launch_path(smx):
+    """measurement_blending_radius beyond the fused kernel's LDS halo (> 17) takes the start + iteration launches."""
+    s = small_stream(obstacle_until=8)
+    po, pg = _pipes(smx, s, 60000, params_kw=dict(measurement_blending_radius=24))
+    run_both(po, pg, s, list(range(4, 14)), lambda f: _compare_state(po, pg))
+
+
+def test_camera_turns_away_and_back(smx):
+    """Frames whose view shares nothing with the map (no visible surfel, empty work lists), then the old view again
+    (surfels outside the regulariser window re-enter it)."""
+    from surfelmeshing_amd._lib import IntegrateParams
+    s = small_stream(obstacle_until=6, yaw_deg_per_frame=2.0)
+    po, pg = _pipes(smx, s, 90000, params_kw=dict(regularization_frame_window_size=3))
+    frames = list(range(4, 10)) + list(range(94, 100)) + list(range(4 + 180, 10 + 180))   # yaw 2 deg/frame: 180 deg away, back
+    lo, hi = 0, max(frames) + 5
+    for f in range(lo, hi):
+        if any(abs(f - g) <= 4 for g in frames):
+            d, c = s.frame(f)
+            po.upload(f, d, c)
+            pg.upload(f, d, c)
+    for f in frames:
+        others, T, pose = s.outlier_frames(f), s.others_TR_reference(f), s.pose(f)
+        po.process(f, others, T, pose)
+        pg.process(f, others, T, pose)
+        _compare_state(po, pg)
+        st = po.recon.stats()
+        if f == 94:
+            assert st["n_visible"] == 0 and st["n_new"] > 1000          # nothing of the map in view
+        if f == 184:
+            assert st["n_visible"] > 1000 and st["n_integrated"] > 1000  # old surfels, long outside the window
+
+
 def test_full_resolution_parity(smx):
     s = small_stream(640, 480)
     po, pg = _pipes(smx, s, 1200000)
