@@ -208,6 +208,7 @@ typedef struct {
   uint32_t capacity_clamped;  /* 1 if new-surfel creation hit max_surfel_count */
   uint32_t n_window_edges;    /* neighbour links whose target lies inside the regulariser window */
   uint32_t n_contributors;    /* slots with at least one such link */
+  uint32_t n_segments_skipped;  /* 1024-slot segments pass A did not have to read (out of view, unchanged) */
 } smx_recon_stats;
 int smx_recon_get_stats(smx_recon r, smx_stream s, smx_recon_stats* out);
 /* The n_* counters above are single-address atomics; they are collected only while enabled

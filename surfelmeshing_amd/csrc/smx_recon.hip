@@ -46,7 +46,7 @@ struct DevState {
   uint32_t capacity_clamped;
   uint32_t n_visible, n_merged, n_edges, n_integrated, n_replaced, n_conflict_hits;
   uint32_t n_window_edges, n_contributors;
-  uint32_t pad[1];
+  uint32_t n_segments_skipped;
 };
 
 // HBM layout of the surfel attributes.  The reference keeps 25 separate rows (SoA, kernels.cuh:49-78); that is
@@ -139,6 +139,25 @@ __device__ __forceinline__ bool maybe_in_image(const Vec3& g, const FrameCtx& c)
   const float un = c.fx * l.x + c.cx * l.z, vn = c.fy * l.y + c.cy * l.z;  // u * z, v * z
   return un >= -2.0f * l.z && vn >= -2.0f * l.z && un <= ((float)c.W + 2.0f) * l.z && vn <= ((float)c.H + 2.0f) * l.z;
 }
+// Can any point of the axis-aligned box [lo, hi] pass maybe_in_image?  The five conditions of that test are affine
+// in the point, so a condition violated (with a margin far above float rounding) at all eight corners is violated in
+// the whole box.  Returns true when the box is certainly out of view.
+__device__ __forceinline__ bool box_out_of_view(const Vec3& lo, const Vec3& hi, const FrameCtx& c) {
+  float worst[5] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};  // max over the corners of each condition
+  float scale = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const Vec3 g = {(k & 1) ? hi.x : lo.x, (k & 2) ? hi.y : lo.y, (k & 4) ? hi.z : lo.z};
+    const Vec3 l = mul(c.L, g);
+    const float un = c.fx * l.x + c.cx * l.z, vn = c.fy * l.y + c.cy * l.z;
+    const float f[5] = {l.z, un + 2.0f * l.z, ((float)c.W + 2.0f) * l.z - un, vn + 2.0f * l.z, ((float)c.H + 2.0f) * l.z - vn};
+#pragma unroll
+    for (int q = 0; q < 5; ++q) worst[q] = fmaxf(worst[q], f[q]);
+    scale = fmaxf(scale, fabsf(l.x) + fabsf(l.y) + fabsf(l.z));
+  }
+  const float margin = 1.0e-3f * (c.fx + c.fy + (float)c.W + (float)c.H + 4.0f) * (scale + 1.0f);
+  return worst[0] < -margin || worst[1] < -margin || worst[2] < -margin || worst[3] < -margin || worst[4] < -margin;
+}
 __device__ __forceinline__ bool project(const Surfels& S, uint32_t i, const FrameCtx& c, Proj& o) {
   Vec3 g = {S.f(kX, i), S.f(kY, i), S.f(kZ, i)};
   return project_pos(g, c, o);
@@ -175,6 +194,7 @@ constexpr int kSegB = 1024;
 constexpr int kBlockB = kSegB / 4;
 struct Lists {
   uint32_t* vis_list;     // slots that project into the image this frame
+  float* seg_box;         // per pass-A segment: min xyz, max xyz, covered slot count (u32), newest stamp (u32)
   uint32_t* vis_seg;
   uint32_t* recent_list;  // slots whose last update stamp lies inside the regulariser window
   uint32_t* recent_seg;
@@ -222,6 +242,7 @@ k_clear_assoc(Scratch sc, BlendBufs bb, int P, DevState* st) {
   const int k = blockIdx.x * kBlock + threadIdx.x;
   if (k == 0) {
     st->n_visible = 0; st->n_merged = 0; st->n_integrated = 0; st->n_replaced = 0; st->n_conflict_hits = 0;
+    st->n_segments_skipped = 0;
   }
   if (k < P) {
     sc.supporting[k] = kInvalid;
@@ -245,11 +266,41 @@ __device__ __forceinline__ void min_depth_at(float* first_depth, int W, int x, i
 __global__ void __launch_bounds__(kBlock)
 k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, const uint8_t* __restrict__ flags_prev, DevState* st) {
   __shared__ uint32_t wave_tot[kBlock / 64];
+  __shared__ float box_part[kBlock / 64][8];
+  __shared__ int skip_segment;
   const uint32_t N = st->surfel_count;
   const uint32_t base = blockIdx.x * kSeg;
   if (base >= N) return;  // uniform per workgroup
   const uint32_t i0 = base + threadIdx.x * 4;
+  const uint32_t in_seg = (N - base < (uint32_t)kSeg) ? N - base : (uint32_t)kSeg;
+  // Segment culling.  The box below was formed from every slot of the segment the last time it was read; it is still
+  // valid if the segment has not grown since and had no visible slot in the previous frame (only visible slots are
+  // moved, restamped, merged or replaced).  If it is out of view and its newest stamp has left the regulariser
+  // window, this frame's result for the segment is known without reading its 16 KB of P records: nothing visible,
+  // no recent bit.
+  float* box = &L.seg_box[8 * (size_t)blockIdx.x];
+  if (threadIdx.x == 0) {
+    int skip = 0;
+    if (__float_as_uint(box[6]) == in_seg && L.vis_seg[blockIdx.x] == 0 &&
+        stamp_outside_window(__float_as_uint(box[7]), c.frame, c.reg_window)) {
+      const Vec3 lo = {box[0], box[1], box[2]}, hi = {box[3], box[4], box[5]};
+      skip = box_out_of_view(lo, hi, c) ? 1 : 0;
+    }
+    skip_segment = skip;
+    if (skip && c.stats) atomicAdd(&st->n_segments_skipped, 1u);
+  }
+  __syncthreads();
+  if (skip_segment) {
+    if (i0 < N) {
+      const uchar4 of = *reinterpret_cast<const uchar4*>(&flags_prev[i0]);
+      *reinterpret_cast<uchar4*>(&L.flags8[i0]) = make_uchar4(of.x & 2u, of.y & 2u, of.z & 2u, of.w & 2u);
+    }
+    return;  // (vis_seg stays 0, the box stays as it is)
+  }
   uint32_t vis_bits = 0;
+  float bmin[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bmax[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  uint32_t newest = 0;   // in the wrap-around order of stamp_outside_window: compared as signed
+  bool have_stamp = false;
   if (i0 < N) {
     // four consecutive P records (X, Y, Z, stamp) = 64 contiguous bytes per lane; the group arrays are
     // padded to a multiple of 64 slots, so the loads stay inside the array
@@ -268,6 +319,11 @@ k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, const uint8_t* __rest
       new_flags[j] = (uint8_t)((old_flags[j] & 2u) | (stamp_outside_window(stamps[j], c.frame, c.reg_window) ? 0u : 1u));
       Proj p;
       const Vec3 g = {xs[j], ys[j], zs[j]};
+      if (i < N) {
+        bmin[0] = fminf(bmin[0], g.x); bmin[1] = fminf(bmin[1], g.y); bmin[2] = fminf(bmin[2], g.z);
+        bmax[0] = fmaxf(bmax[0], g.x); bmax[1] = fmaxf(bmax[1], g.y); bmax[2] = fmaxf(bmax[2], g.z);
+        if (!have_stamp || (int)stamps[j] > (int)newest) { newest = stamps[j]; have_stamp = true; }
+      }
       if (i < N && maybe_in_image(g, c) && project_pos(g, c, p)) {
         vis_bits |= 1u << j;
         if (is_active(stamps[j], c.frame, c.window)) {
@@ -280,12 +336,41 @@ k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, const uint8_t* __rest
     }
     *reinterpret_cast<uchar4*>(&L.flags8[i0]) = make_uchar4(new_flags[0], new_flags[1], new_flags[2], new_flags[3]);
   }
+  // the segment's bounding box and newest stamp (wave shuffles, then one partial per wavefront through LDS)
+  int newest_s = have_stamp ? (int)newest : (int)0x80000000;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      bmin[k] = fminf(bmin[k], __shfl_xor(bmin[k], off));
+      bmax[k] = fmaxf(bmax[k], __shfl_xor(bmax[k], off));
+    }
+    const int o = __shfl_xor(newest_s, off);
+    newest_s = o > newest_s ? o : newest_s;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    float* bp = box_part[threadIdx.x >> 6];
+    bp[0] = bmin[0]; bp[1] = bmin[1]; bp[2] = bmin[2]; bp[3] = bmax[0]; bp[4] = bmax[1]; bp[5] = bmax[2];
+    bp[6] = __int_as_float(newest_s);
+  }
   uint32_t total;
-  uint32_t off = base + block_excl_scan((uint32_t)__popc(vis_bits), wave_tot, total);
+  uint32_t off = base + block_excl_scan((uint32_t)__popc(vis_bits), wave_tot, total);  // (synchronises)
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     if (vis_bits & (1u << j)) L.vis_list[off++] = i0 + j;
-  if (threadIdx.x == 0) L.vis_seg[blockIdx.x] = total;
+  if (threadIdx.x == 0) {
+    L.vis_seg[blockIdx.x] = total;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    int ns = (int)0x80000000;
+    for (int w = 0; w < kBlock / 64; ++w) {
+      for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], box_part[w][k]); hi[k] = fmaxf(hi[k], box_part[w][3 + k]); }
+      const int o = __float_as_int(box_part[w][6]);
+      ns = o > ns ? o : ns;
+    }
+    box[0] = lo[0]; box[1] = lo[1]; box[2] = lo[2]; box[3] = hi[0]; box[4] = hi[1]; box[5] = hi[2];
+    box[6] = __uint_as_float(in_seg);
+    box[7] = __int_as_float(ns);
+  }
 }
 
 // List kernels walk the segmented list in chunks of kBlock entries (one entry per lane), grid-striding
@@ -1570,6 +1655,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->L.vis_list, (size_t)r->nseg * kSeg, false));
   SMX_TRY(dev_alloc(&r->L.recent_list, (size_t)r->nsegB * kSegB, false));
   SMX_TRY(dev_alloc(&r->L.vis_seg, (size_t)r->nseg, true));
+  SMX_TRY(dev_alloc(&r->L.seg_box, (size_t)r->nseg * 8, true));
   SMX_TRY(dev_alloc(&r->L.recent_seg, (size_t)r->nsegB, true));
   SMX_TRY(dev_alloc(&r->flags_buf[0], (size_t)r->nsegB * kSegB, true));
   SMX_TRY(dev_alloc(&r->flags_buf[1], (size_t)r->nsegB * kSegB, true));
@@ -1622,7 +1708,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
 
 int smx_recon_destroy(smx_recon r) {
   if (!r) return SMX_OK;
-  void* ptrs[] = {r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.recent_seg, r->flags_buf[0], r->flags_buf[1],
+  void* ptrs[] = {r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->flags_buf[0], r->flags_buf[1],
                   r->merge_flag, r->inwin8, r->need_seg, r->sc.supporting, r->sc.counts,
                   r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->block_offsets, r->st};
@@ -1865,6 +1951,7 @@ int smx_recon_get_stats(smx_recon r, smx_stream s, smx_recon_stats* out) {
   out->n_integrated = h.n_integrated; out->n_replaced = h.n_replaced; out->n_conflict_hits = h.n_conflict_hits;
   out->capacity_clamped = h.capacity_clamped;
   out->n_window_edges = h.n_window_edges; out->n_contributors = h.n_contributors;
+  out->n_segments_skipped = h.n_segments_skipped;
   return SMX_OK;
 }
 
@@ -1957,6 +2044,7 @@ int smx_recon_debug_upload_surfels(smx_recon r, smx_stream s, const float* rows,
   SMX_HIP(hipMemsetAsync(r->inbox, 0, 4 * r->S.pitch * sizeof(float4), st));
   SMX_HIP(hipMemsetAsync(r->merge_flag, 0, r->S.pitch, st));
   SMX_HIP(hipMemsetAsync(r->L.vis_seg, 0, (size_t)r->nseg * 4, st));
+  SMX_HIP(hipMemsetAsync(r->L.seg_box, 0, (size_t)r->nseg * 8 * sizeof(float), st));  // (count 0 = no box)
   SMX_HIP(hipMemsetAsync(r->L.recent_seg, 0, (size_t)r->nsegB * 4, st));
   // detach bits of the flag table come from the colour words; the recent bits are refreshed per frame
   hipLaunchKernelGGL(k_rebuild_flags, dim3(r->grid_surfels), dim3(kBlock), 0, st, r->S, 0u, 0x7FFFFFFF, r->L.flags8, r->st);

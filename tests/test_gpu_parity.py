@@ -270,6 +270,9 @@ def test_camera_turns_away_and_back(smx):
         st = po.recon.stats()
         if f == 94:
             assert st["n_visible"] == 0 and st["n_new"] > 1000          # nothing of the map in view
+        if f in (96, 97):
+            # pass A's segment culling: the segments of frames 4..9 are behind the camera and unchanged
+            assert pg.reconstruction.stats()["n_segments_skipped"] >= 4
         if f == 184:
             assert st["n_visible"] > 1000 and st["n_integrated"] > 1000  # old surfels, long outside the window
 
