@@ -90,6 +90,87 @@ k_bilateral(float denom_xy, float sigma_value_factor, int radius, int radius_squ
   }
 }
 
+// The same filter with the radius as a compile-time constant: both tap loops unroll completely, the disc test and
+// the spatial-term index become constants, the taps are branch-free (an excluded tap contributes +0 to both sums,
+// which leaves them bit-identical) and the LDS reads of a row are in flight together.  The generic kernel above
+// spends most of its time waiting on one LDS read and three branches per tap.
+__device__ __forceinline__ float det_expf_branchless(float x) {
+  // det_expf's arithmetic, evaluated unconditionally; its two range tests become selects
+  float t = x * 1.44269504088896341f;
+  float n = __builtin_rintf(t);
+  float r = __builtin_fmaf(n, -0.693359375f, x);
+  r = __builtin_fmaf(n, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+  p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+  p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+  p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+  p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+  float r2 = r * r;
+  float y = __builtin_fmaf(p, r2, r);
+  y = y + 1.0f;
+  const int ni = (int)n;
+  float e = y * __uint_as_float((uint32_t)(ni + 127) << 23);
+  e = (x > 88.0f) ? __builtin_inff() : e;
+  return (x < -86.0f) ? 0.0f : e;
+}
+
+template <int R>
+__global__ void __launch_bounds__(kThreads)
+k_bilateral_r(float denom_xy, float sigma_value_factor, uint16_t value_to_ignore, uint16_t max_depth, float region_r2,
+              Img<const uint16_t> in, Img<uint16_t> out, int tiles_x, int n_tiles) {
+  constexpr int TW = kBilTileW + 2 * R, TH = kBilTileH + 2 * R;
+  __shared__ uint16_t tile[TH * TW];
+  __shared__ float spatial[R * R + 1];
+  const int W = out.width, H = out.height;
+  for (int g2 = threadIdx.x; g2 <= R * R; g2 += kThreads) spatial[g2] = (float)(-g2) / denom_xy;
+  __syncthreads();
+  float sp[R * R + 1];  // (constant indices after unrolling: the entries in use live in registers)
+#pragma unroll
+  for (int g2 = 0; g2 <= R * R; ++g2) sp[g2] = spatial[g2];
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int bx = t % tiles_x, by = t / tiles_x;
+    __syncthreads();  // (the previous tile's readers are done)
+    const int x0 = bx * kBilTileW - R, y0 = by * kBilTileH - R;
+    for (int i = threadIdx.x; i < TW * TH; i += kThreads) {
+      const int ty = i / TW, tx = i - ty * TW;
+      const int gx = x0 + tx, gy = y0 + ty;
+      // cells outside the image read as "ignore": the reference's clamped loop bounds never visit them
+      tile[i] = (gx >= 0 && gy >= 0 && gx < W && gy < H) ? in(gy, gx) : value_to_ignore;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & (kBilTileW - 1), ly = threadIdx.x / kBilTileW;
+    const int x = bx * kBilTileW + lx, y = by * kBilTileH + ly;
+    if (x >= W || y >= H) continue;
+    const unsigned half_w = (unsigned)(W / 2), half_h = (unsigned)(H / 2);
+    const unsigned dxc = (unsigned)x - half_w, dyc = (unsigned)y - half_h;
+    const float center_distance_squared = (float)(dxc * dxc + dyc * dyc);
+    if (center_distance_squared > region_r2) { out(y, x) = value_to_ignore; continue; }
+    const uint16_t* tc = &tile[(ly + R) * TW + (lx + R)];
+    const uint16_t center_value = tc[0];
+    if (center_value == value_to_ignore || center_value > max_depth) { out(y, x) = value_to_ignore; continue; }
+    const float adapted_sigma_value = (float)center_value * sigma_value_factor;
+    const float adapted_denom_value = 2.0f * adapted_sigma_value * adapted_sigma_value;
+    const float inv_denom_value = 1.0f / adapted_denom_value;
+    float sum = 0, weight = 0;
+#pragma unroll
+    for (int dy = -R; dy <= R; ++dy) {
+#pragma unroll
+      for (int dx = -R; dx <= R; ++dx) {
+        if (dx * dx + dy * dy > R * R) continue;  // (compile time)
+        const uint16_t sample = tc[dy * TW + dx];
+        float vd = (float)((int)center_value - (int)sample);
+        vd *= vd;
+        float w = det_expf_branchless(sp[dx * dx + dy * dy] + (-vd) * inv_denom_value);
+        w = (sample == value_to_ignore) ? 0.0f : w;
+        sum += w * (float)sample;
+        weight += w;
+      }
+    }
+    out(y, x) = (weight == 0) ? value_to_ignore : f2u16(sum / weight + 0.5f);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Multi-frame outlier cull.  Reference: OutlierDepthMapFusionCUDAKernel (both overloads),
 // cuda_depth_processing.cu:168-227 and :337-397.  Matrices and image descriptors travel in the
@@ -270,10 +351,21 @@ int smx_bilateral_filtering_and_depth_cutoff(
   // Two workgroups per CU: the filter is ALU-bound and runs beside the surfel kernels (preprocessing of the next
   // frame overlaps Integrate); a launch that floods every CU slows those down more than it gains here.
   static const int max_blocks = 2 * device_cu_count();
-  hipLaunchKernelGGL(k_bilateral, dim3(n_tiles < max_blocks ? n_tiles : max_blocks), dim3(kThreads), 0, (hipStream_t)s,
-                     2.0f * sigma_xy * sigma_xy, sigma_value_factor, radius, radius * radius, value_to_ignore,
-                     max_depth, depth_valid_region_radius * depth_valid_region_radius,
-                     as_img<const uint16_t>(input_depth), as_img<uint16_t>(output_depth), tiles_x, n_tiles);
+  const dim3 grid(n_tiles < max_blocks ? n_tiles : max_blocks);
+  const float denom_xy = 2.0f * sigma_xy * sigma_xy, region_r2 = depth_valid_region_radius * depth_valid_region_radius;
+  const Img<const uint16_t> src = as_img<const uint16_t>(input_depth);
+  const Img<uint16_t> dst = as_img<uint16_t>(output_depth);
+#define SMX_BILATERAL(R)                                                                                          \
+  case R: hipLaunchKernelGGL(k_bilateral_r<R>, grid, dim3(kThreads), 0, (hipStream_t)s, denom_xy, sigma_value_factor, \
+                             value_to_ignore, max_depth, region_r2, src, dst, tiles_x, n_tiles); break
+  switch (radius) {
+    SMX_BILATERAL(1); SMX_BILATERAL(2); SMX_BILATERAL(3); SMX_BILATERAL(4);
+    SMX_BILATERAL(5); SMX_BILATERAL(6); SMX_BILATERAL(7); SMX_BILATERAL(8);
+    default:  // radius 0: the generic kernel
+      hipLaunchKernelGGL(k_bilateral, grid, dim3(kThreads), 0, (hipStream_t)s, denom_xy, sigma_value_factor, radius,
+                         radius * radius, value_to_ignore, max_depth, region_r2, src, dst, tiles_x, n_tiles);
+  }
+#undef SMX_BILATERAL
   SMX_LAUNCH_CHECK();
   return SMX_OK;
 }
