@@ -30,7 +30,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # or write counted once, cache effects and line granularity excluded.  N = slots, V = visible slots, R = slots
 # inside the regulariser window, C = slots with a link into the window, Ew = such links, E = all links, P = pixels.
 ALG_BYTES = {
-    "scan_visible": lambda st, P: 18.0 * st["surfels_size"] + 24.0 * st["n_visible"],
+    # P records + flag bytes of the segments that are read, 2 flag bytes per slot of the culled ones, list + z-buffer
+    "scan_visible": lambda st, P: 18.0 * (st["surfels_size"] - 1024.0 * st.get("n_segments_skipped", 0))
+                                  + 2.0 * 1024.0 * st.get("n_segments_skipped", 0) + 24.0 * st["n_visible"],
     "neighbor_scan": lambda st, P: 18.0 * st["surfels_size"] + 1.0 * st["n_edges"] + 4.0 * st["n_recent"],
     # slots served: contributors and recent slots (mostly the same slots): 50 B own records each; 48 B per link into
     # the window (target S + T records, 16 B inbox/accumulator store); 16 B own-term record per recent slot
