@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libsmx.so")
+# (SMX_LIB_PATH: A/B measurements of two builds in one session; the product loads the in-tree library)
+SO_PATH = os.environ.get("SMX_LIB_PATH") or os.path.join(_HERE, "libsmx.so")
 
 
 class SmxError(RuntimeError):
