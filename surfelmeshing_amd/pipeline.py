@@ -99,6 +99,12 @@ class FramePipeline:
         self.reconstruction.IntegrateP(self.stream, frame_index, self.pre.depth_scaling, self.depth_final,
                                        self.normals, self.radius, self.color[frame_index], global_T_frame, self.params)
 
+    def integrate_as(self, frame_index, data_frame, global_T_frame):
+        """Integrate the preprocessed images of `data_frame` under the frame index (stamp) `frame_index`
+        (revisiting a pose with a stored frame)."""
+        self.reconstruction.IntegrateP(self.stream, frame_index, self.pre.depth_scaling, self.depth_final,
+                                       self.normals, self.radius, self.color[data_frame], global_T_frame, self.params)
+
     def process(self, frame_index, other_frames, others_TR_reference, global_T_frame):
         self.preprocess(frame_index, other_frames, others_TR_reference)
         self.integrate(frame_index, global_T_frame)

@@ -51,6 +51,11 @@ class OraclePipeline:
         self.recon.integrate(f, self.pre.depth_scaling, self.depth_final, self.normals, self.radius, self.color[f],
                              global_T_frame, self.params)
 
+    def integrate_as(self, frame_index, data_frame, global_T_frame):
+        """Integrate the preprocessed images of `data_frame` under the frame index (stamp) `frame_index`."""
+        self.recon.integrate(frame_index, self.pre.depth_scaling, self.depth_final, self.normals, self.radius,
+                             self.color[data_frame], global_T_frame, self.params)
+
     def process(self, f, other_frames, others_TR_reference, global_T_frame):
         self.preprocess(f, other_frames, others_TR_reference)
         self.integrate(f, global_T_frame)

@@ -277,6 +277,32 @@ def test_camera_turns_away_and_back(smx):
             assert st["n_visible"] > 1000 and st["n_integrated"] > 1000  # old surfels, long outside the window
 
 
+def test_segment_culling_while_panning(smx):
+    """Pass A's segment culling with segments leaving and re-entering the view gradually: a pan of 3 deg/frame
+    one way and back, short regulariser window (a segment can only be culled once its newest stamp left the window).
+    Every frame is compared; culled segments must have occurred."""
+    s = small_stream(obstacle_until=6, yaw_deg_per_frame=3.0)
+    po, pg = _pipes(smx, s, 120000, params_kw=dict(regularization_frame_window_size=2))
+    out = list(range(4, 44))
+    frames = out + [88 - f for f in range(45, 80)]          # forward, then the same poses backwards (frames 43 .. 9)
+    need = sorted(set(g for f in frames for g in range(f - 4, f + 5)))
+    for f in need:
+        d, c = s.frame(f)
+        po.upload(f, d, c)
+        pg.upload(f, d, c)
+    skipped = 0
+    for k, f in enumerate(frames):
+        # logical frame index k + 4 keeps the stamps increasing while the pose index f goes back and forth
+        others, T, pose = s.outlier_frames(f), s.others_TR_reference(f), s.pose(f)
+        po.preprocess(f, others, T)
+        pg.preprocess(f, others, T)
+        po.integrate_as(k + 4, f, pose)
+        pg.integrate_as(k + 4, f, pose)
+        _compare_state(po, pg)
+        skipped += pg.reconstruction.stats()["n_segments_skipped"]
+    assert skipped >= 10, skipped
+
+
 def test_full_resolution_parity(smx):
     s = small_stream(640, 480)
     po, pg = _pipes(smx, s, 1200000)
