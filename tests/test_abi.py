@@ -43,3 +43,22 @@ def test_no_device_errors_are_loud():
         api.CUDASurfelReconstruction(1000, api.PinholeCamera4f(64, 48, 50.0, 50.0, 32.0, 24.0))
     with pytest.raises(_lib.SmxError):
         api.SurfelNeighborIndex()
+
+
+def test_headers_are_plain_c_and_pod_sizes_match(tmp_path):
+    """include/smx.h and include/smx_driver.h compile as C11 (no C++ / torch types at the boundary); the PODs that
+    cross it have the sizes the ctypes mirrors assume."""
+    import subprocess
+    src = tmp_path / "abi_probe.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "smx.h"\n#include "smx_driver.h"\n'
+        'int main(void) { printf("%zu %zu %zu %zu %zu\\n", sizeof(smx_buffer_desc), sizeof(smx_integrate_params),\n'
+        '  sizeof(smx_surfel_buffers_cpu), sizeof(smx_recon_stats), sizeof(smx_driver_config)); return 0; }\n')
+    exe = tmp_path / "abi_probe"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True)
+    sizes = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    from surfelmeshing_amd._lib import BufferDesc, IntegrateParams, ReconStats, SurfelBuffersCPU
+    from surfelmeshing_amd.pipeline import DriverConfig
+    assert sizes == [ctypes.sizeof(BufferDesc), ctypes.sizeof(IntegrateParams), ctypes.sizeof(SurfelBuffersCPU),
+                     ctypes.sizeof(ReconStats), ctypes.sizeof(DriverConfig)]
