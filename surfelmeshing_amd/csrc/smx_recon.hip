@@ -7,17 +7,21 @@
 // Structure (DESIGN.md "Frame pipeline") -- this is NOT the reference's launch
 // sequence.  The reference scans all N surfel slots in every surfel kernel
 // (~140 B/slot/frame) and blocks the host twice per frame.  Here:
-//   pass A  k_scan_visible     one streaming pass over stamp,X,Y,Z (16 B/slot):
-//                              z-buffer atomics + a compacted list of the
-//                              slots that project into the image;
+//   pass A  k_scan_visible     one streaming pass over stamp,X,Y,Z (16 B/slot), minus
+//                              the 1024-slot segments whose bounding box is out of view:
+//                              z-buffer atomics + a compacted list of the slots that
+//                              project into the image;
 //   list kernels               associate / merge-decide / integrate /
-//                              update-neighbors run over that list only;
+//                              update-neighbors (+ creation) run over that list only;
 //   pass B  k_neighbor_scan    one streaming pass over the neighbour records
 //                              (16 B/slot): detach, which links point into the
 //                              regulariser window, list of recently updated slots;
 //   k_reg_accumulate           gradient terms of those links (inbox stores / LDS
-//                              sums / global atomics), needy segments only;
-//   list kernels               regulariser step / update over the recent list only.
+//                              sums / packed global atomics) and every recent slot's
+//                              own smoothness term, needy segments only;
+//   k_reg_step                 regulariser step over the recent list only, no gathers.
+// Across calls the work is pipelined on two streams (smx_recon_integrate): the
+// read-only first kernels of frame f+1 run beside the regulariser of frame f.
 // The surfel count, merge count and all list lengths live in device memory;
 // no kernel launch needs a host round trip.
 #include <math.h>
