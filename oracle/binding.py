@@ -270,6 +270,23 @@ class Recon:
 
 
 # ---- neighbor search -----------------------------------------------------------------------
+def set_race_overrides(supporting=None, conflicting=None):
+    """See orc_set_race_overrides (smx_oracle.h).  The arrays must stay alive until the overrides are switched off."""
+    if supporting is None and conflicting is None:
+        lib().orc_set_race_overrides(None, None, C.c_size_t(0))
+        return
+    assert supporting.dtype == np.uint32 and conflicting.dtype == np.uint32
+    assert supporting.flags.c_contiguous and conflicting.flags.c_contiguous
+    lib().orc_set_race_overrides(_p(supporting), _p(conflicting), C.c_size_t(supporting.size))
+
+
+def race_override_stats():
+    out = (C.c_uint32 * 4)()
+    lib().orc_get_race_override_stats(out)
+    return {"applied_supporting": out[0], "rejected_supporting": out[1], "applied_conflicting": out[2],
+            "rejected_conflicting": out[3]}
+
+
 def nn_bruteforce(px, py, pz, q, radius_sq, k, state=None, skip_mask=0):
     px, py, pz = (_c(a, np.float32) for a in (px, py, pz))
     d2 = np.zeros(k, np.float32)

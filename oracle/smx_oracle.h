@@ -15,12 +15,25 @@
  *   APP/octree.cc:313-470 + APP/test/test_octree.cc:116-143  radius-neighbor search
  *
  * PARITY PINNING: the reference ships no golden vectors / known-answer tests
- * for the integration and preprocessing kernels, and it cannot be compiled in
- * this environment (needs nvcc, CUB, Eigen, Qt).  For those stages this oracle
- * is therefore "parity unpinned" by reference artefacts: it is pinned only by
- * hand-derived known answers (tests/test_oracle_known_answers.py).  The
- * radius-neighbor search IS pinned the way the reference pins it: equality
- * with brute force (APP/test/test_octree.cc:369-495).
+ * for the integration and preprocessing kernels, and its application cannot
+ * be built here (nvcc, Eigen, Sophus, Qt are missing).  But its two CUDA
+ * KERNEL files (cuda_depth_processing.cu, cuda_surfel_reconstruction_kernels.cu)
+ * depend only on cuda_runtime.h, CUB and three small libvis headers, and
+ * hipcc compiles them for gfx950 from where they lie (oracle/ref_build.py,
+ * four shim headers in oracle/ref_shim/, host harness oracle/ref_harness.cpp
+ * -> oracle/_ref/libsmx_ref.so).  This oracle is PINNED AGAINST THOSE KERNELS
+ * RUNNING ON THE MI355X (tests/test_gpu_reference_pin.py): depth stages
+ * bit-identical (bilateral filter: <= 1 depth unit on a handful of pixels,
+ * device expf), Integrate frame by frame from a common state with the
+ * reference run's race outcomes imposed where this oracle finds them legal
+ * (all are): counts, images and every surfel row bit-identical except the
+ * reference's order-dependent float atomicAdd sums (a stray blended-depth
+ * LSB, smooth positions within 2e-6 m).  What stays unpinned is NVIDIA's
+ * -use_fast_math code generation, which no other compiler reproduces.
+ * Also pinned: hand-derived known answers
+ * (tests/test_oracle_known_answers.py), and the radius-neighbor search the
+ * way the reference pins it: equality with brute force
+ * (APP/test/test_octree.cc:369-495).
  *
  * Deterministic rules adopted where the reference is racy (each is a legal
  * outcome of the reference's races; see DESIGN.md "Determinism"):
@@ -155,6 +168,12 @@ void orc_recon_integrate(orc_recon* r, uint32_t frame_index, float depth_scaling
 void orc_recon_regularize(orc_recon* r, uint32_t frame_index, float regularizer_weight,
                           float radius_factor_for_regularization_neighbors,
                           int regularization_frame_window_size);
+
+/* Impose the race outcomes (supporting / conflicting surfel images, [H][W], ORC_INVALID = none) of a run of the
+ * reference's own kernels on the following orc_recon_integrate calls; NULL, NULL switches it off.  Only outcomes this
+ * oracle finds legal are accepted.  stats: applied / rejected supporting, applied / rejected conflicting. */
+void orc_set_race_overrides(const uint32_t* supporting, const uint32_t* conflicting, size_t pixels);
+void orc_get_race_override_stats(uint32_t out[4]);
 
 /* TransferAllToCPU row selection, APP/cuda_surfel_reconstruction.cc:348-358 */
 void orc_recon_transfer_all(const orc_recon* r, float* x, float* y, float* z, float* radius_sq,

@@ -148,6 +148,25 @@ void orc_recon_destroy(orc_recon* r) {
   free(r);
 }
 
+/* ---- race-outcome overrides (pinning against the reference's own kernels, tests/test_gpu_reference_pin.py) ----
+ * The reference decides two things by races: the supporting surfel of a pixel (first atomicCAS wins, :1688) and
+ * the conflicting surfel (last plain store wins, :1615 / :1887).  This oracle replaces each race by a fixed legal
+ * rule.  To compare it with a run of the reference's kernels, the outcome THAT run produced can be imposed: a value
+ * is accepted only if this oracle saw the same surfel qualify for the same pixel in the same phase (so only legal
+ * outcomes pass; the rest is counted as rejected), and everything downstream is then computed from it. */
+static const uint32_t* g_ovr_sup = NULL;
+static const uint32_t* g_ovr_conf = NULL;
+static uint8_t* g_ovr_seen = NULL;   /* bit 0: supporting candidate, bit 1 / 2: conflict writer in the associate / merge phase */
+static uint32_t g_ovr_stats[4];      /* applied supporting, rejected supporting, applied conflicting, rejected conflicting */
+void orc_set_race_overrides(const uint32_t* supporting, const uint32_t* conflicting, size_t pixels) {
+  free(g_ovr_seen);
+  g_ovr_seen = NULL;
+  g_ovr_sup = supporting; g_ovr_conf = conflicting;
+  if (supporting || conflicting) g_ovr_seen = (uint8_t*)calloc(pixels, 1);
+  memset(g_ovr_stats, 0, sizeof(g_ovr_stats));
+}
+void orc_get_race_override_stats(uint32_t out[4]) { memcpy(out, g_ovr_stats, sizeof(g_ovr_stats)); }
+
 /* ---- stage: 5 clears, cuda_surfel_reconstruction.cc:134-138 ---- */
 static void stage_clear(orc_recon* r) {
   const size_t P = (size_t)r->width * r->height;
@@ -190,6 +209,7 @@ static void associate_at(orc_recon* r, const frame_ctx* c, const uint16_t* depth
       /* :1615 plain store; deterministic rule: class-1 key, lowest index wins */
       const uint32_t key = 0x80000000u | i;
       if (key < r->conflicting_key[k]) r->conflicting_key[k] = key;
+      if (g_ovr_conf && g_ovr_conf[k] == i) g_ovr_seen[k] |= 2;
     }
     return;
   }
@@ -213,6 +233,7 @@ static void associate_at(orc_recon* r, const frame_ctx* c, const uint16_t* depth
 
   /* :1688 atomicCAS first-wins -> lowest index; ascending loop == first wins */
   if (i < r->supporting[k]) r->supporting[k] = i;
+  if (g_ovr_sup && g_ovr_sup[k] == i) g_ovr_seen[k] |= 1;
   r->support_counts[k] += 1;
   r->depth_sums_f[k] += p->l[2];
   r->depth_sums_q[k] += q_from_float(p->l[2]);
@@ -225,6 +246,15 @@ static void stage_associate(orc_recon* r, const frame_ctx* c, const uint16_t* de
     associate_at(r, c, depth, normals, p.px, p.py, &p, i);
     int ox, oy;
     if (quadrant(r, &p, &ox, &oy)) associate_at(r, c, depth, normals, ox, oy, &p, i);
+  }
+  if (g_ovr_sup) {  /* impose the supporting surfels of a reference run where they are legal (see above) */
+    const size_t P = (size_t)r->width * r->height;
+    for (size_t k = 0; k < P; ++k) {
+      const uint32_t o = g_ovr_sup[k];
+      if (o == r->supporting[k]) continue;
+      if (o != ORC_INVALID && (g_ovr_seen[k] & 1)) { r->supporting[k] = o; g_ovr_stats[0]++; }
+      else g_ovr_stats[1]++;
+    }
   }
 }
 
@@ -241,6 +271,7 @@ static int merge_decide(orc_recon* r, const frame_ctx* c, const uint16_t* depth,
       /* :1887 plain store after the associate kernel finished: merge-phase
        * writers override associate-phase writers -> class-0 key */
       if (i < r->conflicting_key[k]) r->conflicting_key[k] = i;
+      if (g_ovr_conf && g_ovr_conf[k] == i) g_ovr_seen[k] |= 4;
     }
     return 0;
   }
@@ -297,6 +328,22 @@ static void stage_merge(orc_recon* r, const frame_ctx* c, const uint16_t* depth,
   r->last_n_merged = n;
   /* decode the conflicting keys for the consumers */
   const size_t P = (size_t)r->width * r->height;
+  if (g_ovr_conf) {
+    for (size_t k = 0; k < P; ++k) {
+      const uint32_t cur = r->conflicting_key[k];
+      const uint32_t cur_index = (cur == ORC_INVALID) ? ORC_INVALID : (cur & 0x7FFFFFFFu);
+      const uint32_t o = g_ovr_conf[k];
+      if (o == cur_index) continue;
+      /* legal: a writer of the phase whose stores land last (merge phase if it wrote at all) */
+      const int merge_phase = (cur != ORC_INVALID) && ((cur >> 31) == 0);
+      if (cur != ORC_INVALID && o != ORC_INVALID && (g_ovr_seen[k] & (merge_phase ? 4 : 2))) {
+        r->conflicting_key[k] = (merge_phase ? 0u : 0x80000000u) | o;
+        g_ovr_stats[2]++;
+      } else {
+        g_ovr_stats[3]++;
+      }
+    }
+  }
   for (size_t k = 0; k < P; ++k)
     r->conflicting[k] = (r->conflicting_key[k] == ORC_INVALID) ? ORC_INVALID : (r->conflicting_key[k] & 0x7FFFFFFFu);
 }
