@@ -163,6 +163,13 @@ class Recon:
         _check(lib().ref_recon_upload_surfels(self._r, _p(rows), C.c_uint32(rows.shape[1]), C.c_uint32(merge_count)),
                "upload")
 
+    def export_vertices(self):
+        n = self.counts()["surfels_size"]
+        pos, col = np.zeros(3 * n, np.float32), np.zeros(3 * n, np.uint8)
+        if n:
+            _check(lib().ref_recon_export_vertices(self._r, _p(pos), _p(col)), "export")
+        return pos, col
+
     def scratch(self):
         out = {}
         for which, (name, dt) in enumerate([("supporting", np.uint32), ("support_counts", np.uint32),

@@ -354,6 +354,22 @@ int ref_recon_upload_surfels(ref_recon* r, const float* rows, uint32_t count, ui
   r->surfel_count = count; r->merge_count = merge_count;
   return 0;
 }
+/* ExportVertices, cuda_surfel_reconstruction.cc:405-410: positions [3 * count] floats, colours [3 * count] bytes */
+int ref_recon_export_vertices(const ref_recon* r, float* positions, uint8_t* colors) {
+  const u32 n = r->surfel_count;
+  if (n == 0) return 0;
+  Dev<float> pos;
+  Dev<u8> col;
+  if (pos.alloc(1, 3 * (int)n) || col.alloc(1, 3 * (int)n)) return -2;
+  CUDABuffer_<float> pb = pos.cb();
+  CUDABuffer_<u8> cbuf = col.cb();
+  ExportVerticesCUDA(0, n, r->surfels.cb(), &pb, &cbuf);
+  REF_HIP(hipDeviceSynchronize());
+  const int rc = pos.down(positions) | col.down(colors);
+  pos.release(); col.release();
+  return rc;
+}
+
 /* which: 0 supporting u32, 1 counts u32, 2 depth sums f32, 3 conflicting u32, 4 first depth f32 */
 int ref_recon_download_scratch(const ref_recon* r, int which, void* dst) {
   switch (which) {

@@ -84,6 +84,7 @@ def test_depth_kernels_match_the_reference(ref, w, h):
 
 @pytest.mark.parametrize("kw", [
     dict(),
+    dict(regularization_iterations_per_integration_iteration=3),
     dict(regularization_frame_window_size=3, surfel_integration_active_window_size=6, measurement_blending_radius=5,
          sensor_noise_factor=0.02, regularizer_weight=4.0, radius_factor_for_regularization_neighbors=1.5),
     dict(do_blending=0, regularization_iterations_per_integration_iteration=0),
@@ -147,6 +148,20 @@ def test_integrate_matches_the_reference_kernels_frame_by_frame(ref, kw):
                 assert neq.sum() <= 8 * np.count_nonzero(dd), (g, row, neq.sum())
                 if neq.any():   # one depth unit is 1 / depth_scaling = 0.2 mm
                     assert np.abs(a - b)[neq].max() <= 1.01 / pre.depth_scaling, (g, row, np.abs(a - b)[neq].max())
+    # the extra regulariser iteration (Regularize, cc:322-337) and ExportVertices on the final common state
+    n = po.recon.surfels_size
+    rr.upload_surfels(po.recon.surfels()[:, :n].copy(), po.recon.merge_count)
+    po.recon.regularize(frames[-1], 6.0, 1.8, 12)
+    rr.regularize(frames[-1], 6.0, 1.8, 12)
+    So, Sr = po.recon.surfels()[:, :n], rr.surfels(n)
+    for row in INT_ROWS + [r for r in FLOAT_ROWS if r not in SMOOTH_ROWS]:
+        assert np.array_equal(So[row].view(np.uint32), Sr[row].view(np.uint32)), row
+    for row in SMOOTH_ROWS:
+        assert np.abs(So[row] - Sr[row]).max() <= 2e-6
+    rr.upload_surfels(So.copy(), po.recon.merge_count)
+    pos_o, col_o = po.recon.export_vertices()
+    pos_r, col_r = rr.export_vertices()
+    assert np.array_equal(pos_o.view(np.uint32), pos_r.view(np.uint32)) and np.array_equal(col_o, col_r)   # (NaN = merged)
     rr.close()
     assert po.recon.surfels_size > 12000 and applied > 1000
     if not kw:
