@@ -147,6 +147,11 @@ class Recon:
         _check(lib().ref_recon_integrate(self._r, C.c_uint32(frame_index), C.c_float(depth_scaling), _p(depth),
                                          _p(normals), _p(radius), _p(color), _p(G), _p(L), C.byref(params)), "integrate")
 
+    def last_integrate_ms(self):
+        """Device time of the last integrate() (clears .. regulariser; the reference's two host syncs included)."""
+        lib().ref_recon_last_integrate_ms.restype = C.c_float
+        return float(lib().ref_recon_last_integrate_ms(self._r))
+
     def regularize(self, frame_index, regularizer_weight=10.0, radius_factor=2.0, window=30):
         _check(lib().ref_recon_regularize(self._r, C.c_uint32(frame_index), C.c_float(regularizer_weight),
                                           C.c_float(radius_factor), C.c_int(window)), "regularize")

@@ -187,13 +187,16 @@ struct ref_recon {
   void* scan_temp;
   usize scan_temp_bytes;
   u32 last_new;
+  hipEvent_t ev0, ev1;
+  float last_ms;   // device time of the last Integrate (clears .. regulariser, without the image upload / download)
 };
 
 int ref_recon_create(uint32_t max_surfels, int W, int H, float fx, float fy, float cx, float cy, ref_recon** out) {
   ref_recon* r = new ref_recon();
   r->W = W; r->H = H; r->fx = fx; r->fy = fy; r->cx = cx; r->cy = cy;
   r->max_surfels = max_surfels; r->surfel_count = 0; r->merge_count = 0; r->scan_temp = nullptr; r->scan_temp_bytes = 0;
-  r->last_new = 0;
+  r->last_new = 0; r->last_ms = 0;
+  if (hipEventCreate(&r->ev0) != hipSuccess || hipEventCreate(&r->ev1) != hipSuccess) return -2;
   int rc = r->surfels.alloc(kSurfelAttributeCount, (int)max_surfels);
   rc |= r->supporting.alloc(H, W) | r->counts.alloc(H, W) | r->conflicting.alloc(H, W) | r->depth_sums.alloc(H, W);
   rc |= r->first_depth.alloc(H, W) | r->deltas.alloc(H, W) | r->new_deltas.alloc(H, W);
@@ -235,6 +238,7 @@ int ref_recon_integrate(ref_recon* r, uint32_t frame_index, float depth_scaling,
   const float cos_thr = cosf(M_PI / 180.0f * p->normal_compatibility_threshold_deg);  // kernels.cc:261
   const float depth_correction_factor = 1.0f / depth_scaling;
 
+  REF_HIP(hipEventRecord(r->ev0, stream));
   // cc:134-138
   fill(r->supporting, kInvalidIndex);
   fill(r->counts, 0u);
@@ -322,8 +326,10 @@ int ref_recon_integrate(ref_recon* r, uint32_t frame_index, float depth_scaling,
                             p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
                             p->regularization_frame_window_size, r->surfel_count, &sb);
   }
+  REF_HIP(hipEventRecord(r->ev1, stream));
   REF_HIP(hipDeviceSynchronize());
   REF_HIP(hipGetLastError());
+  REF_HIP(hipEventElapsedTime(&r->last_ms, r->ev0, r->ev1));
   return r->depth.down(depth);
 }
 
@@ -335,6 +341,8 @@ int ref_recon_regularize(ref_recon* r, uint32_t frame_index, float regularizer_w
   REF_HIP(hipDeviceSynchronize());
   return 0;
 }
+
+float ref_recon_last_integrate_ms(const ref_recon* r) { return r->last_ms; }
 
 void ref_recon_counts(const ref_recon* r, uint32_t* surfels_size, uint32_t* merge_count, uint32_t* last_new) {
   *surfels_size = r->surfel_count; *merge_count = r->merge_count; *last_new = r->last_new;
