@@ -191,3 +191,41 @@ def test_first_frame_without_any_race_is_identical(ref):
     for row in SMOOTH_ROWS:
         assert np.abs(So[row] - Sr[row]).max() <= 1e-6
     rr.close()
+
+
+def test_product_depth_kernels_against_the_reference_at_full_resolution(ref, smx):
+    """The HIP product path directly against the reference's kernels (not via the oracle): 640x480, the five
+    preprocessing kernels chained as APP/main.cc:1015-1191 chains them.  Identical up to the bilateral filter's expf."""
+    from surfelmeshing_amd.pipeline import FramePipeline
+    w, h = 640, 480
+    s = small_stream(w, h, obstacle_until=8)
+    pre = small_pre(w)
+    pg = FramePipeline(w, h, s.fx, s.fy, s.cx, s.cy, 1000, pre)
+    f = 6
+    frames = {g: s.frame(g) for g in range(f - 4, f + 5)}
+    for g, (d, c) in frames.items():
+        pg.upload(g, d, c)
+    others, T = s.outlier_frames(f), s.others_TR_reference(f)
+    pg.preprocess(f, others, T)
+    smx.StreamSynchronize(None)
+    depth_p, normals_p, radius_p = pg.depth_final.Download(), pg.normals.Download(), pg.radius.Download()
+    cam = (s.fx, s.fy, s.cx, s.cy)
+    a = ref.bilateral_filter_and_cutoff(frames[f][0], pre.bilateral_filter_sigma_xy, pre.bilateral_filter_sigma_depth_factor,
+                                        0, pre.bilateral_filter_radius_factor, pre.max_depth_u16(), pre.depth_valid_region_radius)
+    b = ref.outlier_depth_map_fusion(a, [frames[g][0] for g in others], T, *cam, pre.outlier_filtering_depth_tolerance_factor, -1)
+    e = ref.erode_depth_map(b, pre.depth_erosion_radius)
+    nd, nn = ref.compute_normals_and_drop_bad_pixels(e, *cam, pre.observation_angle_threshold_deg, pre.depth_scaling)
+    rd, rad = ref.compute_point_radii_and_remove_isolated_pixels(nd, *cam, pre.point_radius_extension_factor,
+                                                                pre.point_radius_clamp_factor, pre.depth_scaling)
+    valid = (rd > 0) & (depth_p > 0)
+    # a bilateral LSB can move a pixel across a later threshold: allow a handful of such pixels
+    assert np.count_nonzero((rd > 0) != (depth_p > 0)) <= 20 and valid.sum() > 100000
+    dd = np.abs(rd.astype(np.int32) - depth_p.astype(np.int32))[valid]
+    assert dd.max() <= 1 and np.count_nonzero(dd) <= valid.sum() // 1000
+    same = valid & (rd == depth_p)
+    # normals and radii read the neighbouring depths: only pixels next to one of those LSBs may differ
+    n_lsb = np.count_nonzero(dd) + np.count_nonzero((rd > 0) != (depth_p > 0))
+    n_off = np.count_nonzero(np.any(nn[same].view(np.uint32) != normals_p[same].view(np.uint32), axis=-1))
+    r_off = np.count_nonzero(rad[same].view(np.uint32) != radius_p[same].view(np.uint32))
+    assert n_off <= 8 * n_lsb + 8 and r_off <= 12 * n_lsb + 8, (n_lsb, n_off, r_off)
+    assert np.abs(nn[same] - normals_p[same]).max() <= 0.05
