@@ -1647,7 +1647,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   r->S.pitch = ((size_t)max_surfel_count + 63) / 64 * 64;
   const size_t P = (size_t)width * height;
   int rc;
-#define SMX_TRY(x) do { rc = (x); if (rc != SMX_OK) return rc; } while (0)
+#define SMX_TRY(x) do { rc = (x); if (rc != SMX_OK) { (void)smx_recon_destroy(r); return rc; } } while (0)  /* (no leak on a failed allocation) */
   // cuda_surfel_reconstruction.cc:59 -- 25 rows x max_surfel_count (zero-filled here so that the
   // padded tail of every row is defined)
   SMX_TRY(dev_alloc(&r->S.base, (size_t)kGroups * 4 * r->S.pitch, true));
