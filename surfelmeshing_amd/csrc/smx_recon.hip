@@ -598,6 +598,10 @@ k_blend_iter(int it, float term, float ds, Img<uint16_t> depth, Scratch sc, Blen
 // BFS distance d depends only on pixels within d+1 of it, so a halo of radius-1 pixels makes the tile
 // interior exact; depth, both distance maps and both delta maps of tile + halo live in LDS, the rings
 // advance with workgroup barriers, and only the interior depths are written back.
+// q / d for 0 <= q < 2^16, 0 < d <= 2^8 with one multiplication: (q + 0.5) / d is at least 1 / (2 d) away from every
+// integer, far more than the float rounding error, so truncation gives the exact quotient (the AMD ISA has no integer
+// divide: the generic expansion is ~30 instructions, and the ring loops below did one per cell per ring).
+__device__ __forceinline__ int small_div(int q, float inv_d) { return (int)(((float)q + 0.5f) * inv_d); }
 constexpr int kBlendTile = 32;
 constexpr int kBlendThreads = 1024;  // 16 wavefronts advance the rings of one tile
 constexpr int kBlendMaxHalo = 16;    // radius <= 17 uses this kernel (<= 64 KB LDS), larger radii the multi-launch path
@@ -615,8 +619,9 @@ k_blend_fused(int radius, float term, float ds, Img<uint16_t> depth, Scratch sc,
   uint8_t* ndist = dist + cells;
   uint8_t* flag = ndist + cells;                  // bit 0: supporting surfel valid, bit 1: processed pixel
   const int x0 = blockIdx.x * kBlendTile - halo, y0 = blockIdx.y * kBlendTile - halo;
+  const float inv_rw = 1.0f / (float)rw;
   for (int k = threadIdx.x; k < cells; k += kBlendThreads) {
-    const int ry = k / rw, rx = k - ry * rw;
+    const int ry = small_div(k, inv_rw), rx = k - ry * rw;
     const int x = x0 + rx, y = y0 + ry;
     uint16_t d = 0; uint8_t f = 0;
     if (x >= 0 && y >= 0 && x < W && y < H) {
@@ -641,7 +646,7 @@ k_blend_fused(int radius, float term, float ds, Img<uint16_t> depth, Scratch sc,
           if (dep[kk] == 0) mb = true;
           else if (!(flag[kk] & 1)) sb = true;
         }
-      const int ry = k / rw, rx = k - ry * rw;
+      const int ry = small_div(k, inv_rw), rx = k - ry * rw;
       const size_t g = (size_t)(y0 + ry) * W + (x0 + rx);
       const float own = (float)dep[k];
       if (sb) { ndist[k] = 1; ndelta[k] = depth_sum_avg(sc, g) - own / ds; any = 1; }
@@ -666,9 +671,10 @@ k_blend_fused(int radius, float term, float ds, Img<uint16_t> depth, Scratch sc,
   for (int it = 2; it < radius; ++it) {
     const float f = (float)(it - 1) * term;
     const int side = kBlendTile + 2 * (halo - it);
+    const float inv_side = 1.0f / (float)side;
     int changed = 0;
     for (int q = threadIdx.x; q < side * side; q += kBlendThreads) {
-      const int qy = q / side, qx = q - qy * side;
+      const int qy = small_div(q, inv_side), qx = q - qy * side;
       const int k = (qy + it) * rw + (qx + it);
       if (!(flag[k] & 2)) continue;
       if (dist[k] == 255) {
