@@ -28,7 +28,7 @@
  * reference run's race outcomes imposed where this oracle finds them legal
  * (all are): counts, images and every surfel row bit-identical except the
  * reference's order-dependent float atomicAdd sums (a stray blended-depth
- * LSB, smooth positions within 2e-6 m).  What stays unpinned is NVIDIA's
+ * LSB, smooth positions within 5e-6 m).  What stays unpinned is NVIDIA's
  * -use_fast_math code generation, which no other compiler reproduces.
  * Also pinned: hand-derived known answers
  * (tests/test_oracle_known_answers.py), and the radius-neighbor search the
