@@ -179,6 +179,32 @@ int smx_recon_regularize(smx_recon r, smx_stream s, uint32_t frame_index, float 
  * blocking copy). */
 int smx_recon_transfer_all_to_cpu(smx_recon r, smx_stream s, uint32_t frame_index,
                                   smx_surfel_buffers_cpu* buffers);
+/* Changed-surfel delta for the mesher (not in the reference: SURVEY.md 8f-1, the step right after this path).
+ * TransferAllToCPU moves 32 B x N over PCIe every time and leaves it to the CPU to find out what changed
+ * (SurfelMeshing::IntegrateCUDABuffers, APP/surfel_meshing.cc:190-300 walks all N).  With tracking on, every kernel
+ * that changes one of the eight transferred attributes of a slot marks the slot; the transfer compacts the marked
+ * slots on the GPU, downloads (slot index ascending, the eight attributes) for those only and clears the marks.
+ * Contract: applying every delta since a full transfer to that transfer's arrays reproduces the current full arrays
+ * bit for bit (a delta may contain slots whose values did not change).  Enabling marks every existing slot.
+ * smx_recon_transfer_changed_to_cpu is synchronous (it returns with the arrays filled); if count > capacity it fails,
+ * reports the needed count and keeps the marks. */
+typedef struct {
+  uint32_t capacity;      /* in: entries each array can hold */
+  uint32_t count;         /* out: entries written */
+  uint32_t frame_index;   /* out */
+  uint32_t surfel_count;  /* out: slots in use (as smx_surfel_buffers_cpu.surfel_count) */
+  uint32_t* surfel_index;
+  float* x;
+  float* y;
+  float* z;
+  float* radius_squared;
+  float* normal_x;
+  float* normal_y;
+  float* normal_z;
+  uint32_t* last_update_stamp;
+} smx_surfel_delta_cpu;
+int smx_recon_set_delta_tracking(smx_recon r, smx_stream s, int32_t enabled);
+int smx_recon_transfer_changed_to_cpu(smx_recon r, smx_stream s, uint32_t frame_index, smx_surfel_delta_cpu* delta);
 /* ExportVertices, .h:109-112 / .cc:405-410: position 1 x 3N float, colour 1 x 3N u8 */
 int smx_recon_export_vertices(smx_recon r, smx_stream s, const smx_buffer_desc* position_buffer,
                               const smx_buffer_desc* color_buffer);

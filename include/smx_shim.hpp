@@ -19,6 +19,7 @@
 #include <memory>
 #include <mutex>
 #include <utility>
+#include <vector>
 
 #include "smx.h"
 
@@ -295,6 +296,12 @@ class CUDASurfelReconstruction {
     b->frame_index = pod.frame_index;
     b->surfel_count = pod.surfel_count;
   }
+  // Not in the reference: the changed-surfel delta for the mesher, see smx.h.
+  void SetDeltaTracking(cudaStream_t stream, bool enabled) {
+    SMX_SHIM_CHECK(smx_recon_set_delta_tracking(handle_, stream, enabled ? 1 : 0));
+  }
+  // Fills `delta` (whose vectors are resized to the capacity first) with the slots changed since the previous call.
+  inline void TransferChangedToCPU(cudaStream_t stream, u32 frame_index, struct CUDASurfelDeltaCPU* delta);
   void UpdateVisualizationBuffers(cudaStream_t, u32, u32, u32, int, bool, bool, bool, bool) {}  // viewer only
   void ExportVertices(cudaStream_t stream, CUDABuffer<float>* position_buffer, CUDABuffer<u8>* color_buffer) {
     SMX_SHIM_CHECK(smx_recon_export_vertices(handle_, stream, position_buffer->ToCUDA().desc(), color_buffer->ToCUDA().desc()));
@@ -317,5 +324,37 @@ class CUDASurfelReconstruction {
   smx_recon handle_ = nullptr;
   cudaStream_t last_stream_ = nullptr;
 };
+
+// The changed-surfel delta (not in the reference): slot indices, ascending, and the eight attributes TransferAllToCPU
+// moves, for those slots only.  ApplyTo patches a CUDASurfelBuffersCPU that holds an earlier full transfer.
+struct CUDASurfelDeltaCPU {
+  explicit CUDASurfelDeltaCPU(usize capacity) : capacity(capacity) {
+    surfel_index.resize(capacity); last_update_stamp.resize(capacity);
+    for (auto* v : {&x, &y, &z, &radius_squared, &normal_x, &normal_y, &normal_z}) v->resize(capacity);
+  }
+  void ApplyTo(CUDASurfelBuffersCPU* b) const {
+    for (u32 k = 0; k < count; ++k) {
+      const u32 i = surfel_index[k];
+      b->surfel_x_buffer[i] = x[k]; b->surfel_y_buffer[i] = y[k]; b->surfel_z_buffer[i] = z[k];
+      b->surfel_radius_squared_buffer[i] = radius_squared[k];
+      b->surfel_normal_x_buffer[i] = normal_x[k]; b->surfel_normal_y_buffer[i] = normal_y[k];
+      b->surfel_normal_z_buffer[i] = normal_z[k];
+      b->surfel_last_update_stamp_buffer[i] = last_update_stamp[k];
+    }
+    b->frame_index = frame_index;
+    b->surfel_count = surfel_count;
+  }
+  usize capacity;
+  u32 count = 0, frame_index = 0, surfel_count = 0;
+  std::vector<u32> surfel_index, last_update_stamp;
+  std::vector<float> x, y, z, radius_squared, normal_x, normal_y, normal_z;
+};
+inline void CUDASurfelReconstruction::TransferChangedToCPU(cudaStream_t stream, u32 frame_index, CUDASurfelDeltaCPU* d) {
+  smx_surfel_delta_cpu pod = {(uint32_t)d->capacity, 0, 0, 0, d->surfel_index.data(), d->x.data(), d->y.data(), d->z.data(),
+                              d->radius_squared.data(), d->normal_x.data(), d->normal_y.data(), d->normal_z.data(),
+                              d->last_update_stamp.data()};
+  SMX_SHIM_CHECK(smx_recon_transfer_changed_to_cpu(handle_, stream, frame_index, &pod));
+  d->count = pod.count; d->frame_index = pod.frame_index; d->surfel_count = pod.surfel_count;
+}
 
 }  // namespace vis

@@ -52,6 +52,14 @@ class SurfelBuffersCPU(C.Structure):
                 ("surfel_normal_z_buffer", C.c_void_p), ("surfel_last_update_stamp_buffer", C.c_void_p)]
 
 
+class SurfelDeltaCPU(C.Structure):
+    """smx_surfel_delta_cpu: the changed-surfel delta of smx_recon_transfer_changed_to_cpu."""
+    _fields_ = [("capacity", C.c_uint32), ("count", C.c_uint32), ("frame_index", C.c_uint32), ("surfel_count", C.c_uint32),
+                ("surfel_index", C.c_void_p), ("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p),
+                ("radius_squared", C.c_void_p), ("normal_x", C.c_void_p), ("normal_y", C.c_void_p),
+                ("normal_z", C.c_void_p), ("last_update_stamp", C.c_void_p)]
+
+
 class ReconStats(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in
                 ("surfels_size", "merge_count", "n_visible", "n_new", "n_merged", "n_recent", "n_edges",
@@ -70,7 +78,7 @@ EXPORTS = [
     "smx_copy_without_border", "smx_compute_normals_and_drop_bad_pixels",
     "smx_compute_point_radii_and_remove_isolated_pixels",
     "smx_recon_create", "smx_recon_destroy", "smx_recon_integrate", "smx_recon_regularize",
-    "smx_recon_transfer_all_to_cpu", "smx_recon_export_vertices", "smx_recon_get_timings",
+    "smx_recon_transfer_all_to_cpu", "smx_recon_set_delta_tracking", "smx_recon_transfer_changed_to_cpu", "smx_recon_export_vertices", "smx_recon_get_timings",
     "smx_recon_set_timing_enabled", "smx_recon_counts", "smx_recon_get_stats", "smx_recon_set_stats_enabled",
     "smx_recon_kernel_slot_count", "smx_recon_kernel_slot_name", "smx_recon_get_kernel_timings",
     "smx_recon_profile_begin", "smx_recon_profile_end",

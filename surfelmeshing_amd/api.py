@@ -242,6 +242,41 @@ class CUDASurfelBuffersCPU:
         return p
 
 
+class CUDASurfelDeltaCPU:
+    """Changed surfels: slot indices (ascending) and the eight attributes TransferAllToCPU moves, for those slots."""
+    ROWS = (("x", np.float32, "surfel_x_buffer"), ("y", np.float32, "surfel_y_buffer"), ("z", np.float32, "surfel_z_buffer"),
+            ("radius_squared", np.float32, "surfel_radius_squared_buffer"),
+            ("normal_x", np.float32, "surfel_normal_x_buffer"), ("normal_y", np.float32, "surfel_normal_y_buffer"),
+            ("normal_z", np.float32, "surfel_normal_z_buffer"),
+            ("last_update_stamp", np.uint32, "surfel_last_update_stamp_buffer"))
+
+    def __init__(self, capacity):
+        self.capacity = int(capacity)
+        self.count = 0
+        self.frame_index = 0
+        self.surfel_count = 0
+        self.surfel_index = np.empty(self.capacity, np.uint32)
+        for name, dt, _ in self.ROWS:
+            setattr(self, name, np.empty(self.capacity, dt))
+
+    def _pod(self):
+        from ._lib import SurfelDeltaCPU
+        p = SurfelDeltaCPU()
+        p.capacity = self.capacity
+        p.surfel_index = self.surfel_index.ctypes.data
+        for name, _, _ in self.ROWS:
+            setattr(p, name, getattr(self, name).ctypes.data)
+        return p
+
+    def ApplyTo(self, buffers):
+        """Patch a CUDASurfelBuffersCPU (a previous full transfer + all deltas since) to the current state."""
+        idx = self.surfel_index[:self.count]
+        for name, _, full in self.ROWS:
+            getattr(buffers, full)[idx] = getattr(self, name)[:self.count]
+        buffers.frame_index = self.frame_index
+        buffers.surfel_count = self.surfel_count
+
+
 class CUDASurfelsCPU:
     """Mutex-guarded write/read double buffer, APP/cuda_surfels_cpu.h:83-124."""
 
@@ -341,6 +376,26 @@ class CUDASurfelReconstruction:
                                                              C.byref(pod)))
         wb.frame_index = pod.frame_index
         wb.surfel_count = pod.surfel_count
+
+    def SetDeltaTracking(self, stream, enabled):
+        """Not in the reference: mark the slots whose transferred attributes change, for
+        TransferChangedToCPU.  Enabling marks every existing slot."""
+        _lib.check(_lib.load().smx_recon_set_delta_tracking(self._h, _sv(stream), C.c_int32(1 if enabled else 0)))
+
+    def TransferChangedToCPU(self, stream, frame_index, capacity=None, delta=None):
+        """The changed-surfel delta since the previous call (synchronous): a CUDASurfelDeltaCPU (pass `delta` to
+        reuse one instead of allocating capacity-sized arrays per call)."""
+        cap = int(capacity if capacity is not None else self.max_surfel_count)
+        d = delta if delta is not None else CUDASurfelDeltaCPU(cap)
+        pod = d._pod()
+        rc = _lib.load().smx_recon_transfer_changed_to_cpu(self._h, _sv(stream), C.c_uint32(frame_index), C.byref(pod))
+        d.count, d.frame_index, d.surfel_count = pod.count, pod.frame_index, pod.surfel_count
+        if rc != 0:
+            d.count_needed = pod.count
+            d.count = 0
+            self.last_failed_delta = d
+            _lib.check(rc)
+        return d
 
     def UpdateVisualizationBuffers(self, *args, **kwargs):
         """Viewer-only in the reference (OpenGL interop); nothing to do without a render window."""

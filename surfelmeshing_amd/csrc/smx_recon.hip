@@ -203,6 +203,8 @@ struct Lists {
   uint32_t* recent_list;  // slots whose last update stamp lies inside the regulariser window
   uint32_t* recent_seg;
   uint8_t* flags8;        // per slot: bit 0 = stamp inside the regulariser window, bit 1 = detach request
+  uint8_t* dirty8;        // delta tracking (null = off): 1 = a transferred attribute of the slot changed since the
+                          // last smx_recon_transfer_changed_to_cpu
 };
 
 __device__ __forceinline__ bool stamp_outside_window(uint32_t stamp, uint32_t frame, int window) {
@@ -852,6 +854,7 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
       const uint32_t col = (S.u(kColor, i) & 0x00FFFFFFu) | 0x01000000u;
       S.u(kColor, i) = col;
       L.flags8[i] = make_flags(0u, col, c.frame, c.reg_window);
+      if (L.dirty8) L.dirty8[i] = 1;
       ++merged_here;
       continue;  // r^2 < 0: the integrate kernel does nothing for it (:1050-1052)
     }
@@ -872,6 +875,7 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
     integrate_or_conflict(R, c, px0, true, p.px, p.py, p.l, i, st);
     integrate_or_conflict(R, c, px1, second, ox, oy, p.l, i, st);
     if (R.dirty) {
+      if (L.dirty8) L.dirty8[i] = 1;
       *S.group(kGroupP, i) = R.P; *S.group(kGroupN, i) = R.N; *S.group(kGroupC, i) = R.C;
       if (R.replaced) {
         S.f(kSmoothX, i) = R.new_smooth.x; S.f(kSmoothY, i) = R.new_smooth.y; S.f(kSmoothZ, i) = R.new_smooth.z;
@@ -1037,7 +1041,7 @@ k_new_flags_scan(Img<const uint16_t> depth, Scratch sc, int W, int H, uint8_t* _
 
 struct CreateArgs {
   const uint8_t* flags; const uint32_t* ranks; const uint32_t* block_sums; uint32_t* block_offsets_out;
-  int n_scan_blocks; uint32_t max_surfels; uint8_t* flags8;
+  int n_scan_blocks; uint32_t max_surfels; uint8_t* flags8; uint8_t* dirty8;
 };
 __device__ __forceinline__ void new_create_body(const Surfels& S, const FrameCtx& c, const Scratch& sc, const FrameIn& in,
                                                 const CreateArgs& a, DevState* st, uint32_t block, uint32_t n_blocks) {
@@ -1099,6 +1103,7 @@ __device__ __forceinline__ void new_create_body(const Surfels& S, const FrameCtx
     S.u(kCreationStamp, i) = c.frame;
     S.u(kLastUpdateStamp, i) = c.frame;
     flags8[i] = make_flags(c.frame, 0u, c.frame, c.reg_window);
+    if (a.dirty8) a.dirty8[i] = 1;
     const float r2 = in.radius(y, x);
     S.f(kRadiusSq, i) = r2;
     Vec3 sum = {0, 0, 0};
@@ -1412,6 +1417,7 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long*
     if (step_len > max_step) step = max_step / step_len * kStep;
     // No kernel reads another slot's smooth position after k_reg_accumulate, so the result goes straight to the
     // S record: the reference's parking rows and RegularizeSurfelsCUDAUpdateKernel (:2283-2308) are not needed.
+    if (L.dirty8) L.dirty8[i] = 1;
     S.f(kSmoothX, i) = sp.x - step * grad.x;
     S.f(kSmoothY, i) = sp.y - step * grad.y;
     S.f(kSmoothZ, i) = sp.z - step * grad.z;
@@ -1425,6 +1431,7 @@ k_reg_copy_raw(Surfels S, Lists L, const DevState* st) {
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     uint32_t i;
     if (!chunk_entry<true, kSegB>(L.recent_list, L.recent_seg, n_slots, chunk, i)) continue;
+    if (L.dirty8) L.dirty8[i] = 1;
     S.f(kSmoothX, i) = S.f(kX, i);
     S.f(kSmoothY, i) = S.f(kY, i);
     S.f(kSmoothZ, i) = S.f(kZ, i);
@@ -1432,6 +1439,67 @@ k_reg_copy_raw(Surfels S, Lists L, const DevState* st) {
 }
 
 __global__ void k_reset_recent(DevState* st) { st->recent_count = 0; st->n_edges = 0; st->n_window_edges = 0; st->n_contributors = 0; }
+
+// ---- changed-surfel delta for the mesher ---------------------------------------------------------
+// Three small kernels over the dirty bytes: per-segment counts, one-workgroup scan of the counts, gather of
+// (slot index, the eight transferred attributes) into packed rows + clearing of the marks.
+__global__ void __launch_bounds__(kBlock)
+k_delta_count(const uint8_t* __restrict__ dirty8, uint32_t* __restrict__ seg_count, const DevState* st) {
+  __shared__ uint32_t wave_tot[kBlock / 64];
+  const uint32_t N = st->surfel_count, i0 = blockIdx.x * kSeg + threadIdx.x * 4;
+  uint32_t mine = 0;
+  if (i0 < N) {
+    const uchar4 d = *reinterpret_cast<const uchar4*>(&dirty8[i0]);
+    mine = (d.x != 0) + (i0 + 1 < N && d.y != 0) + (i0 + 2 < N && d.z != 0) + (i0 + 3 < N && d.w != 0);
+  }
+  uint32_t total;
+  (void)block_excl_scan(mine, wave_tot, total);
+  if (threadIdx.x == 0) seg_count[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(1024)
+k_delta_scan(uint32_t* __restrict__ seg_count, int nseg, uint32_t* __restrict__ total_out) {
+  // exclusive scan in place (the segment count is a few thousand)
+  __shared__ uint32_t wave_tot[1024 / 64];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nseg; base += 1024) {
+    const int b = base + threadIdx.x;
+    const uint32_t v = (b < nseg) ? seg_count[b] : 0;
+    uint32_t total;
+    const uint32_t excl = block_excl_scan<1024 / 64>(v, wave_tot, total);
+    if (b < nseg) seg_count[b] = carry + excl;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total_out = carry;
+}
+__global__ void __launch_bounds__(kBlock)
+k_delta_gather(Surfels S, uint8_t* __restrict__ dirty8, const uint32_t* __restrict__ seg_offset, float* __restrict__ out,
+               uint32_t total, const DevState* st) {
+  __shared__ uint32_t wave_tot[kBlock / 64];
+  const uint32_t N = st->surfel_count, i0 = blockIdx.x * kSeg + threadIdx.x * 4;
+  uint32_t bits = 0;
+  if (i0 < N) {
+    const uchar4 d = *reinterpret_cast<const uchar4*>(&dirty8[i0]);
+    bits = (d.x != 0 ? 1u : 0u) | ((i0 + 1 < N && d.y != 0) ? 2u : 0u) | ((i0 + 2 < N && d.z != 0) ? 4u : 0u) |
+           ((i0 + 3 < N && d.w != 0) ? 8u : 0u);
+    if (bits) *reinterpret_cast<uchar4*>(&dirty8[i0]) = make_uchar4(0, 0, 0, 0);
+  }
+  uint32_t seg_total;
+  uint32_t off = seg_offset[blockIdx.x] + block_excl_scan((uint32_t)__popc(bits), wave_tot, seg_total);
+  const int want[8] = {kSmoothX, kSmoothY, kSmoothZ, kRadiusSq, kNormalX, kNormalY, kNormalZ, kLastUpdateStamp};  // cc:348-358
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (bits & (1u << j)) {
+      const uint32_t i = i0 + j;
+      out[off] = __uint_as_float(i);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) out[(size_t)(k + 1) * total + off] = S.f(want[k], i);
+      ++off;
+    }
+}
 
 // Boundary conversion between the grouped records and the reference's row layout: out[k][i] = row rows[k] of
 // slot i (pack) and back (unpack).  Rows without storage read as 0.
@@ -1524,6 +1592,8 @@ struct smx_recon_s {
   int prof_slot;
   int prof_cap, prof_n;
   hipEvent_t* prof_ev;
+  uint32_t* delta_seg;   // delta hand-off: per-segment counts / offsets, and the total
+  uint32_t* delta_total;
   float* staging;    // row-layout staging for the boundary conversions (TransferAllToCPU, debug rows)
   size_t staging_floats;
   int grid_surfels;  // persistent grid for the grid-stride all-slot kernels
@@ -1718,7 +1788,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
 
 int smx_recon_destroy(smx_recon r) {
   if (!r) return SMX_OK;
-  void* ptrs[] = {r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->flags_buf[0], r->flags_buf[1],
+  void* ptrs[] = {r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->flags_buf[0], r->flags_buf[1],
                   r->merge_flag, r->inwin8, r->need_seg, r->sc.supporting, r->sc.counts,
                   r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->block_offsets, r->st};
@@ -1895,7 +1965,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   { SlotTimer t(r, sH, kSlotUpdateNeighbors);
     CreateArgs ca;
     ca.flags = r->new_flags; ca.ranks = r->new_ranks; ca.block_sums = r->block_sums; ca.block_offsets_out = r->block_offsets;
-    ca.n_scan_blocks = r->n_scan_blocks; ca.max_surfels = r->max_surfels; ca.flags8 = r->L.flags8;
+    ca.n_scan_blocks = r->n_scan_blocks; ca.max_surfels = r->max_surfels; ca.flags8 = r->L.flags8; ca.dirty8 = r->L.dirty8;
     const uint32_t ncb = (uint32_t)div_up(P, kBlock);
     const dim3 guc(ncb + (uint32_t)r->grid_list);
     const size_t lds = (size_t)r->n_scan_blocks * sizeof(uint32_t);
@@ -1999,6 +2069,59 @@ int smx_recon_transfer_all_to_cpu(smx_recon r, smx_stream s, uint32_t frame_inde
   return SMX_OK;
 }
 
+int smx_recon_set_delta_tracking(smx_recon r, smx_stream s, int32_t enabled) {
+  SMX_CHECK_ARG(r != nullptr && (enabled == 0 || enabled == 1));
+  hipStream_t st = (hipStream_t)s;
+  { const int rcj = join_regularizer(r, st); if (rcj != SMX_OK) return rcj; }
+  SMX_HIP(hipStreamSynchronize(st));  // no kernel may be using the pointer that changes here
+  if (enabled && !r->L.dirty8) {
+    int rc = dev_alloc(&r->L.dirty8, (size_t)r->nseg * kSeg, false);
+    if (rc == SMX_OK && !r->delta_seg) rc = dev_alloc(&r->delta_seg, (size_t)r->nseg, true);
+    if (rc == SMX_OK && !r->delta_total) rc = dev_alloc(&r->delta_total, 1, true);
+    if (rc != SMX_OK) return rc;
+    SMX_HIP(hipMemset(r->L.dirty8, 1, (size_t)r->nseg * kSeg));  // everything that exists counts as changed
+  } else if (!enabled && r->L.dirty8) {
+    SMX_HIP(hipFree(r->L.dirty8));
+    r->L.dirty8 = nullptr;
+  }
+  return SMX_OK;
+}
+
+int smx_recon_transfer_changed_to_cpu(smx_recon r, smx_stream s, uint32_t frame_index, smx_surfel_delta_cpu* d) {
+  SMX_CHECK_ARG(r != nullptr && d != nullptr);
+  if (!r->L.dirty8) { set_error("delta tracking is off (smx_recon_set_delta_tracking)"); return SMX_ERR_INVALID_ARGUMENT; }
+  hipStream_t st = (hipStream_t)s;
+  { const int rcj = join_regularizer(r, st); if (rcj != SMX_OK) return rcj; }
+  hipLaunchKernelGGL(k_delta_count, dim3(r->nseg), dim3(kBlock), 0, st, r->L.dirty8, r->delta_seg, r->st);
+  hipLaunchKernelGGL(k_delta_scan, dim3(1), dim3(1024), 0, st, r->delta_seg, r->nseg, r->delta_total);
+  SMX_LAUNCH_CHECK();
+  uint32_t total = 0, n = 0;
+  SMX_HIP(hipMemcpyAsync(&total, r->delta_total, 4, hipMemcpyDeviceToHost, st));
+  SMX_HIP(hipMemcpyAsync(&n, &r->st->surfel_count, 4, hipMemcpyDeviceToHost, st));
+  SMX_HIP(hipStreamSynchronize(st));
+  d->frame_index = frame_index;
+  d->surfel_count = n;
+  d->count = total;
+  if (total > d->capacity) {  // (the marks are untouched: call again with larger arrays)
+    set_error("delta of %u slots does not fit the capacity %u", total, d->capacity);
+    return SMX_ERR_INVALID_ARGUMENT;
+  }
+  if (total == 0) return SMX_OK;
+  SMX_CHECK_ARG(d->surfel_index && d->x && d->y && d->z && d->radius_squared && d->normal_x && d->normal_y &&
+                d->normal_z && d->last_update_stamp);
+  int rc = ensure_staging(r, (size_t)9 * total);
+  if (rc != SMX_OK) return rc;
+  hipLaunchKernelGGL(k_delta_gather, dim3(r->nseg), dim3(kBlock), 0, st, r->S, r->L.dirty8, r->delta_seg, r->staging, total,
+                     r->st);
+  SMX_LAUNCH_CHECK();
+  void* dst[9] = {d->surfel_index, d->x, d->y, d->z, d->radius_squared, d->normal_x, d->normal_y, d->normal_z,
+                  d->last_update_stamp};
+  for (int k = 0; k < 9; ++k)
+    SMX_HIP(hipMemcpyAsync(dst[k], r->staging + (size_t)k * total, (size_t)total * 4, hipMemcpyDeviceToHost, st));
+  SMX_HIP(hipStreamSynchronize(st));
+  return SMX_OK;
+}
+
 int smx_recon_export_vertices(smx_recon r, smx_stream s, const smx_buffer_desc* position_buffer,
                               const smx_buffer_desc* color_buffer) {
   SMX_CHECK_ARG(r && position_buffer && color_buffer);
@@ -2053,6 +2176,7 @@ int smx_recon_debug_upload_surfels(smx_recon r, smx_stream s, const float* rows,
   SMX_HIP(hipMemsetAsync(r->grad_local, 0, 2 * r->S.pitch * sizeof(long long), st));
   SMX_HIP(hipMemsetAsync(r->inbox, 0, 4 * r->S.pitch * sizeof(float4), st));
   SMX_HIP(hipMemsetAsync(r->merge_flag, 0, r->S.pitch, st));
+  if (r->L.dirty8) SMX_HIP(hipMemsetAsync(r->L.dirty8, 1, (size_t)r->nseg * kSeg, st));
   SMX_HIP(hipMemsetAsync(r->L.vis_seg, 0, (size_t)r->nseg * 4, st));
   SMX_HIP(hipMemsetAsync(r->L.seg_box, 0, (size_t)r->nseg * 8 * sizeof(float), st));  // (count 0 = no box)
   SMX_HIP(hipMemsetAsync(r->L.recent_seg, 0, (size_t)r->nsegB * 4, st));

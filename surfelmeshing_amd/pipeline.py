@@ -143,9 +143,10 @@ DRIVER_EXPORTS = ["smx_driver_create", "smx_driver_destroy", "smx_driver_recon",
 class _BorrowedRecon(api.CUDASurfelReconstruction):
     """CUDASurfelReconstruction view of the object the native driver owns."""
 
-    def __init__(self, handle, camera):  # noqa: super().__init__ would create a new object
+    def __init__(self, handle, camera, max_surfel_count):  # noqa: super().__init__ would create a new object
         self._h = handle
         self.depth_camera = camera
+        self.max_surfel_count = int(max_surfel_count)
         self._last_stream = None
 
     def close(self):
@@ -175,7 +176,7 @@ class NativeFramePipeline:
         _smxlib.check(L.smx_driver_create(_C.byref(cfg), _C.byref(self._d)))
         rh = _C.c_void_p()
         _smxlib.check(L.smx_driver_recon(self._d, _C.byref(rh)))
-        self.reconstruction = _BorrowedRecon(rh, api.PinholeCamera4f(width, height, fx, fy, cx, cy))
+        self.reconstruction = _BorrowedRecon(rh, api.PinholeCamera4f(width, height, fx, fy, cx, cy), max_surfel_count)
         self.resident = set()
 
     def set_overlap(self, enabled):

@@ -347,6 +347,69 @@ def test_regularize_transfer_export(smx):
     assert len(tm) == 7 and all(x >= 0 for x in tm)
 
 
+def test_changed_surfel_delta_reproduces_full_transfers(smx):
+    """a full transfer patched with every delta since equals the current full transfer bit for bit
+    (merges, replacements, new surfels and the regulariser's moves included); steady-state deltas are small."""
+    s = small_stream(obstacle_until=10, yaw_deg_per_frame=2.0)
+    po, pg = _pipes(smx, s, 60000, params_kw=dict(regularization_frame_window_size=2))
+    rec = pg.reconstruction
+    with pytest.raises(smx.SmxError):
+        rec.TransferChangedToCPU(None, 0)                       # tracking is off
+    rec.SetDeltaTracking(None, True)
+
+    def full():
+        cpu = smx.CUDASurfelsCPU(60000)
+        cpu.LockWriteBuffers()
+        rec.TransferAllToCPU(None, 0, cpu)
+        smx.StreamSynchronize(None)
+        cpu.UnlockWriteBuffers()
+        cpu.WaitForLockAndSwapBuffers()
+        return cpu.read_buffers()
+
+    names = [full_name for _, _, full_name in smx.CUDASurfelDeltaCPU.ROWS]
+    mirror = smx.CUDASurfelBuffersCPU(60000)
+    for n in names:
+        getattr(mirror, n)[:] = 0
+    sizes = []
+    frames = list(range(4, 30))
+    for f in range(0, 36):
+        d, c = s.frame(f)
+        po.upload(f, d, c)
+        pg.upload(f, d, c)
+    for k, f in enumerate(frames):
+        others, T, pose = s.outlier_frames(f), s.others_TR_reference(f), s.pose(f)
+        po.process(f, others, T, pose)
+        pg.process(f, others, T, pose)
+        if k % 3 == 2 or f == frames[-1]:                       # (several frames per delta, like the mesher's cadence)
+            delta = rec.TransferChangedToCPU(None, f)
+            assert np.all(np.diff(delta.surfel_index[:delta.count].astype(np.int64)) > 0)
+            delta.ApplyTo(mirror)
+            sizes.append((delta.count, delta.surfel_count))
+            ref = full()
+            n = ref.surfel_count
+            assert mirror.surfel_count == n == po.recon.surfels_size
+            for name in names:
+                a, b = getattr(mirror, name)[:n], getattr(ref, name)[:n]
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (f, name)
+    # the first delta carries everything, later ones only what moved
+    assert sizes[0][0] == sizes[0][1] and all(c < 0.8 * n_ for c, n_ in sizes[3:]), sizes
+    assert rec.TransferChangedToCPU(None, frames[-1]).count == 0   # nothing changed since
+    # too small a capacity: the needed count is reported and nothing is lost
+    pg.process(30, s.outlier_frames(30), s.others_TR_reference(30), s.pose(30))
+    po.process(30, s.outlier_frames(30), s.others_TR_reference(30), s.pose(30))
+    with pytest.raises(smx.SmxError):
+        rec.TransferChangedToCPU(None, 30, capacity=10)
+    needed = rec.last_failed_delta.count_needed
+    delta = rec.TransferChangedToCPU(None, 30, capacity=needed)
+    assert delta.count == needed > 10
+    delta.ApplyTo(mirror)
+    ref = full()
+    for name in names:
+        assert np.array_equal(getattr(mirror, name)[:ref.surfel_count].view(np.uint32),
+                              getattr(ref, name)[:ref.surfel_count].view(np.uint32)), name
+    rec.SetDeltaTracking(None, False)
+
+
 def test_capacity_clamp(smx):
     s = small_stream()
     cap = 9000                                         # first frame alone wants ~9.4k surfels
