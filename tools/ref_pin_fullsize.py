@@ -1,0 +1,74 @@
+"""The reference pin of tests/test_gpu_reference_pin.py at the bench's size: the 5 M-slot map grown by the product
+(640x480) is handed to the reference's own kernels (oracle/_ref) and to the CPU oracle; per frame, both start from the
+same state, the oracle gets the reference run's race outcomes imposed, and everything is compared.
+      python tools/ref_pin_fullsize.py [frames]"""
+import sys, time
+n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+sys.argv = ['bench.py']
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import numpy as np
+import torch  # noqa
+import bench
+import oracle as orc
+from oracle import ref_binding as ref
+from common import FLOAT_ROWS, INT_ROWS
+from surfelmeshing_amd import api, _lib
+from surfelmeshing_amd.pipeline import FramePipeline
+_lib.require_gpu()
+CAP = 5_500_000
+wl = bench.Workload(api, 640, 480, 5_000_000, CAP, 0x5EED0001, 0.0)
+g_end, n = wl.grow(False)
+first = g_end + 10
+for j in range(-4, n_frames + 5): wl.render(first + j, 4 + j)
+plan = [wl.plan(first + j, 4 + j) for j in range(n_frames)]
+rec = wl.pipe.reconstruction
+api.StreamSynchronize(None)
+S = rec.debug_download_surfels()
+merge0 = rec.surfels_size() - rec.surfel_count()
+print('state: %d slots, %d merged' % (S.shape[1], merge0))
+po = orc.Recon(CAP, 640, 480, wl.fx, wl.fy, wl.cx, wl.cy)
+po.surfels()[:, :S.shape[1]] = S
+po.set_counts(S.shape[1], merge0)
+rr = ref.Recon(CAP, 640, 480, wl.fx, wl.fy, wl.cx, wl.cy)
+pf = FramePipeline(640, 480, wl.fx, wl.fy, wl.cx, wl.cy, 1000, wl.pre)
+need = set()
+for p in plan:
+    need.add(p[0]); need.update(p[1])
+colors = {}
+for f in sorted(need):
+    d, c = wl.pipe.download_frame(f)
+    pf.upload(f, d, c); colors[f] = c
+params = orc.IntegrateParams.defaults()
+for f, others, T, pose in plan:
+    pf.preprocess(f, others, T)
+    api.StreamSynchronize(None)
+    depth, normals, radius = pf.depth_final.Download(), pf.normals.Download(), pf.radius.Download()
+    n0 = po.surfels_size
+    rr.upload_surfels(po.surfels()[:, :n0].copy(), po.merge_count)
+    depth_r, depth_o = np.ascontiguousarray(depth).copy(), np.ascontiguousarray(depth).copy()
+    rr.integrate(f, wl.pre.depth_scaling, depth_r, normals, radius, colors[f], pose, params)
+    sr = rr.scratch()
+    sup_r, conf_r = np.ascontiguousarray(sr['supporting']), np.ascontiguousarray(sr['conflicting'])
+    orc.set_race_overrides(sup_r, conf_r)
+    t = time.time()
+    po.integrate(f, wl.pre.depth_scaling, depth_o, normals, radius, colors[f], pose, params)
+    t = time.time() - t
+    ovr = orc.race_override_stats()
+    orc.set_race_overrides(None, None)
+    cr = rr.counts()
+    n = po.surfels_size
+    so = po.scratch()
+    line = 'frame %d: slots %d/%d merges %d/%d new %d/%d overrides %s | images differ: sup %d cnt %d conf %d first %d, blended depth %d' % (
+        f, n, cr['surfels_size'], po.merge_count, cr['merge_count'], po.stats()['n_new'], cr['n_new'], list(ovr.values()),
+        (so['supporting'] != sr['supporting']).sum(), (so['support_counts'] != sr['support_counts']).sum(),
+        (so['conflicting'] != sr['conflicting']).sum(), (so['first_depth'].view(np.uint32) != sr['first_depth'].view(np.uint32)).sum(),
+        (depth_o != depth_r).sum())
+    So, Sr = po.surfels()[:, :n], rr.surfels(n)
+    bad = []
+    for r_ in INT_ROWS:
+        k = int((So[r_].view(np.uint32) != Sr[r_].view(np.uint32)).sum())
+        if k: bad.append('row%d:%d' % (r_, k))
+    for r_ in FLOAT_ROWS:
+        neq = So[r_].view(np.uint32) != Sr[r_].view(np.uint32)
+        if neq.any(): bad.append('row%d:%d(max|d| %.1e)' % (r_, neq.sum(), np.abs(So[r_] - Sr[r_])[neq].max()))
+    print(line + ' | rows: ' + (' '.join(bad) if bad else 'ALL BIT-EQUAL') + ' | oracle %.1fs' % t)
