@@ -117,6 +117,10 @@ int smx_erode_depth_map(smx_stream s, int32_t radius, const smx_buffer_desc* inp
                         const smx_buffer_desc* output_depth);
 int smx_copy_without_border(smx_stream s, const smx_buffer_desc* input_depth,
                             const smx_buffer_desc* output_depth);
+/* MedianFilterAndDensifyDepthMap, APP/main.cc:206-252: in the reference a CPU loop before the upload (its TODO at
+ * main.cc:928 asks for the GPU), one call per `median_filter_and_densify_iterations`.  Input and output must differ. */
+int smx_median_filter_and_densify_depth_map(smx_stream s, const smx_buffer_desc* input_depth,
+                                            const smx_buffer_desc* output_depth);
 /* ComputeNormalsAndDropBadPixelsCUDA, cu:720-762 */
 int smx_compute_normals_and_drop_bad_pixels(
     smx_stream s, float observation_angle_threshold_deg, float depth_scaling,

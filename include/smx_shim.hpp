@@ -159,6 +159,13 @@ void OutlierDepthMapFusionCUDA(cudaStream_t stream, int required_count, float to
                                               depth_fy, depth_cx, depth_cy, others, T, output_depth->desc()));
 }
 
+// MedianFilterAndDensifyDepthMap (APP/main.cc:206-252) is a CPU function in the reference; its TODO (main.cc:928) asks
+// for this: the same filter on device buffers, ahead of the bilateral filter.
+inline void MedianFilterAndDensifyDepthMapCUDA(cudaStream_t stream, const CUDABuffer_<u16>& input_depth,
+                                               CUDABuffer_<u16>* output_depth) {
+  SMX_SHIM_CHECK(smx_median_filter_and_densify_depth_map(stream, input_depth.desc(), output_depth->desc()));
+}
+
 template <typename DepthT>
 void ErodeDepthMapCUDA(cudaStream_t stream, int radius, const CUDABuffer_<DepthT>& input_depth,
                        CUDABuffer_<DepthT>* output_depth) {

@@ -138,6 +138,17 @@ def outlier_depth_map_fusion(depth, others, others_TR_reference, fx, fy, cx, cy,
     return out
 
 
+def median_filter_and_densify(depth, iterations=1):
+    """MedianFilterAndDensifyDepthMap applied `iterations` times (APP/main.cc:929-939)."""
+    depth = _c(depth, np.uint16)
+    h, w = depth.shape
+    for _ in range(iterations):
+        out = np.empty_like(depth)
+        lib().orc_median_filter_and_densify(C.c_int(w), C.c_int(h), _p(depth), _p(out))
+        depth = out
+    return depth
+
+
 def erode_depth_map(depth, radius):
     depth = _c(depth, np.uint16)
     h, w = depth.shape

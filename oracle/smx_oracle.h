@@ -143,6 +143,7 @@ void orc_outlier_depth_map_fusion(
     uint16_t* out);
 
 void orc_erode_depth_map(int radius, int width, int height, const uint16_t* in, uint16_t* out);
+void orc_median_filter_and_densify(int width, int height, const uint16_t* in, uint16_t* out);  /* APP/main.cc:206-252 */
 void orc_copy_without_border(int width, int height, const uint16_t* in, uint16_t* out);
 
 void orc_compute_normals_and_drop_bad_pixels(

@@ -170,6 +170,40 @@ void orc_erode_depth_map(int radius, int width, int height, const uint16_t* in, 
   }
 }
 
+/* MedianFilterAndDensifyDepthMap, APP/main.cc:206-252 (a CPU function of the reference's main.cc; its std::sort +
+ * size() / 2 indexing restated on a 9-element array) */
+void orc_median_filter_and_densify(int width, int height, const uint16_t* in, uint16_t* out) {
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < width; ++x) {
+      uint16_t v[9];
+      int n = 0;
+      const int y0 = y - 1 > 0 ? y - 1 : 0, y1 = y + 1 < height - 1 ? y + 1 : height - 1;
+      const int x0 = x - 1 > 0 ? x - 1 : 0, x1 = x + 1 < width - 1 ? x + 1 : width - 1;
+      for (int dy = y0; dy <= y1; ++dy)
+        for (int dx = x0; dx <= x1; ++dx)
+          if (in[(size_t)dy * width + dx] != 0) v[n++] = in[(size_t)dy * width + dx];
+      if (n >= 2) {                                               /* kMinNeighbors */
+        for (int i = 1; i < n; ++i) {                             /* std::sort */
+          const uint16_t t = v[i];
+          int k = i;
+          while (k > 0 && v[k - 1] > t) { v[k] = v[k - 1]; --k; }
+          v[k] = t;
+        }
+        if (n % 2 == 0) {
+          float sum = 0;
+          for (int i = 0; i < n; ++i) sum += v[i];
+          const float average = sum / n;
+          const float prev_diff = fabsf(v[n / 2 - 1] - average), next_diff = fabsf(v[n / 2] - average);
+          out[(size_t)y * width + x] = (prev_diff < next_diff) ? v[n / 2 - 1] : v[n / 2];
+        } else {
+          out[(size_t)y * width + x] = v[n / 2];
+        }
+      } else {
+        out[(size_t)y * width + x] = in[(size_t)y * width + x];
+      }
+    }
+}
+
 /* cuda_depth_processing.cu:589-607 */
 void orc_copy_without_border(int width, int height, const uint16_t* in, uint16_t* out) {
   for (int y = 0; y < height; ++y)

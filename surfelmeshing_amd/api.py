@@ -189,6 +189,11 @@ def ErodeDepthMapCUDA(stream, radius, input_depth, output_depth):
     _lib.check(_lib.load().smx_erode_depth_map(_sv(stream), C.c_int32(radius), _d(input_depth), _d(output_depth)))
 
 
+def MedianFilterAndDensifyDepthMapCUDA(stream, input_depth, output_depth):
+    """MedianFilterAndDensifyDepthMap (APP/main.cc:206-252, a CPU function in the reference) on the GPU."""
+    _lib.check(_lib.load().smx_median_filter_and_densify_depth_map(_sv(stream), _d(input_depth), _d(output_depth)))
+
+
 def CopyWithoutBorderCUDA(stream, input_depth, output_depth):
     _lib.check(_lib.load().smx_copy_without_border(_sv(stream), _d(input_depth), _d(output_depth)))
 

@@ -238,6 +238,46 @@ k_erode(int radius, Img<const uint16_t> in, Img<uint16_t> out) {
   out(y, x) = all_valid ? in(y, x) : (uint16_t)0;
 }
 
+// MedianFilterAndDensifyDepthMap, APP/main.cc:206-252 -- in the reference a CPU loop ahead of the upload ("TODO: Do
+// this on the GPU", main.cc:928).  3x3 window clipped at the image border, zeros excluded; with fewer than two
+// measurements the pixel is copied, with an odd count the median is taken, with an even count the middle element
+// closer to the mean (the lower one on a tie of the float differences -- `prev_diff < next_diff` picks the upper).
+__global__ void __launch_bounds__(kThreads)
+k_median_densify(Img<const uint16_t> in, Img<uint16_t> out) {
+  const int x = blockIdx.x * kTileW + (threadIdx.x & (kTileW - 1));
+  const int y = blockIdx.y * (kThreads / kTileW) + threadIdx.x / kTileW;
+  const int W = out.width, H = out.height;
+  if (x >= W || y >= H) return;
+  uint16_t v[9];
+  int n = 0;
+  float sum = 0;  // (integers below 2^24: exact in any order)
+  for (int dy = max(0, y - 1); dy <= min(H - 1, y + 1); ++dy) {
+    const uint16_t* row = in.row(dy);
+    for (int dx = max(0, x - 1); dx <= min(W - 1, x + 1); ++dx) {
+      const uint16_t d = row[dx];
+      if (d != 0) {
+        // insertion into the sorted prefix (registers: the loops are unrolled by the compiler for n <= 9)
+        int k = n;
+        while (k > 0 && v[k - 1] > d) { v[k] = v[k - 1]; --k; }
+        v[k] = d;
+        ++n;
+        sum += (float)d;
+      }
+    }
+  }
+  uint16_t r = in(y, x);
+  if (n >= 2) {
+    if ((n & 1) == 0) {
+      const float average = sum / (float)n;
+      const float prev_diff = fabsf((float)v[n / 2 - 1] - average), next_diff = fabsf((float)v[n / 2] - average);
+      r = (prev_diff < next_diff) ? v[n / 2 - 1] : v[n / 2];
+    } else {
+      r = v[n / 2];
+    }
+  }
+  out(y, x) = r;
+}
+
 __global__ void __launch_bounds__(kThreads)
 k_copy_without_border(Img<const uint16_t> in, Img<uint16_t> out) {
   const int x = blockIdx.x * kTileW + (threadIdx.x & (kTileW - 1));
@@ -414,6 +454,16 @@ int smx_erode_depth_map(smx_stream s, int32_t radius, const smx_buffer_desc* inp
   }
   hipLaunchKernelGGL(k_erode, grid_rows(output_depth->width, output_depth->height), dim3(kThreads), 0,
                      (hipStream_t)s, radius, as_img<const uint16_t>(input_depth), as_img<uint16_t>(output_depth));
+  SMX_LAUNCH_CHECK();
+  return SMX_OK;
+}
+
+int smx_median_filter_and_densify_depth_map(smx_stream s, const smx_buffer_desc* input_depth,
+                                            const smx_buffer_desc* output_depth) {
+  SMX_CHECK_ARG(input_depth && output_depth && input_depth->address != output_depth->address);
+  SMX_CHECK_ARG(input_depth->width == output_depth->width && input_depth->height == output_depth->height);
+  hipLaunchKernelGGL(k_median_densify, grid_rows(output_depth->width, output_depth->height), dim3(kThreads), 0,
+                     (hipStream_t)s, as_img<const uint16_t>(input_depth), as_img<uint16_t>(output_depth));
   SMX_LAUNCH_CHECK();
   return SMX_OK;
 }

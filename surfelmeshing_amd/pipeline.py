@@ -28,6 +28,7 @@ class PreprocessParams:
     outlier_filtering_depth_tolerance_factor: float = 0.02
     point_radius_extension_factor: float = 1.5
     point_radius_clamp_factor: float = float("inf")
+    median_filter_and_densify_iterations: int = 0   # main.cc:929-939 (on the CPU there, on the GPU here)
 
     def max_depth_u16(self):
         return int(np.uint16(min(self.depth_scaling * self.max_depth, 65535.0)))  # main.cc:1021
@@ -53,6 +54,13 @@ class FramePipeline:
     def upload(self, frame_index, depth, color):
         d = api.CUDABuffer(self.h, self.w, np.uint16)
         d.UploadAsync(self.stream, depth)
+        if self.pre.median_filter_and_densify_iterations > 0:   # main.cc:929-939, per frame at load time
+            t = api.CUDABuffer(self.h, self.w, np.uint16)
+            for _ in range(self.pre.median_filter_and_densify_iterations):
+                api.MedianFilterAndDensifyDepthMapCUDA(self.stream, d, t)
+                d, t = t, d
+            api.StreamSynchronize(self.stream)
+            t.close()
         c = api.CUDABuffer(self.h, self.w, np.uint8, 3)
         c.UploadAsync(self.stream, color)
         self.raw_depth[frame_index] = d

@@ -17,6 +17,8 @@ class OraclePipeline:
 
     def upload(self, f, depth, color):
         self.raw_depth[f] = np.ascontiguousarray(depth, np.uint16)
+        if getattr(self.pre, "median_filter_and_densify_iterations", 0) > 0:   # main.cc:929-939
+            self.raw_depth[f] = orc.median_filter_and_densify(self.raw_depth[f], self.pre.median_filter_and_densify_iterations)
         self.color[f] = np.ascontiguousarray(color, np.uint8)
 
     def release(self, f):

@@ -111,6 +111,25 @@ def test_depth_stage_edge_cases(smx):
 
 
 # ---- CUDABuffer -----------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h", [(160, 120), (203, 77), (640, 480)])
+def test_median_filter_and_densify_bit_exact(smx, w, h):
+    """The reference's CPU MedianFilterAndDensifyDepthMap (APP/main.cc:206-252) on the GPU: two iterations, sparse
+    input (45 % holes), odd sizes, borders."""
+    rng = np.random.default_rng(w * 7 + h)
+    d = rng.uniform(400, 9000, (h, w)).astype(np.uint16)
+    d[rng.uniform(size=(h, w)) < 0.45] = 0
+    d[:3, :] = 0
+    a, b = smx.CUDABuffer(h, w, np.uint16), smx.CUDABuffer(h, w, np.uint16)
+    a.UploadAsync(None, d)
+    smx.MedianFilterAndDensifyDepthMapCUDA(None, a, b)
+    smx.MedianFilterAndDensifyDepthMapCUDA(None, b, a)
+    smx.StreamSynchronize(None)
+    assert np.array_equal(b.Download(), orc.median_filter_and_densify(d, 1))
+    assert np.array_equal(a.Download(), orc.median_filter_and_densify(d, 2))
+    with pytest.raises(smx.SmxError):
+        smx.MedianFilterAndDensifyDepthMapCUDA(None, a, a)                  # in place is not supported
+
+
 def test_cuda_buffer_roundtrips(smx):
     rng = np.random.default_rng(0)
     for dtype, ch, shape in ((np.uint16, 1, (31, 77)), (np.float32, 2, (9, 130)), (np.uint8, 3, (17, 65)), (np.float32, 1, (25, 1000))):
@@ -301,6 +320,15 @@ def test_segment_culling_while_panning(smx):
         _compare_state(po, pg)
         skipped += pg.reconstruction.stats()["n_segments_skipped"]
     assert skipped >= 10, skipped
+
+
+def test_stream_with_median_densify_iterations(smx):
+    """median_filter_and_densify_iterations = 2 (APP/main.cc:929-939) in front of the preprocessing, whole pipeline."""
+    s = small_stream(obstacle_until=8, dropout=0.03)
+    pre = small_pre(s.width, median_filter_and_densify_iterations=2)
+    po, pg = _pipes(smx, s, 60000, pre=pre)
+    run_both(po, pg, s, list(range(4, 14)), lambda f: _compare_state(po, pg))
+    assert po.recon.surfels_size > 8000
 
 
 def test_full_resolution_parity(smx):

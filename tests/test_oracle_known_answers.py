@@ -381,3 +381,49 @@ def test_properties_on_stream(orc):
         assert np.allclose(nrm, 1.0, atol=1e-4)
         assert int((~live).sum()) == p.recon.merge_count
         assert np.all(S[6][live] <= 5.0)
+
+
+def _median_densify_numpy(d):
+    """Independent restatement of MedianFilterAndDensifyDepthMap (APP/main.cc:206-252) with numpy sorting."""
+    h, w = d.shape
+    out = d.copy()
+    for y in range(h):
+        for x in range(w):
+            win = d[max(0, y - 1):min(h, y + 2), max(0, x - 1):min(w, x + 2)].ravel()
+            vals = np.sort(win[win != 0])
+            n = vals.size
+            if n >= 2:
+                if n % 2 == 0:
+                    avg = np.float32(np.float32(vals.astype(np.float32).sum(dtype=np.float32)) / np.float32(n))
+                    prev_diff = abs(np.float32(vals[n // 2 - 1]) - avg)
+                    next_diff = abs(np.float32(vals[n // 2]) - avg)
+                    out[y, x] = vals[n // 2 - 1] if prev_diff < next_diff else vals[n // 2]
+                else:
+                    out[y, x] = vals[n // 2]
+    return out
+
+
+def test_median_filter_and_densify_known_answers(orc):
+    # hand cases: fewer than two measurements -> copy; odd count -> median; even count -> the middle one nearer the mean
+    d = np.zeros((5, 5), np.uint16)
+    assert np.array_equal(orc.median_filter_and_densify(d), d)
+    d[2, 2] = 1000
+    assert np.array_equal(orc.median_filter_and_densify(d), d)            # one measurement per window: copied
+    d[2, 3] = 2000
+    o = orc.median_filter_and_densify(d)
+    # windows seeing both values (even count 2, mean 1500, equal distances -> the upper one)
+    assert o[2, 2] == 2000 and o[1, 2] == 2000 and o[3, 3] == 2000
+    assert o[2, 1] == 0 and o[2, 4] == 0                                   # one measurement in the window: the (empty) pixel is copied
+    d[1, 2] = 4000
+    o = orc.median_filter_and_densify(d)
+    assert o[2, 2] == 2000 and o[1, 3] == 2000                             # odd count 3 -> the median
+    d2 = np.zeros((3, 3), np.uint16)
+    d2[0, 0], d2[0, 1], d2[1, 0], d2[1, 1] = 100, 200, 300, 1000          # even count 4, mean 400: 300 is nearer than 200
+    assert orc.median_filter_and_densify(d2)[1, 1] == 300 and orc.median_filter_and_densify(d2)[2, 2] == 0
+    # random sparse maps against the independent restatement, two iterations
+    rng = np.random.default_rng(5)
+    for shape in ((17, 23), (40, 31)):
+        m = (rng.uniform(500, 6000, shape)).astype(np.uint16)
+        m[rng.uniform(size=shape) < 0.45] = 0
+        assert np.array_equal(orc.median_filter_and_densify(m), _median_densify_numpy(m))
+        assert np.array_equal(orc.median_filter_and_densify(m, 2), _median_densify_numpy(_median_densify_numpy(m)))
