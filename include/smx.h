@@ -121,6 +121,10 @@ int smx_copy_without_border(smx_stream s, const smx_buffer_desc* input_depth,
  * main.cc:928 asks for the GPU), one call per `median_filter_and_densify_iterations`.  Input and output must differ. */
 int smx_median_filter_and_densify_depth_map(smx_stream s, const smx_buffer_desc* input_depth,
                                             const smx_buffer_desc* output_depth);
+/* Image<u16>::DownscaleUsingMedianWhileExcluding, VIS/image.h:1003-1053 -- the depth half of --pyramid_level
+ * (APP/main.cc:941-962), a CPU loop in the reference.  The output size selects the source blocks. */
+int smx_downscale_using_median_while_excluding(smx_stream s, uint16_t value_to_ignore, const smx_buffer_desc* input,
+                                               const smx_buffer_desc* output);
 /* ComputeNormalsAndDropBadPixelsCUDA, cu:720-762 */
 int smx_compute_normals_and_drop_bad_pixels(
     smx_stream s, float observation_angle_threshold_deg, float depth_scaling,

@@ -159,6 +159,13 @@ void OutlierDepthMapFusionCUDA(cudaStream_t stream, int required_count, float to
                                               depth_fy, depth_cx, depth_cy, others, T, output_depth->desc()));
 }
 
+// Image<u16>::DownscaleUsingMedianWhileExcluding (libvis image.h:1003-1053, --pyramid_level's depth image) on device
+// buffers; the output buffer's size selects the source blocks.
+inline void DownscaleUsingMedianWhileExcludingCUDA(cudaStream_t stream, u16 value_to_ignore,
+                                                   const CUDABuffer_<u16>& input, CUDABuffer_<u16>* output) {
+  SMX_SHIM_CHECK(smx_downscale_using_median_while_excluding(stream, value_to_ignore, input.desc(), output->desc()));
+}
+
 // MedianFilterAndDensifyDepthMap (APP/main.cc:206-252) is a CPU function in the reference; its TODO (main.cc:928) asks
 // for this: the same filter on device buffers, ahead of the bilateral filter.
 inline void MedianFilterAndDensifyDepthMapCUDA(cudaStream_t stream, const CUDABuffer_<u16>& input_depth,

@@ -149,6 +149,15 @@ def median_filter_and_densify(depth, iterations=1):
     return depth
 
 
+def downscale_using_median_while_excluding(depth, out_width, out_height, value_to_ignore=0):
+    depth = _c(depth, np.uint16)
+    h, w = depth.shape
+    out = np.empty((out_height, out_width), np.uint16)
+    lib().orc_downscale_using_median_while_excluding(C.c_uint16(value_to_ignore), C.c_int(w), C.c_int(h), _p(depth),
+                                                     C.c_int(out_width), C.c_int(out_height), _p(out))
+    return out
+
+
 def erode_depth_map(depth, radius):
     depth = _c(depth, np.uint16)
     h, w = depth.shape

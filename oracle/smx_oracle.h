@@ -144,6 +144,8 @@ void orc_outlier_depth_map_fusion(
 
 void orc_erode_depth_map(int radius, int width, int height, const uint16_t* in, uint16_t* out);
 void orc_median_filter_and_densify(int width, int height, const uint16_t* in, uint16_t* out);  /* APP/main.cc:206-252 */
+void orc_downscale_using_median_while_excluding(uint16_t value_to_ignore, int width, int height, const uint16_t* in,
+                                                int out_width, int out_height, uint16_t* out);  /* VIS/image.h:1003-1053 */
 void orc_copy_without_border(int width, int height, const uint16_t* in, uint16_t* out);
 
 void orc_compute_normals_and_drop_bad_pixels(

@@ -8,6 +8,7 @@
 #include "smx_oracle.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 /* ------------------------------------------------------------------------- */
@@ -202,6 +203,38 @@ void orc_median_filter_and_densify(int width, int height, const uint16_t* in, ui
         out[(size_t)y * width + x] = in[(size_t)y * width + x];
       }
     }
+}
+
+/* Image<T>::DownscaleUsingMedianWhileExcluding, VIS/image.h:1003-1053 (u16) */
+void orc_downscale_using_median_while_excluding(uint16_t value_to_ignore, int width, int height, const uint16_t* in,
+                                                int out_width, int out_height, uint16_t* out) {
+  uint16_t* v = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)width * height);
+  for (uint32_t y = 0; y < (uint32_t)out_height; ++y)
+    for (uint32_t x = 0; x < (uint32_t)out_width; ++x) {
+      const uint32_t sx = ((uint32_t)width * x) / out_width, ex = ((uint32_t)width * (x + 1)) / out_width;
+      const uint32_t sy = ((uint32_t)height * y) / out_height, ey = ((uint32_t)height * (y + 1)) / out_height;
+      uint32_t n = 0;
+      float sum = 0;
+      for (uint32_t oy = sy; oy < ey; ++oy)
+        for (uint32_t ox = sx; ox < ex; ++ox) {
+          const uint16_t d = in[(size_t)oy * width + ox];
+          if (d != value_to_ignore) { v[n++] = d; sum += d; }
+        }
+      uint16_t r = value_to_ignore;
+      if (n > 0) {
+        const float average = sum / n;
+        for (uint32_t i = 1; i < n; ++i) {                         /* std::sort */
+          const uint16_t t = v[i];
+          uint32_t k = i;
+          while (k > 0 && v[k - 1] > t) { v[k] = v[k - 1]; --k; }
+          v[k] = t;
+        }
+        if (n % 2 == 1) r = v[n / 2];
+        else r = (fabsf(average - v[n / 2 - 1]) < fabsf(average - v[n / 2])) ? v[n / 2 - 1] : v[n / 2];
+      }
+      out[(size_t)y * out_width + x] = r;
+    }
+  free(v);
 }
 
 /* cuda_depth_processing.cu:589-607 */

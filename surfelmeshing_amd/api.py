@@ -194,6 +194,12 @@ def MedianFilterAndDensifyDepthMapCUDA(stream, input_depth, output_depth):
     _lib.check(_lib.load().smx_median_filter_and_densify_depth_map(_sv(stream), _d(input_depth), _d(output_depth)))
 
 
+def DownscaleUsingMedianWhileExcludingCUDA(stream, value_to_ignore, input_depth, output_depth):
+    """Image<u16>::DownscaleUsingMedianWhileExcluding (VIS/image.h:1003-1053, the depth half of --pyramid_level)."""
+    _lib.check(_lib.load().smx_downscale_using_median_while_excluding(_sv(stream), C.c_uint16(value_to_ignore),
+                                                                      _d(input_depth), _d(output_depth)))
+
+
 def CopyWithoutBorderCUDA(stream, input_depth, output_depth):
     _lib.check(_lib.load().smx_copy_without_border(_sv(stream), _d(input_depth), _d(output_depth)))
 

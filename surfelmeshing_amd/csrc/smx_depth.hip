@@ -278,6 +278,47 @@ k_median_densify(Img<const uint16_t> in, Img<uint16_t> out) {
   out(y, x) = r;
 }
 
+// Image<T>::DownscaleUsingMedianWhileExcluding (VIS/image.h:1003-1053), the depth half of --pyramid_level
+// (APP/main.cc:941-962; a CPU loop in the reference).  One output pixel per lane; its source block
+// [W x / w, W (x + 1) / w) x [H y / h, H (y + 1) / h) holds at most kMaxDownscaleBlock values.
+constexpr int kMaxDownscaleBlock = 81;
+__global__ void __launch_bounds__(kThreads)
+k_downscale_median(uint16_t value_to_ignore, Img<const uint16_t> in, Img<uint16_t> out) {
+  const int x = blockIdx.x * kTileW + (threadIdx.x & (kTileW - 1));
+  const int y = blockIdx.y * (kThreads / kTileW) + threadIdx.x / kTileW;
+  const unsigned w = out.width, h = out.height, W = in.width, H = in.height;
+  if (x >= (int)w || y >= (int)h) return;
+  const unsigned sx = (W * (unsigned)x) / w, ex = (W * ((unsigned)x + 1)) / w;
+  const unsigned sy = (H * (unsigned)y) / h, ey = (H * ((unsigned)y + 1)) / h;
+  uint16_t v[kMaxDownscaleBlock];
+  int n = 0;
+  float sum = 0;  // (exact: below 2^24)
+  for (unsigned oy = sy; oy < ey; ++oy) {
+    const uint16_t* row = in.row((int)oy);
+    for (unsigned ox = sx; ox < ex; ++ox) {
+      const uint16_t d = row[ox];
+      if (d != value_to_ignore) {
+        int k = n;
+        while (k > 0 && v[k - 1] > d) { v[k] = v[k - 1]; --k; }
+        v[k] = d;
+        ++n;
+        sum += (float)d;
+      }
+    }
+  }
+  uint16_t r = value_to_ignore;
+  if (n > 0) {
+    if (n & 1) {
+      r = v[n / 2];
+    } else {
+      const float average = sum / (float)n;
+      const uint16_t lo = v[n / 2 - 1], hi = v[n / 2];
+      r = (fabsf(average - (float)lo) < fabsf(average - (float)hi)) ? lo : hi;
+    }
+  }
+  out(y, x) = r;
+}
+
 __global__ void __launch_bounds__(kThreads)
 k_copy_without_border(Img<const uint16_t> in, Img<uint16_t> out) {
   const int x = blockIdx.x * kTileW + (threadIdx.x & (kTileW - 1));
@@ -464,6 +505,21 @@ int smx_median_filter_and_densify_depth_map(smx_stream s, const smx_buffer_desc*
   SMX_CHECK_ARG(input_depth->width == output_depth->width && input_depth->height == output_depth->height);
   hipLaunchKernelGGL(k_median_densify, grid_rows(output_depth->width, output_depth->height), dim3(kThreads), 0,
                      (hipStream_t)s, as_img<const uint16_t>(input_depth), as_img<uint16_t>(output_depth));
+  SMX_LAUNCH_CHECK();
+  return SMX_OK;
+}
+
+int smx_downscale_using_median_while_excluding(smx_stream s, uint16_t value_to_ignore, const smx_buffer_desc* input,
+                                               const smx_buffer_desc* output) {
+  SMX_CHECK_ARG(input && output && output->width > 0 && output->height > 0);
+  SMX_CHECK_ARG(output->width <= input->width && output->height <= input->height);
+  const int bw = (input->width + output->width - 1) / output->width + 1, bh = (input->height + output->height - 1) / output->height + 1;
+  if ((bw - 1) * (bh - 1) > kMaxDownscaleBlock) {
+    set_error("downscale blocks of up to %d x %d pixels are not supported (at most %d values)", bw - 1, bh - 1, kMaxDownscaleBlock);
+    return SMX_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(k_downscale_median, grid_rows(output->width, output->height), dim3(kThreads), 0, (hipStream_t)s,
+                     value_to_ignore, as_img<const uint16_t>(input), as_img<uint16_t>(output));
   SMX_LAUNCH_CHECK();
   return SMX_OK;
 }

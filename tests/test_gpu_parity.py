@@ -130,6 +130,27 @@ def test_median_filter_and_densify_bit_exact(smx, w, h):
         smx.MedianFilterAndDensifyDepthMapCUDA(None, a, a)                  # in place is not supported
 
 
+@pytest.mark.parametrize("size,out", [((480, 640), (240, 320)), ((480, 640), (120, 160)), ((77, 203), (38, 100)),
+                                      ((96, 128), (12, 16))])
+def test_downscale_using_median_while_excluding_bit_exact(smx, size, out):
+    """Image<u16>::DownscaleUsingMedianWhileExcluding (VIS/image.h:1003-1053; --pyramid_level's depth image): 2x2,
+    4x4, uneven and 8x8 blocks, holes excluded."""
+    rng = np.random.default_rng(size[0] + out[1])
+    d = rng.uniform(400, 9000, size).astype(np.uint16)
+    d[rng.uniform(size=size) < 0.4] = 0
+    d[:8, :16] = 0                                                         # blocks without any value
+    a, b = smx.CUDABuffer(size[0], size[1], np.uint16), smx.CUDABuffer(out[0], out[1], np.uint16)
+    a.UploadAsync(None, d)
+    smx.DownscaleUsingMedianWhileExcludingCUDA(None, 0, a, b)
+    smx.StreamSynchronize(None)
+    ref = orc.downscale_using_median_while_excluding(d, out[1], out[0], 0)
+    assert np.array_equal(b.Download(), ref) and (ref == 0).sum() > 0 and (ref > 0).sum() > ref.size // 2
+    small = smx.CUDABuffer(4, 4, np.uint16)
+    if size == (480, 640):
+        with pytest.raises(smx.SmxError):
+            smx.DownscaleUsingMedianWhileExcludingCUDA(None, 0, a, small)  # 160 x 120 pixel blocks: unsupported
+
+
 def test_cuda_buffer_roundtrips(smx):
     rng = np.random.default_rng(0)
     for dtype, ch, shape in ((np.uint16, 1, (31, 77)), (np.float32, 2, (9, 130)), (np.uint8, 3, (17, 65)), (np.float32, 1, (25, 1000))):

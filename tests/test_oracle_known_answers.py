@@ -427,3 +427,30 @@ def test_median_filter_and_densify_known_answers(orc):
         m[rng.uniform(size=shape) < 0.45] = 0
         assert np.array_equal(orc.median_filter_and_densify(m), _median_densify_numpy(m))
         assert np.array_equal(orc.median_filter_and_densify(m, 2), _median_densify_numpy(_median_densify_numpy(m)))
+
+
+def test_downscale_using_median_while_excluding_known_answers(orc):
+    """VIS/image.h:1003-1053 against an independent numpy restatement, and two hand cases."""
+    d = np.array([[100, 0, 300, 300], [0, 0, 500, 700]], np.uint16)
+    o = orc.downscale_using_median_while_excluding(d, 2, 1, 0)
+    assert o.tolist() == [[100, 500]]        # one value; four values 300,300,500,700: mean 450, 500 is nearer than 300
+    assert orc.downscale_using_median_while_excluding(np.zeros((4, 4), np.uint16), 2, 2, 0).tolist() == [[0, 0], [0, 0]]
+    rng = np.random.default_rng(11)
+    for (h, w), (oh, ow) in (((40, 64), (20, 32)), ((77, 203), (38, 100)), ((64, 64), (8, 8))):
+        m = rng.uniform(500, 6000, (h, w)).astype(np.uint16)
+        m[rng.uniform(size=(h, w)) < 0.4] = 0
+        ref = np.zeros((oh, ow), np.uint16)
+        for y in range(oh):
+            for x in range(ow):
+                blk = m[(h * y) // oh:(h * (y + 1)) // oh, (w * x) // ow:(w * (x + 1)) // ow].ravel()
+                vals = np.sort(blk[blk != 0])
+                n = vals.size
+                if n == 0:
+                    continue
+                if n % 2 == 1:
+                    ref[y, x] = vals[n // 2]
+                else:
+                    avg = np.float32(vals.astype(np.float32).sum(dtype=np.float32) / np.float32(n))
+                    lo, hi = vals[n // 2 - 1], vals[n // 2]
+                    ref[y, x] = lo if abs(avg - np.float32(lo)) < abs(avg - np.float32(hi)) else hi
+        assert np.array_equal(orc.downscale_using_median_while_excluding(m, ow, oh, 0), ref)
