@@ -279,7 +279,8 @@ int smx_recon_set_overlap(smx_recon r, int32_t enabled);
 /* ---- radius-neighbor search (replaces CompressedOctree::FindNearestSurfelsWithinRadius,
  * APP/octree.h:470-477, APP/octree.cc:313-470, for batched queries) ---- */
 /* Build a uniform-grid index over n points given as three device or host rows.
- * cell_size > 0; queries with radius <= cell_size touch at most 27 cells. */
+ * cell_size > 0; queries with radius <= cell_size touch at most 27 cells.  Points with a non-finite coordinate
+ * are not indexed (no finite ball contains them). */
 int smx_nn_create(smx_nn* out);
 int smx_nn_destroy(smx_nn nn);
 int smx_nn_build(smx_nn nn, smx_stream s, const float* x, const float* y, const float* z,
@@ -293,6 +294,25 @@ int smx_nn_query_batch(smx_nn nn, smx_stream s, uint32_t nq, const float* qx, co
                        uint8_t skip_mask, int32_t queries_on_device,
                        uint32_t* out_idx, float* out_d2, int32_t* out_count,
                        int32_t outputs_on_device);
+
+/* ---- candidate lists for the mesher, straight from the device-resident map ----
+ * Replaces, for the surfels of one batch (e.g. one changed-surfel delta), the per-surfel octree query at the top of
+ * SurfelMeshing::TriangulateSurfel (APP/surfel_meshing.cc:417-425) with the widest radius that function can ask for,
+ * radius_factor_squared * radius_squared (surfel_meshing.cc:359-360, --max_neighbor_search_range_increase_factor):
+ * a query with a smaller radius and the same K is the prefix of this list with dist^2 <= that radius.
+ *
+ * build_neighbor_index: (re)builds `nn` over the smooth positions of all surfels_size() slots without a host
+ * round trip; merged slots are left out (cuda_surfel_reconstruction.cc:348-358 hands the mesher the same rows and it
+ * removes merged surfels from its octree).  The index is a snapshot: rebuild it after Integrate / Regularize.
+ * neighbor_candidates: for q < n_indices, up to k (<= 64) nearest indexed surfels within the ball of slot
+ * surfel_indices[q], ascending by (dist^2, index); an out-of-range or merged slot gets count 0.  state / skip_mask
+ * as in smx_nn_query_batch, one byte per slot (surfels_size() bytes).  surfel_indices and state are device or host
+ * pointers according to inputs_on_device, the three outputs according to outputs_on_device. */
+int smx_recon_build_neighbor_index(smx_recon r, smx_stream s, smx_nn nn, float cell_size);
+int smx_recon_neighbor_candidates(smx_recon r, smx_stream s, smx_nn nn, const uint32_t* surfel_indices,
+                                  uint32_t n_indices, float radius_factor_squared, int32_t k,
+                                  const uint8_t* state, uint8_t skip_mask, int32_t inputs_on_device,
+                                  uint32_t* out_idx, float* out_d2, int32_t* out_count, int32_t outputs_on_device);
 
 /* ---- benchmark input generator (not part of the reference's interface) ----
  * Renders one frame of the synthetic room stream into device buffers:

@@ -339,6 +339,46 @@ class CUDASurfelReconstruction {
   cudaStream_t last_stream_ = nullptr;
 };
 
+// ---- batched counterpart of CompressedOctree::FindNearestSurfelsWithinRadius (APP/octree.h:470-477) ----
+// A uniform-grid index on the GPU, queried for many positions at once.  result_* are [query_count][max_result_count]
+// host arrays, result_counts [query_count]; order: ascending (distance^2, index).
+class SurfelNeighborIndex {
+ public:
+  SurfelNeighborIndex() { SMX_SHIM_CHECK(smx_nn_create(&handle_)); }
+  SurfelNeighborIndex(const SurfelNeighborIndex&) = delete;
+  ~SurfelNeighborIndex() { SMX_SHIM_CHECK(smx_nn_destroy(handle_)); }
+  // From three host rows (e.g. CUDASurfelBuffersCPU::surfel_{x,y,z}_buffer).
+  void Build(cudaStream_t stream, const float* x, const float* y, const float* z, u32 count, float cell_size) {
+    SMX_SHIM_CHECK(smx_nn_build(handle_, stream, x, y, z, count, cell_size, 0));
+  }
+  // Straight from the device-resident map; merged surfels are left out.  A snapshot: rebuild after Integrate.
+  void Build(cudaStream_t stream, const CUDASurfelReconstruction& reconstruction, float cell_size) {
+    SMX_SHIM_CHECK(smx_recon_build_neighbor_index(reconstruction.handle(), stream, handle_, cell_size));
+  }
+  void FindNearestSurfelsWithinRadius(cudaStream_t stream, u32 query_count, const float* x, const float* y,
+                                      const float* z, const float* radius_squared, int max_result_count,
+                                      const u8* surfel_state, u8 skip_mask, float* result_distances_squared,
+                                      u32* result_indices, int* result_counts) {
+    SMX_SHIM_CHECK(smx_nn_query_batch(handle_, stream, query_count, x, y, z, radius_squared, max_result_count,
+                                      surfel_state, skip_mask, 0, result_indices, result_distances_squared,
+                                      result_counts, 0));
+  }
+  // The candidate lists of SurfelMeshing::TriangulateSurfel (APP/surfel_meshing.cc:417-425) for a batch of surfels:
+  // ball = radius_factor_squared * the surfel's radius_squared around its position, both read on the device.
+  void FindNeighborCandidates(cudaStream_t stream, const CUDASurfelReconstruction& reconstruction,
+                              const u32* surfel_indices, u32 count, float radius_factor_squared, int max_result_count,
+                              const u8* surfel_state, u8 skip_mask, float* result_distances_squared,
+                              u32* result_indices, int* result_counts) {
+    SMX_SHIM_CHECK(smx_recon_neighbor_candidates(reconstruction.handle(), stream, handle_, surfel_indices, count,
+                                                 radius_factor_squared, max_result_count, surfel_state, skip_mask, 0,
+                                                 result_indices, result_distances_squared, result_counts, 0));
+  }
+  smx_nn handle() const { return handle_; }
+
+ private:
+  smx_nn handle_ = nullptr;
+};
+
 // The changed-surfel delta (not in the reference): slot indices, ascending, and the eight attributes TransferAllToCPU
 // moves, for those slots only.  ApplyTo patches a CUDASurfelBuffersCPU that holds an earlier full transfer.
 struct CUDASurfelDeltaCPU {

@@ -546,6 +546,32 @@ class SurfelNeighborIndex:
             C.c_int32(0)))
         return cnt, d2, idx
 
+    def BuildFromReconstruction(self, reconstruction, cell_size, stream=None):
+        """Index over the smooth positions of all slots of the device-resident map, merged slots left out; no host
+        round trip.  A snapshot: rebuild after Integrate / Regularize."""
+        self._keep = None
+        _lib.check(_lib.load().smx_recon_build_neighbor_index(reconstruction._h, _sv(stream), self._h,
+                                                              C.c_float(cell_size)))
+
+    def FindNeighborCandidates(self, reconstruction, surfel_indices, radius_factor_squared, max_result_count,
+                               state=None, skip_mask=0, stream=None):
+        """Candidate lists of SurfelMeshing::TriangulateSurfel (APP/surfel_meshing.cc:417-425) for a batch of slots:
+        ball = radius_factor_squared * radius_squared of the slot around its smooth position, read on the device.
+        Returns (counts [n], dist2 [n,K], indices [n,K])."""
+        sl = np.ascontiguousarray(surfel_indices, np.uint32).reshape(-1)
+        n, k = sl.size, int(max_result_count)
+        idx = np.zeros((n, k), np.uint32)
+        d2 = np.zeros((n, k), np.float32)
+        cnt = np.zeros(n, np.int32)
+        st = np.ascontiguousarray(state, np.uint8) if state is not None else None
+        _lib.check(_lib.load().smx_recon_neighbor_candidates(
+            reconstruction._h, _sv(stream), self._h, sl.ctypes.data_as(C.c_void_p), C.c_uint32(n),
+            C.c_float(radius_factor_squared), C.c_int32(k),
+            st.ctypes.data_as(C.c_void_p) if st is not None else C.c_void_p(0), C.c_uint8(skip_mask), C.c_int32(0),
+            idx.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p),
+            C.c_int32(0)))
+        return cnt, d2, idx
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.load().smx_nn_destroy(self._h)

@@ -34,11 +34,19 @@ inline float order_unkey(uint32_t k) {
   return f;
 }
 
+// Points with a non-finite coordinate are left out of the index (no finite ball contains them); the
+// reconstruction parks merged surfel slots that way (smx_recon_build_neighbor_index).
+__device__ __forceinline__ bool indexable(float x, float y, float z) {
+  return fabsf(x) <= 3.0e38f && fabsf(y) <= 3.0e38f && fabsf(z) <= 3.0e38f;
+}
+constexpr uint32_t kNoCell = 0xFFFFFFFFu;
+
 __global__ void __launch_bounds__(kBlock)
 k_bbox(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, uint32_t n,
        uint32_t* __restrict__ bb /* min xyz, max xyz as order keys */) {
   uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0, 0, 0};
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    if (!indexable(x[i], y[i], z[i])) continue;
     const uint32_t k[3] = {order_key(x[i]), order_key(y[i]), order_key(z[i])};
 #pragma unroll
     for (int a = 0; a < 3; ++a) { mn[a] = min(mn[a], k[a]); mx[a] = max(mx[a], k[a]); }
@@ -72,6 +80,7 @@ __global__ void __launch_bounds__(kBlock)
 k_count_cells(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, uint32_t n,
               Grid g, uint32_t* __restrict__ cell_of, uint32_t* __restrict__ counts) {
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    if (!indexable(x[i], y[i], z[i])) { cell_of[i] = kNoCell; continue; }
     const int cx = cell_coord(x[i], g.min[0], g.cell, g.dim[0]);
     const int cy = cell_coord(y[i], g.min[1], g.cell, g.dim[1]);
     const int cz = cell_coord(z[i], g.min[2], g.cell, g.dim[2]);
@@ -122,6 +131,7 @@ k_scatter(const float* __restrict__ x, const float* __restrict__ y, const float*
           float4* __restrict__ sorted) {
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const uint32_t c = cell_of[i];
+    if (c == kNoCell) continue;
     const uint32_t pos = start[c] + atomicAdd(&fill[c], 1u);
     sorted[pos] = make_float4(x[i], y[i], z[i], __uint_as_float(i));
   }
@@ -284,6 +294,10 @@ int smx_nn_build(smx_nn nn, smx_stream s, const float* x, const float* y, const 
   uint32_t bb[6];
   SMX_HIP(hipMemcpyAsync(bb, nn->bbox, sizeof(bb), hipMemcpyDeviceToHost, st));
   SMX_HIP(hipStreamSynchronize(st));
+  if (bb[0] > bb[3]) {  // no indexable point
+    nn_free(nn);
+    return SMX_OK;
+  }
   float mn[3], mx[3];
   for (int a = 0; a < 3; ++a) { mn[a] = order_unkey(bb[a]); mx[a] = order_unkey(bb[3 + a]); }
   // grow the cell until the dense grid fits (queries stay exact: they visit every overlapped cell)

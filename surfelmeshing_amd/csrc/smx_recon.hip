@@ -26,6 +26,8 @@
 // no kernel launch needs a host round trip.
 #include <math.h>
 
+#include <algorithm>
+
 #include "smx_common.hpp"
 
 using namespace smx;
@@ -1538,6 +1540,36 @@ k_export(Surfels S, float* __restrict__ pos, uint8_t* __restrict__ col, const De
   }
 }
 
+// Candidate lists for the mesher: the rows the neighbour index is built from (smooth position,
+// NaN for merged slots so that the index leaves them out) and the per-query (position, radius^2) of a list of slots.
+__global__ void __launch_bounds__(kBlock)
+k_index_rows(Surfels S, float* __restrict__ out, uint32_t count) {
+  const float nanv = __builtin_nanf("");
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
+    const float4 s = *S.group(kGroupS, i);
+    const bool merged = S.f(kRadiusSq, i) < 0;
+    out[i] = merged ? nanv : s.x;
+    out[(size_t)count + i] = merged ? nanv : s.y;
+    out[(size_t)2 * count + i] = merged ? nanv : s.z;
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+k_candidate_queries(Surfels S, const uint32_t* __restrict__ slots, uint32_t nq, const DevState* st,
+                    float radius_factor_sq, float* __restrict__ q /* [4][nq]: x, y, z, r^2 */) {
+  const uint32_t N = st->surfel_count;
+  for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < nq; k += gridDim.x * kBlock) {
+    const uint32_t i = slots[k];
+    float4 s = make_float4(0, 0, 0, 0);
+    float r2 = -1.0f;  // out of range or merged: an empty ball
+    if (i < N) {
+      s = *S.group(kGroupS, i);
+      const float rs = S.f(kRadiusSq, i);
+      if (!(rs < 0)) r2 = radius_factor_sq * rs;  // surfel_meshing.cc:359-360
+    }
+    q[k] = s.x; q[(size_t)nq + k] = s.y; q[(size_t)2 * nq + k] = s.z; q[(size_t)3 * nq + k] = r2;
+  }
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_decode_conflicting(const uint32_t* __restrict__ key, uint32_t* __restrict__ out, int P) {
   const int k = blockIdx.x * kBlock + threadIdx.x;
@@ -2130,6 +2162,68 @@ int smx_recon_export_vertices(smx_recon r, smx_stream s, const smx_buffer_desc* 
                      (float*)position_buffer->address, (uint8_t*)color_buffer->address, r->st);
   SMX_LAUNCH_CHECK();
   return SMX_OK;
+}
+
+int smx_recon_build_neighbor_index(smx_recon r, smx_stream s, smx_nn nn, float cell_size) {
+  SMX_CHECK_ARG(r != nullptr && nn != nullptr && cell_size > 0);
+  hipStream_t st = (hipStream_t)s;
+  { const int rcj = join_regularizer(r, st); if (rcj != SMX_OK) return rcj; }
+  uint32_t n = 0;
+  SMX_HIP(hipMemcpyAsync(&n, &r->st->surfel_count, sizeof(n), hipMemcpyDeviceToHost, st));
+  SMX_HIP(hipStreamSynchronize(st));
+  if (n == 0) return smx_nn_build(nn, s, nullptr, nullptr, nullptr, 0, cell_size, 1);
+  int rc = ensure_staging(r, (size_t)3 * n);
+  if (rc != SMX_OK) return rc;
+  hipLaunchKernelGGL(k_index_rows, dim3(r->grid_surfels), dim3(kBlock), 0, st, r->S, r->staging, n);
+  SMX_LAUNCH_CHECK();
+  return smx_nn_build(nn, s, r->staging, r->staging + n, r->staging + (size_t)2 * n, n, cell_size, 1);
+}
+
+int smx_recon_neighbor_candidates(smx_recon r, smx_stream s, smx_nn nn, const uint32_t* surfel_indices,
+                                  uint32_t n_indices, float radius_factor_squared, int32_t k,
+                                  const uint8_t* state, uint8_t skip_mask, int32_t inputs_on_device,
+                                  uint32_t* out_idx, float* out_d2, int32_t* out_count, int32_t outputs_on_device) {
+  SMX_CHECK_ARG(r != nullptr && nn != nullptr && radius_factor_squared >= 0 && k >= 1 && k <= 64);
+  SMX_CHECK_ARG(n_indices == 0 || (surfel_indices && out_idx && out_d2 && out_count));
+  if (n_indices == 0) return SMX_OK;
+  hipStream_t st = (hipStream_t)s;
+  { const int rcj = join_regularizer(r, st); if (rcj != SMX_OK) return rcj; }
+  uint32_t* dslots = nullptr;
+  uint8_t* dstate = nullptr;
+  float* q = nullptr;
+  int rc = SMX_OK;
+  hipError_t e = hipSuccess;
+  auto fail = [&](hipError_t err) { set_error("neighbor candidates failed: %s", hipGetErrorString(err)); rc = SMX_ERR_HIP; };
+  if ((e = hipMalloc(reinterpret_cast<void**>(&q), (size_t)4 * n_indices * sizeof(float))) != hipSuccess) fail(e);
+  if (rc == SMX_OK && !inputs_on_device) {
+    if ((e = hipMalloc(reinterpret_cast<void**>(&dslots), (size_t)n_indices * 4)) != hipSuccess) fail(e);
+    else if ((e = hipMemcpyAsync(dslots, surfel_indices, (size_t)n_indices * 4, hipMemcpyHostToDevice, st)) != hipSuccess) fail(e);
+    if (rc == SMX_OK && state) {
+      uint32_t n = 0;
+      if ((e = hipMemcpyAsync(&n, &r->st->surfel_count, sizeof(n), hipMemcpyDeviceToHost, st)) != hipSuccess ||
+          (e = hipStreamSynchronize(st)) != hipSuccess) fail(e);
+      else if (n > 0) {
+        if ((e = hipMalloc(reinterpret_cast<void**>(&dstate), n)) != hipSuccess) fail(e);
+        else if ((e = hipMemcpyAsync(dstate, state, n, hipMemcpyHostToDevice, st)) != hipSuccess) fail(e);
+      }
+    }
+  }
+  if (rc == SMX_OK) {
+    const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n_indices + kBlock - 1) / kBlock, 4096);
+    hipLaunchKernelGGL(k_candidate_queries, dim3(blocks), dim3(kBlock), 0, st, r->S,
+                       inputs_on_device ? surfel_indices : dslots, n_indices, r->st, radius_factor_squared, q);
+    if ((e = hipGetLastError()) != hipSuccess) fail(e);
+  }
+  if (rc == SMX_OK)
+    rc = smx_nn_query_batch(nn, s, n_indices, q, q + n_indices, q + (size_t)2 * n_indices, q + (size_t)3 * n_indices, k,
+                            inputs_on_device ? state : dstate, skip_mask, 1, out_idx, out_d2, out_count,
+                            outputs_on_device);
+  // the temporaries are read by work queued on `st`
+  if ((e = hipStreamSynchronize(st)) != hipSuccess && rc == SMX_OK) fail(e);
+  if (q) (void)hipFree(q);
+  if (dslots) (void)hipFree(dslots);
+  if (dstate) (void)hipFree(dstate);
+  return rc;
 }
 
 int smx_recon_get_timings(smx_recon r, float out_ms[7]) {
