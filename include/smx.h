@@ -314,6 +314,16 @@ int smx_recon_neighbor_candidates(smx_recon r, smx_stream s, smx_nn nn, const ui
                                   const uint8_t* state, uint8_t skip_mask, int32_t inputs_on_device,
                                   uint32_t* out_idx, float* out_d2, int32_t* out_count, int32_t outputs_on_device);
 
+/* The per-triangle tests of SurfelMeshing::CheckRemeshing (APP/surfel_meshing.cc:590-650) for a batch of triangles
+ * (three slot indices each, [n_triangles][3]) against the device-resident map; the mesher keeps the sequential part
+ * (RemeshTrianglesAt and the visiting order).  long_edge_total_factor_squared as in surfel_meshing.cc:171-173.
+ * flags[t]: bit 0 = long-edge condition (:605-617; independent of the pivot vertex); bits 1..3 = the triangle normal
+ * formed from pivot index(0) / index(1) / index(2) (right = next, left = previous vertex, :576-589) is inconsistent
+ * with all three surfel normals (:632-635); bit 4 = a vertex is merged (:559-570) or out of range (then no other bit
+ * is set).  triangles and flags are device pointers if on_device, host pointers (synchronous call) otherwise. */
+int smx_recon_check_triangles(smx_recon r, smx_stream s, const uint32_t* triangles, uint32_t n_triangles,
+                              float long_edge_total_factor_squared, uint8_t* flags, int32_t on_device);
+
 /* ---- benchmark input generator (not part of the reference's interface) ----
  * Renders one frame of the synthetic room stream into device buffers:
  * depth u16 = round(depth_scaling * z) with sigma = noise_sigma * z^2 noise and coherent 8x8

@@ -316,6 +316,13 @@ class CUDASurfelReconstruction {
   }
   // Fills `delta` (whose vectors are resized to the capacity first) with the slots changed since the previous call.
   inline void TransferChangedToCPU(cudaStream_t stream, u32 frame_index, struct CUDASurfelDeltaCPU* delta);
+  // Not in the reference: the per-triangle tests of SurfelMeshing::CheckRemeshing
+  // (APP/surfel_meshing.cc:590-650) for `count` triangles (3 surfel indices each) against the device map; flag bits in smx.h.
+  void CheckTrianglesForRemeshing(cudaStream_t stream, const u32* triangle_indices, u32 count,
+                                  float long_edge_total_factor_squared, u8* flags) {
+    SMX_SHIM_CHECK(smx_recon_check_triangles(handle_, stream, triangle_indices, count, long_edge_total_factor_squared,
+                                             flags, 0));
+  }
   void UpdateVisualizationBuffers(cudaStream_t, u32, u32, u32, int, bool, bool, bool, bool) {}  // viewer only
   void ExportVertices(cudaStream_t stream, CUDABuffer<float>* position_buffer, CUDABuffer<u8>* color_buffer) {
     SMX_SHIM_CHECK(smx_recon_export_vertices(handle_, stream, position_buffer->ToCUDA().desc(), color_buffer->ToCUDA().desc()));

@@ -327,3 +327,13 @@ def nn_grid_batch(px, py, pz, cell_size, qx, qy, qz, qr2, k):
     lib().orc_nn_grid_batch(_p(px), _p(py), _p(pz), C.c_uint32(px.size), C.c_float(cell_size),
                             _p(qx), _p(qy), _p(qz), _p(qr2), C.c_uint32(nq), C.c_int(k), _p(d2), _p(idx), _p(cnt))
     return cnt, d2, idx
+
+
+def check_triangles(x, y, z, radius_squared, nx, ny, nz, triangles, long_edge_total_factor_squared):
+    """CheckRemeshing's per-triangle tests over host rows; see smx_oracle.h for the flag bits."""
+    rows = [_c(a, np.float32) for a in (x, y, z, radius_squared, nx, ny, nz)]
+    tri = _c(triangles, np.uint32).reshape(-1, 3)
+    flags = np.zeros(tri.shape[0], np.uint8)
+    lib().orc_check_triangles(*[_p(a) for a in rows], C.c_uint32(rows[0].size), _p(tri), C.c_uint32(tri.shape[0]),
+                              C.c_float(long_edge_total_factor_squared), _p(flags))
+    return flags

@@ -199,6 +199,17 @@ void orc_nn_grid_batch(const float* px, const float* py, const float* pz, uint32
                        const float* qx, const float* qy, const float* qz, const float* qr2,
                        uint32_t nq, int k, float* out_d2, uint32_t* out_idx, int32_t* out_count);
 
+/* ---- the per-triangle remesh tests of SurfelMeshing::CheckRemeshing (APP/surfel_meshing.cc:590-650) ----
+ * Over the host mirror of the map (x, y, z, radius_squared, normal rows, n slots) and T triangles (three slot indices
+ * each).  flags[t]: bit 0 = the long-edge condition (:605-617, independent of the pivot vertex); bits 1..3 = the
+ * triangle normal formed from pivot index(0) / index(1) / index(2) (right = next, left = previous vertex, :576-589)
+ * is inconsistent with all three surfel normals (:632-635); bit 4 = a vertex is merged (radius_squared < 0, :561-570)
+ * or its index is >= n (then no other bit is set). */
+void orc_check_triangles(const float* x, const float* y, const float* z, const float* radius_squared,
+                         const float* nx, const float* ny, const float* nz, uint32_t n,
+                         const uint32_t* triangles, uint32_t n_triangles, float long_edge_total_factor_squared,
+                         uint8_t* flags);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,3 +114,46 @@ void orc_nn_grid_batch(const float* px, const float* py, const float* pz, uint32
   }
   free(start); free(cell_of); free(order); free(fill);
 }
+
+/* ---- CheckRemeshing's per-triangle tests (APP/surfel_meshing.cc:590-650) ---- */
+static float sqn3(const float a[3]) { return a[0] * a[0] + a[1] * a[1] + a[2] * a[2]; }
+static float dot3(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+void orc_check_triangles(const float* x, const float* y, const float* z, const float* radius_squared,
+                         const float* nx, const float* ny, const float* nz, uint32_t n,
+                         const uint32_t* triangles, uint32_t n_triangles, float long_edge_total_factor_squared,
+                         uint8_t* flags) {
+  for (uint32_t t = 0; t < n_triangles; ++t) {
+    const uint32_t* v = triangles + 3 * (size_t)t;
+    if (v[0] >= n || v[1] >= n || v[2] >= n) { flags[t] = 16; continue; }
+    float p[3][3], nrm[3][3], maxsq[3];
+    uint8_t f = 0;
+    for (int k = 0; k < 3; ++k) {
+      p[k][0] = x[v[k]]; p[k][1] = y[v[k]]; p[k][2] = z[v[k]];
+      nrm[k][0] = nx[v[k]]; nrm[k][1] = ny[v[k]]; nrm[k][2] = nz[v[k]];
+      maxsq[k] = long_edge_total_factor_squared * radius_squared[v[k]];   /* :556-557, 593-596 */
+      if (radius_squared[v[k]] < 0) f |= 16;                               /* :559 */
+    }
+    /* edge e[k] joins vertex k and vertex k+1 (a difference and its negation have the same squared norm) */
+    float e[3];
+    for (int k = 0; k < 3; ++k) {
+      const int a = k, b = (k + 1) % 3;
+      const float d[3] = {p[b][0] - p[a][0], p[b][1] - p[a][1], p[b][2] - p[a][2]};
+      e[k] = sqn3(d);
+    }
+    /* :605-617 -- an edge longer than both of its ends allow, and the opposite vertex has an over-long edge too */
+    for (int k = 0; k < 3; ++k) {
+      const int a = k, b = (k + 1) % 3, c = (k + 2) % 3;     /* edge a-b = e[k]; c's edges: e[b] (b-c), e[c] (c-a) */
+      if (e[k] > maxsq[a] && e[k] > maxsq[b] && (e[b] > maxsq[c] || e[c] > maxsq[c])) f |= 1;
+    }
+    /* :632-635 with pivot k: right = next vertex, left = previous (:576-589) */
+    for (int k = 0; k < 3; ++k) {
+      const int r = (k + 1) % 3, l = (k + 2) % 3;
+      const float sr[3] = {p[r][0] - p[k][0], p[r][1] - p[k][1], p[r][2] - p[k][2]};
+      const float sl[3] = {p[l][0] - p[k][0], p[l][1] - p[k][1], p[l][2] - p[k][2]};
+      const float c[3] = {sr[1] * sl[2] - sr[2] * sl[1], sr[2] * sl[0] - sr[0] * sl[2], sr[0] * sl[1] - sr[1] * sl[0]};
+      if (dot3(c, nrm[k]) <= 0 && dot3(c, nrm[r]) <= 0 && dot3(c, nrm[l]) <= 0) f |= (uint8_t)(2 << k);
+    }
+    flags[t] = f;
+  }
+}

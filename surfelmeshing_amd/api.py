@@ -408,6 +408,16 @@ class CUDASurfelReconstruction:
             _lib.check(rc)
         return d
 
+    def CheckTrianglesForRemeshing(self, stream, triangles, long_edge_total_factor_squared):
+        """The per-triangle tests of SurfelMeshing::CheckRemeshing (APP/surfel_meshing.cc:590-650) for triangles
+        [T,3] of slot indices against the device-resident map.  Returns flags [T] (bits: see smx.h)."""
+        tri = np.ascontiguousarray(triangles, np.uint32).reshape(-1, 3)
+        flags = np.zeros(tri.shape[0], np.uint8)
+        _lib.check(_lib.load().smx_recon_check_triangles(
+            self._h, _sv(stream), tri.ctypes.data_as(C.c_void_p), C.c_uint32(tri.shape[0]),
+            C.c_float(long_edge_total_factor_squared), flags.ctypes.data_as(C.c_void_p), C.c_int32(0)))
+        return flags
+
     def UpdateVisualizationBuffers(self, *args, **kwargs):
         """Viewer-only in the reference (OpenGL interop); nothing to do without a render window."""
 

@@ -1570,6 +1570,54 @@ k_candidate_queries(Surfels S, const uint32_t* __restrict__ slots, uint32_t nq, 
   }
 }
 
+// The per-triangle tests of SurfelMeshing::CheckRemeshing (APP/surfel_meshing.cc:590-650) over the device-resident
+// map: one thread per triangle, three (S, N) record gathers.  Flag bits: see smx.h.
+__global__ void __launch_bounds__(kBlock)
+k_check_triangles(Surfels S, const uint32_t* __restrict__ tri, uint32_t n_tri, const DevState* st,
+                  float factor_sq, uint8_t* __restrict__ flags) {
+  const uint32_t N = st->surfel_count;
+  for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < n_tri; t += gridDim.x * kBlock) {
+    const uint32_t v[3] = {tri[3 * (size_t)t], tri[3 * (size_t)t + 1], tri[3 * (size_t)t + 2]};
+    if (v[0] >= N || v[1] >= N || v[2] >= N) { flags[t] = 16; continue; }
+    Vec3 p[3], nrm[3];
+    float maxsq[3];
+    uint32_t f = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float4 s = *S.group(kGroupS, v[k]);
+      const float4 n = *S.group(kGroupN, v[k]);
+      p[k] = Vec3{s.x, s.y, s.z};
+      nrm[k] = Vec3{n.x, n.y, n.z};
+      maxsq[k] = factor_sq * n.w;   // :556-557, 593-596
+      if (n.w < 0) f |= 16u;        // :559
+    }
+    float e[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int b = (k + 1) % 3;
+      const float dx = p[b].x - p[k].x, dy = p[b].y - p[k].y, dz = p[b].z - p[k].z;
+      e[k] = dx * dx + dy * dy + dz * dz;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // :605-617
+      const int b = (k + 1) % 3, c = (k + 2) % 3;
+      if (e[k] > maxsq[k] && e[k] > maxsq[b] && (e[b] > maxsq[c] || e[c] > maxsq[c])) f |= 1u;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // :632-635, pivot k
+      const int r = (k + 1) % 3, l = (k + 2) % 3;
+      const float rx = p[r].x - p[k].x, ry = p[r].y - p[k].y, rz = p[r].z - p[k].z;
+      const float lx = p[l].x - p[k].x, ly = p[l].y - p[k].y, lz = p[l].z - p[k].z;
+      const float cx = ry * lz - rz * ly, cy = rz * lx - rx * lz, cz = rx * ly - ry * lx;
+      const float d0 = cx * nrm[k].x + cy * nrm[k].y + cz * nrm[k].z;
+      const float d1 = cx * nrm[r].x + cy * nrm[r].y + cz * nrm[r].z;
+      const float d2 = cx * nrm[l].x + cy * nrm[l].y + cz * nrm[l].z;
+      if (d0 <= 0 && d1 <= 0 && d2 <= 0) f |= (2u << k);
+    }
+    flags[t] = (uint8_t)f;
+  }
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_decode_conflicting(const uint32_t* __restrict__ key, uint32_t* __restrict__ out, int P) {
   const int k = blockIdx.x * kBlock + threadIdx.x;
@@ -2223,6 +2271,37 @@ int smx_recon_neighbor_candidates(smx_recon r, smx_stream s, smx_nn nn, const ui
   if (q) (void)hipFree(q);
   if (dslots) (void)hipFree(dslots);
   if (dstate) (void)hipFree(dstate);
+  return rc;
+}
+
+int smx_recon_check_triangles(smx_recon r, smx_stream s, const uint32_t* triangles, uint32_t n_triangles,
+                              float long_edge_total_factor_squared, uint8_t* flags, int32_t on_device) {
+  SMX_CHECK_ARG(r != nullptr && (n_triangles == 0 || (triangles && flags)));
+  if (n_triangles == 0) return SMX_OK;
+  hipStream_t st = (hipStream_t)s;
+  { const int rcj = join_regularizer(r, st); if (rcj != SMX_OK) return rcj; }
+  uint32_t* dtri = nullptr;
+  uint8_t* dflags = nullptr;
+  int rc = SMX_OK;
+  hipError_t e = hipSuccess;
+  auto fail = [&](hipError_t err) { set_error("check triangles failed: %s", hipGetErrorString(err)); rc = SMX_ERR_HIP; };
+  if (!on_device) {
+    if ((e = hipMalloc(reinterpret_cast<void**>(&dtri), (size_t)n_triangles * 12)) != hipSuccess) fail(e);
+    else if ((e = hipMalloc(reinterpret_cast<void**>(&dflags), n_triangles)) != hipSuccess) fail(e);
+    else if ((e = hipMemcpyAsync(dtri, triangles, (size_t)n_triangles * 12, hipMemcpyHostToDevice, st)) != hipSuccess) fail(e);
+  }
+  if (rc == SMX_OK) {
+    const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n_triangles + kBlock - 1) / kBlock, 8192);
+    hipLaunchKernelGGL(k_check_triangles, dim3(blocks), dim3(kBlock), 0, st, r->S, on_device ? triangles : dtri,
+                       n_triangles, r->st, long_edge_total_factor_squared, on_device ? flags : dflags);
+    if ((e = hipGetLastError()) != hipSuccess) fail(e);
+  }
+  if (!on_device) {
+    if (rc == SMX_OK && (e = hipMemcpyAsync(flags, dflags, n_triangles, hipMemcpyDeviceToHost, st)) != hipSuccess) fail(e);
+    if ((e = hipStreamSynchronize(st)) != hipSuccess && rc == SMX_OK) fail(e);
+    if (dtri) (void)hipFree(dtri);
+    if (dflags) (void)hipFree(dflags);
+  }
   return rc;
 }
 

@@ -164,3 +164,39 @@ def test_candidate_lists_from_the_device_map(smx):
     assert cnt.size == 0
     with pytest.raises(smx.SmxError):
         nn.FindNeighborCandidates(rec, slots, 4.0, 65)
+
+
+def test_check_triangles_against_oracle(smx):
+    """CheckRemeshing's per-triangle tests (APP/surfel_meshing.cc:590-650) on the device-resident map vs
+    the oracle's restatement over the oracle's own map after the same frames; flags bit-equal.  Triangles: each
+    surfel with two of its regulariser neighbours (small, mostly consistent), nearest-neighbour triples in both
+    windings, random triples (long edges), merged and out-of-range vertices."""
+    from common import run_both, small_stream
+    from test_gpu_parity import _pipes
+    s = small_stream(obstacle_until=8, yaw_deg_per_frame=2.0)
+    po, pg = _pipes(smx, s, 60000)
+    run_both(po, pg, s, list(range(4, 18)), None)
+    rec = pg.reconstruction
+    t = po.recon.transfer_all()
+    n = t["surfel_count"]
+    rows = po.recon.surfels()
+    nb = rows[19:23, :n].view(np.uint32)
+    ok = (nb[0] < n) & (nb[1] < n)
+    i = np.flatnonzero(ok).astype(np.uint32)
+    tri_nb = np.stack([i, nb[0, i], nb[1, i]], 1)
+    rng = np.random.default_rng(3)
+    tri_rand = rng.integers(0, n, (3000, 3)).astype(np.uint32)
+    merged = np.flatnonzero(t["radius_squared"] < 0).astype(np.uint32)
+    tri_merged = np.stack([merged, np.roll(merged, 1), rng.integers(0, n, merged.size).astype(np.uint32)], 1)
+    tri_bad = np.array([[0, 1, n], [n + 7, 0, 1], [2, 0xFFFFFFFF, 3]], np.uint32)
+    tris = np.concatenate([tri_nb, tri_nb[:, [0, 2, 1]], tri_rand, tri_merged, tri_bad]).astype(np.uint32)
+    args = [t[a] for a in ("x", "y", "z", "radius_squared", "normal_x", "normal_y", "normal_z")]
+    seen = set()
+    for factor_sq in (16.0, 1.0, 400.0):
+        want = orc.check_triangles(*args, tris, factor_sq)
+        got = rec.CheckTrianglesForRemeshing(None, tris, factor_sq)
+        assert np.array_equal(got, want), (factor_sq, np.flatnonzero(got != want)[:10])
+        seen |= set(np.unique(want).tolist())
+    # the cases all occur: clean, long edge, each winding bit, merged, out of range
+    assert {0, 1, 16}.issubset(seen) and any(f & 14 for f in seen) and any((f & 16) and f != 16 for f in seen)
+    assert rec.CheckTrianglesForRemeshing(None, np.zeros((0, 3), np.uint32), 16.0).size == 0

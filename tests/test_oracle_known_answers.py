@@ -454,3 +454,37 @@ def test_downscale_using_median_while_excluding_known_answers(orc):
                     lo, hi = vals[n // 2 - 1], vals[n // 2]
                     ref[y, x] = lo if abs(avg - np.float32(lo)) < abs(avg - np.float32(hi)) else hi
         assert np.array_equal(orc.downscale_using_median_while_excluding(m, ow, oh, 0), ref)
+
+
+def test_check_triangles_known_answers(orc):
+    """CheckRemeshing's per-triangle tests (APP/surfel_meshing.cc:590-650) on hand-built triangles."""
+    # slots 0..2: a small counter-clockwise triangle in z = 0; 3..5: the same, 10 m further; 6: merged; 7: far point
+    x = np.array([0, .01, 0, 10, 10.01, 10, 0.005, 1.0], np.float32)
+    y = np.array([0, 0, .01, 0, 0, .01, 0.005, 0.5], np.float32)
+    z = np.zeros(8, np.float32)
+    r2 = np.full(8, 1e-4, np.float32)
+    r2[6] = -1
+    up = (np.zeros(8, np.float32), np.zeros(8, np.float32), np.ones(8, np.float32))
+    down = (up[0], up[1], -up[2])
+    tris = np.array([[0, 1, 2],      # fine: short edges, normal +z agrees
+                     [0, 2, 1],      # clockwise: triangle normal -z against all three surfel normals, any pivot
+                     [0, 1, 7],      # two 1 m edges: 0-7 and 1-7 are too long for everybody
+                     [0, 1, 6],      # a merged vertex
+                     [0, 1, 8],      # out of range
+                     [3, 4, 5]], np.uint32)
+    f = orc.check_triangles(x, y, z, r2, *up, tris, 16.0)     # allowed edge^2 = 16 * 1e-4 = (4 cm)^2
+    assert list(f[:3]) == [0, 14, 1] and f[3] & 16 and f[4] == 16 and f[5] == 0
+    assert list(orc.check_triangles(x, y, z, r2, *down, tris, 16.0)[:2]) == [14, 0]
+    # one long edge alone is not enough: 0-7 exceeds what 0 and 7 allow, but vertex 1's own edges must be over-long
+    # for vertex 1 as well (:607-608) -- give vertex 1 a big radius and the condition fails
+    big = r2.copy()
+    big[1] = 1.0
+    assert orc.check_triangles(x, y, z, big, *up, tris[2:3], 16.0)[0] == 0
+    # ... unless another edge qualifies: none does (0-1 is short, 1-7 is allowed by vertex 1)
+    # a single agreeing normal keeps the triangle (:632-634 needs all three to disagree)
+    mixed = (up[0], up[1], np.array([-1, -1, 1, 1, 1, 1, 1, 1], np.float32))
+    assert orc.check_triangles(x, y, z, r2, *mixed, tris[:1], 16.0)[0] == 0
+    assert orc.check_triangles(x, y, z, r2, *mixed, tris[1:2], 16.0)[0] == 0   # clockwise: vertices 0, 1 (now -z) agree
+    # a degenerate triangle (zero-area): dot products are exactly 0 -> "<= 0" holds for every pivot
+    assert orc.check_triangles(x, y, z, r2, *up, np.array([[0, 0, 1]], np.uint32), 16.0)[0] == 14
+    assert orc.check_triangles(x, y, z, r2, *up, np.zeros((0, 3), np.uint32), 16.0).size == 0
