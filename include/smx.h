@@ -295,6 +295,17 @@ int smx_nn_query_batch(smx_nn nn, smx_stream s, uint32_t nq, const float* qx, co
                        uint32_t* out_idx, float* out_d2, int32_t* out_count,
                        int32_t outputs_on_device);
 
+/* ---- the loop-closure hook the reference describes but does not ship (README.md:152-176; its call site is the
+ * "### Loop closures ###" block of main.cc:1194-1200, between preprocessing and Integrate) ----
+ * Every live surfel created at frame c < n_frames moves by the rigid correction frame_T[c] (row-major 3x4,
+ * new_global_T_old_global; identity rows for frames that stay): offset = T * (X,Y,Z) - (X,Y,Z) is added to the raw
+ * and to the smooth position (README.md:160-165), the normal becomes R * normal (:166-168); where reactivate[c] != 0
+ * (array may be NULL) LastUpdateStamp is set to frame_index, which makes the surfel active for integration again
+ * (:172-174).  Merged slots and slots created at c >= n_frames are untouched.  frame_T / reactivate are device
+ * pointers if inputs_on_device, host pointers (synchronous call) otherwise. */
+int smx_recon_deform_by_creation_frame(smx_recon r, smx_stream s, const float* frame_T, uint32_t n_frames,
+                                       const uint8_t* reactivate, uint32_t frame_index, int32_t inputs_on_device);
+
 /* ---- candidate lists for the mesher, straight from the device-resident map ----
  * Replaces, for the surfels of one batch (e.g. one changed-surfel delta), the per-surfel octree query at the top of
  * SurfelMeshing::TriangulateSurfel (APP/surfel_meshing.cc:417-425) with the widest radius that function can ask for,

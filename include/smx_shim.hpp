@@ -316,6 +316,12 @@ class CUDASurfelReconstruction {
   }
   // Fills `delta` (whose vectors are resized to the capacity first) with the slots changed since the previous call.
   inline void TransferChangedToCPU(cudaStream_t stream, u32 frame_index, struct CUDASurfelDeltaCPU* delta);
+  // The loop-closure hook the reference describes but does not ship (README.md:152-176, call site main.cc:1194-1200):
+  // surfels created at frame c move by the rigid correction frame_T[c] (3x4 row-major each); see smx.h.
+  void DeformByCreationFrame(cudaStream_t stream, const float* frame_T, u32 frame_count, const u8* reactivate,
+                             u32 frame_index) {
+    SMX_SHIM_CHECK(smx_recon_deform_by_creation_frame(handle_, stream, frame_T, frame_count, reactivate, frame_index, 0));
+  }
   // Not in the reference: the per-triangle tests of SurfelMeshing::CheckRemeshing
   // (APP/surfel_meshing.cc:590-650) for `count` triangles (3 surfel indices each) against the device map; flag bits in smx.h.
   void CheckTrianglesForRemeshing(cudaStream_t stream, const u32* triangle_indices, u32 count,

@@ -273,6 +273,13 @@ class Recon:
         lib().orc_recon_regularize(self._r, C.c_uint32(frame_index), C.c_float(regularizer_weight),
                                    C.c_float(radius_factor), C.c_int(window))
 
+    def deform_by_creation_frame(self, frame_T, reactivate=None, frame_index=0):
+        T = _c(np.asarray(frame_T, np.float32).reshape(-1, 12), np.float32)
+        ra = _c(reactivate, np.uint8) if reactivate is not None else None
+        assert ra is None or ra.size == T.shape[0]
+        lib().orc_recon_deform_by_creation_frame(self._r, _p(T), C.c_uint32(T.shape[0]),
+                                                 _p(ra) if ra is not None else None, C.c_uint32(frame_index))
+
     def transfer_all(self):
         n = self.surfels_size
         f = [np.empty(n, np.float32) for _ in range(7)]

@@ -185,6 +185,13 @@ void orc_recon_transfer_all(const orc_recon* r, float* x, float* y, float* z, fl
 /* ExportVerticesCUDAKernel, APP/cuda_surfel_reconstruction_kernels.cu:2412-2433 */
 void orc_recon_export_vertices(const orc_recon* r, float* positions /* 3N */, uint8_t* colors /* 3N */);
 
+/* The loop-closure hook the reference describes but does not ship (README.md:152-176, main.cc:1194-1200): every live
+ * surfel created at frame c < n_frames moves by the rigid correction frame_T[c] (row-major 3x4): offset =
+ * T * raw - raw added to the raw and the smooth position, normal = R * normal; reactivate[c] != 0 (array may be NULL)
+ * re-stamps LastUpdateStamp = frame_index. */
+void orc_recon_deform_by_creation_frame(orc_recon* r, const float* frame_T, uint32_t n_frames,
+                                        const uint8_t* reactivate_or_null, uint32_t frame_index);
+
 /* ---- radius-neighbor search (brute force; APP/test/test_octree.cc:116-143),
  * results ordered by (dist^2, index); optional state filter: a point whose
  * state byte has any bit of skip_mask set is skipped (octree.cc:330-335). */

@@ -857,3 +857,37 @@ void orc_recon_export_vertices(const orc_recon* r, float* positions, uint8_t* co
     colors[3 * (size_t)i + 2] = (uint8_t)((c >> 16) & 255u);
   }
 }
+
+/* ---- the loop-closure hook the reference describes but does not ship (README.md:152-176, main.cc:1194-1200) ----
+ * Every live surfel created at frame c < n_frames moves by the rigid correction frame_T[c] (row-major 3x4,
+ * new_global_T_old_global): offset = T * (X,Y,Z) - (X,Y,Z) is added to the raw and to the smooth position
+ * (README.md:160-165), the normal becomes R * normal (:166-168); where reactivate[c] != 0 the surfel's
+ * LastUpdateStamp is set to frame_index so that it takes part in integration again (README.md:172-174). */
+void orc_recon_deform_by_creation_frame(orc_recon* r, const float* frame_T, uint32_t n_frames,
+                                        const uint8_t* reactivate, uint32_t frame_index) {
+  for (uint32_t i = 0; i < r->surfel_count; ++i) {
+    if (SURF(r, ORC_RADIUS_SQ, i) < 0) continue;                 /* merged zombie */
+    const uint32_t c = SURF_U32(r, ORC_CREATION_STAMP, i);
+    if (c >= n_frames) continue;
+    const float* T = frame_T + 12 * (size_t)c;
+    const float p[3] = {SURF(r, ORC_X, i), SURF(r, ORC_Y, i), SURF(r, ORC_Z, i)};
+    float q[3], nn[3];
+    mat_point(T, p, q);
+    const float off[3] = {q[0] - p[0], q[1] - p[1], q[2] - p[2]};
+    const float n[3] = {SURF(r, ORC_NORMAL_X, i), SURF(r, ORC_NORMAL_Y, i), SURF(r, ORC_NORMAL_Z, i)};
+    mat_rotate(T, n, nn);
+    const int restamp = reactivate && reactivate[c] && SURF_U32(r, ORC_LAST_UPDATE_STAMP, i) != frame_index;
+    /* a correction that leaves the slot as it is (identity rows) does not touch it */
+    if (off[0] == 0 && off[1] == 0 && off[2] == 0 && nn[0] == n[0] && nn[1] == n[1] && nn[2] == n[2] && !restamp) continue;
+    SURF(r, ORC_X, i) = p[0] + off[0];
+    SURF(r, ORC_Y, i) = p[1] + off[1];
+    SURF(r, ORC_Z, i) = p[2] + off[2];
+    SURF(r, ORC_SMOOTH_X, i) = SURF(r, ORC_SMOOTH_X, i) + off[0];
+    SURF(r, ORC_SMOOTH_Y, i) = SURF(r, ORC_SMOOTH_Y, i) + off[1];
+    SURF(r, ORC_SMOOTH_Z, i) = SURF(r, ORC_SMOOTH_Z, i) + off[2];
+    SURF(r, ORC_NORMAL_X, i) = nn[0];
+    SURF(r, ORC_NORMAL_Y, i) = nn[1];
+    SURF(r, ORC_NORMAL_Z, i) = nn[2];
+    if (restamp) SET_SURF_U32(r, ORC_LAST_UPDATE_STAMP, i, frame_index);
+  }
+}

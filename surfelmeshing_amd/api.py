@@ -408,6 +408,18 @@ class CUDASurfelReconstruction:
             _lib.check(rc)
         return d
 
+    def DeformByCreationFrame(self, stream, frame_T, reactivate=None, frame_index=0):
+        """The loop-closure hook the reference describes but does not ship (README.md:152-176): surfels created at
+        frame c move by the rigid correction frame_T[c] ([n_frames, 3, 4] / [n_frames, 12]); reactivate[c] != 0
+        re-stamps them with frame_index."""
+        T = np.ascontiguousarray(np.asarray(frame_T, np.float32).reshape(-1, 12))
+        ra = np.ascontiguousarray(reactivate, np.uint8) if reactivate is not None else None
+        if ra is not None and ra.size != T.shape[0]:
+            raise ValueError("reactivate needs one byte per frame")
+        _lib.check(_lib.load().smx_recon_deform_by_creation_frame(
+            self._h, _sv(stream), T.ctypes.data_as(C.c_void_p), C.c_uint32(T.shape[0]),
+            ra.ctypes.data_as(C.c_void_p) if ra is not None else C.c_void_p(0), C.c_uint32(frame_index), C.c_int32(0)))
+
     def CheckTrianglesForRemeshing(self, stream, triangles, long_edge_total_factor_squared):
         """The per-triangle tests of SurfelMeshing::CheckRemeshing (APP/surfel_meshing.cc:590-650) for triangles
         [T,3] of slot indices against the device-resident map.  Returns flags [T] (bits: see smx.h)."""

@@ -1618,6 +1618,41 @@ k_check_triangles(Surfels S, const uint32_t* __restrict__ tri, uint32_t n_tri, c
   }
 }
 
+// The loop-closure hook the reference describes but does not ship (README.md:152-176, main.cc:1194-1200): a rigid
+// correction per creation frame.  Streams the C records (creation stamp); only moved slots touch P, S, N.
+__global__ void __launch_bounds__(kBlock)
+k_deform_by_creation_frame(Surfels S, const float* __restrict__ frame_T, uint32_t n_frames,
+                           const uint8_t* __restrict__ reactivate, uint32_t frame_index, uint8_t* __restrict__ dirty8,
+                           const DevState* st) {
+  const uint32_t N = st->surfel_count;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+    const uint32_t c = S.u(kCreationStamp, i);
+    if (c >= n_frames) continue;
+    float4 nr = *S.group(kGroupN, i);
+    if (nr.w < 0) continue;  // merged
+    Mat34 T;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T.m[k] = frame_T[12 * (size_t)c + k];
+    float4 pr = *S.group(kGroupP, i);
+    float4 sr = *S.group(kGroupS, i);
+    const Vec3 p = {pr.x, pr.y, pr.z};
+    const Vec3 q = mul(T, p);
+    const float ox = q.x - p.x, oy = q.y - p.y, oz = q.z - p.z;  // README.md:160-165: one offset for both positions
+    const Vec3 nn = rotate(T, Vec3{nr.x, nr.y, nr.z});            // README.md:166-168
+    const bool restamp = reactivate != nullptr && reactivate[c] && __float_as_uint(pr.w) != frame_index;
+    // a correction that leaves the slot as it is (identity rows) is not a change for the delta hand-off
+    if (ox == 0 && oy == 0 && oz == 0 && nn.x == nr.x && nn.y == nr.y && nn.z == nr.z && !restamp) continue;
+    pr.x = p.x + ox; pr.y = p.y + oy; pr.z = p.z + oz;
+    sr.x = sr.x + ox; sr.y = sr.y + oy; sr.z = sr.z + oz;
+    nr.x = nn.x; nr.y = nn.y; nr.z = nn.z;
+    if (restamp) pr.w = __uint_as_float(frame_index);             // README.md:172-174
+    *S.group(kGroupP, i) = pr;
+    *S.group(kGroupS, i) = sr;
+    *S.group(kGroupN, i) = nr;
+    if (dirty8) dirty8[i] = 1;
+  }
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_decode_conflicting(const uint32_t* __restrict__ key, uint32_t* __restrict__ out, int P) {
   const int k = blockIdx.x * kBlock + threadIdx.x;
@@ -2328,6 +2363,19 @@ int smx_recon_debug_download_surfels(smx_recon r, smx_stream s, float* rows, uin
   return SMX_OK;
 }
 
+// After surfel attributes were changed from outside the frame loop (state upload, deformation): drop the work
+// lists and segment boxes (count 0 = no box, the segment is scanned) and rebuild the flag table -- its detach bits
+// come from the colour words, the recent bits are refreshed per frame.
+static int invalidate_derived(smx_recon r, hipStream_t st) {
+  SMX_HIP(hipMemsetAsync(r->L.vis_seg, 0, (size_t)r->nseg * 4, st));
+  SMX_HIP(hipMemsetAsync(r->L.seg_box, 0, (size_t)r->nseg * 8 * sizeof(float), st));
+  SMX_HIP(hipMemsetAsync(r->L.recent_seg, 0, (size_t)r->nsegB * 4, st));
+  hipLaunchKernelGGL(k_rebuild_flags, dim3(r->grid_surfels), dim3(kBlock), 0, st, r->S, 0u, 0x7FFFFFFF, r->L.flags8, r->st);
+  SMX_LAUNCH_CHECK();
+  r->table_valid = false;
+  return SMX_OK;
+}
+
 int smx_recon_debug_upload_surfels(smx_recon r, smx_stream s, const float* rows, uint32_t count, uint32_t merge_count) {
   SMX_CHECK_ARG(r != nullptr && count <= r->max_surfels && (rows != nullptr || count == 0));
   { const int rcj = join_regularizer(r, (hipStream_t)s); if (rcj != SMX_OK) return rcj; }
@@ -2350,14 +2398,45 @@ int smx_recon_debug_upload_surfels(smx_recon r, smx_stream s, const float* rows,
   SMX_HIP(hipMemsetAsync(r->inbox, 0, 4 * r->S.pitch * sizeof(float4), st));
   SMX_HIP(hipMemsetAsync(r->merge_flag, 0, r->S.pitch, st));
   if (r->L.dirty8) SMX_HIP(hipMemsetAsync(r->L.dirty8, 1, (size_t)r->nseg * kSeg, st));
-  SMX_HIP(hipMemsetAsync(r->L.vis_seg, 0, (size_t)r->nseg * 4, st));
-  SMX_HIP(hipMemsetAsync(r->L.seg_box, 0, (size_t)r->nseg * 8 * sizeof(float), st));  // (count 0 = no box)
-  SMX_HIP(hipMemsetAsync(r->L.recent_seg, 0, (size_t)r->nsegB * 4, st));
-  // detach bits of the flag table come from the colour words; the recent bits are refreshed per frame
-  hipLaunchKernelGGL(k_rebuild_flags, dim3(r->grid_surfels), dim3(kBlock), 0, st, r->S, 0u, 0x7FFFFFFF, r->L.flags8, r->st);
-  r->table_valid = false;
+  int rc = invalidate_derived(r, st);
+  if (rc != SMX_OK) return rc;
   SMX_HIP(hipStreamSynchronize(st));
   return SMX_OK;
+}
+
+int smx_recon_deform_by_creation_frame(smx_recon r, smx_stream s, const float* frame_T, uint32_t n_frames,
+                                       const uint8_t* reactivate, uint32_t frame_index, int32_t inputs_on_device) {
+  SMX_CHECK_ARG(r != nullptr && (n_frames == 0 || frame_T != nullptr));
+  if (n_frames == 0) return SMX_OK;
+  hipStream_t st = (hipStream_t)s;
+  { const int rcj = join_regularizer(r, st); if (rcj != SMX_OK) return rcj; }
+  float* dT = nullptr;
+  uint8_t* dre = nullptr;
+  int rc = SMX_OK;
+  hipError_t e = hipSuccess;
+  auto fail = [&](hipError_t err) { set_error("deform failed: %s", hipGetErrorString(err)); rc = SMX_ERR_HIP; };
+  if (!inputs_on_device) {
+    if ((e = hipMalloc(reinterpret_cast<void**>(&dT), (size_t)n_frames * 48)) != hipSuccess) fail(e);
+    else if ((e = hipMemcpyAsync(dT, frame_T, (size_t)n_frames * 48, hipMemcpyHostToDevice, st)) != hipSuccess) fail(e);
+    if (rc == SMX_OK && reactivate) {
+      if ((e = hipMalloc(reinterpret_cast<void**>(&dre), n_frames)) != hipSuccess) fail(e);
+      else if ((e = hipMemcpyAsync(dre, reactivate, n_frames, hipMemcpyHostToDevice, st)) != hipSuccess) fail(e);
+    }
+  }
+  if (rc == SMX_OK) {
+    hipLaunchKernelGGL(k_deform_by_creation_frame, dim3(r->grid_surfels), dim3(kBlock), 0, st, r->S,
+                       inputs_on_device ? frame_T : dT, n_frames, inputs_on_device ? reactivate : dre, frame_index,
+                       r->L.dirty8, r->st);
+    if ((e = hipGetLastError()) != hipSuccess) fail(e);
+  }
+  // positions and stamps changed behind the work lists, segment boxes and the flag table
+  if (rc == SMX_OK) rc = invalidate_derived(r, st);
+  if (!inputs_on_device) {
+    if ((e = hipStreamSynchronize(st)) != hipSuccess && rc == SMX_OK) fail(e);
+    if (dT) (void)hipFree(dT);
+    if (dre) (void)hipFree(dre);
+  }
+  return rc;
 }
 
 int smx_recon_debug_download_scratch(smx_recon r, smx_stream s, int32_t which, void* dst) {

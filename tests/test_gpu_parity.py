@@ -547,3 +547,54 @@ def test_native_driver_matches_oracle(smx):
     pn.release(10)
     with pytest.raises(smx.SmxError):
         pn.download_frame(10)
+
+
+def test_loop_closure_deformation_hook(smx):
+    """The hook the reference describes but does not ship (README.md:152-176, call site main.cc:1194-1200): a rigid
+    correction per creation frame, applied between two frames of a stream.  The map right after the deformation and
+    after every following frame equals the oracle's (moved surfels now disagree with the measurements: conflicts,
+    merges and re-activated old surfels follow); the changed-surfel delta covers every moved slot."""
+    s = small_stream(obstacle_until=8, yaw_deg_per_frame=2.0)
+    po, pg = _pipes(smx, s, 60000, params_kw=dict(surfel_integration_active_window_size=6))
+    rec = pg.reconstruction
+    rec.SetDeltaTracking(None, True)
+    run_both(po, pg, s, list(range(4, 12)), None)
+    _compare_state(po, pg)
+    rec.TransferChangedToCPU(None, 11)                          # (drain: everything so far)
+    n = po.recon.surfels_size
+    before = po.recon.surfels().copy()
+    a = np.deg2rad(0.4)
+    T = np.tile(np.eye(4, dtype=np.float32)[:3].reshape(1, 12), (10, 1))       # creation frames 0..9; 10, 11 stay
+    for c in range(4, 8):
+        T[c] = np.array([[np.cos(a), 0, np.sin(a), 0.004], [0, 1, 0, -0.002], [-np.sin(a), 0, np.cos(a), 0.006]],
+                        np.float32).reshape(12)
+    reactivate = np.zeros(10, np.uint8)
+    reactivate[4:6] = 1
+    po.recon.deform_by_creation_frame(T, reactivate, 12)
+    rec.DeformByCreationFrame(None, T, reactivate, 12)
+    _compare_state(po, pg, check_scratch=False)
+    after = po.recon.surfels()
+    live = before[7, :n] >= 0
+    creation = before[17, :n].view(np.uint32)
+    moved = live & (creation >= 4) & (creation < 8)
+    assert moved.sum() > 3000 and (live & ~moved).sum() > 1000
+    assert np.array_equal(after[:, :n][:, ~moved].view(np.uint32), before[:, :n][:, ~moved].view(np.uint32))
+    assert np.all(after[0, :n][moved] != before[0, :n][moved])
+    assert np.all(after[18, :n].view(np.uint32)[live & (creation >= 4) & (creation < 6)] == 12)
+    delta = rec.TransferChangedToCPU(None, 12)
+    assert np.array_equal(delta.surfel_index[:delta.count], np.flatnonzero(moved).astype(np.uint32))
+    # the stream goes on against the deformed map
+    for f in range(8, 26):
+        d, c = s.frame(f)
+        po.upload(f, d, c)
+        pg.upload(f, d, c)
+    for f in range(12, 22):
+        others, Tr, pose = s.outlier_frames(f), s.others_TR_reference(f), s.pose(f)
+        po.process(f, others, Tr, pose)
+        pg.process(f, others, Tr, pose)
+        _compare_state(po, pg)
+    assert po.recon.merge_count > 0
+    # nothing to do / argument errors
+    rec.DeformByCreationFrame(None, np.zeros((0, 12), np.float32))
+    with pytest.raises(ValueError):
+        rec.DeformByCreationFrame(None, T, np.zeros(3, np.uint8), 0)

@@ -488,3 +488,30 @@ def test_check_triangles_known_answers(orc):
     # a degenerate triangle (zero-area): dot products are exactly 0 -> "<= 0" holds for every pivot
     assert orc.check_triangles(x, y, z, r2, *up, np.array([[0, 0, 1]], np.uint32), 16.0)[0] == 14
     assert orc.check_triangles(x, y, z, r2, *up, np.zeros((0, 3), np.uint32), 16.0).size == 0
+
+
+def test_deform_by_creation_frame_known_answers(orc):
+    """The loop-closure hook of README.md:152-176 as a rigid correction per creation frame."""
+    h, w = 20, 30
+    rec = orc.Recon(5000, w, h, 100.0, 100.0, 15.0, 10.0)
+    depth, normals, radius, color = _plane_frame(h, w)
+    rec.integrate(3, 5000.0, depth.copy(), normals, radius, color, IDENT)     # every surfel: creation stamp 3
+    n = rec.surfels_size
+    before = rec.surfels().copy()
+    T = np.tile(np.eye(4, dtype=np.float32)[:3].reshape(1, 12), (5, 1))
+    rec.deform_by_creation_frame(T[:3], None, 9)                                # table ends before frame 3: nothing
+    assert np.array_equal(rec.surfels().view(np.uint32), before.view(np.uint32))
+    rec.deform_by_creation_frame(T, None, 9)                                    # identity: nothing, bit for bit
+    assert np.array_equal(rec.surfels().view(np.uint32), before.view(np.uint32))
+    T[3] = np.array([[0, -1, 0, 0.5], [1, 0, 0, 0.25], [0, 0, 1, -0.125]], np.float32).reshape(12)   # 90 deg about z
+    rec.deform_by_creation_frame(T, np.array([0, 0, 0, 1, 0], np.uint8), 9)
+    after = rec.surfels()
+    x, y, z = before[0, :n], before[1, :n], before[2, :n]
+    # offset = T p - p added to p: exact up to the rounding of that float sum
+    assert np.allclose(after[0, :n], -y + 0.5, atol=1e-6) and np.allclose(after[1, :n], x + 0.25, atol=1e-6)
+    assert np.allclose(after[2, :n], z - 0.125, atol=1e-6)
+    assert np.array_equal(after[3:6, :n] - before[3:6, :n], after[0:3, :n] - before[0:3, :n])   # smooth == raw here
+    assert np.array_equal(after[8:11, :n], np.stack([-before[9, :n], before[8, :n], before[10, :n]]))
+    assert np.all(after[18, :n].view(np.uint32) == 9) and np.all(after[17, :n].view(np.uint32) == 3)
+    untouched = [6, 7, 19, 20, 21, 22, 24]
+    assert np.array_equal(after[untouched].view(np.uint32), before[untouched].view(np.uint32))
