@@ -125,6 +125,12 @@ int smx_median_filter_and_densify_depth_map(smx_stream s, const smx_buffer_desc*
  * (APP/main.cc:941-962), a CPU loop in the reference.  The output size selects the source blocks. */
 int smx_downscale_using_median_while_excluding(smx_stream s, uint16_t value_to_ignore, const smx_buffer_desc* input,
                                                const smx_buffer_desc* output);
+/* The colour half of --pyramid_level (APP/main.cc:973-981): ImagePyramid(frame, pyramid_level) = pyramid_level times
+ * Image<Vec3u8>::DownscaleToHalfSize (VIS/image_cache.h:203-243, VIS/image.h:929-948: per channel
+ * a/4 + b/4 + c/4 + d/4, each term truncated), a CPU loop in the reference.  3-byte pixels; 1 <= pyramid_level <= 4;
+ * the input size must be divisible by 2^pyramid_level and the output buffer must have the resulting size. */
+int smx_color_image_pyramid(smx_stream s, int32_t pyramid_level, const smx_buffer_desc* input,
+                            const smx_buffer_desc* output);
 /* ComputeNormalsAndDropBadPixelsCUDA, cu:720-762 */
 int smx_compute_normals_and_drop_bad_pixels(
     smx_stream s, float observation_angle_threshold_deg, float depth_scaling,

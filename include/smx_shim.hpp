@@ -166,6 +166,13 @@ inline void DownscaleUsingMedianWhileExcludingCUDA(cudaStream_t stream, u16 valu
   SMX_SHIM_CHECK(smx_downscale_using_median_while_excluding(stream, value_to_ignore, input.desc(), output->desc()));
 }
 
+// ImagePyramid(color_frame, pyramid_level) (libvis image_cache.h:203-275 over Image<Vec3u8>::DownscaleToHalfSize,
+// image.h:929-948 -- --pyramid_level's colour image, APP/main.cc:973-981) on device buffers.
+inline void ColorImagePyramidCUDA(cudaStream_t stream, int pyramid_level, const CUDABuffer_<Vec3u8>& input,
+                                  CUDABuffer_<Vec3u8>* output) {
+  SMX_SHIM_CHECK(smx_color_image_pyramid(stream, pyramid_level, input.desc(), output->desc()));
+}
+
 // MedianFilterAndDensifyDepthMap (APP/main.cc:206-252) is a CPU function in the reference; its TODO (main.cc:928) asks
 // for this: the same filter on device buffers, ahead of the bilateral filter.
 inline void MedianFilterAndDensifyDepthMapCUDA(cudaStream_t stream, const CUDABuffer_<u16>& input_depth,

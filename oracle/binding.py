@@ -158,6 +158,15 @@ def downscale_using_median_while_excluding(depth, out_width, out_height, value_t
     return out
 
 
+def color_image_pyramid(color, level):
+    color = _c(color, np.uint8)
+    h, w, ch = color.shape
+    assert ch == 3 and level >= 1 and w % (1 << level) == 0 and h % (1 << level) == 0
+    out = np.zeros((h >> level, w >> level, 3), np.uint8)
+    lib().orc_color_image_pyramid(C.c_int(w), C.c_int(h), _p(color), C.c_int(level), _p(out))
+    return out
+
+
 def erode_depth_map(depth, radius):
     depth = _c(depth, np.uint16)
     h, w = depth.shape

@@ -146,6 +146,9 @@ void orc_erode_depth_map(int radius, int width, int height, const uint16_t* in, 
 void orc_median_filter_and_densify(int width, int height, const uint16_t* in, uint16_t* out);  /* APP/main.cc:206-252 */
 void orc_downscale_using_median_while_excluding(uint16_t value_to_ignore, int width, int height, const uint16_t* in,
                                                 int out_width, int out_height, uint16_t* out);  /* VIS/image.h:1003-1053 */
+/* ImagePyramid(frame, level) for Vec3u8 images: `level` times Image::DownscaleToHalfSize, VIS/image.h:929-948
+ * (a/4 + b/4 + c/4 + d/4 per channel), VIS/image_cache.h:203-275; out is (width >> level) x (height >> level) x 3. */
+void orc_color_image_pyramid(int width, int height, const uint8_t* in, int level, uint8_t* out);
 void orc_copy_without_border(int width, int height, const uint16_t* in, uint16_t* out);
 
 void orc_compute_normals_and_drop_bad_pixels(

@@ -342,3 +342,26 @@ void orc_compute_point_radii_and_remove_isolated_pixels(
     }
   }
 }
+
+/* ImagePyramid over Image<Vec3u8>::DownscaleToHalfSize (VIS/image.h:929-948, VIS/image_cache.h:203-275): one
+ * halving per level, each written out like the reference does. */
+void orc_color_image_pyramid(int width, int height, const uint8_t* in, int level, uint8_t* out) {
+  const uint8_t* src = in;
+  uint8_t* tmp = NULL;
+  int w = width, h = height;
+  for (int l = 0; l < level; ++l) {
+    const int ow = w / 2, oh = h / 2;
+    uint8_t* dst = (l == level - 1) ? out : (uint8_t*)malloc((size_t)ow * oh * 3);
+    for (int y = 0; y < oh; ++y)
+      for (int x = 0; x < ow; ++x)
+        for (int c = 0; c < 3; ++c) {
+          const uint8_t a = src[((size_t)(2 * y) * w + 2 * x) * 3 + c], b = src[((size_t)(2 * y) * w + 2 * x + 1) * 3 + c];
+          const uint8_t d = src[((size_t)(2 * y + 1) * w + 2 * x) * 3 + c], e = src[((size_t)(2 * y + 1) * w + 2 * x + 1) * 3 + c];
+          dst[((size_t)y * ow + x) * 3 + c] = (uint8_t)(a / 4 + b / 4 + d / 4 + e / 4);
+        }
+    free(tmp);
+    tmp = (l == level - 1) ? NULL : dst;
+    src = dst;
+    w = ow; h = oh;
+  }
+}

@@ -200,6 +200,13 @@ def DownscaleUsingMedianWhileExcludingCUDA(stream, value_to_ignore, input_depth,
                                                                       _d(input_depth), _d(output_depth)))
 
 
+def ColorImagePyramidCUDA(stream, pyramid_level, input_color, output_color):
+    """ImagePyramid(color_frame, pyramid_level) (VIS/image_cache.h:203-275 over Image<Vec3u8>::DownscaleToHalfSize,
+    VIS/image.h:929-948): the colour half of --pyramid_level (APP/main.cc:973-981)."""
+    _lib.check(_lib.load().smx_color_image_pyramid(_sv(stream), C.c_int32(pyramid_level), _d(input_color),
+                                                   _d(output_color)))
+
+
 def CopyWithoutBorderCUDA(stream, input_depth, output_depth):
     _lib.check(_lib.load().smx_copy_without_border(_sv(stream), _d(input_depth), _d(output_depth)))
 
@@ -336,6 +343,13 @@ class PinholeCamera4f:
 
     def parameters(self):
         return self._p
+
+    def Scaled(self, factor):
+        """Camera::Scaled (VIS/camera.h:1564-1574): size = factor * size + 0.5 truncated, the four pinhole parameters
+        times factor in float (PinholeProjection::ScaleParameters, camera.h:954-964; origin at the image corner)."""
+        f = np.float32(factor)
+        return PinholeCamera4f(int(factor * self._w + np.float32(0.5)), int(factor * self._h + np.float32(0.5)),
+                               *[float(np.float32(v) * f) for v in self._p])
 
 
 class CUDASurfelReconstruction:

@@ -319,6 +319,34 @@ k_downscale_median(uint16_t value_to_ignore, Img<const uint16_t> in, Img<uint16_
   out(y, x) = r;
 }
 
+// The colour half of --pyramid_level (APP/main.cc:973-981): ImagePyramid(frame, L) = L times
+// Image<Vec3u8>::DownscaleToHalfSize (VIS/image_cache.h:203-243, VIS/image.h:929-948), whose per-channel
+// a/4 + b/4 + c/4 + d/4 truncates each term (the reference's own TODO notes the missing rounding); the levels are
+// nested in registers, one output pixel per lane, so that no intermediate level is stored.
+struct Rgb { unsigned r, g, b; };
+template <int L>
+__device__ __forceinline__ Rgb pyramid_pixel(const Img<const uint8_t>& in, int x, int y) {
+  if constexpr (L == 0) {
+    const uint8_t* p = in.row(y) + 3 * x;
+    return Rgb{p[0], p[1], p[2]};
+  } else {
+    const Rgb a = pyramid_pixel<L - 1>(in, 2 * x, 2 * y), b = pyramid_pixel<L - 1>(in, 2 * x + 1, 2 * y);
+    const Rgb c = pyramid_pixel<L - 1>(in, 2 * x, 2 * y + 1), d = pyramid_pixel<L - 1>(in, 2 * x + 1, 2 * y + 1);
+    return Rgb{a.r / 4 + b.r / 4 + c.r / 4 + d.r / 4, a.g / 4 + b.g / 4 + c.g / 4 + d.g / 4,
+               a.b / 4 + b.b / 4 + c.b / 4 + d.b / 4};
+  }
+}
+template <int L>
+__global__ void __launch_bounds__(kThreads)
+k_color_pyramid(Img<const uint8_t> in /* width in pixels */, Img<uint8_t> out) {
+  const int x = blockIdx.x * kTileW + (threadIdx.x & (kTileW - 1));
+  const int y = blockIdx.y * (kThreads / kTileW) + threadIdx.x / kTileW;
+  if (x >= out.width || y >= out.height) return;
+  const Rgb v = pyramid_pixel<L>(in, x, y);
+  uint8_t* o = out.row(y) + 3 * x;
+  o[0] = (uint8_t)v.r; o[1] = (uint8_t)v.g; o[2] = (uint8_t)v.b;
+}
+
 __global__ void __launch_bounds__(kThreads)
 k_copy_without_border(Img<const uint16_t> in, Img<uint16_t> out) {
   const int x = blockIdx.x * kTileW + (threadIdx.x & (kTileW - 1));
@@ -520,6 +548,26 @@ int smx_downscale_using_median_while_excluding(smx_stream s, uint16_t value_to_i
   }
   hipLaunchKernelGGL(k_downscale_median, grid_rows(output->width, output->height), dim3(kThreads), 0, (hipStream_t)s,
                      value_to_ignore, as_img<const uint16_t>(input), as_img<uint16_t>(output));
+  SMX_LAUNCH_CHECK();
+  return SMX_OK;
+}
+
+int smx_color_image_pyramid(smx_stream s, int32_t pyramid_level, const smx_buffer_desc* input,
+                            const smx_buffer_desc* output) {
+  SMX_CHECK_ARG(input && output && pyramid_level >= 1 && pyramid_level <= 4);
+  // DownscaleToHalfSize CHECKs even sizes at every level (VIS/image.h:930-931)
+  SMX_CHECK_ARG(input->width % (1 << pyramid_level) == 0 && input->height % (1 << pyramid_level) == 0);
+  SMX_CHECK_ARG(output->width == (input->width >> pyramid_level) && output->height == (input->height >> pyramid_level));
+  const dim3 grid = grid_rows(output->width, output->height);
+  const Img<const uint8_t> in = as_img<const uint8_t>(input);
+  const Img<uint8_t> out = as_img<uint8_t>(output);
+  hipStream_t st = (hipStream_t)s;
+  switch (pyramid_level) {
+    case 1: hipLaunchKernelGGL(k_color_pyramid<1>, grid, dim3(kThreads), 0, st, in, out); break;
+    case 2: hipLaunchKernelGGL(k_color_pyramid<2>, grid, dim3(kThreads), 0, st, in, out); break;
+    case 3: hipLaunchKernelGGL(k_color_pyramid<3>, grid, dim3(kThreads), 0, st, in, out); break;
+    default: hipLaunchKernelGGL(k_color_pyramid<4>, grid, dim3(kThreads), 0, st, in, out); break;
+  }
   SMX_LAUNCH_CHECK();
   return SMX_OK;
 }

@@ -29,6 +29,7 @@ class PreprocessParams:
     point_radius_extension_factor: float = 1.5
     point_radius_clamp_factor: float = float("inf")
     median_filter_and_densify_iterations: int = 0   # main.cc:929-939 (on the CPU there, on the GPU here)
+    pyramid_level: int = 0                          # main.cc:299-303, 751, 941-981: work at 1 / 2^level of the input size
 
     def max_depth_u16(self):
         return int(np.uint16(min(self.depth_scaling * self.max_depth, 65535.0)))  # main.cc:1021
@@ -36,12 +37,24 @@ class PreprocessParams:
 
 class FramePipeline:
     def __init__(self, width, height, fx, fy, cx, cy, max_surfel_count, pre=None, params=None, stream=None):
+        """width, height and the intrinsics describe the input frames; with pre.pyramid_level > 0 the pipeline works
+        on the scaled camera (main.cc:751) and upload() reduces the frames on the GPU."""
+        self.pre = pre or PreprocessParams()
+        self.in_w, self.in_h = width, height
+        self.camera = api.PinholeCamera4f(width, height, fx, fy, cx, cy)
+        if self.pre.pyramid_level > 0:
+            if self.pre.median_filter_and_densify_iterations > 0:
+                raise ValueError("Simultaneous downscaling and median filtering of depth maps is not implemented "
+                                 "(main.cc:944-947)")
+            if width % (1 << self.pre.pyramid_level) or height % (1 << self.pre.pyramid_level):
+                raise ValueError("the input size must be divisible by 2^pyramid_level (VIS/image.h:930-931)")
+            self.camera = self.camera.Scaled(1.0 / 2 ** self.pre.pyramid_level)
+        width, height = self.camera.width(), self.camera.height()
+        fx, fy, cx, cy = self.camera.parameters()
         self.w, self.h = width, height
         self.fx, self.fy, self.cx, self.cy = fx, fy, cx, cy
-        self.pre = pre or PreprocessParams()
         self.params = params or IntegrateParams.defaults()
         self.stream = stream
-        self.camera = api.PinholeCamera4f(width, height, fx, fy, cx, cy)
         self.reconstruction = api.CUDASurfelReconstruction(max_surfel_count, self.camera)
         self.filtered_A = api.CUDABuffer(height, width, np.uint16)
         self.filtered_B = api.CUDABuffer(height, width, np.uint16)
@@ -52,8 +65,10 @@ class FramePipeline:
         self.color = {}       # frame index -> CUDABuffer<Vec3u8>
 
     def upload(self, frame_index, depth, color):
-        d = api.CUDABuffer(self.h, self.w, np.uint16)
+        d = api.CUDABuffer(self.in_h, self.in_w, np.uint16)
         d.UploadAsync(self.stream, depth)
+        c = api.CUDABuffer(self.in_h, self.in_w, np.uint8, 3)
+        c.UploadAsync(self.stream, color)
         if self.pre.median_filter_and_densify_iterations > 0:   # main.cc:929-939, per frame at load time
             t = api.CUDABuffer(self.h, self.w, np.uint16)
             for _ in range(self.pre.median_filter_and_densify_iterations):
@@ -61,8 +76,14 @@ class FramePipeline:
                 d, t = t, d
             api.StreamSynchronize(self.stream)
             t.close()
-        c = api.CUDABuffer(self.h, self.w, np.uint8, 3)
-        c.UploadAsync(self.stream, color)
+        if self.pre.pyramid_level > 0:   # main.cc:941-962 (depth), 973-981 (colour); CPU loops in the reference
+            ds, cs = api.CUDABuffer(self.h, self.w, np.uint16), api.CUDABuffer(self.h, self.w, np.uint8, 3)
+            api.DownscaleUsingMedianWhileExcludingCUDA(self.stream, 0, d, ds)
+            api.ColorImagePyramidCUDA(self.stream, self.pre.pyramid_level, c, cs)
+            api.StreamSynchronize(self.stream)
+            d.close()
+            c.close()
+            d, c = ds, cs
         self.raw_depth[frame_index] = d
         self.color[frame_index] = c
 

@@ -7,6 +7,11 @@ import oracle as orc
 
 class OraclePipeline:
     def __init__(self, width, height, fx, fy, cx, cy, max_surfel_count, pre, params=None, sum_mode=orc.SUM_EXACT):
+        self.level = getattr(pre, "pyramid_level", 0)
+        if self.level > 0:   # Camera::Scaled(1 / 2^level), main.cc:751, VIS/camera.h:954-964, 1564-1574
+            f = np.float32(1.0 / 2 ** self.level)
+            width, height = int(float(f) * width + np.float32(0.5)), int(float(f) * height + np.float32(0.5))
+            fx, fy, cx, cy = (float(np.float32(v) * f) for v in (fx, fy, cx, cy))
         self.w, self.h, self.fx, self.fy, self.cx, self.cy = width, height, fx, fy, cx, cy
         self.pre = pre
         self.params = params or orc.IntegrateParams.defaults()
@@ -20,6 +25,9 @@ class OraclePipeline:
         if getattr(self.pre, "median_filter_and_densify_iterations", 0) > 0:   # main.cc:929-939
             self.raw_depth[f] = orc.median_filter_and_densify(self.raw_depth[f], self.pre.median_filter_and_densify_iterations)
         self.color[f] = np.ascontiguousarray(color, np.uint8)
+        if self.level > 0:                                                     # main.cc:941-962, 973-981
+            self.raw_depth[f] = orc.downscale_using_median_while_excluding(self.raw_depth[f], self.w, self.h, 0)
+            self.color[f] = orc.color_image_pyramid(self.color[f], self.level)
 
     def release(self, f):
         self.raw_depth.pop(f, None)

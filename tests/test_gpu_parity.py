@@ -151,6 +151,27 @@ def test_downscale_using_median_while_excluding_bit_exact(smx, size, out):
             smx.DownscaleUsingMedianWhileExcludingCUDA(None, 0, a, small)  # 160 x 120 pixel blocks: unsupported
 
 
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+def test_color_image_pyramid_bit_exact(smx, level):
+    """ImagePyramid(color, level) (VIS/image_cache.h:203-275 over Image<Vec3u8>::DownscaleToHalfSize,
+    VIS/image.h:929-948; --pyramid_level's colour image, APP/main.cc:973-981)."""
+    rng = np.random.default_rng(level)
+    for h, w in ((480, 640), (48, 80)):
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        a, b = smx.CUDABuffer(h, w, np.uint8, 3), smx.CUDABuffer(h >> level, w >> level, np.uint8, 3)
+        a.UploadAsync(None, img)
+        smx.ColorImagePyramidCUDA(None, level, a, b)
+        smx.StreamSynchronize(None)
+        assert np.array_equal(b.Download(), orc.color_image_pyramid(img, level))
+    with pytest.raises(smx.SmxError):
+        smx.ColorImagePyramidCUDA(None, level, a, a)                         # wrong output size
+    odd = smx.CUDABuffer(50, 80, np.uint8, 3)
+    with pytest.raises(smx.SmxError):
+        smx.ColorImagePyramidCUDA(None, 2, odd, smx.CUDABuffer(12, 20, np.uint8, 3))   # 50 is not divisible by 4
+    with pytest.raises(smx.SmxError):
+        smx.ColorImagePyramidCUDA(None, 5, a, b)
+
+
 def test_cuda_buffer_roundtrips(smx):
     rng = np.random.default_rng(0)
     for dtype, ch, shape in ((np.uint16, 1, (31, 77)), (np.float32, 2, (9, 130)), (np.uint8, 3, (17, 65)), (np.float32, 1, (25, 1000))):
@@ -350,6 +371,24 @@ def test_stream_with_median_densify_iterations(smx):
     po, pg = _pipes(smx, s, 60000, pre=pre)
     run_both(po, pg, s, list(range(4, 14)), lambda f: _compare_state(po, pg))
     assert po.recon.surfels_size > 8000
+
+
+def test_stream_with_pyramid_level(smx):
+    """--pyramid_level 1 (APP/main.cc:299-303, 751, 941-981): 320 x 240 input frames, depth reduced by the median of the
+    valid pixels, colour by the truncating 2 x 2 mean, camera scaled by 1/2 -- whole pipeline, every frame."""
+    s = small_stream(320, 240, obstacle_until=8, dropout=0.03)
+    pre = small_pre(160, pyramid_level=1)
+    po, pg = _pipes(smx, s, 60000, pre=pre)
+    assert (pg.w, pg.h, po.w, po.h) == (160, 120, 160, 120) and pg.fx == po.fx == s.fx / 2 and pg.cx == po.cx == s.cx / 2
+    run_both(po, pg, s, list(range(4, 12)), lambda f: _compare_state(po, pg))
+    assert po.recon.surfels_size > 2000
+    f = 8
+    assert np.array_equal(pg.color[f].Download(), po.color[f]) and np.array_equal(pg.raw_depth[f].Download(), po.raw_depth[f])
+    from surfelmeshing_amd.pipeline import FramePipeline
+    with pytest.raises(ValueError):
+        FramePipeline(320, 240, s.fx, s.fy, s.cx, s.cy, 1000, small_pre(160, pyramid_level=1, median_filter_and_densify_iterations=1))
+    with pytest.raises(ValueError):
+        FramePipeline(322, 240, s.fx, s.fy, s.cx, s.cy, 1000, small_pre(160, pyramid_level=2))
 
 
 def test_full_resolution_parity(smx):

@@ -515,3 +515,27 @@ def test_deform_by_creation_frame_known_answers(orc):
     assert np.all(after[18, :n].view(np.uint32) == 9) and np.all(after[17, :n].view(np.uint32) == 3)
     untouched = [6, 7, 19, 20, 21, 22, 24]
     assert np.array_equal(after[untouched].view(np.uint32), before[untouched].view(np.uint32))
+
+
+def test_color_image_pyramid_known_answers(orc):
+    """ImagePyramid over Image<Vec3u8>::DownscaleToHalfSize (VIS/image.h:929-948).  The reference's own test
+    (VIS/test/image_cache.cc:40-57) pins the size: 32 x 16, two levels -> 8 x 4; with its constant 42 every term is
+    42 / 4 = 10, so level 1 is 40 and level 2 is 40 / 4 * 4 = 40."""
+    img = np.full((16, 32, 3), 42, np.uint8)
+    out = orc.color_image_pyramid(img, 2)
+    assert out.shape == (4, 8, 3) and np.all(out == 40)
+    # each term is truncated before the sum (the reference's TODO at :940-941): 3, 3, 3, 3 -> 0, not 3
+    assert np.all(orc.color_image_pyramid(np.full((2, 2, 3), 3, np.uint8), 1) == 0)
+    assert np.all(orc.color_image_pyramid(np.full((2, 2, 3), 255, np.uint8), 1) == 252)
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (24, 40, 3)).astype(np.uint8)
+
+    def half(a):
+        a = a.astype(np.uint16)
+        return (a[0::2, 0::2] // 4 + a[0::2, 1::2] // 4 + a[1::2, 0::2] // 4 + a[1::2, 1::2] // 4).astype(np.uint8)
+
+    assert np.array_equal(orc.color_image_pyramid(img, 1), half(img))
+    assert np.array_equal(orc.color_image_pyramid(img, 3), half(half(half(img))))
+    chan = np.zeros((4, 4, 3), np.uint8)
+    chan[..., 1] = 200                                                       # channels stay separate
+    assert orc.color_image_pyramid(chan, 2).tolist() == [[[0, 200, 0]]]
