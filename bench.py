@@ -143,6 +143,40 @@ class Workload:
         return g, n
 
 
+def host_frames_pass(wl, plan, base, count, api, torch):
+    """Not `value`: the same frame loop with the inputs arriving over PCIe.  Every step's newest frame (f + 4) is copied
+    from page-locked host memory on an upload stream, one frame ahead of the kernels (smx_driver_run_streamed, the
+    reference caller's staging of APP/main.cc:905-984), into the slot the resident run used."""
+    pipe = wl.pipe
+    warm = min(10, count // 2)
+    keep, uploads = [], []
+    for j in range(base, base + count):
+        f = plan[j][0] + 4
+        d, c = pipe.download_frame(f)
+        pd, pc = api.PagelockedArray(d.shape, np.uint16), api.PagelockedArray(c.shape, np.uint8)
+        pd.array[...] = d
+        pc.array[...] = c
+        keep += [pd, pc]
+        uploads.append((f, pd.array, pc.array))
+    steps = [pipe.make_step(*plan[j]) for j in range(base, base + count)]
+    up = api.Stream()
+    pipe.run_streamed(steps[:warm], uploads[:warm], up)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    pipe.run_streamed(steps[warm:], uploads[warm:], up)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    up.close()
+    n = count - warm
+    nbytes = wl.w * wl.h * 5
+    for k in keep:
+        k.close()
+    return {"value": n / dt, "unit": "frames/s", "steps": n, "ms_per_step": 1e3 * dt / n,
+            "h2d_bytes_per_frame": nbytes, "h2d_GBs": nbytes * n / dt / 1e9,
+            "note": "inputs copied from page-locked host memory on an upload stream, one frame ahead "
+                    "(smx_driver_run_streamed); not the headline value"}
+
+
 def algorithmic_bytes(st, P):
     """SURVEY.md 8(d) byte model of the REFERENCE's per-frame traffic (for comparison only) and this
     design's own compulsory traffic (DESIGN.md 'Bytes')."""
@@ -162,6 +196,8 @@ def main():
     ap.add_argument("--surfels", type=int, default=5_000_000, help="live surfels to reach before timing")
     ap.add_argument("--cap", type=int, default=0, help="max_surfel_count (default: surfels * 1.1)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--host-frames", type=int, default=100,
+                    help="frames of the extra pass whose inputs arrive from page-locked host memory (0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the full-size GPU-vs-oracle check")
     ap.add_argument("--no-overlap", action="store_true", help="A/B: no frame pipelining inside Integrate")
     ap.add_argument("--quiet", action="store_true")
@@ -193,9 +229,10 @@ def main():
     first = g_end + 10
     cal, reps = 10, 20
     total = W + cal + K
-    for j in range(-4, total + 1 + reps + 4):
+    do_host = args.host_frames if (rank == 0 and world == 1) else 0   # PCIe-inclusive pass: rank 0 at N = 1 only
+    for j in range(-4, total + 1 + reps + do_host + 4):
         wl.render(first + j, 4 + j)
-    plan = [wl.plan(first + j, 4 + j) for j in range(total + 1 + reps)]
+    plan = [wl.plan(first + j, 4 + j) for j in range(total + 1 + reps + do_host)]
     api.StreamSynchronize(None)
 
     rec = wl.pipe.reconstruction
@@ -260,6 +297,12 @@ def main():
     kernel_ms /= reps
     rec.set_timing_enabled(0)
 
+    host_pass = None
+    if do_host > 0:
+        rec.set_overlap(not args.no_overlap)
+        host_pass = host_frames_pass(wl, plan, total + 1 + reps, do_host, api, torch)
+        rec.set_overlap(False)
+
     ref_bytes, own_bytes = algorithmic_bytes(st, args.width * args.height)
     result = {
         "metric": "RGB-D frames/s integrated @640x480, 5M live surfels; achieved HBM GB/s",
@@ -282,6 +325,8 @@ def main():
     if rank == 0:
         result["roofline"] = roofline_block(st, args.width * args.height, dominant, dom_ms, dom_n,
                                             dict(zip(names, [float(x) for x in kernel_ms])))
+        if host_pass is not None:
+            result["host_frames"] = host_pass
         if do_cpu:
             result["cpu_baseline"] = cpu_baseline(wl, plan, W + cal, args.cpu_frames, state0, merge0, cap,
                                                   not args.no_check, log)

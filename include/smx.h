@@ -67,6 +67,11 @@ int smx_device_name(int device, char* name, size_t capacity);
 int smx_stream_create(smx_stream* out);
 /* priority_class: -1 = lowest, 0 = default, +1 = highest priority the device offers (cudaStreamCreateWithPriority) */
 int smx_stream_create_with_priority(smx_stream* out, int32_t priority_class);
+/* Page-locked host memory for upload staging (cudaHostAlloc(..., cudaHostAllocWriteCombined) / cudaFreeHost,
+ * APP/main.cc:825-829, 917): copies from it are asynchronous to the host.  write_combined memory is fast to
+ * upload from and slow for the CPU to read. */
+int smx_host_alloc(void** out, size_t bytes, int32_t write_combined);
+int smx_host_free(void* p);
 int smx_stream_destroy(smx_stream s);
 int smx_stream_synchronize(smx_stream s);
 /* Events for cross-stream ordering (hipEvent_t, timing disabled): the frame driver overlaps depth

@@ -56,6 +56,32 @@ class Stream:
             self.handle = C.c_void_p()
 
 
+class PagelockedArray:
+    """Page-locked host memory as a numpy array (cudaHostAlloc in the reference's upload staging,
+    APP/main.cc:825-829, 917): uploads from `.array` are asynchronous to the host.  Keep the object alive while
+    copies are in flight."""
+
+    def __init__(self, shape, dtype, write_combined=False):
+        self._p = C.c_void_p()
+        self.dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * self.dtype.itemsize
+        _lib.check(_lib.load().smx_host_alloc(C.byref(self._p), C.c_size_t(max(n, 1)), C.c_int32(1 if write_combined else 0)))
+        buf = (C.c_char * n).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype).reshape(shape)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            _lib.load().smx_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _sv(stream):
     if stream is None:
         return C.c_void_p(0)

@@ -93,6 +93,20 @@ int smx_stream_create_with_priority(smx_stream* out, int32_t priority_class) {
   return SMX_OK;
 }
 
+// cudaHostAlloc / cudaFreeHost of the caller's upload staging (APP/main.cc:917, 825-829)
+int smx_host_alloc(void** out, size_t bytes, int32_t write_combined) {
+  SMX_CHECK_ARG(out != nullptr && bytes > 0);
+  void* p = nullptr;
+  SMX_HIP(hipHostMalloc(&p, bytes, write_combined ? hipHostMallocWriteCombined : hipHostMallocDefault));
+  *out = p;
+  return SMX_OK;
+}
+
+int smx_host_free(void* p) {
+  if (p) SMX_HIP(hipHostFree(p));
+  return SMX_OK;
+}
+
 int smx_stream_destroy(smx_stream s) {
   if (s) SMX_HIP(hipStreamDestroy((hipStream_t)s));
   return SMX_OK;

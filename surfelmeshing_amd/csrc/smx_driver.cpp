@@ -13,6 +13,7 @@ using namespace vis;
 struct Frame {
   CUDABuffer<u16> depth;
   CUDABuffer<Vec3u8> color;
+  unsigned long long last_reader = 0;   // 1 + index of the last enqueued step that reads this frame (0 = none)
   Frame(int h, int w) : depth(h, w), color(h, w) {}
 };
 
@@ -43,6 +44,7 @@ struct smx_driver_s {
   std::map<u32, std::unique_ptr<Frame>> frames;
   cudaStream_t pre_stream = nullptr;   // depth preprocessing of the next frame
   smx_event run_start = nullptr;
+  smx_event uploaded[4] = {nullptr, nullptr, nullptr, nullptr};   // upload staging: one event per step in flight
   bool overlap = true;
   unsigned long long frame_counter = 0;
 
@@ -52,9 +54,13 @@ struct smx_driver_s {
     // preprocessing runs ahead of the frame loop: it only has to keep up, so it yields to the surfel kernels
     SMX_SHIM_CHECK(smx_stream_create_with_priority(&pre_stream, -1));
     SMX_SHIM_CHECK(smx_event_create(&run_start));
+    for (auto& e : uploaded) SMX_SHIM_CHECK(smx_event_create(&e));
     SMX_SHIM_CHECK(smx_stream_synchronize(nullptr));
   }
-  ~smx_driver_s() { smx_stream_synchronize(pre_stream); smx_stream_destroy(pre_stream); smx_event_destroy(run_start); }
+  ~smx_driver_s() {
+    smx_stream_synchronize(pre_stream); smx_stream_destroy(pre_stream); smx_event_destroy(run_start);
+    for (auto& e : uploaded) smx_event_destroy(e);
+  }
 };
 
 namespace smx { void set_error(const char* fmt, ...); }  // libsmx's thread-local error text (smx_last_error)
@@ -66,6 +72,7 @@ static int preprocess_frame(smx_driver d, cudaStream_t stream, const smx_driver_
   auto it = d->frames.find(st.frame_index);
   if (it == d->frames.end()) return fail("frame not resident");
   CUDABuffer<u16>& depth_buffer = it->second->depth;
+  it->second->last_reader = d->frame_counter;   // (run_one has already counted this step)
   const float* cam = d->camera.parameters();
 
   // Bilateral filtering and depth cutoff (:1015-1024)
@@ -85,6 +92,7 @@ static int preprocess_frame(smx_driver d, cudaStream_t stream, const smx_driver_
       auto o = d->frames.find(st.other_frames[i]);
       if (o == d->frames.end()) return fail("outlier-cull neighbour frame not resident");
       other_depths[i] = &o->second->depth.ToCUDA();
+      o->second->last_reader = d->frame_counter;
       others_TR_reference[i] = CUDAMatrix3x4(st.others_TR_reference[i]);
     }
     const int req = c.outlier_filtering_required_inliers;
@@ -197,6 +205,33 @@ int smx_driver_frame_descs(smx_driver d, uint32_t frame_index, smx_buffer_desc* 
   return SMX_OK;
 }
 
+// One frame of the loop: preprocessing (own stream when overlapping) + Integrate.  `frame_ready`: an event the
+// preprocessing has to wait for first (the frame's upload), or null.
+static int run_one(smx_driver d, smx_stream s, const smx_driver_step& step, smx_event frame_ready) {
+  WorkSet* ws = (d->frame_counter++ & 1) ? &d->work1 : &d->work0;
+  int rc;
+  if (d->overlap) {
+    // preprocessing(f) on its own stream: it may start as soon as Integrate(f-2) has released this work set,
+    // i.e. it overlaps Integrate(f-1); Integrate(f) then waits for it.
+    if (ws->used) SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, ws->integrated));
+    if (frame_ready) SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, frame_ready));
+    rc = preprocess_frame(d, d->pre_stream, step, ws);
+    if (rc != SMX_OK) return rc;
+    SMX_SHIM_CHECK(smx_event_record(ws->preprocessed, d->pre_stream));
+    SMX_SHIM_CHECK(smx_stream_wait_event(s, ws->preprocessed));
+  } else {
+    if (frame_ready) SMX_SHIM_CHECK(smx_stream_wait_event(s, frame_ready));
+    rc = preprocess_frame(d, s, step, ws);
+    if (rc != SMX_OK) return rc;
+  }
+  rc = integrate_frame(d, s, step, ws);
+  if (rc != SMX_OK) return rc;
+  SMX_SHIM_CHECK(smx_event_record(ws->integrated, s));
+  ws->used = true;
+  d->last = ws;
+  return SMX_OK;
+}
+
 int smx_driver_run(smx_driver d, smx_stream s, const smx_driver_step* steps, int32_t n) {
   if (!d || (!steps && n > 0)) return fail("null argument");
   // Everything already enqueued on s (frame uploads / renders, earlier runs) precedes the first preprocessing.
@@ -205,25 +240,46 @@ int smx_driver_run(smx_driver d, smx_stream s, const smx_driver_step* steps, int
     SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, d->run_start));
   }
   for (int i = 0; i < n; ++i) {
-    WorkSet* ws = (d->frame_counter++ & 1) ? &d->work1 : &d->work0;
-    int rc;
-    if (d->overlap) {
-      // preprocessing(f) on its own stream: it may start as soon as Integrate(f-2) has released this work set,
-      // i.e. it overlaps Integrate(f-1); Integrate(f) then waits for it.
-      if (ws->used) SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, ws->integrated));
-      rc = preprocess_frame(d, d->pre_stream, steps[i], ws);
-      if (rc != SMX_OK) return rc;
-      SMX_SHIM_CHECK(smx_event_record(ws->preprocessed, d->pre_stream));
-      SMX_SHIM_CHECK(smx_stream_wait_event(s, ws->preprocessed));
-    } else {
-      rc = preprocess_frame(d, s, steps[i], ws);
+    const int rc = run_one(d, s, steps[i], nullptr);
+    if (rc != SMX_OK) return rc;
+  }
+  return SMX_OK;
+}
+
+int smx_driver_run_streamed(smx_driver d, smx_stream s, smx_stream upload_stream, const smx_driver_step* steps,
+                            const smx_driver_host_frame* uploads, int32_t n) {
+  if (!d || ((!steps || !uploads) && n > 0)) return fail("null argument");
+  if (upload_stream == s) return fail("the upload stream must differ from the frame stream");
+  SMX_SHIM_CHECK(smx_event_record(d->run_start, s));
+  if (d->overlap) SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, d->run_start));
+  SMX_SHIM_CHECK(smx_stream_wait_event(upload_stream, d->run_start));
+  // A copy may overwrite a slot only after the steps that read it: none (a new frame: no wait at all -- the normal
+  // case of a stream), the last enqueued step, or older ones (the other work set's event covers every step before
+  // the last).
+  auto issue_upload = [&](int i) -> int {
+    if (uploads[i].depth == nullptr) return SMX_OK;
+    if (uploads[i].color == nullptr) return fail("upload without a colour image");
+    Frame* f = get_or_make(d, uploads[i].frame_index);
+    if (f->last_reader != 0) {
+      WorkSet* other = (d->last == &d->work0) ? &d->work1 : &d->work0;
+      WorkSet* w = (f->last_reader >= d->frame_counter) ? d->last : other;
+      if (w->used) SMX_SHIM_CHECK(smx_stream_wait_event(upload_stream, w->integrated));
+    }
+    f->depth.UploadAsync(upload_stream, uploads[i].depth);
+    f->color.UploadAsync(upload_stream, reinterpret_cast<const Vec3u8*>(uploads[i].color));
+    SMX_SHIM_CHECK(smx_event_record(d->uploaded[i & 3], upload_stream));
+    return SMX_OK;
+  };
+  int rc = n > 0 ? issue_upload(0) : SMX_OK;
+  if (rc != SMX_OK) return rc;
+  for (int i = 0; i < n; ++i) {
+    if (i + 1 < n) {
+      // one frame ahead (main.cc:905-968): the next copy runs beside this step's kernels
+      rc = issue_upload(i + 1);
       if (rc != SMX_OK) return rc;
     }
-    rc = integrate_frame(d, s, steps[i], ws);
+    rc = run_one(d, s, steps[i], uploads[i].depth ? d->uploaded[i & 3] : nullptr);
     if (rc != SMX_OK) return rc;
-    if (d->overlap) SMX_SHIM_CHECK(smx_event_record(ws->integrated, s));
-    ws->used = true;
-    d->last = ws;
   }
   return SMX_OK;
 }

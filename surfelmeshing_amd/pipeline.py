@@ -166,7 +166,12 @@ class DriverStep(_C.Structure):
 
 DRIVER_EXPORTS = ["smx_driver_create", "smx_driver_destroy", "smx_driver_recon", "smx_driver_upload_frame",
                   "smx_driver_render_frame", "smx_driver_release_frame", "smx_driver_frame_descs", "smx_driver_run",
-                  "smx_driver_work_descs", "smx_driver_download_frame", "smx_driver_download_work", "smx_driver_set_overlap"]
+                  "smx_driver_work_descs", "smx_driver_download_frame", "smx_driver_download_work", "smx_driver_set_overlap",
+                  "smx_driver_run_streamed"]
+
+
+class DriverHostFrame(_C.Structure):
+    _fields_ = [("frame_index", _C.c_uint32), ("depth", _C.c_void_p), ("color", _C.c_void_p)]
 
 
 class _BorrowedRecon(api.CUDASurfelReconstruction):
@@ -256,6 +261,23 @@ class NativeFramePipeline:
 
     def run_array(self, arr, n):
         _smxlib.check(_smxlib.load().smx_driver_run(self._d, self._s(), arr, _C.c_int32(n)))
+
+    def run_streamed(self, steps, uploads, upload_stream):
+        """smx_driver_run_streamed: steps (list of DriverStep), uploads = per step None or (frame_index, depth, color)
+        host arrays -- page-locked (api.PagelockedArray) for copies that overlap the kernels -- which must stay alive
+        until the streams are synchronised."""
+        arr = (DriverStep * len(steps))(*steps)
+        up = (DriverHostFrame * len(steps))()
+        for i, u in enumerate(uploads):
+            if u is None:
+                continue
+            f, d, c = u
+            assert d.dtype == np.uint16 and d.shape == (self.h, self.w) and d.flags.c_contiguous
+            assert c.dtype == np.uint8 and c.shape == (self.h, self.w, 3) and c.flags.c_contiguous
+            up[i].frame_index, up[i].depth, up[i].color = f, d.ctypes.data, c.ctypes.data
+            self.resident.add(f)
+        _smxlib.check(_smxlib.load().smx_driver_run_streamed(self._d, self._s(), api._sv(upload_stream), arr, up,
+                                                            _C.c_int32(len(steps))))
 
     def process(self, frame_index, other_frames, others_TR_reference, global_T_frame):
         self.run([self.make_step(frame_index, other_frames, others_TR_reference, global_T_frame)])

@@ -588,6 +588,63 @@ def test_native_driver_matches_oracle(smx):
         pn.download_frame(10)
 
 
+@pytest.mark.parametrize("overlap", [True, False])
+def test_native_driver_streamed_uploads(smx, overlap):
+    """smx_driver_run_streamed: the frames arrive from (page-locked) host memory on an upload stream, one frame ahead of
+    the frame loop (APP/main.cc:905-984).  Frame f+4 is copied in for the step of frame f -- the first one over a
+    slot that holds zeros, a later round over slots that earlier steps were reading -- and the map equals the oracle's."""
+    from surfelmeshing_amd.pipeline import NativeFramePipeline
+    from surfelmeshing_amd._lib import IntegrateParams
+    s = small_stream(obstacle_until=8)
+    pre = small_pre(s.width)
+    po = OraclePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, 60000, pre)
+    pn = NativeFramePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, 60000, pre, IntegrateParams.defaults())
+    pn.set_overlap(overlap)
+    up = smx.Stream()
+    for f in range(0, 30):
+        d, c = s.frame(f)
+        po.upload(f, d, c)
+        if f < 8:
+            pn.upload(f, d, c)
+    pn.upload(8, np.zeros((s.height, s.width), np.uint16), np.zeros((s.height, s.width, 3), np.uint8))
+    pn.upload(21, *s.frame(21))
+    keep, steps, uploads = [], [], []
+    for f in range(4, 20):
+        others, T, pose = s.outlier_frames(f), s.others_TR_reference(f), s.pose(f)
+        po.process(f, others, T, pose)
+        steps.append(pn.make_step(f, others, T, pose))
+        src = f + 4
+        if f == 17:                                      # frame 21 is resident already: copy frame 13 again instead,
+            src = 13                                     # a slot the steps up to this one read (ordered after them)
+        d, c = s.frame(src)
+        if f % 3 == 0:                                   # pageable memory works too (the copy then blocks the host)
+            hd, hc = np.ascontiguousarray(d), np.ascontiguousarray(c)
+        else:
+            pd, pc = smx.PagelockedArray(d.shape, np.uint16, write_combined=(f % 2 == 0)), smx.PagelockedArray(c.shape, np.uint8)
+            pd.array[...] = d
+            pc.array[...] = c
+            keep += [pd, pc]
+            hd, hc = pd.array, pc.array
+        uploads.append((src, hd, hc))
+    pn.run_streamed(steps[:9], uploads[:9], up)
+    pn.run_streamed(steps[9:], uploads[9:], up)          # a second call continues the stream
+    smx.StreamSynchronize(None)
+    n = po.recon.surfels_size
+    assert pn.reconstruction.surfels_size() == n
+    assert_surfels_match(pn.reconstruction.debug_download_surfels(n), po.recon.surfels(), n)
+    dd, cc = pn.download_frame(8)
+    assert np.array_equal(dd, s.frame(8)[0]) and np.array_equal(cc, s.frame(8)[1])
+    # steps without an upload, and the argument checks
+    others, T, pose = s.outlier_frames(20), s.others_TR_reference(20), s.pose(20)
+    po.process(20, others, T, pose)
+    pn.upload(24, *s.frame(24))
+    pn.run_streamed([pn.make_step(20, others, T, pose)], [None], up)
+    assert_surfels_match(pn.reconstruction.debug_download_surfels(po.recon.surfels_size), po.recon.surfels(), po.recon.surfels_size)
+    with pytest.raises(smx.SmxError):
+        pn.run_streamed([pn.make_step(20, others, T, pose)], [None], None)      # upload stream == frame stream
+    up.close()
+
+
 def test_loop_closure_deformation_hook(smx):
     """The hook the reference describes but does not ship (README.md:152-176, call site main.cc:1194-1200): a rigid
     correction per creation frame, applied between two frames of a stream.  The map right after the deformation and
