@@ -35,6 +35,23 @@ class PreprocessParams:
         return int(np.uint16(min(self.depth_scaling * self.max_depth, 65535.0)))  # main.cc:1021
 
 
+def others_TR_reference(global_T_reference, global_T_others, depth_scaling):
+    """The relative poses of the outlier-cull neighbours as APP/main.cc:1037-1059 forms them: translations scaled to
+    depth units, (reference_scaled_frame_T_global * global_T_other_scaled)^-1, one 3x4 per neighbour (float32).
+    Inputs: 3x4 global_T_frame matrices."""
+    G = np.asarray(global_T_reference, np.float64).reshape(3, 4)
+    Rr, tr = G[:, :3], G[:, 3]
+    out = []
+    for O in global_T_others:
+        O = np.asarray(O, np.float64).reshape(3, 4)
+        Ro, to = O[:, :3], O[:, 3]
+        R = Rr.T @ Ro
+        t = Rr.T @ (to * depth_scaling) - Rr.T @ (tr * depth_scaling)
+        Ri = R.T
+        out.append(np.concatenate([Ri, (-Ri @ t)[:, None]], axis=1))
+    return np.asarray(out, np.float32).reshape(len(out), 3, 4)
+
+
 class FramePipeline:
     def __init__(self, width, height, fx, fy, cx, cy, max_surfel_count, pre=None, params=None, stream=None):
         """width, height and the intrinsics describe the input frames; with pre.pyramid_level > 0 the pipeline works

@@ -694,3 +694,43 @@ def test_loop_closure_deformation_hook(smx):
     rec.DeformByCreationFrame(None, np.zeros((0, 12), np.float32))
     with pytest.raises(ValueError):
         rec.DeformByCreationFrame(None, T, np.zeros(3, np.uint8), 0)
+
+
+def test_export_obj_and_ply_files(smx, tmp_path):
+    """SaveMeshAsOBJ / SavePointCloudAsPLY (APP/main.cc:128-203) from the GPU map: vertices = the live surfels in slot
+    order with the oracle's positions, colours and normals; merged surfels dropped and triangle indices renumbered."""
+    from surfelmeshing_amd import export
+    s = small_stream(obstacle_until=8)
+    po, pg = _pipes(smx, s, 60000)
+    run_both(po, pg, s, list(range(4, 14)), None)
+    rec = pg.reconstruction
+    pos, col = po.recon.export_vertices()
+    pos, col = pos.reshape(-1, 3), col.reshape(-1, 3)
+    live = ~np.isnan(pos[:, 0])
+    n = live.size
+    assert (~live).sum() > 20
+    merged = np.flatnonzero(~live)
+    tris = np.array([[0, 1, 2], [merged[0], 0, 1], [n - 1, n - 2, n - 3], [5, n + 3, 6]], np.int64)
+    obj = str(tmp_path / "mesh.obj")
+    assert export.SaveMeshAsOBJ(rec, obj, None, tris)
+    lines = open(obj).read().splitlines()
+    v = [ln for ln in lines if ln.startswith("v ")]
+    f = [ln for ln in lines if ln.startswith("f ")]
+    assert len(v) == live.sum() and len(v) + len(f) == len(lines)
+    k = np.float32(1) / np.float32(255)
+    for j, i in list(enumerate(np.flatnonzero(live)))[::97]:
+        want = "v " + " ".join("%g" % x for x in list(pos[i]) + list(col[i].astype(np.float32) * k))
+        assert v[j] == want, (i, v[j], want)
+    remap = np.cumsum(live) - 1
+    keep = [t for t in tris if all(0 <= a < n and live[a] for a in t)]
+    assert len(keep) == 2 and f == ["f %d %d %d" % tuple(remap[t] + 1) for t in keep]
+    ply = str(tmp_path / "cloud.ply")
+    assert export.SavePointCloudAsPLY(rec, ply, None, export_colors=True)
+    r = export.read_ply(ply)
+    t = po.recon.transfer_all()
+    assert r.size == live.sum()
+    for name, row in (("x", "x"), ("y", "y"), ("z", "z"), ("nx", "normal_x"), ("ny", "normal_y"), ("nz", "normal_z")):
+        assert np.array_equal(r[name].view(np.uint32), t[row][live].view(np.uint32)), name
+    assert np.array_equal(np.stack([r["red"], r["green"], r["blue"]], 1), col[live])
+    export.SavePointCloudAsPLY(rec, ply)                                  # the reference writes white (main.cc:194)
+    assert np.all(export.read_ply(ply)["green"] == 255)
