@@ -58,17 +58,18 @@ int smx_driver_release_frame(smx_driver d, uint32_t frame_index);
 int smx_driver_frame_descs(smx_driver d, uint32_t frame_index, smx_buffer_desc* depth, smx_buffer_desc* color);
 /* Enqueue n frames (preprocessing + Integrate each) on the stream; returns without synchronising. */
 int smx_driver_run(smx_driver d, smx_stream s, const smx_driver_step* steps, int32_t n);
-/* The same with the frames arriving from host memory, like the reference's caller (APP/main.cc:905-984: page-locked
- * staging buffers, an upload stream, one frame ahead): uploads[i] = a frame (index + dense host images, ideally from
- * smx_host_alloc) that has to be in the frame store before step i reads it, or depth == NULL for none.  The copy for
- * step i+1 is issued on upload_stream before step i's kernels are enqueued, so it runs beside them.  A slot that
- * earlier steps read is overwritten only after those steps have finished; a new frame is copied without waiting. */
+/* The same with the frames arriving from host memory (the reference caller's staging, APP/main.cc:905-984):
+ * uploads[i] = a frame (index + dense host images) that has to be in the frame store before step i reads it, or
+ * depth == NULL for none.  The copy is enqueued on the stream that runs step i's preprocessing, directly in front of
+ * it -- with the overlap on that is the driver's preprocessing stream, so the copy runs beside Integrate(i-1) -- and
+ * is asynchronous to the host for page-locked sources (smx_host_alloc); pageable sources work and block the caller.
+ * A slot that earlier steps read is overwritten only after those steps have finished. */
 typedef struct {
   uint32_t frame_index;
   const uint16_t* depth;   /* [height][width] */
   const uint8_t* color;    /* [height][width][3] */
 } smx_driver_host_frame;
-int smx_driver_run_streamed(smx_driver d, smx_stream s, smx_stream upload_stream, const smx_driver_step* steps,
+int smx_driver_run_streamed(smx_driver d, smx_stream s, const smx_driver_step* steps,
                             const smx_driver_host_frame* uploads, int32_t n);
 /* Overlap of the depth preprocessing of frame f+1 (own stream, second set of work images) with Integrate(f);
  * default on.  Results are identical either way. */

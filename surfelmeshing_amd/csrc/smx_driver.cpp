@@ -44,7 +44,6 @@ struct smx_driver_s {
   std::map<u32, std::unique_ptr<Frame>> frames;
   cudaStream_t pre_stream = nullptr;   // depth preprocessing of the next frame
   smx_event run_start = nullptr;
-  smx_event uploaded[4] = {nullptr, nullptr, nullptr, nullptr};   // upload staging: one event per step in flight
   bool overlap = true;
   unsigned long long frame_counter = 0;
 
@@ -54,13 +53,9 @@ struct smx_driver_s {
     // preprocessing runs ahead of the frame loop: it only has to keep up, so it yields to the surfel kernels
     SMX_SHIM_CHECK(smx_stream_create_with_priority(&pre_stream, -1));
     SMX_SHIM_CHECK(smx_event_create(&run_start));
-    for (auto& e : uploaded) SMX_SHIM_CHECK(smx_event_create(&e));
     SMX_SHIM_CHECK(smx_stream_synchronize(nullptr));
   }
-  ~smx_driver_s() {
-    smx_stream_synchronize(pre_stream); smx_stream_destroy(pre_stream); smx_event_destroy(run_start);
-    for (auto& e : uploaded) smx_event_destroy(e);
-  }
+  ~smx_driver_s() { smx_stream_synchronize(pre_stream); smx_stream_destroy(pre_stream); smx_event_destroy(run_start); }
 };
 
 namespace smx { void set_error(const char* fmt, ...); }  // libsmx's thread-local error text (smx_last_error)
@@ -205,22 +200,45 @@ int smx_driver_frame_descs(smx_driver d, uint32_t frame_index, smx_buffer_desc* 
   return SMX_OK;
 }
 
-// One frame of the loop: preprocessing (own stream when overlapping) + Integrate.  `frame_ready`: an event the
-// preprocessing has to wait for first (the frame's upload), or null.
-static int run_one(smx_driver d, smx_stream s, const smx_driver_step& step, smx_event frame_ready) {
-  WorkSet* ws = (d->frame_counter++ & 1) ? &d->work1 : &d->work0;
+// Copy of one host frame into the frame store, on the stream whose next kernels read it.  (Not on a stream of its
+// own: a copy-engine write followed by a kernel in the SAME stream gets the cache invalidation it needs, while a
+// cross-stream event wait that finds the event already complete is dropped by the runtime together with it --
+// measured: frames copied on a separate upload stream one step ahead were read stale from L2 now and then.)
+// A slot that steps still in flight read is overwritten only after the last of them has finished.
+static int upload_on(smx_driver d, cudaStream_t stream, const smx_driver_host_frame& u) {
+  if (u.depth == nullptr) return SMX_OK;
+  if (u.color == nullptr) return fail("upload without a colour image");
+  Frame* f = get_or_make(d, u.frame_index);
+  if (f->last_reader != 0) {
+    // readers: the last enqueued step (its event), or older ones (the other work set's event covers every step
+    // before the last)
+    WorkSet* other = (d->last == &d->work0) ? &d->work1 : &d->work0;
+    WorkSet* w = (f->last_reader >= d->frame_counter) ? d->last : other;
+    if (w->used) SMX_SHIM_CHECK(smx_stream_wait_event(stream, w->integrated));
+  }
+  f->depth.UploadAsync(stream, u.depth);
+  f->color.UploadAsync(stream, reinterpret_cast<const Vec3u8*>(u.color));
+  return SMX_OK;
+}
+
+// One frame of the loop: [copy of a frame that arrives with this step] + preprocessing (own stream when
+// overlapping) + Integrate.
+static int run_one(smx_driver d, smx_stream s, const smx_driver_step& step, const smx_driver_host_frame* arriving) {
   int rc;
+  if (arriving) {
+    rc = upload_on(d, d->overlap ? d->pre_stream : (cudaStream_t)s, *arriving);
+    if (rc != SMX_OK) return rc;
+  }
+  WorkSet* ws = (d->frame_counter++ & 1) ? &d->work1 : &d->work0;
   if (d->overlap) {
     // preprocessing(f) on its own stream: it may start as soon as Integrate(f-2) has released this work set,
     // i.e. it overlaps Integrate(f-1); Integrate(f) then waits for it.
     if (ws->used) SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, ws->integrated));
-    if (frame_ready) SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, frame_ready));
     rc = preprocess_frame(d, d->pre_stream, step, ws);
     if (rc != SMX_OK) return rc;
     SMX_SHIM_CHECK(smx_event_record(ws->preprocessed, d->pre_stream));
     SMX_SHIM_CHECK(smx_stream_wait_event(s, ws->preprocessed));
   } else {
-    if (frame_ready) SMX_SHIM_CHECK(smx_stream_wait_event(s, frame_ready));
     rc = preprocess_frame(d, s, step, ws);
     if (rc != SMX_OK) return rc;
   }
@@ -246,39 +264,15 @@ int smx_driver_run(smx_driver d, smx_stream s, const smx_driver_step* steps, int
   return SMX_OK;
 }
 
-int smx_driver_run_streamed(smx_driver d, smx_stream s, smx_stream upload_stream, const smx_driver_step* steps,
+int smx_driver_run_streamed(smx_driver d, smx_stream s, const smx_driver_step* steps,
                             const smx_driver_host_frame* uploads, int32_t n) {
   if (!d || ((!steps || !uploads) && n > 0)) return fail("null argument");
-  if (upload_stream == s) return fail("the upload stream must differ from the frame stream");
-  SMX_SHIM_CHECK(smx_event_record(d->run_start, s));
-  if (d->overlap) SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, d->run_start));
-  SMX_SHIM_CHECK(smx_stream_wait_event(upload_stream, d->run_start));
-  // A copy may overwrite a slot only after the steps that read it: none (a new frame: no wait at all -- the normal
-  // case of a stream), the last enqueued step, or older ones (the other work set's event covers every step before
-  // the last).
-  auto issue_upload = [&](int i) -> int {
-    if (uploads[i].depth == nullptr) return SMX_OK;
-    if (uploads[i].color == nullptr) return fail("upload without a colour image");
-    Frame* f = get_or_make(d, uploads[i].frame_index);
-    if (f->last_reader != 0) {
-      WorkSet* other = (d->last == &d->work0) ? &d->work1 : &d->work0;
-      WorkSet* w = (f->last_reader >= d->frame_counter) ? d->last : other;
-      if (w->used) SMX_SHIM_CHECK(smx_stream_wait_event(upload_stream, w->integrated));
-    }
-    f->depth.UploadAsync(upload_stream, uploads[i].depth);
-    f->color.UploadAsync(upload_stream, reinterpret_cast<const Vec3u8*>(uploads[i].color));
-    SMX_SHIM_CHECK(smx_event_record(d->uploaded[i & 3], upload_stream));
-    return SMX_OK;
-  };
-  int rc = n > 0 ? issue_upload(0) : SMX_OK;
-  if (rc != SMX_OK) return rc;
+  if (d->overlap) {
+    SMX_SHIM_CHECK(smx_event_record(d->run_start, s));
+    SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, d->run_start));
+  }
   for (int i = 0; i < n; ++i) {
-    if (i + 1 < n) {
-      // one frame ahead (main.cc:905-968): the next copy runs beside this step's kernels
-      rc = issue_upload(i + 1);
-      if (rc != SMX_OK) return rc;
-    }
-    rc = run_one(d, s, steps[i], uploads[i].depth ? d->uploaded[i & 3] : nullptr);
+    const int rc = run_one(d, s, steps[i], &uploads[i]);
     if (rc != SMX_OK) return rc;
   }
   return SMX_OK;

@@ -279,7 +279,7 @@ class NativeFramePipeline:
     def run_array(self, arr, n):
         _smxlib.check(_smxlib.load().smx_driver_run(self._d, self._s(), arr, _C.c_int32(n)))
 
-    def run_streamed(self, steps, uploads, upload_stream):
+    def run_streamed(self, steps, uploads):
         """smx_driver_run_streamed: steps (list of DriverStep), uploads = per step None or (frame_index, depth, color)
         host arrays -- page-locked (api.PagelockedArray) for copies that overlap the kernels -- which must stay alive
         until the streams are synchronised."""
@@ -293,7 +293,7 @@ class NativeFramePipeline:
             assert c.dtype == np.uint8 and c.shape == (self.h, self.w, 3) and c.flags.c_contiguous
             up[i].frame_index, up[i].depth, up[i].color = f, d.ctypes.data, c.ctypes.data
             self.resident.add(f)
-        _smxlib.check(_smxlib.load().smx_driver_run_streamed(self._d, self._s(), api._sv(upload_stream), arr, up,
+        _smxlib.check(_smxlib.load().smx_driver_run_streamed(self._d, self._s(), arr, up,
                                                             _C.c_int32(len(steps))))
 
     def process(self, frame_index, other_frames, others_TR_reference, global_T_frame):

@@ -590,9 +590,9 @@ def test_native_driver_matches_oracle(smx):
 
 @pytest.mark.parametrize("overlap", [True, False])
 def test_native_driver_streamed_uploads(smx, overlap):
-    """smx_driver_run_streamed: the frames arrive from (page-locked) host memory on an upload stream, one frame ahead of
-    the frame loop (APP/main.cc:905-984).  Frame f+4 is copied in for the step of frame f -- the first one over a
-    slot that holds zeros, a later round over slots that earlier steps were reading -- and the map equals the oracle's."""
+    """smx_driver_run_streamed: the frames arrive from (page-locked) host memory with the frame loop
+    (APP/main.cc:905-984).  Frame f+4 is copied in for the step of frame f -- the first one over a slot that holds
+    zeros, one over a slot that the steps in flight read -- and the map equals the oracle's."""
     from surfelmeshing_amd.pipeline import NativeFramePipeline
     from surfelmeshing_amd._lib import IntegrateParams
     s = small_stream(obstacle_until=8)
@@ -600,7 +600,6 @@ def test_native_driver_streamed_uploads(smx, overlap):
     po = OraclePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, 60000, pre)
     pn = NativeFramePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, 60000, pre, IntegrateParams.defaults())
     pn.set_overlap(overlap)
-    up = smx.Stream()
     for f in range(0, 30):
         d, c = s.frame(f)
         po.upload(f, d, c)
@@ -620,14 +619,14 @@ def test_native_driver_streamed_uploads(smx, overlap):
         if f % 3 == 0:                                   # pageable memory works too (the copy then blocks the host)
             hd, hc = np.ascontiguousarray(d), np.ascontiguousarray(c)
         else:
-            pd, pc = smx.PagelockedArray(d.shape, np.uint16, write_combined=(f % 2 == 0)), smx.PagelockedArray(c.shape, np.uint8)
+            pd, pc = smx.PagelockedArray(d.shape, np.uint16, write_combined=(f % 4 == 1)), smx.PagelockedArray(c.shape, np.uint8)
             pd.array[...] = d
             pc.array[...] = c
             keep += [pd, pc]
             hd, hc = pd.array, pc.array
         uploads.append((src, hd, hc))
-    pn.run_streamed(steps[:9], uploads[:9], up)
-    pn.run_streamed(steps[9:], uploads[9:], up)          # a second call continues the stream
+    pn.run_streamed(steps[:9], uploads[:9])
+    pn.run_streamed(steps[9:], uploads[9:])          # a second call continues the stream
     smx.StreamSynchronize(None)
     n = po.recon.surfels_size
     assert pn.reconstruction.surfels_size() == n
@@ -638,11 +637,8 @@ def test_native_driver_streamed_uploads(smx, overlap):
     others, T, pose = s.outlier_frames(20), s.others_TR_reference(20), s.pose(20)
     po.process(20, others, T, pose)
     pn.upload(24, *s.frame(24))
-    pn.run_streamed([pn.make_step(20, others, T, pose)], [None], up)
+    pn.run_streamed([pn.make_step(20, others, T, pose)], [None])
     assert_surfels_match(pn.reconstruction.debug_download_surfels(po.recon.surfels_size), po.recon.surfels(), po.recon.surfels_size)
-    with pytest.raises(smx.SmxError):
-        pn.run_streamed([pn.make_step(20, others, T, pose)], [None], None)      # upload stream == frame stream
-    up.close()
 
 
 def test_loop_closure_deformation_hook(smx):
