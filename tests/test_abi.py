@@ -6,8 +6,8 @@ import re
 from common import ROOT
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "smx.h")).read()
+def _declared_symbols(header="smx.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(smx_[a-z0-9_]+)\s*\(", text)))
 
@@ -22,6 +22,11 @@ def test_header_symbols_are_exported():
     assert not missing, missing
     # the Python binding lists exactly the header's functions
     assert sorted(_lib.EXPORTS) == declared
+    # the native frame driver (include/smx_driver.h) lives in the same library
+    from surfelmeshing_amd.pipeline import DRIVER_EXPORTS
+    driver = _declared_symbols("smx_driver.h")
+    assert len(driver) >= 13 and not [s for s in driver if not hasattr(lib, s)]
+    assert sorted(DRIVER_EXPORTS) == driver
 
 
 def test_integrate_params_layout_matches_oracle_and_header():
@@ -52,13 +57,15 @@ def test_headers_are_plain_c_and_pod_sizes_match(tmp_path):
     src = tmp_path / "abi_probe.c"
     src.write_text(
         '#include <stdio.h>\n#include "smx.h"\n#include "smx_driver.h"\n'
-        'int main(void) { printf("%zu %zu %zu %zu %zu\\n", sizeof(smx_buffer_desc), sizeof(smx_integrate_params),\n'
-        '  sizeof(smx_surfel_buffers_cpu), sizeof(smx_recon_stats), sizeof(smx_driver_config)); return 0; }\n')
+        'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(smx_buffer_desc), sizeof(smx_integrate_params),\n'
+        '  sizeof(smx_surfel_buffers_cpu), sizeof(smx_recon_stats), sizeof(smx_driver_config), sizeof(smx_driver_step),\n'
+        '  sizeof(smx_driver_host_frame), sizeof(smx_surfel_delta_cpu)); return 0; }\n')
     exe = tmp_path / "abi_probe"
     subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
                    check=True)
     sizes = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
-    from surfelmeshing_amd._lib import BufferDesc, IntegrateParams, ReconStats, SurfelBuffersCPU
-    from surfelmeshing_amd.pipeline import DriverConfig
+    from surfelmeshing_amd._lib import BufferDesc, IntegrateParams, ReconStats, SurfelBuffersCPU, SurfelDeltaCPU
+    from surfelmeshing_amd.pipeline import DriverConfig, DriverHostFrame, DriverStep
     assert sizes == [ctypes.sizeof(BufferDesc), ctypes.sizeof(IntegrateParams), ctypes.sizeof(SurfelBuffersCPU),
-                     ctypes.sizeof(ReconStats), ctypes.sizeof(DriverConfig)]
+                     ctypes.sizeof(ReconStats), ctypes.sizeof(DriverConfig), ctypes.sizeof(DriverStep),
+                     ctypes.sizeof(DriverHostFrame), ctypes.sizeof(SurfelDeltaCPU)]
