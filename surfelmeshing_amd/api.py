@@ -56,30 +56,37 @@ class Stream:
             self.handle = C.c_void_p()
 
 
-class PagelockedArray:
-    """Page-locked host memory as a numpy array (cudaHostAlloc in the reference's upload staging,
-    APP/main.cc:825-829, 917): uploads from `.array` are asynchronous to the host.  Keep the object alive while
-    copies are in flight."""
+class _PagelockedBlock:
+    """Owner of one smx_host_alloc block; numpy arrays made from it keep it alive (it is their base object)."""
 
-    def __init__(self, shape, dtype, write_combined=False):
+    def __init__(self, nbytes, write_combined):
         self._p = C.c_void_p()
-        self.dtype = np.dtype(dtype)
-        n = int(np.prod(shape)) * self.dtype.itemsize
-        _lib.check(_lib.load().smx_host_alloc(C.byref(self._p), C.c_size_t(max(n, 1)), C.c_int32(1 if write_combined else 0)))
-        buf = (C.c_char * n).from_address(self._p.value)
-        self.array = np.frombuffer(buf, dtype=self.dtype).reshape(shape)
-
-    def close(self):
-        if getattr(self, "_p", None):
-            self.array = None
-            _lib.load().smx_host_free(self._p)
-            self._p = C.c_void_p()
+        _lib.check(_lib.load().smx_host_alloc(C.byref(self._p), C.c_size_t(max(nbytes, 1)),
+                                              C.c_int32(1 if write_combined else 0)))
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (self._p.value, False), "version": 3}
 
     def __del__(self):
         try:
-            self.close()
+            if self._p:
+                _lib.load().smx_host_free(self._p)
+                self._p = C.c_void_p()
         except Exception:
             pass
+
+
+class PagelockedArray:
+    """Page-locked host memory as a numpy array (cudaHostAlloc in the reference's upload staging,
+    APP/main.cc:825-829, 917): uploads from `.array` are asynchronous to the host.  The memory lives as long as this
+    object or any view of `.array` does; keep one of them until the copies that read it have finished."""
+
+    def __init__(self, shape, dtype, write_combined=False):
+        self.dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * self.dtype.itemsize
+        self.array = np.asarray(_PagelockedBlock(n, write_combined)).view(self.dtype).reshape(shape)
+
+    def close(self):
+        """Drop this object's reference (the block is freed once no view is left)."""
+        self.array = None
 
 
 def _sv(stream):
