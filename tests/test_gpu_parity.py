@@ -730,3 +730,45 @@ def test_export_obj_and_ply_files(smx, tmp_path):
     assert np.array_equal(np.stack([r["red"], r["green"], r["blue"]], 1), col[live])
     export.SavePointCloudAsPLY(rec, ply)                                  # the reference writes white (main.cc:194)
     assert np.all(export.read_ply(ply)["green"] == 255)
+
+
+def test_tum_dataset_through_the_pipeline(smx, tmp_path):
+    """Input side end to end: a TUM-format folder (PNG files, associated.txt, calibration.txt, a
+    trajectory sampled between the frames) read by surfelmeshing_amd.tum, fed to the GPU pipeline and to the oracle
+    with the reader's interpolated poses and the caller-side relative poses of APP/main.cc:1037-1059."""
+    from scipy.spatial.transform import Rotation
+    from surfelmeshing_amd import tum
+    from surfelmeshing_amd.pipeline import FramePipeline, others_TR_reference
+    from surfelmeshing_amd._lib import IntegrateParams
+    s = small_stream(obstacle_until=6)
+    n = 16
+    stamps = [50.0 + f / 30.0 for f in range(n)]
+    traj = []
+    for k in range(-1, 2 * n + 1):                                         # poses at twice the frame rate, offset
+        t = 50.0 + (k + 0.37) / 60.0
+        T = np.asarray(s.pose64(k / 2.0 + 0.37 / 2.0)[0]), np.asarray(s.pose64(k / 2.0 + 0.37 / 2.0)[1])
+        traj.append((t, T[1], Rotation.from_matrix(T[0]).as_quat()))
+    folder = str(tmp_path / "seq")
+    tum.write_tum_dataset(folder, [s.frame(f) for f in range(n)], stamps, (s.fx, s.fy, s.cx - 0.5, s.cy - 0.5), traj)
+    video = tum.ReadTUMRGBDDatasetAssociatedAndCalibrated(folder, "groundtruth.txt")
+    assert video.frame_count() == n
+    cam = video.depth_camera
+    fx, fy, cx, cy = cam.parameters()
+    pre = small_pre(cam.width())
+    po = OraclePipeline(cam.width(), cam.height(), fx, fy, cx, cy, 60000, pre)
+    pg = FramePipeline(cam.width(), cam.height(), fx, fy, cx, cy, 60000, pre, IntegrateParams.defaults())
+    for f in range(n):
+        d, c = video.depth_frame(f).GetImage(), video.color_frame(f).GetImage()
+        assert np.array_equal(d, s.frame(f)[0])
+        po.upload(f, d, c)
+        pg.upload(f, d, c)
+    for f in range(4, n - 4):
+        others = [f - k for k in range(1, 5)] + [f + k for k in range(1, 5)]
+        G = video.depth_frame(f).global_T_frame()
+        assert np.allclose(G[:, :3] @ G[:, :3].T, np.eye(3), atol=1e-6)
+        assert np.allclose(G, np.asarray(s.pose(f)).reshape(3, 4), atol=2e-3)        # interpolated, close to the true pose
+        T = others_TR_reference(G, [video.depth_frame(g).global_T_frame() for g in others], pre.depth_scaling)
+        po.process(f, others, T, G)
+        pg.process(f, others, T, G)
+        _compare_state(po, pg)
+    assert po.recon.surfels_size > 5000
