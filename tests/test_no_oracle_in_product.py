@@ -27,3 +27,14 @@ def test_library_does_not_link_the_oracle():
     assert "oracle" not in out
     syms = subprocess.run(["nm", "-D", so], capture_output=True, text=True).stdout
     assert "orc_" not in syms
+
+
+def test_tools_do_not_use_the_oracle():
+    """Development tools outside tests/ stay on the product path; checker-side utilities live in tests/tools/."""
+    offenders = []
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith((".py", ".sh")):
+            text = open(os.path.join(ROOT, "tools", f), errors="ignore").read()
+            if re.search(r"^\s*(import oracle|from oracle)|oracle_pipeline|ref_binding", text, flags=re.M):
+                offenders.append(f)
+    assert not offenders, offenders

@@ -2,7 +2,7 @@
 timed on this GPU at the bench's C2 state: the surfel map grown by the product (5 M slots) is handed to the reference's
 kernels, which then integrate the same preprocessed frames.  Device time per Integrate (clears .. regulariser, the
 reference's launch sequence with its two host round trips), no preprocessing.  A baseline for BASELINE.md, not part of
-bench.py.      python tools/ref_bench.py [frames]
+bench.py.      python tests/tools/ref_bench.py [frames]
 """
 import sys, time
 n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 20

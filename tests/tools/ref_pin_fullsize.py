@@ -1,7 +1,7 @@
 """The reference pin of tests/test_gpu_reference_pin.py at the bench's size: the 5 M-slot map grown by the product
 (640x480) is handed to the reference's own kernels (oracle/_ref) and to the CPU oracle; per frame, both start from the
 same state, the oracle gets the reference run's race outcomes imposed, and everything is compared.
-      python tools/ref_pin_fullsize.py [frames]"""
+      python tests/tools/ref_pin_fullsize.py [frames]"""
 import sys, time
 n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 sys.argv = ['bench.py']
