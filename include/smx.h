@@ -178,12 +178,21 @@ typedef struct {
   uint32_t* surfel_last_update_stamp_buffer;
 } smx_surfel_buffers_cpu;
 
-/* ctor, .h:47-53 / .cc:44-91 (the three GL resources and the render window are dropped) */
+/* ctor, .h:47-53 / .cc:44-91 (the three GL resources and the render window are dropped).
+ * device_id: the HIP device the object lives on, -1 = the calling thread's current device.  The object remembers
+ * it: every smx_recon_* call makes it current for its duration (and restores the caller's device), so one process
+ * can hold one object per GPU and call them from one thread each -- or from one thread -- without smx_set_device
+ * in between.  Streams and buffers passed to a call must belong to the object's device. */
 int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
-                     float fx, float fy, float cx, float cy, smx_recon* out);
+                     float fx, float fy, float cx, float cy, int32_t device_id, smx_recon* out);
 int smx_recon_destroy(smx_recon r);
 /* Integrate, .h:59-77 / .cc:112-320.  depth is MUTATED by blending as in the
- * reference; global_T_local is row-major 3x4 (SE3f::matrix3x4()). */
+ * reference; global_T_local is row-major 3x4 (SE3f::matrix3x4()).
+ * frame_index must not decrease from call to call (the reference's caller counts frames up, APP/main.cc:1015;
+ * stamps are compared with it in windows, kernels.cu:77-87, 2132): pass A keeps, per 1024-slot segment, the newest
+ * stamp it has seen and skips segments whose stamps have left the regulariser window, which presumes that time
+ * moves forward.  A call with a smaller frame_index than the previous one is rejected (SMX_ERR_INVALID_ARGUMENT).
+ * measurement_blending_radius is only read (and range-checked, 2..255) when do_blending != 0. */
 int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float depth_scaling,
                         const smx_buffer_desc* depth /*u16*/, const smx_buffer_desc* normals /*float2*/,
                         const smx_buffer_desc* radius /*float*/, const smx_buffer_desc* color /*uchar3*/,
@@ -254,6 +263,11 @@ typedef struct {
   uint32_t n_window_edges;    /* neighbour links whose target lies inside the regulariser window */
   uint32_t n_contributors;    /* slots with at least one such link */
   uint32_t n_segments_skipped;  /* 1024-slot segments pass A did not have to read (out of view, unchanged) */
+  uint32_t regularizer_saturated;  /* sticky since creation / state upload: a regulariser gradient term reached the
+                                    * +-16 m range of the exact fixed-point sums, or one slot collected >= 100 senders
+                                    * of one neighbour-count class; smooth positions may then deviate from the
+                                    * reference.  Terms are 2 * regularizer_weight / count * (n . d) * n: with
+                                    * neighbour distances of centimetres any weight below ~100 is far inside. */
 } smx_recon_stats;
 int smx_recon_get_stats(smx_recon r, smx_stream s, smx_recon_stats* out);
 /* The n_* counters above are single-address atomics; they are collected only while enabled
@@ -292,7 +306,8 @@ int smx_recon_set_overlap(smx_recon r, int32_t enabled);
 /* Build a uniform-grid index over n points given as three device or host rows.
  * cell_size > 0; queries with radius <= cell_size touch at most 27 cells.  Points with a non-finite coordinate
  * are not indexed (no finite ball contains them). */
-int smx_nn_create(smx_nn* out);
+/* device_id as in smx_recon_create; the index owns its workspace and reuses it from call to call. */
+int smx_nn_create(int32_t device_id, smx_nn* out);
 int smx_nn_destroy(smx_nn nn);
 int smx_nn_build(smx_nn nn, smx_stream s, const float* x, const float* y, const float* z,
                  uint32_t n, float cell_size, int32_t rows_on_device);

@@ -44,13 +44,77 @@ typedef smx_stream cudaStream_t;  // a hipStream_t
 struct float2_ { float x, y; };
 struct Vec3u8 { u8 v[3]; };
 
-// Row-major 3x4 rigid transform.  The reference builds it from Sophus' SE3f::matrix3x4().
+// Row-major 3x4 rigid transform (host part of VIS/cuda/cuda_matrix.cuh:67-116).  As in the reference it is
+// constructible from ANY matrix type with (row, col) element access -- the call sites hand it an Eigen 3x4 from
+// Sophus' SE3f::matrix3x4() (APP/main.cc:1051, 1057) -- so those lines compile unchanged; the storage order of the
+// source type does not matter.  The float-pointer constructor (12 row-major floats) is an addition.
 struct CUDAMatrix3x4 {
   float m[12];
   CUDAMatrix3x4() {}
   explicit CUDAMatrix3x4(const float* row_major_3x4) { for (int i = 0; i < 12; ++i) m[i] = row_major_3x4[i]; }
+  template <typename T, typename = decltype(static_cast<float>(std::declval<const T&>()(0, 0)))>
+  explicit CUDAMatrix3x4(const T& matrix) {
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) m[4 * r + c] = static_cast<float>(matrix(r, c));
+  }
 };
-typedef CUDAMatrix3x4 SE3f;  // the hot path only ever needs matrix3x4() (and inverse(), done inside libsmx)
+
+#ifndef SMX_SHIM_NO_SE3F
+// Stand-in for libvis' SE3f (= Sophus::SE3f, VIS/libvis.h) for callers that build without Sophus / Eigen: the members
+// the hot path's call sites use (APP/main.cc:1039-1059, 1205-1223) -- matrix3x4(), inverse(), operator*, translation().
+// Inside the reference tree define SMX_SHIM_NO_SE3F and keep Sophus: Integrate() below accepts any pose type that
+// has matrix3x4().
+struct Vec3f_ {
+  float v[3];
+  float& operator()(int i) { return v[i]; }
+  float operator()(int i) const { return v[i]; }
+};
+inline Vec3f_ operator*(float s, const Vec3f_& a) { return Vec3f_{{s * a.v[0], s * a.v[1], s * a.v[2]}}; }
+struct Matrix3x4f_ {
+  float m[12];  // row-major
+  float operator()(int r, int c) const { return m[4 * r + c]; }
+};
+class SE3f {
+ public:
+  SE3f() : R_{1, 0, 0, 0, 1, 0, 0, 0, 1}, t_{{0, 0, 0}} {}
+  explicit SE3f(const float* row_major_3x4) {
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) R_[3 * r + c] = row_major_3x4[4 * r + c];
+      t_.v[r] = row_major_3x4[4 * r + 3];
+    }
+  }
+  Matrix3x4f_ matrix3x4() const {
+    Matrix3x4f_ o;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) o.m[4 * r + c] = R_[3 * r + c];
+      o.m[4 * r + 3] = t_.v[r];
+    }
+    return o;
+  }
+  SE3f inverse() const {  // R^T, -(R^T t)
+    SE3f o;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) o.R_[3 * r + c] = R_[3 * c + r];
+      o.t_.v[r] = -(R_[0 + r] * t_.v[0] + R_[3 + r] * t_.v[1] + R_[6 + r] * t_.v[2]);
+    }
+    return o;
+  }
+  SE3f operator*(const SE3f& b) const {
+    SE3f o;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c)
+        o.R_[3 * r + c] = R_[3 * r] * b.R_[c] + R_[3 * r + 1] * b.R_[3 + c] + R_[3 * r + 2] * b.R_[6 + c];
+      o.t_.v[r] = R_[3 * r] * b.t_.v[0] + R_[3 * r + 1] * b.t_.v[1] + R_[3 * r + 2] * b.t_.v[2] + t_.v[r];
+    }
+    return o;
+  }
+  Vec3f_& translation() { return t_; }
+  const Vec3f_& translation() const { return t_; }
+ private:
+  float R_[9];
+  Vec3f_ t_;
+};
+#endif  // SMX_SHIM_NO_SE3F
 
 // Accessors of VIS/camera.h's PinholeCamera4f that the hot path uses.
 class PinholeCamera4f {
@@ -268,18 +332,22 @@ class CUDASurfelReconstruction {
  public:
   // The three cudaGraphicsResource_t arguments and the render window of the reference's constructor are
   // viewer plumbing (OpenGL interop); pass nullptr.
+  // device_id (an addition): the GPU the object lives on, -1 = the calling thread's current device (as in the reference).
   CUDASurfelReconstruction(usize max_surfel_count, const PinholeCamera4f& depth_camera, void* = nullptr,
-                           void* = nullptr, void* = nullptr, void* = nullptr) {
+                           void* = nullptr, void* = nullptr, void* = nullptr, int device_id = -1) {
     const float* p = depth_camera.parameters();
     SMX_SHIM_CHECK(smx_recon_create((uint32_t)max_surfel_count, depth_camera.width(), depth_camera.height(), p[0], p[1],
-                                    p[2], p[3], &handle_));
+                                    p[2], p[3], device_id, &handle_));
   }
   CUDASurfelReconstruction(const CUDASurfelReconstruction&) = delete;
   ~CUDASurfelReconstruction() { SMX_SHIM_CHECK(smx_recon_destroy(handle_)); }
 
+  // Pose: any type with matrix3x4() returning something with (row, col) access -- Sophus::SE3f in the reference
+  // (.h:59-77; the reference takes its inverse() on the host, cc:144: done inside libsmx here) or the SE3f above.
+  template <typename Pose>
   void Integrate(cudaStream_t stream, u32 frame_index, float depth_scaling, CUDABuffer<u16>* depth_buffer,
                  const CUDABuffer<float2_>& normals_buffer, const CUDABuffer<float>& radius_buffer,
-                 const CUDABuffer<Vec3u8>& color_buffer, const SE3f& global_T_local, float sensor_noise_factor,
+                 const CUDABuffer<Vec3u8>& color_buffer, const Pose& global_T_local, float sensor_noise_factor,
                  float max_surfel_confidence, float regularizer_weight, int regularization_frame_window_size,
                  bool do_blending, int measurement_blending_radius,
                  int regularization_iterations_per_integration_iteration,
@@ -297,9 +365,10 @@ class CUDASurfelReconstruction {
     p.normal_compatibility_threshold_deg = normal_compatibility_threshold_deg;
     p.surfel_integration_active_window_size = surfel_integration_active_window_size;
     last_stream_ = stream;
+    const CUDAMatrix3x4 global_T_local_3x4(global_T_local.matrix3x4());
     SMX_SHIM_CHECK(smx_recon_integrate(handle_, stream, frame_index, depth_scaling, depth_buffer->ToCUDA().desc(),
                                        normals_buffer.ToCUDA().desc(), radius_buffer.ToCUDA().desc(),
-                                       color_buffer.ToCUDA().desc(), global_T_local.m, &p));
+                                       color_buffer.ToCUDA().desc(), global_T_local_3x4.m, &p));
   }
   void Regularize(cudaStream_t stream, u32 frame_index, float regularizer_weight,
                   float radius_factor_for_regularization_neighbors, int regularization_frame_window_size) {
@@ -364,7 +433,7 @@ class CUDASurfelReconstruction {
 // host arrays, result_counts [query_count]; order: ascending (distance^2, index).
 class SurfelNeighborIndex {
  public:
-  SurfelNeighborIndex() { SMX_SHIM_CHECK(smx_nn_create(&handle_)); }
+  explicit SurfelNeighborIndex(int device_id = -1) { SMX_SHIM_CHECK(smx_nn_create(device_id, &handle_)); }
   SurfelNeighborIndex(const SurfelNeighborIndex&) = delete;
   ~SurfelNeighborIndex() { SMX_SHIM_CHECK(smx_nn_destroy(handle_)); }
   // From three host rows (e.g. CUDASurfelBuffersCPU::surfel_{x,y,z}_buffer).

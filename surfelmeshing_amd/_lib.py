@@ -64,7 +64,7 @@ class ReconStats(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in
                 ("surfels_size", "merge_count", "n_visible", "n_new", "n_merged", "n_recent", "n_edges",
                  "n_integrated", "n_replaced", "n_conflict_hits", "capacity_clamped", "n_window_edges", "n_contributors",
-                 "n_segments_skipped")]
+                 "n_segments_skipped", "regularizer_saturated")]
 
 
 # every symbol include/smx.h declares (tests/test_abi.py checks the .so exports them all)

@@ -387,7 +387,9 @@ class PinholeCamera4f:
 
 class CUDASurfelReconstruction:
     def __init__(self, max_surfel_count, depth_camera, vertex_buffer_resource=None,
-                 neighbor_index_buffer_resource=None, normal_vertex_buffer_resource=None, render_window=None):
+                 neighbor_index_buffer_resource=None, normal_vertex_buffer_resource=None, render_window=None,
+                 device_id=-1):
+        """device_id (not in the reference's constructor): the GPU the object lives on, -1 = the current device."""
         _lib.require_gpu()
         self.max_surfel_count = int(max_surfel_count)
         self.depth_camera = depth_camera
@@ -395,7 +397,7 @@ class CUDASurfelReconstruction:
         self._h = C.c_void_p()
         _lib.check(_lib.load().smx_recon_create(C.c_uint32(self.max_surfel_count), depth_camera.width(),
                                                 depth_camera.height(), C.c_float(fx), C.c_float(fy), C.c_float(cx),
-                                                C.c_float(cy), C.byref(self._h)))
+                                                C.c_float(cy), C.c_int32(device_id), C.byref(self._h)))
         self._last_stream = None
 
     def Integrate(self, stream, frame_index, depth_scaling, depth_buffer, normals_buffer, radius_buffer, color_buffer,
@@ -583,10 +585,10 @@ class SurfelNeighborIndex:
     """Batched replacement of CompressedOctree::FindNearestSurfelsWithinRadius (APP/octree.h:470-477):
     uniform-grid index rebuilt from the surfel position rows, queried for many positions at once."""
 
-    def __init__(self):
+    def __init__(self, device_id=-1):
         _lib.require_gpu()
         self._h = C.c_void_p()
-        _lib.check(_lib.load().smx_nn_create(C.byref(self._h)))
+        _lib.check(_lib.load().smx_nn_create(C.c_int32(device_id), C.byref(self._h)))
 
     def Build(self, x, y, z, cell_size, stream=None):
         x, y, z = (np.ascontiguousarray(a, np.float32) for a in (x, y, z))

@@ -47,6 +47,49 @@ void set_error(const char* fmt, ...);
     }                                                                                  \
   } while (0)
 
+// Objects (smx_recon, smx_nn) remember the device they were created on and make it the calling thread's current
+// device for the duration of every entry point, so that one process can drive one object per GPU from one thread
+// per GPU -- or from a single thread -- without calling smx_set_device between the calls.  The
+// previous device is restored on return.
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceScope(int device) {
+    if (device < 0) return;
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != device) {
+      err = hipSetDevice(device);
+      switched = (err == hipSuccess);
+    }
+  }
+  ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+  DeviceScope(const DeviceScope&) = delete;
+};
+#define SMX_ON_DEVICE(device)                                                          \
+  ::smx::DeviceScope smx_device_scope__(device);                                       \
+  do {                                                                                 \
+    if (smx_device_scope__.err != hipSuccess) {                                        \
+      ::smx::set_error("cannot select device %d: %s", (int)(device), hipGetErrorString(smx_device_scope__.err)); \
+      return SMX_ERR_HIP;                                                              \
+    }                                                                                  \
+  } while (0)
+
+// device_id argument of the create functions: -1 = the calling thread's current device
+inline int resolve_device(int32_t device_id, int* out) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    (void)hipGetLastError();
+    set_error("no HIP device available");
+    return SMX_ERR_NO_DEVICE;
+  }
+  int dev = device_id;
+  if (dev < 0) SMX_HIP(hipGetDevice(&dev));
+  if (dev >= ndev) { set_error("device_id %d out of range (%d devices)", dev, ndev); return SMX_ERR_INVALID_ARGUMENT; }
+  *out = dev;
+  return SMX_OK;
+}
+
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
 
 // Typed view of smx_buffer_desc for kernels (same layout as CUDABuffer_<T>).

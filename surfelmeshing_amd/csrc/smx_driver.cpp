@@ -64,8 +64,13 @@ static int fail(const char* msg) { smx::set_error("smx_driver: %s", msg); return
 // Depth preprocessing of one frame, APP/main.cc:1015-1191.
 static int preprocess_frame(smx_driver d, cudaStream_t stream, const smx_driver_step& st, WorkSet* ws) {
   const smx_driver_config& c = d->cfg;
+  // validated before any array below is indexed and before any frame is stamped (main.cc:1084 rejects the same values)
+  if (st.other_count != 0 && st.other_count != 2 && st.other_count != 4 && st.other_count != 6 && st.other_count != 8)
+    return fail("Unsupported value for outlier_filtering_frame_count");
   auto it = d->frames.find(st.frame_index);
   if (it == d->frames.end()) return fail("frame not resident");
+  for (int i = 0; i < st.other_count; ++i)
+    if (d->frames.find(st.other_frames[i]) == d->frames.end()) return fail("outlier-cull neighbour frame not resident");
   CUDABuffer<u16>& depth_buffer = it->second->depth;
   it->second->last_reader = d->frame_counter;   // (run_one has already counted this step)
   const float* cam = d->camera.parameters();

@@ -219,6 +219,7 @@ k_query(uint32_t nq, const float* __restrict__ qx, const float* __restrict__ qy,
 }  // namespace
 
 struct smx_nn_s {
+  int device;
   uint32_t n;
   Grid grid;
   size_t ncell;
@@ -257,16 +258,20 @@ void nn_free(smx_nn nn) {
 
 extern "C" {
 
-int smx_nn_create(smx_nn* out) {
+int smx_nn_create(int32_t device_id, smx_nn* out) {
   SMX_CHECK_ARG(out != nullptr);
+  int device = 0;
+  { const int rcd = resolve_device(device_id, &device); if (rcd != SMX_OK) return rcd; }
   smx_nn_s* nn = new smx_nn_s();
   memset(nn, 0, sizeof(*nn));
+  nn->device = device;
   *out = nn;
   return SMX_OK;
 }
 
 int smx_nn_destroy(smx_nn nn) {
   if (!nn) return SMX_OK;
+  SMX_ON_DEVICE(nn->device);
   nn_free(nn);
   delete nn;
   return SMX_OK;
@@ -275,6 +280,7 @@ int smx_nn_destroy(smx_nn nn) {
 int smx_nn_build(smx_nn nn, smx_stream s, const float* x, const float* y, const float* z, uint32_t n,
                  float cell_size, int32_t rows_on_device) {
   SMX_CHECK_ARG(nn != nullptr && cell_size > 0 && (n == 0 || (x && y && z)));
+  SMX_ON_DEVICE(nn->device);
   hipStream_t st = (hipStream_t)s;
   nn_free(nn);
   nn->n = n;
@@ -342,6 +348,7 @@ int smx_nn_query_batch(smx_nn nn, smx_stream s, uint32_t nq, const float* qx, co
                        const float* r2, int32_t k, const uint8_t* state, uint8_t skip_mask, int32_t queries_on_device,
                        uint32_t* out_idx, float* out_d2, int32_t* out_count, int32_t outputs_on_device) {
   SMX_CHECK_ARG(nn != nullptr && k >= 1 && k <= 64);
+  SMX_ON_DEVICE(nn->device);
   SMX_CHECK_ARG(nq == 0 || (qx && qy && qz && r2 && out_idx && out_d2 && out_count));
   if (nq == 0) return SMX_OK;
   hipStream_t st = (hipStream_t)s;

@@ -53,6 +53,7 @@ struct DevState {
   uint32_t n_visible, n_merged, n_edges, n_integrated, n_replaced, n_conflict_hits;
   uint32_t n_window_edges, n_contributors;
   uint32_t n_segments_skipped;
+  uint32_t reg_saturated;  // sticky: a regulariser term hit the +-16 m clamp or a sender-class counter came near its byte
 };
 
 // HBM layout of the surfel attributes.  The reference keeps 25 separate rows (SoA, kernels.cuh:49-78); that is
@@ -1249,7 +1250,7 @@ __global__ void __launch_bounds__(kBlockAcc)
 k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ grad_acc,
                  long long* __restrict__ grad_local, float4* __restrict__ inbox,
                  const uint8_t* __restrict__ inwin8, const uint8_t* __restrict__ flags8,
-                 const uint32_t* __restrict__ need_seg, const DevState* st, uint32_t epoch) {
+                 const uint32_t* __restrict__ need_seg, DevState* st, uint32_t epoch) {
   __shared__ unsigned long long lacc[kSegAcc * 2];  // per target: (gx | gy), (gz | sender classes)
   const uint32_t N = st->surfel_count;
   const uint32_t base = blockIdx.x * kSegAcc;
@@ -1306,6 +1307,9 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
       if (mask & (1u << q)) {
         const float f = factor * nd;
         const float4 term = make_float4(f * nrm.x, f * nrm.y, f * nrm.z, wk);
+        // the fixed-point channel carries |component| < 16 m (q22_from_float clamps): a huge regularizer_weight or a
+        // corrupt position is reported instead of silently bending the gradient
+        if (!(fabsf(term.x) < 16.0f && fabsf(term.y) < 16.0f && fabsf(term.z) < 16.0f)) st->reg_saturated = 1u;
         // the exclusive inbox slot is only usable if this source has ONE in-window edge to that target
         bool once = true;
 #pragma unroll
@@ -1365,7 +1369,7 @@ k_rebuild_flags(Surfels S, uint32_t frame, int reg_window, uint8_t* __restrict__
 // RegularizeSurfelsCUDAKernel, kernels.cu:2197-2290, over the recent list.
 __global__ void __launch_bounds__(kBlock)
 k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long* __restrict__ grad_local,
-           const float4* __restrict__ inbox, Lists L, const DevState* st, uint32_t epoch) {
+           const float4* __restrict__ inbox, Lists L, DevState* st, uint32_t epoch) {
   const uint32_t n_slots = st->surfel_count, n_chunks = (n_slots + kBlock - 1) / kBlock;
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     uint32_t i;
@@ -1396,6 +1400,9 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long*
       sum[0] += q22_from_float(ins[k].x); sum[1] += q22_from_float(ins[k].y); sum[2] += q22_from_float(ins[k].z);
       senders[((code & 7u) - 1u) & 3u] += 1u;
     }
+    // the packed class counters are bytes (the top one signed): far more senders than any real map produces, but a
+    // count near the limit may already have carried -- reported, never silent
+    if (senders[0] >= 100u || senders[1] >= 100u || senders[2] >= 100u || senders[3] >= 100u) st->reg_saturated = 1u;
     // sum over the senders of weight / (sender's neighbour count) (:2182), exact: per class, count x 2^-32 quotient
     long long wsum_q = 0;
 #pragma unroll
@@ -1670,6 +1677,7 @@ k_global_ranks(const uint32_t* __restrict__ local_rank, const uint32_t* __restri
 
 // =============================================================================================
 struct smx_recon_s {
+  int device;               // the HIP device the object lives on (every entry point runs on it)
   uint32_t max_surfels;
   int W, H;
   float fx, fy, cx, cy;
@@ -1711,6 +1719,8 @@ struct smx_recon_s {
   uint32_t* delta_total;
   float* staging;    // row-layout staging for the boundary conversions (TransferAllToCPU, debug rows)
   size_t staging_floats;
+  hipEvent_t ev_staging;  // recorded after the last enqueued read of `staging`: TransferAllToCPU returns with its
+  bool staging_busy;      // row downloads in flight, and the next user may come on another stream
   int grid_surfels;  // persistent grid for the grid-stride all-slot kernels
   int grid_list;     // persistent grid of the chunked list kernels
   uint32_t reg_epoch = 0;  // regulariser calls so far (stamps the inbox slots)
@@ -1723,6 +1733,8 @@ struct smx_recon_s {
   hipEvent_t ev_mid, ev_reg, ev_front;
   bool reg_pending;
   uint8_t* flags_buf[2];    // the flag table is double-buffered by frame (L.flags8 = the current frame's)
+  bool have_frame;          // an Integrate call has been made since creation / the last state upload
+  uint32_t last_frame;      // its frame_index: the segment culling of pass A presumes that it never decreases
 };
 
 // kernel slots of one Integrate call (launch order)
@@ -1754,10 +1766,9 @@ namespace {
 
 // Orders stream st after the regulariser that may still run on the internal stream.
 int join_regularizer(smx_recon r, hipStream_t st) {
-  if (r->reg_pending) {
-    SMX_HIP(hipStreamWaitEvent(st, r->ev_reg, 0));
-    r->reg_pending = false;
-  }
+  // (the flag stays set: a later call may come with another stream, which has to be ordered as well; waiting on a
+  // completed event costs nothing on the device)
+  if (r->reg_pending) SMX_HIP(hipStreamWaitEvent(st, r->ev_reg, 0));
   return SMX_OK;
 }
 
@@ -1810,6 +1821,17 @@ int ensure_staging(smx_recon r, size_t floats) {
   return SMX_OK;
 }
 
+// Every user of the shared staging buffer first orders its stream after the previous user's last read.
+int acquire_staging(smx_recon r, hipStream_t st, size_t floats) {
+  if (r->staging_busy) SMX_HIP(hipStreamWaitEvent(st, r->ev_staging, 0));
+  return ensure_staging(r, floats);
+}
+int release_staging(smx_recon r, hipStream_t st) {
+  SMX_HIP(hipEventRecord(r->ev_staging, st));
+  r->staging_busy = true;
+  return SMX_OK;
+}
+
 template <typename T>
 int dev_alloc(T** p, size_t count, bool zero) {
   SMX_HIP(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
@@ -1822,17 +1844,15 @@ int dev_alloc(T** p, size_t count, bool zero) {
 extern "C" {
 
 int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
-                     float fx, float fy, float cx, float cy, smx_recon* out) {
+                     float fx, float fy, float cx, float cy, int32_t device_id, smx_recon* out) {
   SMX_CHECK_ARG(out != nullptr && max_surfel_count > 0 && max_surfel_count < 0x7FFFFFFFu);
   SMX_CHECK_ARG(width >= 3 && height >= 3);
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
-    (void)hipGetLastError();
-    set_error("no HIP device available");
-    return SMX_ERR_NO_DEVICE;
-  }
+  int device = 0;
+  { const int rcd = resolve_device(device_id, &device); if (rcd != SMX_OK) return rcd; }
+  SMX_ON_DEVICE(device);
   smx_recon_s* r = new smx_recon_s();
   memset(r, 0, sizeof(*r));
+  r->device = device;
   r->max_surfels = max_surfel_count;
   r->W = width; r->H = height; r->fx = fx; r->fy = fy; r->cx = cx; r->cy = cy;
   r->S.pitch = ((size_t)max_surfel_count + 63) / 64 * 64;
@@ -1886,13 +1906,12 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_HIP(hipEventCreateWithFlags(&r->ev_front, hipEventDisableTiming));
   SMX_HIP(hipEventCreateWithFlags(&r->ev_mid, hipEventDisableTiming));
   SMX_HIP(hipEventCreateWithFlags(&r->ev_reg, hipEventDisableTiming));
+  SMX_HIP(hipEventCreateWithFlags(&r->ev_staging, hipEventDisableTiming));
   r->overlap_enabled = 1;
   r->prof_slot = -1;
   r->timing_enabled = 1;
   hipDeviceProp_t prop;
-  int dev = 0;
-  SMX_HIP(hipGetDevice(&dev));
-  SMX_HIP(hipGetDeviceProperties(&prop, dev));
+  SMX_HIP(hipGetDeviceProperties(&prop, device));
   const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   r->grid_surfels = cus * 8;  // 8 x 256-thread workgroups per CU: full occupancy, >> 256 workgroups
   r->grid_list = cus * 32;  // the lists are sparse: most chunks are empty, so more, shorter walks
@@ -1903,6 +1922,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
 
 int smx_recon_destroy(smx_recon r) {
   if (!r) return SMX_OK;
+  SMX_ON_DEVICE(r->device);
   void* ptrs[] = {r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->flags_buf[0], r->flags_buf[1],
                   r->merge_flag, r->inwin8, r->need_seg, r->sc.supporting, r->sc.counts,
                   r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth, r->bb.distance_map, r->bb.new_distance_map,
@@ -1911,6 +1931,7 @@ int smx_recon_destroy(smx_recon r) {
   if (r->ev_front) (void)hipEventDestroy(r->ev_front);
   if (r->ev_mid) (void)hipEventDestroy(r->ev_mid);
   if (r->ev_reg) (void)hipEventDestroy(r->ev_reg);
+  if (r->ev_staging) (void)hipEventDestroy(r->ev_staging);
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int i = 0; i < 14; ++i) if (r->ev[i]) (void)hipEventDestroy(r->ev[i]);
   for (int i = 0; i < 2 * 16; ++i) if (r->kev[i]) (void)hipEventDestroy(r->kev[i]);
@@ -1921,6 +1942,7 @@ int smx_recon_destroy(smx_recon r) {
 
 int smx_recon_set_timing_enabled(smx_recon r, int32_t enabled) {
   SMX_CHECK_ARG(r != nullptr && enabled >= 0 && enabled <= 3);
+  SMX_ON_DEVICE(r->device);
   r->timing_enabled = enabled;
   return SMX_OK;
 }
@@ -1930,6 +1952,7 @@ const char* smx_recon_kernel_slot_name(int32_t slot) { return (slot >= 0 && slot
 
 int smx_recon_get_kernel_timings(smx_recon r, float* out_ms, int32_t capacity) {
   SMX_CHECK_ARG(r != nullptr && out_ms != nullptr && capacity >= kSlotCount);
+  SMX_ON_DEVICE(r->device);
   for (int i = 0; i < kSlotCount; ++i) {
     out_ms[i] = 0;
     if (!r->kev_recorded[i]) continue;
@@ -1941,6 +1964,7 @@ int smx_recon_get_kernel_timings(smx_recon r, float* out_ms, int32_t capacity) {
 
 int smx_recon_profile_begin(smx_recon r, int32_t slot, int32_t max_frames) {
   SMX_CHECK_ARG(r != nullptr && slot >= 0 && slot < kSlotCount && max_frames > 0);
+  SMX_ON_DEVICE(r->device);
   if (r->prof_ev) { for (int i = 0; i < 2 * r->prof_cap; ++i) (void)hipEventDestroy(r->prof_ev[i]); delete[] r->prof_ev; }
   r->prof_ev = new hipEvent_t[2 * max_frames];
   for (int i = 0; i < 2 * max_frames; ++i) SMX_HIP(hipEventCreate(&r->prof_ev[i]));
@@ -1950,6 +1974,7 @@ int smx_recon_profile_begin(smx_recon r, int32_t slot, int32_t max_frames) {
 
 int smx_recon_profile_end(smx_recon r, float* avg_ms, int32_t* frames) {
   SMX_CHECK_ARG(r != nullptr && avg_ms != nullptr && frames != nullptr);
+  SMX_ON_DEVICE(r->device);
   double sum = 0;
   for (int i = 0; i < r->prof_n; ++i) {
     float ms = 0;
@@ -1965,12 +1990,14 @@ int smx_recon_profile_end(smx_recon r, float* avg_ms, int32_t* frames) {
 
 int smx_recon_set_stats_enabled(smx_recon r, int32_t enabled) {
   SMX_CHECK_ARG(r != nullptr);
+  SMX_ON_DEVICE(r->device);
   r->stats_enabled = enabled ? 1 : 0;
   return SMX_OK;
 }
 
 int smx_recon_set_overlap(smx_recon r, int32_t enabled) {
   SMX_CHECK_ARG(r != nullptr && (enabled == 0 || enabled == 1));
+  SMX_ON_DEVICE(r->device);
   if (r->reg_pending) { SMX_HIP(hipStreamSynchronize(r->reg_stream)); r->reg_pending = false; }
   r->overlap_enabled = enabled;
   return SMX_OK;
@@ -1978,6 +2005,7 @@ int smx_recon_set_overlap(smx_recon r, int32_t enabled) {
 
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
   SMX_CHECK_ARG(r != nullptr && mode >= 0 && mode <= 3);
+  SMX_ON_DEVICE(r->device);
   r->scan_mode = mode & 1;
   r->blend_multi_launch = (mode >> 1) & 1;
   return SMX_OK;
@@ -1988,9 +2016,16 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
                         const smx_buffer_desc* radius, const smx_buffer_desc* color,
                         const float global_T_local[12], const smx_integrate_params* p) {
   SMX_CHECK_ARG(r && depth && normals && radius && color && global_T_local && p);
+  SMX_ON_DEVICE(r->device);
   SMX_CHECK_ARG(depth->width == r->W && depth->height == r->H && normals->width == r->W && normals->height == r->H);
   SMX_CHECK_ARG(radius->width == r->W && radius->height == r->H && color->width == r->W && color->height == r->H);
-  SMX_CHECK_ARG(p->measurement_blending_radius >= 2 && p->measurement_blending_radius <= 255);
+  // (the radius is only read when blending is on: do_blending is an independent flag, APP/main.cc:348-354)
+  SMX_CHECK_ARG(!p->do_blending || (p->measurement_blending_radius >= 2 && p->measurement_blending_radius <= 255));
+  if (r->have_frame && (int32_t)(frame_index - r->last_frame) < 0) {
+    set_error("frame_index %u after %u: Integrate must be called with non-decreasing frame indices", frame_index, r->last_frame);
+    return SMX_ERR_INVALID_ARGUMENT;
+  }
+  r->have_frame = true; r->last_frame = frame_index;
   hipStream_t st = (hipStream_t)s;
   FrameCtx c;
   memcpy(c.G.m, global_T_local, sizeof(float) * 12);
@@ -2118,6 +2153,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
 int smx_recon_regularize(smx_recon r, smx_stream s, uint32_t frame_index, float regularizer_weight,
                          float radius_factor_for_regularization_neighbors, int32_t regularization_frame_window_size) {
   SMX_CHECK_ARG(r != nullptr);
+  SMX_ON_DEVICE(r->device);
   { const int rcj = join_regularizer(r, (hipStream_t)s); if (rcj != SMX_OK) return rcj; }
   return enqueue_regularize(r, (hipStream_t)s, frame_index, radius_factor_for_regularization_neighbors,
                             regularizer_weight, regularization_frame_window_size, false, false);
@@ -2125,6 +2161,7 @@ int smx_recon_regularize(smx_recon r, smx_stream s, uint32_t frame_index, float 
 
 int smx_recon_counts(smx_recon r, smx_stream s, uint32_t* surfel_count, uint32_t* surfels_size) {
   SMX_CHECK_ARG(r != nullptr);
+  SMX_ON_DEVICE(r->device);
   { const int rcj = join_regularizer(r, (hipStream_t)s); if (rcj != SMX_OK) return rcj; }
   DevState h;
   SMX_HIP(hipMemcpyAsync(&h, r->st, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)s));
@@ -2136,6 +2173,7 @@ int smx_recon_counts(smx_recon r, smx_stream s, uint32_t* surfel_count, uint32_t
 
 int smx_recon_get_stats(smx_recon r, smx_stream s, smx_recon_stats* out) {
   SMX_CHECK_ARG(r != nullptr && out != nullptr);
+  SMX_ON_DEVICE(r->device);
   { const int rcj = join_regularizer(r, (hipStream_t)s); if (rcj != SMX_OK) return rcj; }
   DevState h;
   SMX_HIP(hipMemcpyAsync(&h, r->st, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)s));
@@ -2147,11 +2185,13 @@ int smx_recon_get_stats(smx_recon r, smx_stream s, smx_recon_stats* out) {
   out->capacity_clamped = h.capacity_clamped;
   out->n_window_edges = h.n_window_edges; out->n_contributors = h.n_contributors;
   out->n_segments_skipped = h.n_segments_skipped;
+  out->regularizer_saturated = h.reg_saturated;
   return SMX_OK;
 }
 
 int smx_recon_transfer_all_to_cpu(smx_recon r, smx_stream s, uint32_t frame_index, smx_surfel_buffers_cpu* buf) {
   SMX_CHECK_ARG(r != nullptr && buf != nullptr);
+  SMX_ON_DEVICE(r->device);
   { const int rcj = join_regularizer(r, (hipStream_t)s); if (rcj != SMX_OK) return rcj; }
   hipStream_t st = (hipStream_t)s;
   uint32_t n = 0;
@@ -2162,7 +2202,7 @@ int smx_recon_transfer_all_to_cpu(smx_recon r, smx_stream s, uint32_t frame_inde
   if (n == 0) return SMX_OK;
   const size_t bytes = (size_t)n * 4;
   // the 8 rows are packed out of the grouped records into a row-layout staging buffer, then copied row by row
-  int rc = ensure_staging(r, (size_t)8 * n);
+  int rc = acquire_staging(r, st, (size_t)8 * n);
   if (rc != SMX_OK) return rc;
   RowList rl;
   rl.n = 8;
@@ -2181,11 +2221,12 @@ int smx_recon_transfer_all_to_cpu(smx_recon r, smx_stream s, uint32_t frame_inde
     SMX_HIP(hipMemcpyAsync(q.dst, r->staging + (size_t)k * n, bytes, hipMemcpyDeviceToHost, st));
     ++k;
   }
-  return SMX_OK;
+  return release_staging(r, st);  // (the copies are still in flight: the caller synchronises, main.cc:1266-1267)
 }
 
 int smx_recon_set_delta_tracking(smx_recon r, smx_stream s, int32_t enabled) {
   SMX_CHECK_ARG(r != nullptr && (enabled == 0 || enabled == 1));
+  SMX_ON_DEVICE(r->device);
   hipStream_t st = (hipStream_t)s;
   { const int rcj = join_regularizer(r, st); if (rcj != SMX_OK) return rcj; }
   SMX_HIP(hipStreamSynchronize(st));  // no kernel may be using the pointer that changes here
@@ -2204,6 +2245,7 @@ int smx_recon_set_delta_tracking(smx_recon r, smx_stream s, int32_t enabled) {
 
 int smx_recon_transfer_changed_to_cpu(smx_recon r, smx_stream s, uint32_t frame_index, smx_surfel_delta_cpu* d) {
   SMX_CHECK_ARG(r != nullptr && d != nullptr);
+  SMX_ON_DEVICE(r->device);
   if (!r->L.dirty8) { set_error("delta tracking is off (smx_recon_set_delta_tracking)"); return SMX_ERR_INVALID_ARGUMENT; }
   hipStream_t st = (hipStream_t)s;
   { const int rcj = join_regularizer(r, st); if (rcj != SMX_OK) return rcj; }
@@ -2224,7 +2266,7 @@ int smx_recon_transfer_changed_to_cpu(smx_recon r, smx_stream s, uint32_t frame_
   if (total == 0) return SMX_OK;
   SMX_CHECK_ARG(d->surfel_index && d->x && d->y && d->z && d->radius_squared && d->normal_x && d->normal_y &&
                 d->normal_z && d->last_update_stamp);
-  int rc = ensure_staging(r, (size_t)9 * total);
+  int rc = acquire_staging(r, st, (size_t)9 * total);
   if (rc != SMX_OK) return rc;
   hipLaunchKernelGGL(k_delta_gather, dim3(r->nseg), dim3(kBlock), 0, st, r->S, r->L.dirty8, r->delta_seg, r->staging, total,
                      r->st);
@@ -2240,6 +2282,7 @@ int smx_recon_transfer_changed_to_cpu(smx_recon r, smx_stream s, uint32_t frame_
 int smx_recon_export_vertices(smx_recon r, smx_stream s, const smx_buffer_desc* position_buffer,
                               const smx_buffer_desc* color_buffer) {
   SMX_CHECK_ARG(r && position_buffer && color_buffer);
+  SMX_ON_DEVICE(r->device);
   { const int rcj = join_regularizer(r, (hipStream_t)s); if (rcj != SMX_OK) return rcj; }
   hipLaunchKernelGGL(k_export, dim3(r->grid_surfels), dim3(kBlock), 0, (hipStream_t)s, r->S,
                      (float*)position_buffer->address, (uint8_t*)color_buffer->address, r->st);
@@ -2249,17 +2292,20 @@ int smx_recon_export_vertices(smx_recon r, smx_stream s, const smx_buffer_desc* 
 
 int smx_recon_build_neighbor_index(smx_recon r, smx_stream s, smx_nn nn, float cell_size) {
   SMX_CHECK_ARG(r != nullptr && nn != nullptr && cell_size > 0);
+  SMX_ON_DEVICE(r->device);
   hipStream_t st = (hipStream_t)s;
   { const int rcj = join_regularizer(r, st); if (rcj != SMX_OK) return rcj; }
   uint32_t n = 0;
   SMX_HIP(hipMemcpyAsync(&n, &r->st->surfel_count, sizeof(n), hipMemcpyDeviceToHost, st));
   SMX_HIP(hipStreamSynchronize(st));
   if (n == 0) return smx_nn_build(nn, s, nullptr, nullptr, nullptr, 0, cell_size, 1);
-  int rc = ensure_staging(r, (size_t)3 * n);
+  int rc = acquire_staging(r, st, (size_t)3 * n);
   if (rc != SMX_OK) return rc;
   hipLaunchKernelGGL(k_index_rows, dim3(r->grid_surfels), dim3(kBlock), 0, st, r->S, r->staging, n);
   SMX_LAUNCH_CHECK();
-  return smx_nn_build(nn, s, r->staging, r->staging + n, r->staging + (size_t)2 * n, n, cell_size, 1);
+  rc = smx_nn_build(nn, s, r->staging, r->staging + n, r->staging + (size_t)2 * n, n, cell_size, 1);
+  if (rc != SMX_OK) return rc;
+  return release_staging(r, st);
 }
 
 int smx_recon_neighbor_candidates(smx_recon r, smx_stream s, smx_nn nn, const uint32_t* surfel_indices,
@@ -2267,6 +2313,7 @@ int smx_recon_neighbor_candidates(smx_recon r, smx_stream s, smx_nn nn, const ui
                                   const uint8_t* state, uint8_t skip_mask, int32_t inputs_on_device,
                                   uint32_t* out_idx, float* out_d2, int32_t* out_count, int32_t outputs_on_device) {
   SMX_CHECK_ARG(r != nullptr && nn != nullptr && radius_factor_squared >= 0 && k >= 1 && k <= 64);
+  SMX_ON_DEVICE(r->device);
   SMX_CHECK_ARG(n_indices == 0 || (surfel_indices && out_idx && out_d2 && out_count));
   if (n_indices == 0) return SMX_OK;
   hipStream_t st = (hipStream_t)s;
@@ -2312,6 +2359,7 @@ int smx_recon_neighbor_candidates(smx_recon r, smx_stream s, smx_nn nn, const ui
 int smx_recon_check_triangles(smx_recon r, smx_stream s, const uint32_t* triangles, uint32_t n_triangles,
                               float long_edge_total_factor_squared, uint8_t* flags, int32_t on_device) {
   SMX_CHECK_ARG(r != nullptr && (n_triangles == 0 || (triangles && flags)));
+  SMX_ON_DEVICE(r->device);
   if (n_triangles == 0) return SMX_OK;
   hipStream_t st = (hipStream_t)s;
   { const int rcj = join_regularizer(r, st); if (rcj != SMX_OK) return rcj; }
@@ -2342,6 +2390,7 @@ int smx_recon_check_triangles(smx_recon r, smx_stream s, const uint32_t* triangl
 
 int smx_recon_get_timings(smx_recon r, float out_ms[7]) {
   SMX_CHECK_ARG(r != nullptr && out_ms != nullptr);
+  SMX_ON_DEVICE(r->device);
   if (!r->have_timings) { for (int i = 0; i < 7; ++i) out_ms[i] = 0; return SMX_OK; }
   SMX_HIP(hipEventSynchronize(r->ev[13]));  // cc:420
   for (int i = 0; i < 7; ++i) SMX_HIP(hipEventElapsedTime(&out_ms[i], r->ev[2 * i], r->ev[2 * i + 1]));
@@ -2350,9 +2399,10 @@ int smx_recon_get_timings(smx_recon r, float out_ms[7]) {
 
 int smx_recon_debug_download_surfels(smx_recon r, smx_stream s, float* rows, uint32_t count) {
   SMX_CHECK_ARG(r != nullptr && rows != nullptr && count <= r->max_surfels);
+  SMX_ON_DEVICE(r->device);
   if (count == 0) return SMX_OK;
   { const int rcj = join_regularizer(r, (hipStream_t)s); if (rcj != SMX_OK) return rcj; }
-  int rc = ensure_staging(r, (size_t)kRows * count);
+  int rc = acquire_staging(r, (hipStream_t)s, (size_t)kRows * count);
   if (rc != SMX_OK) return rc;
   RowList rl;
   rl.n = kRows;
@@ -2373,15 +2423,17 @@ static int invalidate_derived(smx_recon r, hipStream_t st) {
   hipLaunchKernelGGL(k_rebuild_flags, dim3(r->grid_surfels), dim3(kBlock), 0, st, r->S, 0u, 0x7FFFFFFF, r->L.flags8, r->st);
   SMX_LAUNCH_CHECK();
   r->table_valid = false;
+  r->have_frame = false;  // (the boxes are gone, so any frame index may follow)
   return SMX_OK;
 }
 
 int smx_recon_debug_upload_surfels(smx_recon r, smx_stream s, const float* rows, uint32_t count, uint32_t merge_count) {
   SMX_CHECK_ARG(r != nullptr && count <= r->max_surfels && (rows != nullptr || count == 0));
+  SMX_ON_DEVICE(r->device);
   { const int rcj = join_regularizer(r, (hipStream_t)s); if (rcj != SMX_OK) return rcj; }
   hipStream_t st = (hipStream_t)s;
   if (count) {
-    int rc = ensure_staging(r, (size_t)kRows * count);
+    int rc = acquire_staging(r, st, (size_t)kRows * count);
     if (rc != SMX_OK) return rc;
     SMX_HIP(hipMemcpyAsync(r->staging, rows, (size_t)kRows * count * 4, hipMemcpyHostToDevice, st));
     RowList rl;
@@ -2407,6 +2459,7 @@ int smx_recon_debug_upload_surfels(smx_recon r, smx_stream s, const float* rows,
 int smx_recon_deform_by_creation_frame(smx_recon r, smx_stream s, const float* frame_T, uint32_t n_frames,
                                        const uint8_t* reactivate, uint32_t frame_index, int32_t inputs_on_device) {
   SMX_CHECK_ARG(r != nullptr && (n_frames == 0 || frame_T != nullptr));
+  SMX_ON_DEVICE(r->device);
   if (n_frames == 0) return SMX_OK;
   hipStream_t st = (hipStream_t)s;
   { const int rcj = join_regularizer(r, st); if (rcj != SMX_OK) return rcj; }
@@ -2441,6 +2494,7 @@ int smx_recon_deform_by_creation_frame(smx_recon r, smx_stream s, const float* f
 
 int smx_recon_debug_download_scratch(smx_recon r, smx_stream s, int32_t which, void* dst) {
   SMX_CHECK_ARG(r != nullptr && dst != nullptr);
+  SMX_ON_DEVICE(r->device);
   { const int rcj = join_regularizer(r, (hipStream_t)s); if (rcj != SMX_OK) return rcj; }
   hipStream_t st = (hipStream_t)s;
   const size_t P = (size_t)r->W * r->H;

@@ -10,6 +10,86 @@ SRC = r'''
 #include "smx_shim.hpp"
 using namespace vis;
 
+// A pose type shaped like Sophus::SE3f over Eigen (column-major storage, (row, col) access, matrix3x4(), inverse(),
+// operator*, translation()): what the reference's call sites hand to CUDAMatrix3x4 and Integrate.  The shim has to take
+// it as it is (VIS/cuda/cuda_matrix.cuh:67-116, APP/cuda_surfel_reconstruction.h:59-77).
+namespace sophus_like {
+struct Mat34 {                       // Eigen::Matrix<float, 3, 4>: column-major
+  float d[12];
+  float operator()(int r, int c) const { return d[3 * c + r]; }
+  float& operator()(int r, int c) { return d[3 * c + r]; }
+};
+struct Vec3 { float d[3]; };
+inline Vec3 operator*(float s, const Vec3& v) { return Vec3{{s * v.d[0], s * v.d[1], s * v.d[2]}}; }
+struct SE3 {
+  Mat34 M;
+  SE3() { for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) M(r, c) = (r == c) ? 1.f : 0.f; }
+  Mat34 matrix3x4() const { return M; }
+  SE3 inverse() const {
+    SE3 o;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) o.M(r, c) = M(c, r);
+      o.M(r, 3) = -(M(0, r) * M(0, 3) + M(1, r) * M(1, 3) + M(2, r) * M(2, 3));
+    }
+    return o;
+  }
+  SE3 operator*(const SE3& b) const {
+    SE3 o;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c)
+        o.M(r, c) = M(r, 0) * b.M(0, c) + M(r, 1) * b.M(1, c) + M(r, 2) * b.M(2, c) + (c == 3 ? M(r, 3) : 0.f);
+    return o;
+  }
+  Vec3& translation() { return *reinterpret_cast<Vec3*>(&M.d[9]); }
+};
+}  // namespace sophus_like
+
+// the reference's pose handling around the outlier cull and Integrate (APP/main.cc:1039-1059, 1205-1223), token for token
+// apart from the container, once with the Sophus-shaped type and once with the shim's own SE3f
+template <typename Pose>
+void poses_like_main_cc(cudaStream_t stream, CUDASurfelReconstruction& reconstruction, CUDABuffer<u16>* depth,
+                        CUDABuffer<float2_>& normals_buffer, CUDABuffer<float>& radius_buffer,
+                        CUDABuffer<Vec3u8>& color_buffer, Pose frame_T_global, Pose global_T_other, float depth_scaling) {
+  Pose input_depth_frame_scaled_frame_T_global = frame_T_global;
+  input_depth_frame_scaled_frame_T_global.translation() = depth_scaling * input_depth_frame_scaled_frame_T_global.translation();
+  std::vector<Pose> global_TR_others(8);
+  std::vector<CUDAMatrix3x4> others_TR_reference(8);
+  for (int i = 0; i < 8; ++i) {
+    global_TR_others[i] = global_T_other;
+    global_TR_others[i].translation() = depth_scaling * global_TR_others[i].translation();
+    others_TR_reference[i] = CUDAMatrix3x4((input_depth_frame_scaled_frame_T_global * global_TR_others[i]).inverse().matrix3x4());
+  }
+  reconstruction.Integrate(stream, 7, depth_scaling, depth, normals_buffer, radius_buffer, color_buffer,
+                           frame_T_global.inverse(), 0.05f, 5.f, 10.f, 30, false, 0, 1, 2.f, 40.f, 0x7fffffff);
+}
+template void poses_like_main_cc<sophus_like::SE3>(cudaStream_t, CUDASurfelReconstruction&, CUDABuffer<u16>*, CUDABuffer<float2_>&,
+    CUDABuffer<float>&, CUDABuffer<Vec3u8>&, sophus_like::SE3, sophus_like::SE3, float);
+template void poses_like_main_cc<SE3f>(cudaStream_t, CUDASurfelReconstruction&, CUDABuffer<u16>*, CUDABuffer<float2_>&,
+    CUDABuffer<float>&, CUDABuffer<Vec3u8>&, SE3f, SE3f, float);
+
+// host-only value checks (run by the test: none of this touches the GPU)
+int check_pose_conversions() {
+  sophus_like::SE3 a;
+  const float rot[9] = {0.f, -1.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};   // 90 degrees about z
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) a.M(r, c) = rot[3 * r + c];
+  a.M(0, 3) = 1.f; a.M(1, 3) = 2.f; a.M(2, 3) = 3.f;
+  const CUDAMatrix3x4 m(a.matrix3x4());   // column-major source -> row-major rows
+  const float want[12] = {0.f, -1.f, 0.f, 1.f, 1.f, 0.f, 0.f, 2.f, 0.f, 0.f, 1.f, 3.f};
+  for (int i = 0; i < 12; ++i) if (m.m[i] != want[i]) return 1;
+  const SE3f b(want);
+  const CUDAMatrix3x4 mb(b.matrix3x4());
+  for (int i = 0; i < 12; ++i) if (mb.m[i] != want[i]) return 2;
+  const CUDAMatrix3x4 inv_a(a.inverse().matrix3x4()), inv_b(b.inverse().matrix3x4());
+  for (int i = 0; i < 12; ++i) if (inv_a.m[i] != inv_b.m[i]) return 3;
+  const CUDAMatrix3x4 id((b * b.inverse()).matrix3x4());
+  const float ident[12] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+  for (int i = 0; i < 12; ++i) if (id.m[i] != ident[i]) return 4;
+  SE3f c = b;
+  c.translation() = 5000.f * c.translation();
+  if (c.matrix3x4()(0, 3) != 5000.f || c.matrix3x4()(2, 3) != 15000.f || c.matrix3x4()(1, 0) != 1.f) return 5;
+  return 0;
+}
+
 // the reference caller's sequence (APP/main.cc:1015-1267) in the reference's own names
 int frame(cudaStream_t stream, CUDASurfelReconstruction& reconstruction, CUDASurfelsCPU& cuda_surfels_cpu,
           CUDABuffer<u16>& depth_buffer, CUDABuffer<u16>& A, CUDABuffer<u16>& B, CUDABuffer<float2_>& normals_buffer,
@@ -59,7 +139,7 @@ int frame(cudaStream_t stream, CUDASurfelReconstruction& reconstruction, CUDASur
   reconstruction.SetFramePipelining(true);
   return (int)reconstruction.surfel_count();
 }
-int main() { return 0; }
+int main(int argc, char**) { return argc > 1 ? check_pose_conversions() : 0; }
 '''
 
 
@@ -74,3 +154,6 @@ def test_reference_style_host_code_compiles_and_links(tmp_path):
                         str(src), "-o", str(exe), "-L", lib_dir, "-l:libsmx.so", "-Wl,-rpath," + lib_dir,
                         "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+    # the pose conversions are pure host code: run them (libsmx.so is only loaded, no entry point is called)
+    r = subprocess.run([str(exe), "check"], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])

@@ -65,7 +65,7 @@ def main():
     bx, by, bz = (dev_array(pts[:, k]) for k in range(3))
     ptr = lambda b: C.c_void_p(b.ToCUDA().address)  # noqa: E731
     nn = C.c_void_p()
-    _lib.check(L.smx_nn_create(C.byref(nn)))
+    _lib.check(L.smx_nn_create(C.c_int32(-1), C.byref(nn)))
     K = 64
     batch = min(n, 4_000_000)
     out_idx = api.CUDABuffer(1, batch * K, np.uint32)
