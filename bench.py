@@ -1,18 +1,26 @@
 #!/usr/bin/env python
 """Benchmark of the surfel-integration hot path (BASELINE.json: RGB-D frames/s integrated @640x480 with
-5 M live surfels; achieved HBM GB/s).
+5 M live surfels; achieved HBM GB/s).  One command per BASELINE.json config:
 
-One "step" = one frame of the reference's per-frame call sequence (APP/main.cc:1015-1223): bilateral filter,
-9-frame outlier cull, erosion, normals, radii, CUDASurfelReconstruction::Integrate -- with the raw depth and
-colour frames already resident in HBM.  Workload = config C2 of SURVEY.md 8(d): the synthetic room stream at
-640x480; the map is first grown to >= 5 M surfels by running the real pipeline over a sweeping trajectory
-(untimed), then the timed window re-traverses mapped area (steady state).
+    python bench.py [--config C2] --gpus N --steps K --warmup W     (default; the driver's command)
+    python bench.py --config C3      1280x960 stream, 20 M surfel cap        (same code path as C2)
+    python bench.py --config C5      50 M surfels, radius-neighbor search for all of them (K = 64)
+    python bench.py --config C1      one 640x480 frame through the naive CPU loops (no GPU)
 
-    python bench.py --gpus N --steps K --warmup W
-N > 1: launched by torch.distributed.run, one rank per GPU, one independent stream per rank, no data-path
-collective -- weak scaling; value = all frames of all ranks / max-over-ranks time.
+C2 / C3: one "step" = one frame of the reference's per-frame call sequence (APP/main.cc:1015-1223): bilateral filter,
+9-frame outlier cull, erosion, normals, radii, CUDASurfelReconstruction::Integrate -- with the raw depth and colour
+frames already resident in HBM.  The synthetic room stream of SURVEY.md 8(d); the map is first grown to the target
+number of LIVE surfels by running the real pipeline over a sweeping trajectory (untimed), then the timed window
+re-traverses mapped area (steady state).
+C5: one "step" = every indexed surfel queries its own neighbourhood once (r^2 = its own radius^2, K = 64).
+
+N > 1: launched by torch.distributed.run, one rank per GPU, one independent stream / cloud per rank, no data-path
+collective -- weak scaling; value = all units of all ranks / max-over-ranks time.
+--dry-run: the rank path (rank_info -> process group -> device selection -> stream assignment -> plan generation ->
+barrier -> aggregate) without touching a GPU, over gloo; tests/test_multistream_gloo.py runs it with two ranks.
 """
 import argparse
+import hashlib
 import json
 import math
 import os
@@ -24,7 +32,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 (vector)
 
 # ALGORITHMIC bytes per launch of each kernel (DESIGN.md "Kernels and bytes"): every record a kernel has to read
 # or write counted once, cache effects and line granularity excluded.  N = slots, V = visible slots, R = slots
@@ -49,6 +58,22 @@ ALG_BYTES = {
     "clear_assoc": lambda st, P: 26.0 * P,
     "new_flags_scan": lambda st, P: 15.0 * P,
 }
+
+CONFIGS = {
+    "C2": dict(width=640, height=480, surfels=5_000_000),
+    "C3": dict(width=1280, height=960, surfels=20_000_000),
+}
+
+
+def source_sha():
+    """Hash of the kernel sources: PMC files under profiles/ are only used for the build they were collected on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "surfelmeshing_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pose64(g, seed_phase=0.0):
@@ -85,10 +110,16 @@ def others_tr_reference(g, phase, count, scaling):
     return frames, np.asarray(out, np.float32)
 
 
-class Workload:
-    """The synthetic C2 stream driven through the native frame loop (include/smx_driver.h)."""
+def frame_plan(logical, pose_index, phase, depth_scaling):
+    """(frame, outlier-cull neighbour frames, their relative poses, camera pose) of one step -- host arithmetic only."""
+    frames, T = others_tr_reference(pose_index, phase, 8, depth_scaling)
+    return logical, [logical + (f - pose_index) for f in frames], T, pose32(pose_index, phase)
 
-    def __init__(self, api, width, height, target_surfels, cap_surfels, seed, phase):
+
+class Workload:
+    """The synthetic C2 / C3 stream driven through the native frame loop (include/smx_driver.h)."""
+
+    def __init__(self, api, width, height, target_live, cap_surfels, seed, phase):
         from surfelmeshing_amd.pipeline import NativeFramePipeline, PreprocessParams
         self.api = api
         sc = width / 640.0
@@ -96,7 +127,7 @@ class Workload:
         self.fx = self.fy = 525.0 * sc
         self.cx, self.cy = 320.0 * sc, 240.0 * sc
         self.seed, self.phase = seed, phase
-        self.target = target_surfels
+        self.target = target_live
         self.pre = PreprocessParams(max_depth=10.0, depth_valid_region_radius=333.0 * sc)
         self.pipe = NativeFramePipeline(width, height, self.fx, self.fy, self.cx, self.cy, cap_surfels, self.pre)
         self.pipe.reconstruction.set_timing_enabled(0)
@@ -107,9 +138,7 @@ class Workload:
             self.pipe.render(logical, pose32(pose_index, self.phase), self.seed)
 
     def plan(self, logical, pose_index):
-        """(frame, outlier-cull neighbour frames, their relative poses, camera pose) of one step."""
-        frames, T = others_tr_reference(pose_index, self.phase, 8, self.pre.depth_scaling)
-        return logical, [logical + (f - pose_index) for f in frames], T, pose32(pose_index, self.phase)
+        return frame_plan(logical, pose_index, self.phase, self.pre.depth_scaling)
 
     def steps(self, plans):
         from surfelmeshing_amd.pipeline import DriverStep
@@ -117,13 +146,15 @@ class Workload:
         return arr, len(plans)
 
     def grow(self, log):
-        """Untimed: run the real pipeline along the trajectory until the map holds >= target surfels."""
+        """Untimed: run the real pipeline along the trajectory until the map holds >= target LIVE surfels
+        (surfel_count() = slots - merged, as BASELINE.json's metric counts them)."""
         g = 4
         for f in range(0, 9):
             self.render(f, f)
-        n = 0
+        live = 0
+        rec = self.pipe.reconstruction
         t0 = time.time()
-        while n < self.target and g < 20000:
+        while live < self.target and g < 40000:
             batch = []
             for _ in range(50):
                 batch.append(self.plan(g, g))
@@ -134,13 +165,13 @@ class Workload:
             self.pipe.run_array(*self.steps(batch))
             for f in range(batch[0][0] - 4, batch[-1][0] - 3):
                 self.pipe.release(f)
-            n = self.pipe.reconstruction.surfels_size()
+            live = rec.surfel_count()
             if log and (g - 4) % 500 == 0:
-                print("# grow: frame %d surfels %d (%.1fs)" % (g, n, time.time() - t0), file=sys.stderr, flush=True)
+                print("# grow: frame %d live surfels %d (%.1fs)" % (g, live, time.time() - t0), file=sys.stderr, flush=True)
         for f in list(self.pipe.resident):
             self.pipe.release(f)
         self.api.StreamSynchronize(None)
-        return g, n
+        return g, live
 
 
 def host_frames_pass(wl, plan, base, count, api, torch):
@@ -185,46 +216,102 @@ def algorithmic_bytes(st, P):
     return ref, ours
 
 
+def init_ranks(args):
+    """rank / world from the launcher's environment; process group (RCCL, or gloo for --dry-run); device selection."""
+    from surfelmeshing_amd import multistream
+    rank, local_rank, world = multistream.rank_info()
+    dist = None
+    torch = None
+    if world > 1 or not args.dry_run:
+        import torch  # first: libsmx then binds to the HIP runtime torch loaded
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.dry_run:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not args.dry_run:
+        from surfelmeshing_amd import _lib
+        _lib.require_gpu()
+        _lib.check(_lib.load().smx_set_device(local_rank if world > 1 else 0))
+    return rank, local_rank, world, dist, torch
+
+
+def finish_ranks(world, dist):
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", choices=["C1", "C2", "C3", "C5"], default="C2", help="BASELINE.json config (SURVEY.md 8d)")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--surfels", type=int, default=5_000_000, help="live surfels to reach before timing")
-    ap.add_argument("--cap", type=int, default=0, help="max_surfel_count (default: surfels * 1.1)")
-    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--surfels", type=int, default=0, help="LIVE surfels to reach before timing (C2: 5 M, C3: 20 M)")
+    ap.add_argument("--cap", type=int, default=0, help="max_surfel_count (default: surfels * 1.25)")
+    ap.add_argument("--points", type=int, default=50_000_000, help="C5: surfel positions in the index")
+    ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the CPU baseline sample (0 = skip; C3 default 4)")
     ap.add_argument("--host-frames", type=int, default=100,
                     help="frames of the extra pass whose inputs arrive from page-locked host memory (0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the full-size GPU-vs-oracle check")
     ap.add_argument("--no-overlap", action="store_true", help="A/B: no frame pipelining inside Integrate")
+    ap.add_argument("--dry-run", action="store_true", help="rank path only (no GPU, gloo): see the module docstring")
     ap.add_argument("--quiet", action="store_true")
     args = ap.parse_args()
+    if args.config == "C1":
+        return run_c1(args)
+    if args.config == "C5":
+        return run_c5(args)
+    return run_integrate(args)
 
-    import torch  # first: libsmx then binds to the HIP runtime torch loaded
-    import torch.distributed as dist
+
+# =====================================================================================================================
+# C2 / C3
+def run_integrate(args):
+    cfg = CONFIGS[args.config]
+    width, height = args.width or cfg["width"], args.height or cfg["height"]
+    target_live = args.surfels or cfg["surfels"]
+    K = args.steps if args.steps is not None else (300 if args.config == "C2" else 100)
+    W = args.warmup if args.warmup is not None else (20 if args.config == "C2" else 10)
+    cpu_frames = args.cpu_frames if args.cpu_frames is not None else (16 if args.config == "C2" else 4)
     from surfelmeshing_amd import multistream
-    rank, local_rank, world = multistream.rank_info()
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    from surfelmeshing_amd import _lib, api
-    _lib.require_gpu()
-    _lib.check(_lib.load().smx_set_device(local_rank if world > 1 else 0))
+    rank, local_rank, world, dist, torch = init_ranks(args)
     log = (rank == 0) and not args.quiet
-
-    cap = args.cap or int(args.surfels * 1.1)
+    cap = args.cap or int(target_live * 1.25)
     assign = multistream.stream_assignment(rank)   # one independent stream per rank, no data-path collective
-    wl = Workload(api, args.width, args.height, args.surfels, cap, assign["seed"], assign["phase"])
+
+    if args.dry_run:
+        # everything the rank does on the host for one run: the plans of the timed window (poses, outlier-cull
+        # neighbours and their relative transforms), then the same barrier / reduction protocol as the real run
+        t0 = time.perf_counter()
+        first = 1000
+        plans = [frame_plan(first + j, 4 + j, assign["phase"], 5000.0) for j in range(W + K)]
+        assert all(len(p[1]) == 8 and p[2].shape == (8, 3, 4) and p[3].shape == (3, 4) for p in plans)
+        if world > 1:
+            dist.barrier()
+        elapsed_local = max(time.perf_counter() - t0, 1e-9)
+        fps, elapsed, units = multistream.aggregate_throughput(K, elapsed_local, world, dist, "cpu")
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "config": {"workload": args.config}, "n_gpus": world, "steps": K, "warmup": W,
+                              "value": fps, "unit": "frames/s (host-side plan generation only)", "units_all_ranks": units,
+                              "seed": assign["seed"], "scaling": "weak"}))
+        finish_ranks(world, dist)
+        return 0
+
+    from surfelmeshing_amd import _lib, api
+    wl = Workload(api, width, height, target_live, cap, assign["seed"], assign["phase"])
     t0 = time.time()
-    g_end, n_grown = wl.grow(log)
+    g_end, n_live = wl.grow(log)
     if log:
-        print("# grown to %d surfels in %d frames, %.1fs" % (n_grown, g_end, time.time() - t0), file=sys.stderr)
+        print("# grown to %d live surfels in %d frames, %.1fs" % (n_live, g_end, time.time() - t0), file=sys.stderr)
 
     # timed window: re-traverse the start of the trajectory (mapped area) with new frame indices
-    K, W = args.steps, args.warmup
     first = g_end + 10
     cal, reps = 10, 20
     total = W + cal + K
@@ -237,7 +324,7 @@ def main():
     rec = wl.pipe.reconstruction
     rec.set_stats_enabled(False)   # the distribution counters are single-address atomics: off while timing
     wl.pipe.run_array(*wl.steps(plan[:W]))
-    # short calibration pass with HIP events around every kernel: which kernel dominates the frame?
+    # short calibration pass with HIP events around every kernel: which Integrate kernel dominates the frame?
     # (frame pipelining off here and in the per-kernel pass below, so that kernels are timed one at a time)
     rec.set_overlap(False)
     rec.set_timing_enabled(2)
@@ -250,7 +337,7 @@ def main():
     rec.set_overlap(not args.no_overlap)
     dominant = names[int(np.argmax(cal_ms))]
     api.StreamSynchronize(None)
-    do_cpu = rank == 0 and world == 1 and args.cpu_frames > 0   # CPU baseline: rank 0 at N = 1 only
+    do_cpu = rank == 0 and world == 1 and cpu_frames > 0   # CPU baseline: rank 0 at N = 1 only
     state0 = rec.debug_download_surfels() if do_cpu else None
     merge0 = (rec.surfels_size() - rec.surfel_count()) if state0 is not None else 0
     timed_steps = wl.steps(plan[W + cal:W + cal + K])
@@ -271,7 +358,6 @@ def main():
     enqueue_local = time.perf_counter() - t_start   # host side done (returns without synchronising)
     torch.cuda.synchronize()
     elapsed_local = time.perf_counter() - t_start
-    from surfelmeshing_amd import multistream
     fps, elapsed, _ = multistream.aggregate_throughput(K, elapsed_local, world, dist if world > 1 else None, "cuda")
     if world > 1:
         dist.barrier()
@@ -303,16 +389,18 @@ def main():
         host_pass = host_frames_pass(wl, plan, total + 1 + reps, do_host, api, torch)
         rec.set_overlap(False)
 
-    ref_bytes, own_bytes = algorithmic_bytes(st, args.width * args.height)
+    P = width * height
+    ref_bytes, own_bytes = algorithmic_bytes(st, P)
+    live = st["surfels_size"] - st["merge_count"]
     result = {
-        "metric": "RGB-D frames/s integrated @640x480, 5M live surfels; achieved HBM GB/s",
+        "metric": "RGB-D frames/s integrated @640x480, 5M live surfels; achieved HBM GB/s" if args.config == "C2" else
+                  "RGB-D frames/s integrated @%dx%d, %dM surfel cap; achieved HBM GB/s" % (width, height, target_live // 1000000),
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * elapsed / K, "host_enqueue_ms_per_step": 1e3 * enqueue_local / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: synthetic room stream %dx%d, full preprocessing + Integrate per frame, "
-                               "%d surfel slots (%d live), steady-state re-traversal" %
-                               ("C2" if args.width == 640 else "C3" if args.width == 1280 else "custom", args.width,
-                                args.height, st["surfels_size"], st["surfels_size"] - st["merge_count"]),
+                               "%d live surfels (%d slots), steady-state re-traversal" %
+                               (args.config, width, height, live, st["surfels_size"]),
                    "max_surfel_count": cap, "streams": world, "parallelism": "1 independent stream per GPU"},
         "distributions": st,
         "stage_ms": dict(zip(["data_association", "surfel_merging", "measurement_blending", "integration",
@@ -323,17 +411,17 @@ def main():
     }
 
     if rank == 0:
-        result["roofline"] = roofline_block(st, args.width * args.height, dominant, dom_ms, dom_n,
-                                            dict(zip(names, [float(x) for x in kernel_ms])))
+        result["roofline"] = roofline_block(st, P, dominant, dom_ms, dom_n, dict(zip(names, [float(x) for x in kernel_ms])),
+                                            1e3 * elapsed / K)
+        result["roofline_valu"] = bilateral_valu_roofline(wl, api, torch, plan[0][0])
         if host_pass is not None:
             result["host_frames"] = host_pass
         if do_cpu:
-            result["cpu_baseline"] = cpu_baseline(wl, plan, W + cal, args.cpu_frames, state0, merge0, cap,
+            result["cpu_baseline"] = cpu_baseline(wl, plan, W + cal, cpu_frames, state0, merge0, cap,
                                                   not args.no_check, log)
         print(json.dumps(result))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish_ranks(world, dist)
+    return 0
 
 
 # kernel-slot name -> kernel name in rocprofv3 output
@@ -343,26 +431,36 @@ SLOT_KERNEL = {"reg_accumulate": "k_reg_accumulate", "reg_step": "k_reg_step", "
                "blend": "k_blend_fused", "clear_assoc": "k_clear_assoc", "new_flags_scan": "k_new_flags_scan"}
 
 
-def pmc_traffic(dominant):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
-    (profiles/pmc_traffic.json, written by tools/pmc_summary.py; FETCH_SIZE and WRITE_SIZE are in KB and need
-    separate passes).  Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE
-    reports half of the bytes read, so it is doubled; WRITE_SIZE is taken as is.  None if there is no such file."""
+def pmc_file():
+    """The committed rocprofv3 --pmc summary of this same command (profiles/pmc_traffic.json, written by
+    tools/pmc_summary.py through tools/profile_round.sh, which stamps it with the hash of the kernel sources it was
+    collected on).  A file collected on other sources is REFUSED: (None, reason)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
-        return None, None
+        return None, "no profiles/pmc_traffic.json"
     try:
-        k = json.load(open(path)).get(SLOT_KERNEL.get(dominant, ""), {})
-        if "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
-            return None, None
-        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0, {"FETCH_SIZE_KB": k["FETCH_SIZE"], "WRITE_SIZE_KB": k["WRITE_SIZE"]}
-    except (ValueError, OSError):
-        return None, None
+        d = json.load(open(path))
+    except (ValueError, OSError) as e:
+        return None, "unreadable: %s" % e
+    meta = d.get("_meta", {})
+    if meta.get("source_sha") != source_sha():
+        return None, "stale: collected on kernel sources %s, this build is %s" % (meta.get("source_sha"), source_sha())
+    return d, None
 
 
-def roofline_block(st, P, dominant, dom_ms, dom_n, kernel_ms):
-    """Roofline of the dominant kernel: algorithmic bytes per launch (ALG_BYTES) / average launch
-    duration measured with HIP events on the launch stream over the timed region."""
+def pmc_bytes(k):
+    """HBM bytes per launch from FETCH_SIZE / WRITE_SIZE (KB; separate passes).  Correction per
+    /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half of the bytes read, so it is
+    doubled; WRITE_SIZE is taken as is."""
+    if "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
+        return None
+    return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+
+
+def roofline_block(st, P, dominant, dom_ms, dom_n, kernel_ms, ms_per_step):
+    """Roofline of the dominant Integrate kernel: algorithmic bytes per launch (ALG_BYTES) / average launch
+    duration measured with HIP events on the launch stream over the timed region; `frame` = all kernels of one frame
+    (PMC bytes of the committed profile of the same build) / the measured frame time."""
     alg = ALG_BYTES[dominant](st, P)
     achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     per_kernel = {}
@@ -371,40 +469,113 @@ def roofline_block(st, P, dominant, dom_ms, dom_n, kernel_ms):
             b = ALG_BYTES[k](st, P)
             # the per-kernel pass brackets every launch with two event records (~6 us of overhead per kernel)
             per_kernel[k] = {"ms_with_event_overhead": ms, "algorithmic_MB": b / 1e6}
-    traffic, raw = pmc_traffic(dominant)
+    pmc, why = pmc_file()
+    traffic = raw = frame = None
+    if pmc is not None:
+        k = pmc.get(SLOT_KERNEL.get(dominant, ""), {})
+        traffic = pmc_bytes(k)
+        raw = {"FETCH_SIZE_KB": k.get("FETCH_SIZE"), "WRITE_SIZE_KB": k.get("WRITE_SIZE"),
+               "collected_at_surfel_slots": pmc.get("_meta", {}).get("surfel_slots")}
+        total = sum(b for b in (pmc_bytes(v) for n, v in pmc.items() if n != "_meta") if b)
+        frame = {"pmc_bytes_per_frame": total, "GBs": total / (ms_per_step * 1e-3) / 1e9,
+                 "frac": total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "note": "sum over the kernels of one frame of 2 x FETCH_SIZE + WRITE_SIZE / the measured frame time"}
     return {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_pmc_raw": raw,
-            "algorithmic_bytes_per_launch": alg,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_pmc_raw": raw, "traffic_refused": why,
+            "frame": frame, "algorithmic_bytes_per_launch": alg,
             "avg_launch_ms": dom_ms, "launches_timed": dom_n, "surfel_slots": st["surfels_size"],
             "kernels_untimed_pass": per_kernel}
 
 
+def bilateral_valu_roofline(wl, api, torch, frame):
+    """The longest single dispatch of a frame is the bilateral filter, and it is VALU-bound (113 taps x exp at radius 6):
+    its roofline is the FP32 vector peak.  Flops per in-region pixel and tap: range term 5 (sub, mul, mul, add + the
+    spatial table value), det_expf 19 (2 mul/rint, 2 fma range reduction, 6 fma polynomial, 2 mul + add, scale),
+    accumulation 4 (cvt + fma, add) = 28.  Timed alone (no other chain on the chip), 50 back-to-back launches."""
+    import ctypes as C
+    from surfelmeshing_amd import _lib
+    L = _lib.load()
+    p = wl.pre
+    depth = api.CUDABuffer(wl.h, wl.w, np.uint16)
+    out = api.CUDABuffer(wl.h, wl.w, np.uint16)
+    d, _ = wl.pipe.download_frame(frame)
+    depth.UploadAsync(None, d)
+    radius = int(p.bilateral_filter_radius_factor * p.bilateral_filter_sigma_xy + 0.5)
+    taps = sum(1 for dy in range(-radius, radius + 1) for dx in range(-radius, radius + 1) if dx * dx + dy * dy <= radius * radius)
+    yy, xx = np.mgrid[0:wl.h, 0:wl.w]
+    inside = ((xx - wl.w // 2) ** 2 + (yy - wl.h // 2) ** 2 <= p.depth_valid_region_radius ** 2) & (d > 0) & (d <= p.max_depth_u16())
+    flops = 28.0 * taps * float(inside.sum())
+
+    def run(n):
+        for _ in range(n):
+            api.BilateralFilteringAndDepthCutoffCUDA(None, p.bilateral_filter_sigma_xy, p.bilateral_filter_sigma_depth_factor, 0,
+                                                     p.bilateral_filter_radius_factor, p.max_depth_u16(),
+                                                     p.depth_valid_region_radius, depth, out)
+    run(5)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    run(50)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t) / 50 * 1e3
+    depth.close()
+    out.close()
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"bound": "valu_fp32", "kernel": "k_bilateral_r<%d>" % radius, "achieved": tf, "peak": VALU_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS, "flop_per_launch": flops, "taps": taps,
+            "avg_launch_ms_alone": ms, "note": "timed alone, back to back; inside the frame it shares the chip with two other chains"}
+
+
 def cpu_baseline(wl, plan, W, frames, state0, merge0, cap, check, log):
-    """The oracle (plain single-threaded C loops) on the first `frames` frames of the timed window, starting
-    from the same surfel state; also used as a full-size parity check of the HIP path."""
+    """The oracle (plain C loops) on the first `frames` frames of the timed window, starting from the same surfel
+    state: once with the per-pixel stages row-parallel on all host cores (the headline CPU number; Integrate itself is
+    a sequential scan over the surfels and stays on one core) and once on a single core; the run also serves as a
+    full-size parity check of the HIP path.  Plus config C1 (single frame, bilateral + erosion + normals)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle as orc
+    from oracle import binding
     from oracle_pipeline import OraclePipeline
     api = wl.api
-    po = OraclePipeline(wl.w, wl.h, wl.fx, wl.fy, wl.cx, wl.cy, cap, wl.pre)
-    n0 = state0.shape[1]
-    po.recon.surfels()[:, :n0] = state0
-    po.recon.set_counts(n0, merge0)
     need = set()
     for j in range(W, W + frames):
         need.add(plan[j][0])
         need.update(plan[j][1])
     host_frames = {f: wl.pipe.download_frame(f) for f in sorted(need)}
-    for f, (d, c) in host_frames.items():
-        po.upload(f, d, c)
-    t0 = time.perf_counter()
-    for j in range(W, W + frames):
-        po.process(*plan[j])
-    dt = time.perf_counter() - t0
-    out = {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": "%d frames of the timed window from the same %d-surfel state (oracle, -O2, 1 thread)" % (frames, n0)}
+    n0 = state0.shape[1]
+    cores = os.cpu_count() or 1
+    po = None
+    timings = {}
+    for threads in (cores, 1):
+        binding.set_row_threads(threads)
+        po = OraclePipeline(wl.w, wl.h, wl.fx, wl.fy, wl.cx, wl.cy, cap, wl.pre)
+        po.recon.surfels()[:, :n0] = state0
+        po.recon.set_counts(n0, merge0)
+        for f, (d, c) in host_frames.items():
+            po.upload(f, d, c)
+        nf = frames if threads == cores else max(2, frames // 4)
+        t_pre = t_int = 0.0
+        for j in range(W, W + nf):
+            t0 = time.perf_counter()
+            po.preprocess(*plan[j][:3])
+            t1 = time.perf_counter()
+            po.integrate(plan[j][0], plan[j][3])
+            t_int += time.perf_counter() - t1
+            t_pre += t1 - t0
+        timings[threads] = (nf, t_pre, t_int)
+        if threads == cores:
+            po_full = po
+    binding.set_row_threads(1)
+    nf, t_pre, t_int = timings[cores]
+    nf1, t_pre1, t_int1 = timings[1]
+    out = {"value": nf / (t_pre + t_int), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": "%d frames of the timed window from the same %d-surfel state (oracle, gcc -O2): per-pixel stages "
+                     "row-parallel on %d threads (%.1f ms/frame), Integrate on 1 thread (%.1f ms/frame)" %
+                     (nf, n0, cores, 1e3 * t_pre / nf, 1e3 * t_int / nf),
+           "one_core": {"value": nf1 / (t_pre1 + t_int1), "unit": "frames/s", "cores": 1, "frames": nf1,
+                        "per_pixel_stages_ms": 1e3 * t_pre1 / nf1, "integrate_ms": 1e3 * t_int1 / nf1},
+           "c1_single_frame": c1_timing(wl.w, wl.h)}
     if check:
         from surfelmeshing_amd.pipeline import FramePipeline
+        po = po_full
         pg = FramePipeline(wl.w, wl.h, wl.fx, wl.fy, wl.cx, wl.cy, cap, wl.pre)
         pg.reconstruction.debug_upload_surfels(state0, merge0)
         for f, (d, c) in host_frames.items():
@@ -427,5 +598,194 @@ def cpu_baseline(wl, plan, W, frames, state0, merge0, cap, check, log):
     return out
 
 
+# =====================================================================================================================
+# C1: BASELINE.json configs[0] -- single 640x480 synthetic depth frame, bilateral filter + erosion + normals via the
+# naive CPU loops (erosion supplies the zero border the normals stage assumes, cuda_depth_processing.cu:659-662)
+def c1_timing(width=640, height=480, reps_all=10, reps_one=3):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as orc
+    from oracle import binding
+    from surfelmeshing_amd.synth import SyntheticStream
+    sc = width / 640.0
+    s = SyntheticStream(width=width, height=height, fx=525.0 * sc, fy=525.0 * sc, cx=320.0 * sc, cy=240.0 * sc)
+    depth, _ = s.frame(0)
+    cores = os.cpu_count() or 1
+    res = {}
+    for threads, reps in ((cores, reps_all), (1, reps_one)):
+        binding.set_row_threads(threads)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            a = orc.bilateral_filter_and_cutoff(depth, max_depth=50000, depth_valid_region_radius=333.0 * sc)
+            a = orc.erode_depth_map(a, 2)
+            orc.compute_normals_and_drop_bad_pixels(a, s.fx, s.fy, s.cx, s.cy)
+        res[threads] = (time.perf_counter() - t0) / reps
+    binding.set_row_threads(1)
+    return {"workload": "C1: one %dx%d frame, bilateral + erosion(2) + normals (oracle, gcc -O2)" % (width, height),
+            "ms_all_cores": 1e3 * res[cores], "cores": cores, "ms_one_core": 1e3 * res[1],
+            "ns_per_pixel_one_core": 1e9 * res[1] / (width * height)}
+
+
+def run_c1(args):
+    r = c1_timing()
+    print(json.dumps({"metric": "single 640x480 depth frame: bilateral filter + erosion + normals, naive CPU loop (BASELINE.json configs[0])",
+                      "value": 1e3 / r["ms_all_cores"], "unit": "frames/s", "n_gpus": 0, "steps": 10, "warmup": 0,
+                      "ms_per_step": r["ms_all_cores"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": "f32", "data": "synthetic", "config": {"workload": r["workload"]},
+                      "cpu_baseline": {"value": 1e3 / r["ms_all_cores"], "unit": "frames/s", "cores": r["cores"], "kind": "port",
+                                       "sample": "10 repetitions of the frame", "one_core_ms": r["ms_one_core"],
+                                       "ns_per_pixel_one_core": r["ns_per_pixel_one_core"]}}))
+    return 0
+
+
+# =====================================================================================================================
+# C5: BASELINE.json configs[4] -- 50 M live surfels, neighbor search dominant
+def run_c5(args):
+    import ctypes as C
+    from surfelmeshing_amd import multistream
+    rank, local_rank, world, dist, torch = init_ranks(args)
+    if args.dry_run:
+        finish_ranks(world, dist)
+        return 0
+    from surfelmeshing_amd import _lib, api
+    from surfelmeshing_amd.synth import room_surface_points
+    L = _lib.load()
+    log = (rank == 0) and not args.quiet
+    steps = args.steps if args.steps is not None else 5
+    warm = args.warmup if args.warmup is not None else 1
+    Kn = 64
+    t0 = time.time()
+    pts, spacing = room_surface_points(args.points, seed=0x5EED0005 + rank)
+    n = len(pts)
+    r = np.float32(1.5 * spacing)                       # surfel radius = 1.5 x local spacing
+    if log:
+        print("# C5: %d points, spacing %.2f mm, radius %.2f mm (generated in %.1fs)" % (n, spacing * 1e3, r * 1e3, time.time() - t0), file=sys.stderr)
+
+    def dev(host):
+        host = np.ascontiguousarray(host)
+        b = api.CUDABuffer(1, host.size, host.dtype)
+        b.UploadAsync(None, host.reshape(1, -1))
+        return b
+    bx, by, bz = (dev(pts[:, k]) for k in range(3))
+    br2 = dev(np.full(n, r * r, np.float32))
+    ptr = lambda b: C.c_void_p(b.ToCUDA().address)  # noqa: E731
+    out_idx = api.CUDABuffer(1, n * Kn, np.uint32)
+    out_d2 = api.CUDABuffer(1, n * Kn, np.float32)
+    out_cnt = api.CUDABuffer(1, n, np.int32)
+    api.StreamSynchronize(None)
+    nn = api.SurfelNeighborIndex()
+
+    def build():
+        _lib.check(L.smx_nn_build(nn._h, None, ptr(bx), ptr(by), ptr(bz), C.c_uint32(n), C.c_float(float(r)), C.c_int32(1)))
+
+    def query_self(factor):
+        _lib.check(L.smx_nn_query_self(nn._h, None, ptr(br2), C.c_float(factor), C.c_int32(Kn), C.c_void_p(0), C.c_uint8(0),
+                                       ptr(out_idx), ptr(out_d2), ptr(out_cnt)))
+
+    def timed(fn, reps):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps
+
+    build()
+    t_build = timed(build, 3)
+    info = nn.stats()
+    for _ in range(warm):
+        query_self(1.0)
+    _lib.check(L.smx_debug_marker(None, 1))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(steps):
+        query_self(1.0)
+    torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - t_start
+    qps, elapsed, _ = multistream.aggregate_throughput(float(n) * steps, elapsed_local, world, dist if world > 1 else None, "cuda")
+    _lib.check(L.smx_debug_marker(None, 2))
+    # counters of one more pass -> algorithmic bytes per query (16 (position + r^2) + 12 x the candidates
+    # staged per tile, amortised over the queries of the tile + 8 per result + 4 (count))
+    nn.set_stats_enabled(True)
+    query_self(1.0)
+    st1 = nn.stats()
+    nn.set_stats_enabled(False)
+    cnt1 = out_cnt.Download()[0].copy()
+    bytes_per_query = 16.0 + 12.0 * st1["staged_candidates"] / n + 8.0 * st1["results"] / n + 4.0
+    ms_step = 1e3 * elapsed / steps
+    achieved = bytes_per_query * n / (ms_step * 1e-3) / 1e9
+    # secondary numbers: twice the radius (max search-range factor, main.cc:392), and the general batch entry point
+    t_2r = timed(lambda: query_self(4.0), 2)
+    cnt2 = out_cnt.Download()[0].copy()
+    batch = min(n, 16_000_000)
+    def query_batch():
+        for q0 in range(0, n, batch):
+            nq = min(batch, n - q0)
+            off = lambda b: C.c_void_p(b.ToCUDA().address + 4 * q0)  # noqa: E731
+            _lib.check(L.smx_nn_query_batch(nn._h, None, C.c_uint32(nq), off(bx), off(by), off(bz), off(br2), C.c_int32(Kn),
+                                            C.c_void_p(0), C.c_uint8(0), C.c_int32(1), ptr(out_idx), ptr(out_d2),
+                                            ptr(out_cnt), C.c_int32(1)))
+    query_batch()
+    t_batch = timed(query_batch, 2)
+    build_bytes = 12.0 * n + 8.0 * n + 16.0 * info["n_bricks"]
+    result = {
+        "metric": "radius-neighbor queries/s, every one of 50M surfels queries its own neighbourhood, K=64 (BASELINE.json configs[4])",
+        "value": qps, "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": ms_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C5: %d surfel positions on the room surface (spacing %.2f mm), index cell = search radius = "
+                               "1.5 x spacing, self-queries for all points (smx_nn_query_self), K = 64" % (n, spacing * 1e3),
+                   "streams": world, "parallelism": "1 independent cloud per GPU"},
+        "distributions": {"n_points": n, "n_bricks": info["n_bricks"], "grid_cells": info["dim"], "key_bits": info["key_bits"],
+                          "mean_results": float(cnt1.mean()), "max_results": int(cnt1.max()), "tiles": st1["tiles"],
+                          "staged_candidates_per_query": st1["staged_candidates"] / n, "distance_tests_per_query": st1["distance_tests"] / n},
+        "roofline": {"bound": "hbm", "kernel": "k_query_tiles<true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bytes_per_query * n,
+                     "algorithmic_bytes_per_query": bytes_per_query, "avg_launch_ms": ms_step,
+                     "note": "one launch per step: the step time is the kernel time; the kernel is bound by cross-lane "
+                             "top-K insertion (VALU / DPP), not by bytes -- see DESIGN.md"},
+        "index_build": {"ms": 1e3 * t_build, "algorithmic_bytes": build_bytes, "GBs": build_bytes / t_build / 1e9,
+                        "frac": build_bytes / t_build / 1e9 / HBM_PEAK_GBS, "note": "12 N read + 8 N written + 16 B per occupied brick"},
+        "radius_x2": {"queries_per_s": n / t_2r, "ms": 1e3 * t_2r, "mean_results": float(cnt2.mean()), "max_results": int(cnt2.max())},
+        "general_batch_entry_point": {"queries_per_s": n / t_batch, "ms": 1e3 * t_batch,
+                                      "note": "smx_nn_query_batch over the same positions: keys + radix sort + gather of the queries first"},
+    }
+    if rank == 0:
+        if world == 1 and (args.cpu_frames is None or args.cpu_frames > 0):
+            result["cpu_baseline"] = c5_cpu_baseline(nn, pts, r, Kn, not args.no_check)
+        print(json.dumps(result))
+    nn.close()
+    finish_ranks(world, dist)
+    return 0
+
+
+def c5_cpu_baseline(nn, pts, r, Kn, check):
+    """The oracle's uniform-grid search (plain C, one thread; pinned to brute force by tests/test_nn_oracle.py) over ALL
+    points, on a bounded sample of the self-queries; the same sample through the GPU index is compared bit for bit."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as orc
+    n = len(pts)
+    rng = np.random.default_rng(0xC5)
+    sel = np.sort(rng.choice(n, min(n, 100_000), replace=False))
+    x, y, z = (np.ascontiguousarray(pts[:, k]) for k in range(3))
+    r2 = np.full(len(sel), r * r, np.float32)
+    t0 = time.perf_counter()
+    ocnt, od2, oidx = orc.nn_grid_batch(x, y, z, 0.05, x[sel], y[sel], z[sel], r2, Kn)
+    dt = time.perf_counter() - t0
+    out = {"value": len(sel) / dt, "unit": "queries/s", "cores": 1, "kind": "port",
+           "sample": "%d sampled self-queries over all %d points (oracle grid, 5 cm cells, gcc -O2, 1 thread; the time "
+                     "includes building its grid)" % (len(sel), n)}
+    if check:
+        cnt, d2, idx = nn.FindNearestSurfelsWithinRadius(pts[sel], r2, Kn)
+        m = np.arange(Kn)[None, :] < ocnt[:, None]
+        out["parity_check"] = {"queries": int(len(sel)), "counts_equal": bool(np.array_equal(cnt, ocnt)),
+                               "indices_equal": bool(np.array_equal(idx[m], oidx[m])),
+                               "dist2_bit_equal": bool(np.array_equal(d2[m].view(np.uint32), od2[m].view(np.uint32)))}
+    return out
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -305,7 +305,9 @@ int smx_recon_set_overlap(smx_recon r, int32_t enabled);
  * APP/octree.h:470-477, APP/octree.cc:313-470, for batched queries) ---- */
 /* Build a uniform-grid index over n points given as three device or host rows.
  * cell_size > 0; queries with radius <= cell_size touch at most 27 cells.  Points with a non-finite coordinate
- * are not indexed (no finite ball contains them). */
+ * are not indexed (no finite ball contains them).  The grid is sparse (sorted cell keys + a hash table of the occupied
+ * 4x4x4-cell bricks), so cell_size is kept at any scene extent; results do not depend on it.  Synchronises s (two
+ * small read-backs); the rows may be released / overwritten when the call returns.  Workspace is kept in the handle. */
 /* device_id as in smx_recon_create; the index owns its workspace and reuses it from call to call. */
 int smx_nn_create(int32_t device_id, smx_nn* out);
 int smx_nn_destroy(smx_nn nn);
@@ -314,12 +316,40 @@ int smx_nn_build(smx_nn nn, smx_stream s, const float* x, const float* y, const 
 /* For each query: up to k nearest points with dist^2 <= r2[q], ascending by
  * (dist^2, index).  state (may be NULL): points whose state byte has a bit of
  * skip_mask set are skipped (octree.cc:330-335).  Outputs are device or host
- * pointers according to outputs_on_device; out_idx/out_d2 are [nq][k]. */
+ * pointers according to outputs_on_device; out_idx/out_d2 are [nq][k].
+ * With device-resident queries and outputs the call only enqueues kernels on s (no allocation once the workspace
+ * has grown to the batch size, no synchronisation); with host pointers it returns after the results have arrived. */
 int smx_nn_query_batch(smx_nn nn, smx_stream s, uint32_t nq, const float* qx, const float* qy,
                        const float* qz, const float* r2, int32_t k, const uint8_t* state,
                        uint8_t skip_mask, int32_t queries_on_device,
                        uint32_t* out_idx, float* out_d2, int32_t* out_count,
                        int32_t outputs_on_device);
+
+/* Index geometry and (while enabled) counters of the queries since smx_nn_set_stats_enabled: what the C5 roofline of
+ * SURVEY.md 8(d) is computed from.  The counters are single-address atomics (one per tile): off by default. */
+typedef struct {
+  uint32_t n_points, n_indexed, n_bricks;   /* given to the last build / with finite coordinates / occupied 4x4x4-cell bricks */
+  float cell_size;                          /* the caller's, unless the 2^21-cells-per-axis key range forced it up */
+  int32_t dim[3];                           /* cells per axis of the (sparse) grid */
+  int32_t key_bits;                         /* width of the sort keys = 8 bits per radix pass */
+  uint64_t tiles;                           /* query tiles (<= 64 queries of one brick) */
+  uint64_t staged_candidates;               /* points staged in LDS, summed over the tiles */
+  uint64_t distance_tests;                  /* exact tests, summed over the queries */
+  uint64_t results;                         /* entries returned */
+} smx_nn_stats;
+/* Every indexed point queries its own neighbourhood (the full-retriangulation pattern, config C5 of SURVEY.md 8d;
+ * APP/surfel_meshing.cc:549, 819-823): the same results as smx_nn_query_batch with the points' own positions, with
+ * r^2 = factor * radius_squared[i] (device array indexed like the build rows) or, if radius_squared is NULL, r^2 =
+ * factor for all.  Rows are indexed by point; points without finite coordinates get count 0.  Nothing is keyed, sorted
+ * or gathered: a tile is an occupied brick, its queries are the brick's own records.  Device pointers only; enqueues
+ * kernels on s, no allocation, no synchronisation. */
+int smx_nn_query_self(smx_nn nn, smx_stream s, const float* radius_squared, float factor, int32_t k,
+                      const uint8_t* state, uint8_t skip_mask, uint32_t* out_idx, float* out_d2, int32_t* out_count);
+/* A/B switch of the query kernel (results are identical): 0 = the brick tiles staged in LDS (default), 1 = one wavefront
+ * per query reading the same brick ranges through L1 / L2. */
+int smx_nn_set_query_mode(smx_nn nn, int32_t mode);
+int smx_nn_set_stats_enabled(smx_nn nn, smx_stream s, int32_t enabled);
+int smx_nn_get_stats(smx_nn nn, smx_stream s, smx_nn_stats* out);
 
 /* ---- the loop-closure hook the reference describes but does not ship (README.md:152-176; its call site is the
  * "### Loop closures ###" block of main.cc:1194-1200, between preprocessing and Integrate) ----

@@ -112,15 +112,57 @@ def expf(x):
 
 
 # ---- depth preprocessing -------------------------------------------------------------------
+# Row-parallel mode of the per-pixel stages (bilateral, outlier cull, erosion / border copy, normals, radii): every output
+# pixel depends on the input images only, so the rows are split into bands, one OS thread per band, each with its own
+# thread-local row range (orc_set_row_range) over the same C loops (ctypes releases the GIL during the calls).  Results
+# are identical to the single-threaded run.  Used by bench.py's all-host-cores CPU baseline.
+_ROW_THREADS = 1
+_POOL = None
+
+
+def set_row_threads(n):
+    """Number of row bands / threads of the per-pixel stages (1 = the plain single-threaded loops)."""
+    global _ROW_THREADS, _POOL
+    n = max(1, int(n))
+    if _POOL is not None and n != _ROW_THREADS:
+        _POOL.shutdown()
+        _POOL = None
+    _ROW_THREADS = n
+
+
+def _rows(height, call):
+    """Runs call() over all rows, in bands if row threads are enabled."""
+    global _POOL
+    n = min(_ROW_THREADS, height)
+    if n <= 1:
+        call()
+        return
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=_ROW_THREADS)
+    L = lib()
+
+    def band(lo, hi):
+        L.orc_set_row_range(C.c_int(lo), C.c_int(hi))
+        try:
+            call()
+        finally:
+            L.orc_set_row_range(C.c_int(0), C.c_int(0x7FFFFFFF))
+
+    edges = [height * k // n for k in range(n + 1)]
+    for f in [_POOL.submit(band, edges[k], edges[k + 1]) for k in range(n)]:
+        f.result()
+
+
 def bilateral_filter_and_cutoff(depth, sigma_xy=3.0, sigma_value_factor=0.05, value_to_ignore=0,
                                 radius_factor=2.0, max_depth=15000, depth_valid_region_radius=333.0):
     depth = _c(depth, np.uint16)
     h, w = depth.shape
     out = np.empty_like(depth)
-    lib().orc_bilateral_filter_and_cutoff(
+    _rows(h, lambda: lib().orc_bilateral_filter_and_cutoff(
         C.c_float(sigma_xy), C.c_float(sigma_value_factor), C.c_uint16(value_to_ignore),
         C.c_float(radius_factor), C.c_uint16(max_depth), C.c_float(depth_valid_region_radius),
-        C.c_int(w), C.c_int(h), _p(depth), _p(out))
+        C.c_int(w), C.c_int(h), _p(depth), _p(out)))
     return out
 
 
@@ -132,9 +174,9 @@ def outlier_depth_map_fusion(depth, others, others_TR_reference, fx, fy, cx, cy,
     T = _c(np.asarray(others_TR_reference, np.float32).reshape(len(others), 12), np.float32)
     ptrs = (C.c_void_p * len(others))(*[o.ctypes.data for o in others])
     out = np.empty_like(depth)
-    lib().orc_outlier_depth_map_fusion(
+    _rows(h, lambda: lib().orc_outlier_depth_map_fusion(
         C.c_int(len(others)), C.c_int(required_count), C.c_float(tolerance), C.c_int(w), C.c_int(h),
-        _p(depth), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), ptrs, _p(T), _p(out))
+        _p(depth), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), ptrs, _p(T), _p(out)))
     return out
 
 
@@ -172,9 +214,9 @@ def erode_depth_map(depth, radius):
     h, w = depth.shape
     out = np.empty_like(depth)
     if radius == 0:
-        lib().orc_copy_without_border(C.c_int(w), C.c_int(h), _p(depth), _p(out))
+        _rows(h, lambda: lib().orc_copy_without_border(C.c_int(w), C.c_int(h), _p(depth), _p(out)))
     else:
-        lib().orc_erode_depth_map(C.c_int(radius), C.c_int(w), C.c_int(h), _p(depth), _p(out))
+        _rows(h, lambda: lib().orc_erode_depth_map(C.c_int(radius), C.c_int(w), C.c_int(h), _p(depth), _p(out)))
     return out
 
 
@@ -184,10 +226,10 @@ def compute_normals_and_drop_bad_pixels(depth, fx, fy, cx, cy, observation_angle
     h, w = depth.shape
     out = np.empty_like(depth)
     normals = np.zeros((h, w, 2), np.float32)
-    lib().orc_compute_normals_and_drop_bad_pixels(
+    _rows(h, lambda: lib().orc_compute_normals_and_drop_bad_pixels(
         C.c_float(observation_angle_threshold_deg), C.c_float(depth_scaling),
         C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
-        C.c_int(w), C.c_int(h), _p(depth), _p(out), _p(normals))
+        C.c_int(w), C.c_int(h), _p(depth), _p(out), _p(normals)))
     return out, normals
 
 
@@ -199,10 +241,10 @@ def compute_point_radii_and_remove_isolated_pixels(depth, fx, fy, cx, cy, point_
     out = np.empty_like(depth)
     # the kernel leaves radius untouched where depth == 0; callers compare only where out > 0
     radius = np.zeros((h, w), np.float32) if radius_init is None else _c(radius_init, np.float32).copy()
-    lib().orc_compute_point_radii_and_remove_isolated_pixels(
+    _rows(h, lambda: lib().orc_compute_point_radii_and_remove_isolated_pixels(
         C.c_float(point_radius_extension_factor), C.c_float(point_radius_clamp_factor), C.c_float(depth_scaling),
         C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
-        C.c_int(w), C.c_int(h), _p(depth), _p(radius), _p(out))
+        C.c_int(w), C.c_int(h), _p(depth), _p(radius), _p(out)))
     return out, radius
 
 

@@ -220,6 +220,10 @@ void orc_check_triangles(const float* x, const float* y, const float* z, const f
                          const uint32_t* triangles, uint32_t n_triangles, float long_edge_total_factor_squared,
                          uint8_t* flags);
 
+/* Thread-local row range [lo, hi) for the per-pixel depth stages (bilateral, outlier cull, erosion / border copy,
+ * normals, radii): the all-cores CPU baseline splits the rows over threads.  Default: all rows. */
+void orc_set_row_range(int lo, int hi);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,14 @@ float orc_expf(float x) {
   return y * s;
 }
 
+/* Row range of the calling thread for the per-pixel stages below (each output pixel depends on input images only, so
+ * any partition of the rows gives the same images): the all-host-cores CPU baseline of bench.py runs one thread per
+ * row band, each with its own range (thread-local), over the same loops.  Default: all rows. */
+static __thread int g_row_lo = 0, g_row_hi = 0x7FFFFFFF;
+void orc_set_row_range(int lo, int hi) { g_row_lo = lo < 0 ? 0 : lo; g_row_hi = hi; }
+#define ORC_ROWS_BEGIN(height) (g_row_lo < (height) ? g_row_lo : (height))
+#define ORC_ROWS_END(height) (g_row_hi < (height) ? g_row_hi : (height))
+
 static inline uint16_t f2u16(float v) {
   /* float -> u16 store: truncate toward zero, saturating (CUDA cvt.rzi.u16.f32
    * saturates; C leaves out-of-range undefined, so it is pinned here). */
@@ -66,7 +74,7 @@ void orc_bilateral_filter_and_cutoff(
   const float region_r2 = depth_valid_region_radius * depth_valid_region_radius;
   const unsigned half_w = (unsigned)(width / 2), half_h = (unsigned)(height / 2);
 
-  for (int y = 0; y < height; ++y) {
+  for (int y = ORC_ROWS_BEGIN(height); y < ORC_ROWS_END(height); ++y) {
     for (int x = 0; x < width; ++x) {
       uint16_t* o = &out[(size_t)y * width + x];
       /* :64-72 unsigned arithmetic, then one conversion to float */
@@ -121,7 +129,7 @@ void orc_outlier_depth_map_fusion(
   const float cx_pc = cx - 0.5f, cy_pc = cy - 0.5f;
   const float cx_inv = -cx_pc / fx, cy_inv = -cy_pc / fy;
 
-  for (int y = 0; y < height; ++y) {
+  for (int y = ORC_ROWS_BEGIN(height); y < ORC_ROWS_END(height); ++y) {
     for (int x = 0; x < width; ++x) {
       uint16_t d = in[(size_t)y * width + x];
       uint16_t* o = &out[(size_t)y * width + x];
@@ -158,7 +166,7 @@ void orc_outlier_depth_map_fusion(
 
 /* cuda_depth_processing.cu:514-538 */
 void orc_erode_depth_map(int radius, int width, int height, const uint16_t* in, uint16_t* out) {
-  for (int y = 0; y < height; ++y) {
+  for (int y = ORC_ROWS_BEGIN(height); y < ORC_ROWS_END(height); ++y) {
     for (int x = 0; x < width; ++x) {
       uint16_t* o = &out[(size_t)y * width + x];
       if (x < radius || y < radius || x >= width - radius || y >= height - radius) { *o = 0; continue; }
@@ -239,7 +247,7 @@ void orc_downscale_using_median_while_excluding(uint16_t value_to_ignore, int wi
 
 /* cuda_depth_processing.cu:589-607 */
 void orc_copy_without_border(int width, int height, const uint16_t* in, uint16_t* out) {
-  for (int y = 0; y < height; ++y)
+  for (int y = ORC_ROWS_BEGIN(height); y < ORC_ROWS_END(height); ++y)
     for (int x = 0; x < width; ++x)
       out[(size_t)y * width + x] =
           (x < 1 || y < 1 || x >= width - 1 || y >= height - 1) ? 0 : in[(size_t)y * width + x];
@@ -264,7 +272,7 @@ void orc_compute_normals_and_drop_bad_pixels(
   const float fx_inv = 1.0f / fx, fy_inv = 1.0f / fy;
   const float cx_inv = -(cx - 0.5f) / fx, cy_inv = -(cy - 0.5f) / fy;
 
-  for (int y = 0; y < height; ++y) {
+  for (int y = ORC_ROWS_BEGIN(height); y < ORC_ROWS_END(height); ++y) {
     for (int x = 0; x < width; ++x) {
       const size_t idx = (size_t)y * width + x;
       const uint16_t c = in[idx];
@@ -313,7 +321,7 @@ void orc_compute_point_radii_and_remove_isolated_pixels(
   const float fx_inv = 1.0f / fx, fy_inv = 1.0f / fy;
   const float cx_inv = -(cx - 0.5f) / fx, cy_inv = -(cy - 0.5f) / fy;
 
-  for (int y = 0; y < height; ++y) {
+  for (int y = ORC_ROWS_BEGIN(height); y < ORC_ROWS_END(height); ++y) {
     for (int x = 0; x < width; ++x) {
       const size_t idx = (size_t)y * width + x;
       if (in[idx] == 0) { out[idx] = 0; continue; }   /* radius left untouched, :777-780 */

@@ -67,6 +67,13 @@ class ReconStats(C.Structure):
                  "n_segments_skipped", "regularizer_saturated")]
 
 
+class NNStats(C.Structure):
+    """smx_nn_stats"""
+    _fields_ = [("n_points", C.c_uint32), ("n_indexed", C.c_uint32), ("n_bricks", C.c_uint32), ("cell_size", C.c_float),
+                ("dim", C.c_int32 * 3), ("key_bits", C.c_int32), ("tiles", C.c_uint64), ("staged_candidates", C.c_uint64),
+                ("distance_tests", C.c_uint64), ("results", C.c_uint64)]
+
+
 # every symbol include/smx.h declares (tests/test_abi.py checks the .so exports them all)
 EXPORTS = [
     "smx_last_error", "smx_device_count", "smx_set_device", "smx_device_name",
@@ -85,7 +92,7 @@ EXPORTS = [
     "smx_recon_profile_begin", "smx_recon_profile_end",
     "smx_recon_debug_download_surfels", "smx_recon_debug_upload_surfels", "smx_recon_debug_download_scratch",
     "smx_recon_set_scan_mode", "smx_recon_set_overlap",
-    "smx_nn_create", "smx_nn_destroy", "smx_nn_build", "smx_nn_query_batch",
+    "smx_nn_create", "smx_nn_destroy", "smx_nn_build", "smx_nn_query_batch", "smx_nn_query_self", "smx_nn_set_query_mode", "smx_nn_set_stats_enabled", "smx_nn_get_stats",
     "smx_synth_render_room",
 ]
 

@@ -643,6 +643,48 @@ class SurfelNeighborIndex:
             C.c_int32(0)))
         return cnt, d2, idx
 
+    def FindNearestOfIndexedPoints(self, n_points, max_result_count, radius_squared=None, factor=1.0, state=None,
+                                   skip_mask=0, stream=None):
+        """Every indexed point queries its own neighbourhood (smx_nn_query_self): r^2 = factor * radius_squared[i], or
+        r^2 = factor for all if radius_squared is None.  n_points = the number of points given to Build.  Returns
+        (counts [n], dist2 [n,K], indices [n,K]); device staging is allocated here (the C entry point takes device
+        pointers only)."""
+        n, k = int(n_points), int(max_result_count)
+        didx, dd2, dcnt = CUDABuffer(1, n * k, np.uint32), CUDABuffer(1, n * k, np.float32), CUDABuffer(1, n, np.int32)
+        dr2 = dst = None
+        if radius_squared is not None:
+            dr2 = CUDABuffer(1, n, np.float32)
+            dr2.UploadAsync(stream, np.ascontiguousarray(radius_squared, np.float32).reshape(1, n))
+        if state is not None:
+            dst = CUDABuffer(1, n, np.uint8)
+            dst.UploadAsync(stream, np.ascontiguousarray(state, np.uint8).reshape(1, n))
+        _lib.check(_lib.load().smx_nn_query_self(
+            self._h, _sv(stream), C.c_void_p(dr2.ToCUDA().address if dr2 else 0), C.c_float(factor), C.c_int32(k),
+            C.c_void_p(dst.ToCUDA().address if dst else 0), C.c_uint8(skip_mask), C.c_void_p(didx.ToCUDA().address),
+            C.c_void_p(dd2.ToCUDA().address), C.c_void_p(dcnt.ToCUDA().address)))
+        cnt = dcnt.Download(stream)[0].copy()
+        d2 = dd2.Download(stream)[0].reshape(n, k).copy()
+        idx = didx.Download(stream)[0].reshape(n, k).copy()
+        for b in (didx, dd2, dcnt, dr2, dst):
+            if b is not None:
+                b.close()
+        return cnt, d2, idx
+
+    def set_query_mode(self, mode):
+        """A/B switch (results identical): 0 = LDS-staged brick tiles, 1 = one wavefront per query through L1 / L2."""
+        _lib.check(_lib.load().smx_nn_set_query_mode(self._h, C.c_int32(mode)))
+
+    def set_stats_enabled(self, enabled, stream=None):
+        _lib.check(_lib.load().smx_nn_set_stats_enabled(self._h, _sv(stream), C.c_int32(1 if enabled else 0)))
+
+    def stats(self, stream=None):
+        """Index geometry and, while enabled, the tile / candidate / test / result counters of the queries (smx_nn_stats)."""
+        st = _lib.NNStats()
+        _lib.check(_lib.load().smx_nn_get_stats(self._h, _sv(stream), C.byref(st)))
+        d = {n: getattr(st, n) for n, _ in _lib.NNStats._fields_ if n != "dim"}
+        d["dim"] = [int(v) for v in st.dim]
+        return d
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.load().smx_nn_destroy(self._h)

@@ -1719,6 +1719,8 @@ struct smx_recon_s {
   uint32_t* delta_total;
   float* staging;    // row-layout staging for the boundary conversions (TransferAllToCPU, debug rows)
   size_t staging_floats;
+  float* cand_q; uint32_t* cand_slots; uint8_t* cand_state;   // workspace of smx_recon_neighbor_candidates
+  uint32_t cand_cap, cand_state_cap;
   hipEvent_t ev_staging;  // recorded after the last enqueued read of `staging`: TransferAllToCPU returns with its
   bool staging_busy;      // row downloads in flight, and the next user may come on another stream
   int grid_surfels;  // persistent grid for the grid-stride all-slot kernels
@@ -1923,7 +1925,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
 int smx_recon_destroy(smx_recon r) {
   if (!r) return SMX_OK;
   SMX_ON_DEVICE(r->device);
-  void* ptrs[] = {r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->flags_buf[0], r->flags_buf[1],
+  void* ptrs[] = {r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->flags_buf[0], r->flags_buf[1],
                   r->merge_flag, r->inwin8, r->need_seg, r->sc.supporting, r->sc.counts,
                   r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->block_offsets, r->st};
@@ -2318,42 +2320,48 @@ int smx_recon_neighbor_candidates(smx_recon r, smx_stream s, smx_nn nn, const ui
   if (n_indices == 0) return SMX_OK;
   hipStream_t st = (hipStream_t)s;
   { const int rcj = join_regularizer(r, st); if (rcj != SMX_OK) return rcj; }
-  uint32_t* dslots = nullptr;
-  uint8_t* dstate = nullptr;
-  float* q = nullptr;
-  int rc = SMX_OK;
-  hipError_t e = hipSuccess;
-  auto fail = [&](hipError_t err) { set_error("neighbor candidates failed: %s", hipGetErrorString(err)); rc = SMX_ERR_HIP; };
-  if ((e = hipMalloc(reinterpret_cast<void**>(&q), (size_t)4 * n_indices * sizeof(float))) != hipSuccess) fail(e);
-  if (rc == SMX_OK && !inputs_on_device) {
-    if ((e = hipMalloc(reinterpret_cast<void**>(&dslots), (size_t)n_indices * 4)) != hipSuccess) fail(e);
-    else if ((e = hipMemcpyAsync(dslots, surfel_indices, (size_t)n_indices * 4, hipMemcpyHostToDevice, st)) != hipSuccess) fail(e);
-    if (rc == SMX_OK && state) {
+  // workspace owned by the object, grown only when a batch is larger than any before it (then, and only then, the
+  // device is synchronised: earlier batches may still be reading the old buffers)
+  if (n_indices > r->cand_cap) {
+    SMX_HIP(hipDeviceSynchronize());
+    if (r->cand_q) { SMX_HIP(hipFree(r->cand_q)); r->cand_q = nullptr; }
+    if (r->cand_slots) { SMX_HIP(hipFree(r->cand_slots)); r->cand_slots = nullptr; }
+    r->cand_cap = 0;
+    const size_t cap = (size_t)n_indices + n_indices / 8 + 1024;
+    int rca = dev_alloc(&r->cand_q, 4 * cap, false);
+    if (rca == SMX_OK) rca = dev_alloc(&r->cand_slots, cap, false);
+    if (rca != SMX_OK) return rca;
+    r->cand_cap = (uint32_t)cap;
+  }
+  const uint8_t* dstate = state;
+  const uint32_t* dslots = surfel_indices;
+  if (!inputs_on_device) {
+    SMX_HIP(hipMemcpyAsync(r->cand_slots, surfel_indices, (size_t)n_indices * 4, hipMemcpyHostToDevice, st));
+    dslots = r->cand_slots;
+    if (state) {
       uint32_t n = 0;
-      if ((e = hipMemcpyAsync(&n, &r->st->surfel_count, sizeof(n), hipMemcpyDeviceToHost, st)) != hipSuccess ||
-          (e = hipStreamSynchronize(st)) != hipSuccess) fail(e);
-      else if (n > 0) {
-        if ((e = hipMalloc(reinterpret_cast<void**>(&dstate), n)) != hipSuccess) fail(e);
-        else if ((e = hipMemcpyAsync(dstate, state, n, hipMemcpyHostToDevice, st)) != hipSuccess) fail(e);
+      SMX_HIP(hipMemcpyAsync(&n, &r->st->surfel_count, sizeof(n), hipMemcpyDeviceToHost, st));
+      SMX_HIP(hipStreamSynchronize(st));
+      if (n > r->cand_state_cap) {
+        SMX_HIP(hipDeviceSynchronize());
+        if (r->cand_state) { SMX_HIP(hipFree(r->cand_state)); r->cand_state = nullptr; }
+        r->cand_state_cap = 0;
+        const int rca = dev_alloc(&r->cand_state, (size_t)r->S.pitch, false);
+        if (rca != SMX_OK) return rca;
+        r->cand_state_cap = (uint32_t)r->S.pitch;
       }
+      if (n > 0) SMX_HIP(hipMemcpyAsync(r->cand_state, state, n, hipMemcpyHostToDevice, st));
+      dstate = r->cand_state;
     }
   }
-  if (rc == SMX_OK) {
-    const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n_indices + kBlock - 1) / kBlock, 4096);
-    hipLaunchKernelGGL(k_candidate_queries, dim3(blocks), dim3(kBlock), 0, st, r->S,
-                       inputs_on_device ? surfel_indices : dslots, n_indices, r->st, radius_factor_squared, q);
-    if ((e = hipGetLastError()) != hipSuccess) fail(e);
-  }
-  if (rc == SMX_OK)
-    rc = smx_nn_query_batch(nn, s, n_indices, q, q + n_indices, q + (size_t)2 * n_indices, q + (size_t)3 * n_indices, k,
-                            inputs_on_device ? state : dstate, skip_mask, 1, out_idx, out_d2, out_count,
-                            outputs_on_device);
-  // the temporaries are read by work queued on `st`
-  if ((e = hipStreamSynchronize(st)) != hipSuccess && rc == SMX_OK) fail(e);
-  if (q) (void)hipFree(q);
-  if (dslots) (void)hipFree(dslots);
-  if (dstate) (void)hipFree(dstate);
-  return rc;
+  float* q = r->cand_q;
+  const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n_indices + kBlock - 1) / kBlock, 4096);
+  hipLaunchKernelGGL(k_candidate_queries, dim3(blocks), dim3(kBlock), 0, st, r->S, dslots, n_indices, r->st,
+                     radius_factor_squared, q);
+  SMX_LAUNCH_CHECK();
+  // (device inputs and outputs: nothing below allocates or synchronises either)
+  return smx_nn_query_batch(nn, s, n_indices, q, q + n_indices, q + (size_t)2 * n_indices, q + (size_t)3 * n_indices, k,
+                            dstate, skip_mask, 1, out_idx, out_d2, out_count, outputs_on_device);
 }
 
 int smx_recon_check_triangles(smx_recon r, smx_stream s, const uint32_t* triangles, uint32_t n_triangles,

@@ -158,3 +158,25 @@ def config_c1():
     z = np.minimum(z_plane, z_sphere)
     depth = np.rint(5000.0 * z).astype(np.uint16)
     return depth, dict(width=w, height=h, fx=fx, fy=fy, cx=cx, cy=cy)
+
+
+def room_surface_points(n, seed=0x5EED0005):
+    """Config C5: about n surfel positions on the six faces of the room (with the same relief), a
+    jittered grid of the local spacing; returns ([m, 3] float32, spacing in metres).  Face after face, row-major
+    within a face -- the index order carries no more locality than a map built frame by frame would."""
+    rng = np.random.default_rng(seed)
+    half = ROOM_HALF
+    total = sum(2 * 4 * half[a] * half[b] for a, b in ((1, 2), (0, 2), (0, 1)))
+    spacing = float(np.sqrt(total / n))
+    pts = []
+    for axis in range(3):
+        a, b = [k for k in range(3) if k != axis]
+        for sign in (-1.0, 1.0):
+            na, nb = int(2 * half[a] / spacing), int(2 * half[b] / spacing)
+            ga, gb = np.meshgrid((np.arange(na) + 0.5) * spacing - half[a], (np.arange(nb) + 0.5) * spacing - half[b])
+            p = np.empty((ga.size, 3), np.float32)
+            p[:, a] = (ga.ravel() + rng.uniform(-0.3, 0.3, ga.size) * spacing).astype(np.float32)
+            p[:, b] = (gb.ravel() + rng.uniform(-0.3, 0.3, ga.size) * spacing).astype(np.float32)
+            p[:, axis] = sign * half[axis] + _relief(p[:, a], p[:, b]).astype(np.float32)
+            pts.append(p)
+    return np.concatenate(pts), spacing

@@ -200,3 +200,109 @@ def test_check_triangles_against_oracle(smx):
     # the cases all occur: clean, long edge, each winding bit, merged, out of range
     assert {0, 1, 16}.issubset(seen) and any(f & 14 for f in seen) and any((f & 16) and f != 16 for f in seen)
     assert rec.CheckTrianglesForRemeshing(None, np.zeros((0, 3), np.uint32), 16.0).size == 0
+
+
+def test_c5_scale_parity_against_oracle_grid(smx):
+    """Config C5 at 5 M points (the full 50 M run with true brute force is tests/tools/c5_pin.py, its
+    record is kept under profiles/): the room-surface cloud, index cell = 1.5 x spacing, self-queries with the surfel
+    radius and with twice the radius (max search-range factor, main.cc:392), K = 64 -- counts, indices and squared
+    distances equal the oracle's grid search (itself pinned to brute force, tests/test_nn_oracle.py) bit for bit."""
+    from surfelmeshing_amd.synth import room_surface_points
+    pts, spacing = room_surface_points(5_000_000)
+    n = len(pts)
+    assert n > 4_900_000
+    r = np.float32(1.5 * spacing)
+    rng = np.random.default_rng(55)
+    sel = rng.choice(n, 4000, replace=False)
+    nn = smx.SurfelNeighborIndex()
+    nn.Build(pts[:, 0], pts[:, 1], pts[:, 2], float(r))
+    info = nn.stats()
+    assert info["n_indexed"] == n and info["cell_size"] == r        # cell = r at this extent: no dense-grid cap
+    assert max(info["dim"]) > 700 and info["n_bricks"] > 100_000   # (a dense grid of these cells would have 2 * 10^8 entries)
+    for factor in (1.0, 2.0):
+        r2 = np.full(len(sel), (factor * r) ** 2, np.float32)
+        nn.set_stats_enabled(True)
+        cnt, d2, idx = nn.FindNearestSurfelsWithinRadius(pts[sel], r2, 64)
+        st = nn.stats()
+        nn.set_stats_enabled(False)
+        ocnt, od2, oidx = orc.nn_grid_batch(pts[:, 0], pts[:, 1], pts[:, 2], 0.05, pts[sel, 0], pts[sel, 1], pts[sel, 2], r2, 64)   # (the oracle's grid is dense: a coarser cell, same answers)
+        assert np.array_equal(cnt, ocnt)
+        for q in range(len(sel)):
+            k = cnt[q]
+            assert idx[q, 0] == sel[q] and d2[q, 0] == 0            # a self-query returns the surfel first (surfel_meshing.cc:433-465)
+            assert np.array_equal(idx[q, :k], oidx[q, :k]) and np.array_equal(d2[q, :k].view(np.uint32), od2[q, :k].view(np.uint32))
+        assert st["results"] == int(cnt.sum()) and st["distance_tests"] >= st["results"]
+    nn.close()
+
+
+def test_far_from_origin_small_radius(smx):
+    """Coordinates of tens of metres with millimetre radii: the conservative cell range has to absorb the rounding of
+    q -+ r itself (half an ulp of the coordinate is comparable to the radius margin there)."""
+    rng = np.random.default_rng(9)
+    base = np.array([70.0, -45.0, 120.0], np.float32)
+    pts = (base + rng.uniform(-0.05, 0.05, (20000, 3))).astype(np.float32)
+    sel = rng.choice(len(pts), 200, replace=False)
+    _check(smx, pts, pts[sel], np.float32(0.003 ** 2), 64, 0.003)
+    _check(smx, pts, pts[sel[:50]] + np.float32(0.0015), np.float32(0.004 ** 2), 16, 0.002)
+
+
+def test_workspace_is_reused_and_queries_of_any_size_and_k(smx):
+    """One handle, several builds and batches of different sizes and K (the list capacity is a template parameter:
+    K <= 16, <= 32, <= 64); more than 64 queries per brick (several tiles per brick), K smaller than the matches."""
+    rng = np.random.default_rng(21)
+    nn = smx.SurfelNeighborIndex()
+    for n, cell in ((3000, 0.2), (50000, 0.05), (700, 0.5)):
+        pts = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+        nn.Build(pts[:, 0], pts[:, 1], pts[:, 2], cell)
+        for nq, k, rad in ((1, 1, 0.3), (70, 5, 0.3), (500, 16, 0.15), (333, 17, 0.2), (900, 33, 0.25), (64, 64, 0.4)):
+            q = rng.uniform(-1.1, 1.1, (nq, 3)).astype(np.float32)
+            q[: nq // 2] = q[0]                                       # many queries in one brick
+            r2 = (rng.uniform(0.5, 1.0, nq) * rad).astype(np.float32) ** 2
+            cnt, d2, idx = nn.FindNearestSurfelsWithinRadius(q, r2, k)
+            for j in range(0, nq, max(1, nq // 40)):
+                c, od2, oidx = orc.nn_bruteforce(pts[:, 0], pts[:, 1], pts[:, 2], q[j], float(r2[j]), k)
+                assert cnt[j] == c and np.array_equal(idx[j, :c], oidx[:c]) and np.array_equal(d2[j, :c].view(np.uint32), od2[:c].view(np.uint32)), (n, nq, k, j)
+    nn.close()
+
+
+def test_self_queries_and_kernel_modes_agree(smx):
+    """smx_nn_query_self (every indexed point asks for its own neighbourhood; no query keys / sort) and both query
+    kernels of smx_nn_query_batch give the same rows; points that are not indexed get count 0; bricks with more than 64
+    points (several sub-tiles) and a state mask are covered."""
+    rng = np.random.default_rng(31)
+    n = 60_000
+    u = rng.uniform(-1, 1, n).astype(np.float32)
+    v = rng.uniform(-0.5, 0.5, n).astype(np.float32)
+    pts = np.stack([u, v, (0.05 * np.sin(4 * u) * np.cos(3 * v)).astype(np.float32)], 1)
+    pts[:3000, :2] *= 0.02                                              # a dense clump: > 64 points per brick
+    nanrows = rng.choice(n, 500, replace=False)
+    pts[nanrows, 0] = np.nan
+    r2 = (rng.uniform(0.004, 0.012, n).astype(np.float32)) ** 2
+    state = (rng.random(n) < 0.3).astype(np.uint8)
+    nn = smx.SurfelNeighborIndex()
+    nn.Build(pts[:, 0], pts[:, 1], pts[:, 2], 0.01)
+    for st, mask in ((None, 0), (state, 1)):
+        cs, ds, is_ = nn.FindNearestOfIndexedPoints(n, 64, radius_squared=r2, factor=1.0, state=st, skip_mask=mask)
+        assert np.all(cs[nanrows] == 0)
+        rows = {}
+        for mode in (0, 1):
+            nn.set_query_mode(mode)
+            rows[mode] = nn.FindNearestSurfelsWithinRadius(pts, r2, 64, state=st, skip_mask=mask)
+        nn.set_query_mode(0)
+        for mode in (0, 1):
+            cb, db, ib = rows[mode]
+            assert np.all(cb[nanrows] == 0)                             # NaN query: empty ball
+            assert np.array_equal(cb, cs), mode
+            m = np.arange(64)[None, :] < cb[:, None]
+            assert np.array_equal(ib[m], is_[m]) and np.array_equal(db[m].view(np.uint32), ds[m].view(np.uint32)), mode
+        assert cs.max() == 64 and cs.min() == 0
+        for j in rng.choice(n, 60, replace=False):                      # and against brute force
+            if np.isnan(pts[j, 0]):
+                continue
+            c, od2, oidx = orc.nn_bruteforce(pts[:, 0], pts[:, 1], pts[:, 2], pts[j], float(r2[j]), 64, state=st, skip_mask=mask)
+            assert cs[j] == c and np.array_equal(is_[j, :c], oidx[:c]) and np.array_equal(ds[j, :c].view(np.uint32), od2[:c].view(np.uint32))
+    cu, du, iu = nn.FindNearestOfIndexedPoints(n, 16, radius_squared=None, factor=float(np.float32(0.008) ** 2))
+    cb, db, ib = nn.FindNearestSurfelsWithinRadius(pts, np.float32(0.008) ** 2, 16)
+    m = np.arange(16)[None, :] < cb[:, None]
+    assert np.array_equal(cu, cb) and np.array_equal(iu[m], ib[m])
+    nn.close()

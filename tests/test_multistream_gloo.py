@@ -60,3 +60,37 @@ def test_single_rank_passthrough():
     fps, t, n = multistream.aggregate_throughput(50, 0.25, 1)
     assert fps == 200.0 and t == 0.25 and n == 50
     assert multistream.stream_assignment(3)["seed"] == 0x5EED0004
+
+
+def test_bench_rank_path_dry_run_two_ranks():
+    """bench.py's own N > 1 path, as the driver launches it (python -m torch.distributed.run --nproc-per-node N bench.py
+    --gpus N ...), without GPUs: --dry-run keeps rank_info -> process group (gloo instead of RCCL) -> stream assignment ->
+    per-rank plan generation -> barrier -> MAX / SUM aggregation -> one JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    from common import ROOT
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "6", "--warmup", "2", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # rank 0 only
+    d = json.loads(lines[0])
+    assert d["dry_run"] and d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2
+    assert d["units_all_ranks"] == 12.0 and d["value"] > 0 and d["scaling"] == "weak"
+
+
+def test_bench_dry_run_single_rank():
+    import json
+    import subprocess
+    import sys
+    from common import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["dry_run"] and d["n_gpus"] == 1 and d["units_all_ranks"] == 4

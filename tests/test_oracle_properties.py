@@ -131,3 +131,30 @@ def test_deformation_and_its_inverse(data):
     assert np.allclose(after[0:6, :n], before[0:6, :n], atol=2e-5) and np.allclose(after[8:11, :n], before[8:11, :n], atol=1e-5)
     keep = [6, 7, 17, 18, 19, 20, 21, 22, 24]
     assert np.array_equal(after[keep].view(np.uint32), before[keep].view(np.uint32))
+
+
+def test_row_parallel_depth_stages_are_identical():
+    """The all-host-cores CPU baseline of bench.py splits the rows of the per-pixel stages over threads
+    (orc_set_row_range, thread-local): every image equals the single-threaded one, for band counts that do and do not
+    divide the height, and the calling thread's own range stays "all rows"."""
+    from common import small_pre, small_stream
+    from oracle import binding
+    from oracle_pipeline import OraclePipeline
+    s = small_stream(200, 77)
+    pre = small_pre(200)
+    imgs = {}
+    for threads in (1, 3, 8):
+        binding.set_row_threads(threads)
+        try:
+            po = OraclePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, 1000, pre)
+            for f in range(0, 9):
+                po.upload(f, *s.frame(f))
+            po.preprocess(4, s.outlier_frames(4), s.others_TR_reference(4))
+            imgs[threads] = (po.stages["bilateral"].copy(), po.stages["outlier"].copy(), po.stages["erode"].copy(),
+                             po.depth_final.copy(), po.normals.copy(), po.radius.copy())
+        finally:
+            binding.set_row_threads(1)
+    for threads in (3, 8):
+        for a, b in zip(imgs[1], imgs[threads]):
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), threads
+    assert (imgs[1][3] > 0).sum() > 1000

@@ -17,33 +17,7 @@ sys.path.insert(0, ROOT)
 from surfelmeshing_amd import _lib, api  # noqa: E402
 
 
-def surface_points(n, seed=0x5EED0005):
-    """n points on the six faces of the 6 x 3 x 6 m room, jittered grid."""
-    rng = np.random.default_rng(seed)
-    half = np.array([3.0, 1.5, 3.0])
-    faces = []
-    areas = []
-    for axis in range(3):
-        a, b = [k for k in range(3) if k != axis]
-        areas += [4 * half[a] * half[b]] * 2
-    areas = np.array(areas)
-    total = areas.sum()
-    spacing = np.sqrt(total / n)
-    pts = []
-    fi = 0
-    for axis in range(3):
-        a, b = [k for k in range(3) if k != axis]
-        for sign in (-1.0, 1.0):
-            na, nb = int(2 * half[a] / spacing), int(2 * half[b] / spacing)
-            ga, gb = np.meshgrid((np.arange(na) + 0.5) * spacing - half[a], (np.arange(nb) + 0.5) * spacing - half[b])
-            p = np.empty((ga.size, 3), np.float32)
-            p[:, a] = (ga.ravel() + rng.uniform(-0.3, 0.3, ga.size) * spacing).astype(np.float32)
-            p[:, b] = (gb.ravel() + rng.uniform(-0.3, 0.3, ga.size) * spacing).astype(np.float32)
-            p[:, axis] = sign * half[axis] + (0.02 * np.sin(5 * p[:, a]) * np.sin(5 * p[:, b])).astype(np.float32)
-            pts.append(p)
-            fi += 1
-    p = np.concatenate(pts)
-    return p, float(spacing)
+from surfelmeshing_amd.synth import room_surface_points as surface_points  # noqa: E402
 
 
 def dev_array(host):
@@ -91,6 +65,8 @@ def main():
             total += nq
         api.StreamSynchronize(None)
         t_query = time.perf_counter() - t0
+        # the same all-points workload through smx_nn_query_self (no query keys / sort; rows indexed by point): first batch only
+        # of the outputs is kept (the buffers hold `batch` rows), so it runs on an index over the first `batch` points
         cnt = out_cnt.Download()[0][:min(batch, n)]
         res[factor] = (t_build, t_query, float(cnt.mean()), int(cnt.max()))
         print("radius %.1f x spacing: build %.1f ms, %d queries in %.1f ms = %.1f Mq/s, mean results %.1f (max %d)" % (

@@ -19,4 +19,17 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATO
   timeout 600 rocprofv3 --pmc $C --output-format csv -d /tmp/prof_pmc -o run -- $CMDS > /tmp/pmc_$N.log 2>&1
   python tools/pmc_summary.py /tmp/prof_pmc $OUT/${TAG}_${N}.md $OUT/pmc_traffic.json > /dev/null || tail -5 /tmp/pmc_$N.log
 done
+# stamp the PMC file with the kernel sources it was collected on (bench.py refuses it for any other build) and the map size
+python - <<EOF
+import json, sys
+sys.path.insert(0, ".")
+import bench
+p = "$OUT/pmc_traffic.json"
+d = json.load(open(p))
+line = [l for l in open("$OUT/${TAG}_bench.log") if l.startswith('{"metric"')]
+slots = json.loads(line[0])["distributions"]["surfels_size"] if line else None
+d["_meta"] = {"source_sha": bench.source_sha(), "tag": "$TAG", "surfel_slots": slots,
+              "command": "rocprofv3 --pmc <counter> -- $CMDS (one pass per counter group)"}
+json.dump(d, open(p, "w"), indent=1, sort_keys=True)
+EOF
 grep -h '^{"metric"' $OUT/${TAG}_bench.log | head -1 | cut -c1-400
