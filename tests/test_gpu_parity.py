@@ -400,39 +400,40 @@ def test_full_resolution_parity(smx):
 
 
 def test_c3_resolution_parity_with_state_injection(smx):
-    """Config C3's frame size (1280x960, fx = fy = 1050; BASELINE.json configs[2], APP/main.cc:318): three frames from an
-    empty map (> 2 M slots), the GPU state re-injected into a fresh object through debug_upload_surfels, then five more
+    """Config C3's frame size (1280x960, fx = fy = 1050; BASELINE.json configs[2], APP/main.cc:318): six frames from an
+    empty map (> 1 M slots), the GPU state re-injected into a fresh object through debug_upload_surfels, then five more
     frames on both sides -- every surfel row, the association images, the blended depth and the counters bit-equal after
-    EVERY frame.  (The 20 M-slot state itself is compared inside `bench.py --config C3`: parity_check in its JSON line,
-    kept under profiles/.)"""
+    EVERY frame.  The camera pans 6 degrees per frame with the counting variant of the outlier cull (4 of 8 neighbours),
+    so every frame adds ~10^5 surfels.  (The 20 M-slot state itself is compared inside `bench.py --config C3`:
+    parity_check in its JSON line, kept under profiles/.)"""
     import os
     from oracle import binding
-    from surfelmeshing_amd.pipeline import FramePipeline
-    s = small_stream(1280, 960, yaw_deg_per_frame=1.0)
-    pre = small_pre(1280)
+    from surfelmeshing_amd.pipeline import FramePipeline, PreprocessParams
+    s = small_stream(1280, 960, yaw_deg_per_frame=6.0)
+    pre = PreprocessParams(max_depth=10.0, depth_valid_region_radius=2000.0, outlier_filtering_required_inliers=4)
     cap = 4_000_000
-    binding.set_row_threads(os.cpu_count() or 1)   # (row-parallel oracle stages: identical images, tests/test_oracle_properties.py)
+    binding.set_row_threads(min(os.cpu_count() or 1, 32))   # (row-parallel oracle stages: identical images, tests/test_oracle_properties.py)
     try:
         po, pg = _pipes(smx, s, cap, pre)
-        run_both(po, pg, s, list(range(4, 7)), lambda f: _compare_state(po, pg))
+        run_both(po, pg, s, list(range(4, 10)), lambda f: _compare_state(po, pg))
         n = po.recon.surfels_size
-        assert n > 2_000_000
+        assert n > 1_000_000
         rows = pg.reconstruction.debug_download_surfels(n)
         pg2 = FramePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, cap, pre)
         pg2.reconstruction.debug_upload_surfels(rows, po.recon.merge_count)
         assert pg2.reconstruction.surfels_size() == n and pg2.reconstruction.surfel_count() == po.recon.surfel_count
-        for f in range(3, 16):
+        for f in range(6, 19):
             d, c = s.frame(f)
             pg2.upload(f, d, c)
             if f not in po.raw_depth:
                 po.upload(f, d, c)
         merged_before = po.recon.merge_count
-        for f in range(7, 12):
+        for f in range(10, 15):
             for p in (po, pg2):
                 p.process(f, s.outlier_frames(f), s.others_TR_reference(f), s.pose(f))
             _compare_state(po, pg2)
         st = pg2.reconstruction.stats()
-        assert st["n_integrated"] > 500_000 and po.recon.merge_count > merged_before and po.recon.surfels_size > n
+        assert st["n_integrated"] > 300_000 and po.recon.merge_count > merged_before and po.recon.surfels_size > n
     finally:
         binding.set_row_threads(1)
 
