@@ -51,7 +51,8 @@ ALG_BYTES = {
     "reg_step": lambda st, P: 224.0 * st["n_recent"],
     "reg_update": lambda st, P: 36.0 * st["n_recent"],
     "associate": lambda st, P: 90.0 * st["n_visible"],
-    "merge_decide": lambda st, P: 60.0 * st["n_visible"],
+    # (one launch with the measurement blending since round 2: the slot "blend" is only timed in the multi-launch fallback)
+    "merge_decide": lambda st, P: 60.0 * st["n_visible"] + 26.0 * P,
     "integrate": lambda st, P: 160.0 * st["n_visible"],
     "update_neighbors+create": lambda st, P: 190.0 * st["n_visible"] + 6.0 * P + 122.0 * st["n_new"],
     "blend": lambda st, P: 26.0 * P,
@@ -426,9 +427,9 @@ def run_integrate(args):
 
 # kernel-slot name -> kernel name in rocprofv3 output
 SLOT_KERNEL = {"reg_accumulate": "k_reg_accumulate", "reg_step": "k_reg_step", "neighbor_scan": "k_neighbor_scan<true, true>",
-               "scan_visible": "k_scan_visible", "associate": "k_associate<true>", "merge_decide": "k_merge_decide<true>",
+               "scan_visible": "k_scan_visible", "associate": "k_associate<true>", "merge_decide": "k_merge_and_blend<true>",
                "integrate": "k_integrate<true>", "update_neighbors+create": "k_update_and_create<true>",
-               "blend": "k_blend_fused", "clear_assoc": "k_clear_assoc", "new_flags_scan": "k_new_flags_scan"}
+               "blend": "k_blend_start", "clear_assoc": "k_clear_assoc", "new_flags_scan": "k_new_flags_scan"}
 
 
 def pmc_file():

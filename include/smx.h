@@ -149,6 +149,16 @@ int smx_compute_point_radii_and_remove_isolated_pixels(
     const smx_buffer_desc* depth_buffer, const smx_buffer_desc* radius_buffer /*float*/,
     const smx_buffer_desc* out_depth);
 
+/* The three calls above that always follow each other in the caller (APP/main.cc:1128-1191: ErodeDepthMapCUDA or, for
+ * erosion_radius 0, CopyWithoutBorderCUDA; ComputeNormalsAndDropBadPixelsCUDA; ComputePointRadiiAndRemoveIsolatedPixelsCUDA)
+ * as ONE launch: the two intermediate depth images stay in LDS tiles.  out_depth, out_normals and radius_buffer receive
+ * exactly what the three separate calls leave in their last outputs.  in_depth and out_depth must differ. */
+int smx_erode_normals_radii(smx_stream s, int32_t erosion_radius, float observation_angle_threshold_deg,
+                            float point_radius_extension_factor, float point_radius_clamp_factor, float depth_scaling,
+                            float fx, float fy, float cx, float cy, const smx_buffer_desc* in_depth,
+                            const smx_buffer_desc* out_depth, const smx_buffer_desc* out_normals /*float2*/,
+                            const smx_buffer_desc* radius_buffer /*float*/);
+
 /* ---- CUDASurfelReconstruction (APP/cuda_surfel_reconstruction.h:44-176) ---- */
 /* trailing arguments of Integrate(), .h:59-77; defaults APP/main.cc:323-368 */
 typedef struct {

@@ -74,6 +74,8 @@ int smx_driver_run_streamed(smx_driver d, smx_stream s, const smx_driver_step* s
 /* Overlap of the depth preprocessing of frame f+1 (own stream, second set of work images) with Integrate(f);
  * default on.  Results are identical either way. */
 int smx_driver_set_overlap(smx_driver d, int32_t enabled);
+/* A/B switch: erosion + normals + radii as one fused launch (default) or as the reference's three calls; same images. */
+int smx_driver_set_fused_tail(smx_driver d, int32_t enabled);
 /* Working buffers after the last frame: final (blended) depth, normals, radius. */
 int smx_driver_work_descs(smx_driver d, smx_buffer_desc* depth, smx_buffer_desc* normals, smx_buffer_desc* radius);
 

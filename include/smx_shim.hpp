@@ -271,6 +271,20 @@ inline void ComputePointRadiiAndRemoveIsolatedPixelsCUDA(cudaStream_t stream, fl
       depth_cy, depth_buffer.desc(), radius_buffer->desc(), out_depth->desc()));
 }
 
+// Not in the reference: the last three preprocessing calls of its frame loop (APP/main.cc:1128-1191: erosion or, for
+// radius 0, the border copy; normals; radii) as one launch with the intermediate images in LDS -- the same final depth,
+// normals and radii.
+inline void ErodeNormalsRadiiCUDA(cudaStream_t stream, int erosion_radius, float observation_angle_threshold_deg,
+                                  float point_radius_extension_factor, float point_radius_clamp_factor,
+                                  float depth_scaling, float depth_fx, float depth_fy, float depth_cx, float depth_cy,
+                                  const CUDABuffer_<u16>& in_depth, CUDABuffer_<u16>* out_depth,
+                                  CUDABuffer_<float2_>* out_normals, CUDABuffer_<float>* radius_buffer) {
+  SMX_SHIM_CHECK(smx_erode_normals_radii(stream, erosion_radius, observation_angle_threshold_deg,
+                                         point_radius_extension_factor, point_radius_clamp_factor, depth_scaling, depth_fx,
+                                         depth_fy, depth_cx, depth_cy, in_depth.desc(), out_depth->desc(),
+                                         out_normals->desc(), radius_buffer->desc()));
+}
+
 // ---- APP/cuda_surfels_cpu.h ---------------------------------------------------------------------------
 struct CUDASurfelBuffersCPU {
   explicit CUDASurfelBuffersCPU(usize max_surfel_count) {

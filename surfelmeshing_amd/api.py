@@ -261,6 +261,18 @@ def ComputePointRadiiAndRemoveIsolatedPixelsCUDA(stream, point_radius_extension_
         _d(depth_buffer), _d(radius_buffer), _d(out_depth)))
 
 
+def ErodeNormalsRadiiCUDA(stream, erosion_radius, observation_angle_threshold_deg, point_radius_extension_factor,
+                          point_radius_clamp_factor, depth_scaling, depth_fx, depth_fy, depth_cx, depth_cy, in_depth,
+                          out_depth, out_normals, radius_buffer):
+    """Erosion (radius 0: border copy) + normals + radii as one launch (smx_erode_normals_radii): the final depth, the
+    normals and the radii of the three separate calls (APP/main.cc:1128-1191)."""
+    _lib.check(_lib.load().smx_erode_normals_radii(
+        _sv(stream), C.c_int32(erosion_radius), C.c_float(observation_angle_threshold_deg),
+        C.c_float(point_radius_extension_factor), C.c_float(point_radius_clamp_factor), C.c_float(depth_scaling),
+        C.c_float(depth_fx), C.c_float(depth_fy), C.c_float(depth_cx), C.c_float(depth_cy), _d(in_depth), _d(out_depth),
+        _d(out_normals), _d(radius_buffer)))
+
+
 def SynthRenderRoom(stream, depth_out, color_out, fx, fy, cx, cy, global_T_frame, seed, frame_index,
                     depth_scaling=5000.0, noise_sigma=0.001, dropout=0.01):
     """Benchmark input generator (smx_synth_render_room): one synthetic room frame into device buffers."""

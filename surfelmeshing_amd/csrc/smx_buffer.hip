@@ -120,7 +120,8 @@ int smx_stream_synchronize(smx_stream s) {
 int smx_event_create(smx_event* out) {
   SMX_CHECK_ARG(out != nullptr);
   hipEvent_t e;
-  SMX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  // (ordering of GPU streams only: device-scope release at the record, no flush towards the host)
+  SMX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice));
   *out = (smx_event)e;
   return SMX_OK;
 }

@@ -154,9 +154,10 @@ __device__ __forceinline__ float q_to_float(long long s) {
 // Regulariser gradient terms: 2^-22 fixed point (0.24 um), clamped to +-16 so that two of them share one 64-bit
 // accumulator word and the sum of up to 31 terms cannot leave its 32-bit half (NaN maps to the lower bound).
 __device__ __forceinline__ int q22_from_float(float v) {
-  double d = (double)v * 4194304.0;
-  if (!(d > -67108864.0)) d = -67108864.0;
-  if (d > 67108864.0) d = 67108864.0;
+  // (single precision: the scaling by 2^22 is exact, the same value as the product formed in double precision)
+  float d = v * 4194304.0f;
+  if (!(d > -67108864.0f)) d = -67108864.0f;
+  if (d > 67108864.0f) d = 67108864.0f;
   return (int)d;
 }
 __device__ __forceinline__ float q22_to_float(long long s) {

@@ -3,6 +3,7 @@
 // per kernel); the implementation is new: 64-lane-wide row tiles, LDS-staged
 // stencils, coalesced u16 row loads.
 #include <math.h>
+#include <stdlib.h>
 
 #include "smx_common.hpp"
 
@@ -97,8 +98,11 @@ k_bilateral(float denom_xy, float sigma_value_factor, int radius, int radius_squ
 // code into a deep software pipeline (260 VGPRs at R = 6, one wavefront per SIMD; 45 us alone).  A variant with a
 // rolled row loop (100 VGPRs) runs in 31 us alone but lowers the frame rate by 2 %: the filter runs beside the
 // memory-bound surfel kernels, and few fat wavefronts disturb those less than many thin ones.
-__device__ __forceinline__ float det_expf_branchless(float x) {
-  // det_expf's arithmetic, evaluated unconditionally; its two range tests become selects
+// det_expf for arguments <= 0 (every tap's exponent is: both terms are non-positive), evaluated unconditionally.  Same
+// arithmetic and the same bits as det_expf: the x > 88 branch cannot be taken; the final scaling y * 2^n is exact either
+// as a multiplication by the constructed power of two or as v_ldexp_f32 (one instruction instead of add + shift + mul)
+// wherever the result is a normal number, and below -86 the result is replaced by 0 anyway.
+__device__ __forceinline__ float det_expf_nonpositive(float x) {
   float t = x * 1.44269504088896341f;
   float n = __builtin_rintf(t);
   float r = __builtin_fmaf(n, -0.693359375f, x);
@@ -112,9 +116,7 @@ __device__ __forceinline__ float det_expf_branchless(float x) {
   float r2 = r * r;
   float y = __builtin_fmaf(p, r2, r);
   y = y + 1.0f;
-  const int ni = (int)n;
-  float e = y * __uint_as_float((uint32_t)(ni + 127) << 23);
-  e = (x > 88.0f) ? __builtin_inff() : e;
+  const float e = __builtin_amdgcn_ldexpf(y, (int)n);
   return (x < -86.0f) ? 0.0f : e;
 }
 
@@ -156,17 +158,19 @@ k_bilateral_r(float denom_xy, float sigma_value_factor, uint16_t value_to_ignore
     const float adapted_denom_value = 2.0f * adapted_sigma_value * adapted_sigma_value;
     const float inv_denom_value = 1.0f / adapted_denom_value;
     float sum = 0, weight = 0;
+    const float fcenter = (float)center_value;
 #pragma unroll
     for (int dy = -R; dy <= R; ++dy) {
 #pragma unroll
       for (int dx = -R; dx <= R; ++dx) {
         if (dx * dx + dy * dy > R * R) continue;  // (compile time)
         const uint16_t sample = tc[dy * TW + dx];
-        float vd = (float)((int)center_value - (int)sample);
+        const float fsample = (float)sample;
+        float vd = fcenter - fsample;   // == (float)((int)center - (int)sample): integers below 2^16, the difference is exact
         vd *= vd;
-        float w = det_expf_branchless(sp[dx * dx + dy * dy] + (-vd) * inv_denom_value);
+        float w = det_expf_nonpositive(sp[dx * dx + dy * dy] + (-vd) * inv_denom_value);
         w = (sample == value_to_ignore) ? 0.0f : w;
-        sum += w * (float)sample;
+        sum += w * fsample;
         weight += w;
       }
     }
@@ -372,20 +376,13 @@ __device__ __forceinline__ Vec3 unproject(int x, int y, float depth, const Unpro
 
 // ---------------------------------------------------------------------------------------------
 // Normals + grazing-angle drop.  Reference: ComputeNormalsAndDropBadPixelsCUDAKernel, cu:642-718.
-__global__ void __launch_bounds__(kThreads)
-k_normals(float normal_dot_threshold, float inv_depth_scaling, Unproj up,
-          Img<const uint16_t> in, Img<uint16_t> out, Img<float2> out_normals) {
-  const int x = blockIdx.x * kTileW + (threadIdx.x & (kTileW - 1));
-  const int y = blockIdx.y * (kThreads / kTileW) + threadIdx.x / kTileW;
-  const int W = in.width, H = in.height;
-  if (x >= W || y >= H) return;
-  const uint16_t c = in(y, x);
-  const uint16_t right = rd0(in, y, x + 1), left = rd0(in, y, x - 1);
-  const uint16_t bottom = rd0(in, y + 1, x), top = rd0(in, y - 1, x);
+// One pixel: the centre depth and its four neighbours in, the depth after the drop (0 = dropped) and the normal out.
+__device__ __forceinline__ uint16_t normals_pixel(float normal_dot_threshold, float inv_depth_scaling, const Unproj& up,
+                                                  int x, int y, uint16_t c, uint16_t left, uint16_t right, uint16_t top,
+                                                  uint16_t bottom, float2& normal) {
   if (c == 0 || right == 0 || left == 0 || bottom == 0 || top == 0) {
-    out(y, x) = 0;
-    out_normals(y, x) = make_float2(0, 0);
-    return;
+    normal = make_float2(0, 0);
+    return 0;
   }
   const Vec3 lp = unproject(x - 1, y, inv_depth_scaling * (float)left, up);
   const Vec3 tp = unproject(x, y - 1, inv_depth_scaling * (float)top, up);
@@ -401,35 +398,46 @@ k_normals(float normal_dot_threshold, float inv_depth_scaling, Unproj up,
     const float inv_length = ((up.fy_inv < 0) ? -1.0f : 1.0f) / length;
     n.x *= inv_length; n.y *= inv_length; n.z *= inv_length;
   }
-  out_normals(y, x) = make_float2(n.x, n.y);
+  normal = make_float2(n.x, n.y);
   Vec3 vd = {up.fx_inv * (float)x + up.cx_inv, up.fy_inv * (float)y + up.cy_inv, 1.0f};
   const float inv_dir_length = 1.0f / sqrtf(vd.x * vd.x + vd.y * vd.y + vd.z * vd.z);
   vd.x = inv_dir_length * vd.x; vd.y = inv_dir_length * vd.y; vd.z = inv_dir_length * vd.z;
   const float dot = vd.x * n.x + vd.y * n.y + vd.z * n.z;
-  out(y, x) = (dot >= normal_dot_threshold) ? (uint16_t)0 : c;
+  return (dot >= normal_dot_threshold) ? (uint16_t)0 : c;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_normals(float normal_dot_threshold, float inv_depth_scaling, Unproj up,
+          Img<const uint16_t> in, Img<uint16_t> out, Img<float2> out_normals) {
+  const int x = blockIdx.x * kTileW + (threadIdx.x & (kTileW - 1));
+  const int y = blockIdx.y * (kThreads / kTileW) + threadIdx.x / kTileW;
+  const int W = in.width, H = in.height;
+  if (x >= W || y >= H) return;
+  float2 n;
+  out(y, x) = normals_pixel(normal_dot_threshold, inv_depth_scaling, up, x, y, in(y, x), rd0(in, y, x - 1), rd0(in, y, x + 1),
+                            rd0(in, y - 1, x), rd0(in, y + 1, x), n);
+  out_normals(y, x) = n;
 }
 
 // ---------------------------------------------------------------------------------------------
 // Point radii + isolated-pixel removal.  Reference:
 // ComputePointRadiiAndRemoveIsolatedPixelsCUDAKernel, cu:765-837.
-__global__ void __launch_bounds__(kThreads)
-k_radii(float ext2, float clamp_term, float inv_depth_scaling, Unproj up,
-        Img<const uint16_t> in, Img<float> out_radius, Img<uint16_t> out) {
-  const int x = blockIdx.x * kTileW + (threadIdx.x & (kTileW - 1));
-  const int y = blockIdx.y * (kThreads / kTileW) + threadIdx.x / kTileW;
-  const int W = in.width, H = in.height;
-  if (x >= W || y >= H) return;
-  const uint16_t c = in(y, x);
-  if (c == 0) { out(y, x) = 0; return; }
+// One pixel with a non-zero centre: d[3][3] = the 3x3 depths around it (0 outside the image); returns the output depth.
+__device__ __forceinline__ uint16_t radii_pixel(float ext2, float clamp_term, float inv_depth_scaling, const Unproj& up,
+                                                int x, int y, const uint16_t d[3][3], float& radius_squared_out) {
+  const uint16_t c = d[1][1];
   const float depth = inv_depth_scaling * (float)c;
   const Vec3 lp = {depth * (up.fx_inv * (float)x + up.cx_inv), depth * (up.fy_inv * (float)y + up.cy_inv), depth};
   int neighbor_count = 0;
   float radius_squared = 0;
   float min_d2 = __builtin_inff();
-  for (int dy = y - 1; dy < y + 2; ++dy) {
-    for (int dx = x - 1; dx < x + 2; ++dx) {
-      const float dd = inv_depth_scaling * (float)rd0(in, dy, dx);
-      if ((dx == x && dy == y) || dd <= 0) continue;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int dx = x - 1 + i, dy = y - 1 + j;
+      const float dd = inv_depth_scaling * (float)d[j][i];
+      if ((i == 1 && j == 1) || dd <= 0) continue;
       ++neighbor_count;
       const Vec3 op = {dd * (up.fx_inv * (float)dx + up.cx_inv), dd * (up.fy_inv * (float)dy + up.cy_inv), dd};
       const Vec3 v = {op.x - lp.x, op.y - lp.y, op.z - lp.z};
@@ -441,8 +449,100 @@ k_radii(float ext2, float clamp_term, float inv_depth_scaling, Unproj up,
   radius_squared *= ext2;
   const float clamp = clamp_term * min_d2;
   if (radius_squared > clamp) radius_squared = clamp;
-  out_radius(y, x) = radius_squared;
-  out(y, x) = (neighbor_count < 8) ? (uint16_t)0 : c;
+  radius_squared_out = radius_squared;
+  return (neighbor_count < 8) ? (uint16_t)0 : c;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_radii(float ext2, float clamp_term, float inv_depth_scaling, Unproj up,
+        Img<const uint16_t> in, Img<float> out_radius, Img<uint16_t> out) {
+  const int x = blockIdx.x * kTileW + (threadIdx.x & (kTileW - 1));
+  const int y = blockIdx.y * (kThreads / kTileW) + threadIdx.x / kTileW;
+  const int W = in.width, H = in.height;
+  if (x >= W || y >= H) return;
+  if (in(y, x) == 0) { out(y, x) = 0; return; }   // (radius left untouched, cu:777-780)
+  uint16_t d[3][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[j][i] = rd0(in, y - 1 + j, x - 1 + i);
+  float r2;
+  out(y, x) = radii_pixel(ext2, clamp_term, inv_depth_scaling, up, x, y, d, r2);
+  out_radius(y, x) = r2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Erosion (or the border copy) + normals + radii of one frame in ONE launch (the three calls of APP/main.cc:1128-1191 that
+// always follow each other): each stage's zeroing feeds the next stage's validity tests, so the intermediate depth
+// images of a 32x8 pixel tile and their shrinking halos (erosion radius + 2, 2, 1) live in LDS; only the final depth,
+// the normals and the radii are written.  Same per-pixel routines as the separate kernels: identical images.
+constexpr int kFuseTW = 32, kFuseTH = 8, kFuseMaxR = 3;
+__global__ void __launch_bounds__(kThreads)
+k_erode_normals_radii(int radius /* 0 = copy without border */, float normal_dot_threshold, float ext2, float clamp_term,
+                      float inv_depth_scaling, Unproj up, Img<const uint16_t> in, Img<uint16_t> out_depth,
+                      Img<float2> out_normals, Img<float> out_radius) {
+  constexpr int kIW = kFuseTW + 2 * (kFuseMaxR + 2), kIH = kFuseTH + 2 * (kFuseMaxR + 2);
+  constexpr int kEW = kFuseTW + 4, kEH = kFuseTH + 4, kNW = kFuseTW + 2, kNH = kFuseTH + 2;
+  __shared__ uint16_t ti[kIH * kIW];   // input with halo radius + 2
+  __shared__ uint16_t te[kEH * kEW];   // after erosion / border copy, halo 2
+  __shared__ uint16_t tn[kNH * kNW];   // after the normals stage, halo 1
+  const int W = in.width, H = in.height;
+  const int bx = blockIdx.x * kFuseTW, by = blockIdx.y * kFuseTH;
+  const int hi = radius + 2, iw = kFuseTW + 2 * hi, ih = kFuseTH + 2 * hi;
+  for (int k = threadIdx.x; k < iw * ih; k += kThreads) {
+    const int ty = k / iw, tx = k - ty * iw;
+    const int gx = bx - hi + tx, gy = by - hi + ty;
+    ti[ty * kIW + tx] = (gx >= 0 && gy >= 0 && gx < W && gy < H) ? in(gy, gx) : (uint16_t)0;
+  }
+  __syncthreads();
+  // erosion, cu:514-538 (radius >= 1) / border copy, cu:589-607
+  for (int k = threadIdx.x; k < kEW * kEH; k += kThreads) {
+    const int ty = k / kEW, tx = k - ty * kEW;
+    const int gx = bx - 2 + tx, gy = by - 2 + ty;
+    uint16_t v = 0;
+    if (gx >= 0 && gy >= 0 && gx < W && gy < H) {
+      const uint16_t* c = &ti[(ty + radius) * kIW + (tx + radius)];   // the same pixel in the input tile
+      if (radius == 0) {
+        v = (gx < 1 || gy < 1 || gx >= W - 1 || gy >= H - 1) ? (uint16_t)0 : c[0];
+      } else if (!(gx < radius || gy < radius || gx >= W - radius || gy >= H - radius)) {
+        bool all_valid = true;
+        for (int dy = -radius; dy <= radius; ++dy)
+          for (int dx = -radius; dx <= radius; ++dx)
+            if (c[dy * kIW + dx] == 0) all_valid = false;
+        v = all_valid ? c[0] : (uint16_t)0;
+      }
+    }
+    te[k] = v;
+  }
+  __syncthreads();
+  // normals, cu:642-718 (pixels outside the image stay 0: the next stage reads them as "no measurement")
+  for (int k = threadIdx.x; k < kNW * kNH; k += kThreads) {
+    const int ty = k / kNW, tx = k - ty * kNW;
+    const int gx = bx - 1 + tx, gy = by - 1 + ty;
+    uint16_t v = 0;
+    if (gx >= 0 && gy >= 0 && gx < W && gy < H) {
+      const uint16_t* c = &te[(ty + 1) * kEW + (tx + 1)];
+      float2 n;
+      v = normals_pixel(normal_dot_threshold, inv_depth_scaling, up, gx, gy, c[0], c[-1], c[1], c[-kEW], c[kEW], n);
+      if (tx >= 1 && ty >= 1 && tx <= kFuseTW && ty <= kFuseTH) out_normals(gy, gx) = n;
+    }
+    tn[k] = v;
+  }
+  __syncthreads();
+  // radii + isolated-pixel removal, cu:765-837
+  const int lx = threadIdx.x & (kFuseTW - 1), ly = threadIdx.x / kFuseTW;
+  const int x = bx + lx, y = by + ly;
+  if (x >= W || y >= H) return;
+  const uint16_t* c = &tn[(ly + 1) * kNW + (lx + 1)];
+  if (c[0] == 0) { out_depth(y, x) = 0; return; }   // (radius left untouched, cu:777-780)
+  uint16_t d[3][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[j][i] = c[(j - 1) * kNW + (i - 1)];
+  float r2;
+  out_depth(y, x) = radii_pixel(ext2, clamp_term, inv_depth_scaling, up, x, y, d, r2);
+  out_radius(y, x) = r2;
 }
 
 inline dim3 grid_rows(int W, int H) { return dim3(div_up(W, kTileW), div_up(H, kThreads / kTileW), 1); }
@@ -603,6 +703,30 @@ int smx_compute_point_radii_and_remove_isolated_pixels(
   hipLaunchKernelGGL(k_radii, grid_rows(depth_buffer->width, depth_buffer->height), dim3(kThreads), 0,
                      (hipStream_t)s, ext2, clamp_term, 1.0f / depth_scaling, make_unproj(fx, fy, cx, cy),
                      as_img<const uint16_t>(depth_buffer), as_img<float>(radius_buffer), as_img<uint16_t>(out_depth));
+  SMX_LAUNCH_CHECK();
+  return SMX_OK;
+}
+
+int smx_erode_normals_radii(smx_stream s, int32_t erosion_radius, float observation_angle_threshold_deg,
+                            float point_radius_extension_factor, float point_radius_clamp_factor, float depth_scaling,
+                            float fx, float fy, float cx, float cy, const smx_buffer_desc* in_depth,
+                            const smx_buffer_desc* out_depth, const smx_buffer_desc* out_normals,
+                            const smx_buffer_desc* radius_buffer) {
+  SMX_CHECK_ARG(in_depth && out_depth && out_normals && radius_buffer && in_depth->address != out_depth->address);
+  SMX_CHECK_ARG(in_depth->width == out_depth->width && in_depth->height == out_depth->height);
+  SMX_CHECK_ARG(out_normals->width == in_depth->width && out_normals->height == in_depth->height);
+  SMX_CHECK_ARG(radius_buffer->width == in_depth->width && radius_buffer->height == in_depth->height);
+  if (erosion_radius < 0 || erosion_radius > kFuseMaxR) {                          // cu:572-574
+    set_error("radius value of %d is not supported.", erosion_radius);
+    return SMX_ERR_UNSUPPORTED;
+  }
+  const float thr = -1 * cosf((float)(M_PI / 180.f * observation_angle_threshold_deg));  // cu:752
+  const float ext2 = point_radius_extension_factor * point_radius_extension_factor;
+  const float clamp_term = point_radius_clamp_factor * point_radius_clamp_factor * sqrtf(2) * sqrtf(2);  // cu:873
+  const dim3 grid(div_up(in_depth->width, kFuseTW), div_up(in_depth->height, kFuseTH));
+  hipLaunchKernelGGL(k_erode_normals_radii, grid, dim3(kThreads), 0, (hipStream_t)s, (int)erosion_radius, thr, ext2,
+                     clamp_term, 1.0f / depth_scaling, make_unproj(fx, fy, cx, cy), as_img<const uint16_t>(in_depth),
+                     as_img<uint16_t>(out_depth), as_img<float2>(out_normals), as_img<float>(radius_buffer));
   SMX_LAUNCH_CHECK();
   return SMX_OK;
 }

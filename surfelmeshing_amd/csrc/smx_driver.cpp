@@ -45,6 +45,7 @@ struct smx_driver_s {
   cudaStream_t pre_stream = nullptr;   // depth preprocessing of the next frame
   smx_event run_start = nullptr;
   bool overlap = true;
+  bool fuse_tail = true;   // erosion + normals + radii as one launch (A/B: smx_driver_set_fused_tail)
   unsigned long long frame_counter = 0;
 
   explicit smx_driver_s(const smx_driver_config& c, const float* intr)
@@ -116,19 +117,24 @@ static int preprocess_frame(smx_driver d, cudaStream_t stream, const smx_driver_
 #undef SMX_CALL_OUTLIER_FUSION
     std::swap(src, dst);
   }
-  // Depth map erosion (:1128-1140)
-  if (c.depth_erosion_radius > 0) ErodeDepthMapCUDA(stream, c.depth_erosion_radius, src->ToCUDA(), &dst->ToCUDA());
-  else CopyWithoutBorderCUDA(stream, src->ToCUDA(), &dst->ToCUDA());
-  std::swap(src, dst);
-  // Normals (:1154-1164)
-  ComputeNormalsAndDropBadPixelsCUDA(stream, c.observation_angle_threshold_deg, c.depth_scaling, cam[0], cam[1], cam[2],
-                                     cam[3], src->ToCUDA(), &dst->ToCUDA(), &ws->normals_buffer.ToCUDA());
-  std::swap(src, dst);
-  // Radii (:1180-1191)
-  ComputePointRadiiAndRemoveIsolatedPixelsCUDA(stream, c.point_radius_extension_factor, c.point_radius_clamp_factor,
-                                               c.depth_scaling, cam[0], cam[1], cam[2], cam[3], src->ToCUDA(),
-                                               &ws->radius_buffer.ToCUDA(), &dst->ToCUDA());
-  std::swap(src, dst);
+  // Depth map erosion (:1128-1140), normals (:1154-1164), radii (:1180-1191): one fused launch (same images)
+  if (d->fuse_tail) {
+    ErodeNormalsRadiiCUDA(stream, c.depth_erosion_radius, c.observation_angle_threshold_deg, c.point_radius_extension_factor,
+                          c.point_radius_clamp_factor, c.depth_scaling, cam[0], cam[1], cam[2], cam[3], src->ToCUDA(),
+                          &dst->ToCUDA(), &ws->normals_buffer.ToCUDA(), &ws->radius_buffer.ToCUDA());
+    std::swap(src, dst);
+  } else {
+    if (c.depth_erosion_radius > 0) ErodeDepthMapCUDA(stream, c.depth_erosion_radius, src->ToCUDA(), &dst->ToCUDA());
+    else CopyWithoutBorderCUDA(stream, src->ToCUDA(), &dst->ToCUDA());
+    std::swap(src, dst);
+    ComputeNormalsAndDropBadPixelsCUDA(stream, c.observation_angle_threshold_deg, c.depth_scaling, cam[0], cam[1], cam[2],
+                                       cam[3], src->ToCUDA(), &dst->ToCUDA(), &ws->normals_buffer.ToCUDA());
+    std::swap(src, dst);
+    ComputePointRadiiAndRemoveIsolatedPixelsCUDA(stream, c.point_radius_extension_factor, c.point_radius_clamp_factor,
+                                                 c.depth_scaling, cam[0], cam[1], cam[2], cam[3], src->ToCUDA(),
+                                                 &ws->radius_buffer.ToCUDA(), &dst->ToCUDA());
+    std::swap(src, dst);
+  }
   ws->final_depth = src;
   return SMX_OK;
 }
@@ -286,6 +292,12 @@ int smx_driver_run_streamed(smx_driver d, smx_stream s, const smx_driver_step* s
 int smx_driver_set_overlap(smx_driver d, int32_t enabled) {
   if (!d) return fail("null argument");
   d->overlap = enabled != 0;
+  return SMX_OK;
+}
+
+int smx_driver_set_fused_tail(smx_driver d, int32_t enabled) {
+  if (!d) return fail("null argument");
+  d->fuse_tail = enabled != 0;
   return SMX_OK;
 }
 

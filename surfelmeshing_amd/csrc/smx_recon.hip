@@ -25,6 +25,7 @@
 // The surfel count, merge count and all list lengths live in device memory;
 // no kernel launch needs a host round trip.
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -66,30 +67,48 @@ struct DevState {
 //   T  Neighbor0..3                  -- what pass B streams (16 B/slot)
 //   C  Confidence, CreationStamp, Color, -
 //   G  GradientX, GradientY, GradientZ, -  (parked next smooth position)
+// S is a 32-byte record: the second half is a COPY of the slot's T record.  The regulariser needs, per link, the
+// neighbour's smooth position and the neighbour's own links (does it list me back?): two 16-byte gathers from two arrays
+// cost two cache-line requests, one 32-byte record costs one (profiles/r02a_ubench.txt: 61 us vs 32 us for the 1.6 M
+// links of a frame).  T stays a dense 16-byte array for pass B's all-slot stream; every writer of T writes both.
 // The reference's row order only matters at the boundary (TransferAllToCPU, ExportVertices, the debug row
 // accessors); pack/unpack kernels convert there.  Rows 14-16 (Accum*, never used) and 23 (GradientCount,
 // replaced by the fixed-point accumulators) have no storage.
 enum : int { kGroupP = 0, kGroupS, kGroupN, kGroupT, kGroupC, kGroupG, kGroups };
 __host__ __device__ constexpr int row_group(int row) {
   return row <= 2 ? kGroupP : row <= 5 ? kGroupS : row == 6 ? kGroupC : row == 7 ? kGroupN : row <= 10 ? kGroupN
-       : row <= 13 ? kGroupG : row == 17 ? kGroupC : row == 18 ? kGroupP : row <= 22 ? kGroupT : row == 24 ? kGroupC : -1;
+       : row <= 13 ? kGroupG : row <= 16 ? -1 : row == 17 ? kGroupC : row == 18 ? kGroupP : row <= 22 ? kGroupT
+       : row == 24 ? kGroupC : -1;
 }
 __host__ __device__ constexpr int row_sub(int row) {
   return row <= 2 ? row : row <= 5 ? row - 3 : row == 6 ? 0 : row == 7 ? 3 : row <= 10 ? row - 8
        : row <= 13 ? row - 11 : row == 17 ? 1 : row == 18 ? 3 : row <= 22 ? row - 19 : row == 24 ? 2 : -1;
 }
+// start of each group array and its record size, in 16-byte units (x pitch / per slot)
+__host__ __device__ constexpr int group_start(int g) { return g == kGroupP ? 0 : g == kGroupS ? 1 : g == kGroupN ? 3 : g == kGroupT ? 4 : g == kGroupC ? 5 : 6; }
+__host__ __device__ constexpr int group_stride(int g) { return g == kGroupS ? 2 : 1; }
+constexpr int kQuadsPerSlot = 7;   // 112 bytes per slot
 struct Surfels {
   float* base;
   size_t pitch;  // slots per group array (multiple of 64)
-  __device__ __forceinline__ float& f(int row, uint32_t i) const {
-    return base[((size_t)row_group(row) * pitch + i) * 4 + row_sub(row)];
+  __host__ __device__ __forceinline__ size_t quad(int g, uint32_t i) const {
+    return (size_t)group_start(g) * pitch + (size_t)i * group_stride(g);
   }
+  __device__ __forceinline__ float& f(int row, uint32_t i) const { return base[quad(row_group(row), i) * 4 + row_sub(row)]; }
   __device__ __forceinline__ uint32_t& u(int row, uint32_t i) const {
-    return reinterpret_cast<uint32_t*>(base)[((size_t)row_group(row) * pitch + i) * 4 + row_sub(row)];
+    return reinterpret_cast<uint32_t*>(base)[quad(row_group(row), i) * 4 + row_sub(row)];
   }
-  // whole 16-byte group of slot i
-  __device__ __forceinline__ float4* group(int g, uint32_t i) const {
-    return reinterpret_cast<float4*>(base) + ((size_t)g * pitch + i);
+  // whole 16-byte group of slot i (S: the first half of its 32-byte record)
+  __device__ __forceinline__ float4* group(int g, uint32_t i) const { return reinterpret_cast<float4*>(base) + quad(g, i); }
+  // the copy of the T record inside the S record, and the only two ways T is ever written
+  __device__ __forceinline__ uint4* tcopy(uint32_t i) const { return reinterpret_cast<uint4*>(group(kGroupS, i) + 1); }
+  __device__ __forceinline__ void set_neighbors(uint32_t i, const uint4& t) const {
+    *reinterpret_cast<uint4*>(group(kGroupT, i)) = t;
+    *tcopy(i) = t;
+  }
+  __device__ __forceinline__ void set_neighbor(uint32_t i, int q, uint32_t v) const {
+    u(kNeighbor0 + q, i) = v;
+    reinterpret_cast<uint32_t*>(tcopy(i))[q] = v;
   }
 };
 
@@ -247,21 +266,19 @@ struct BlendBufs {
 };
 
 __global__ void __launch_bounds__(kBlock)
-k_clear_assoc(Scratch sc, BlendBufs bb, int P, DevState* st) {
+k_clear_assoc(Scratch sc, int P) {
   const int k = blockIdx.x * kBlock + threadIdx.x;
-  if (k == 0) {
-    st->n_visible = 0; st->n_merged = 0; st->n_integrated = 0; st->n_replaced = 0; st->n_conflict_hits = 0;
-    st->n_segments_skipped = 0;
-  }
   if (k < P) {
     sc.supporting[k] = kInvalid;
     sc.counts[k] = 0;
     sc.depth_sums[k] = 0;
     sc.confl_key[k] = kInvalid;
     sc.first_depth[k] = __builtin_inff();
-    bb.distance_map[k] = 0;
-    bb.new_distance_map[k] = 0;
   }
+}
+__global__ void k_reset_frame_stats(DevState* st) {   // (value-distribution counters: only while statistics are on)
+  st->n_visible = 0; st->n_merged = 0; st->n_integrated = 0; st->n_replaced = 0; st->n_conflict_hits = 0;
+  st->n_segments_skipped = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -387,10 +404,10 @@ k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, const uint8_t* __rest
 // whole chip.  In the A/B "scan mode" every slot of the chunk is visited instead of the list entries.
 template <bool kUseList, int kSegSize = kSeg>
 __device__ __forceinline__ bool chunk_entry(const uint32_t* __restrict__ list, const uint32_t* __restrict__ seg,
-                                            uint32_t n_slots, uint32_t chunk, uint32_t& i) {
+                                            uint32_t n_slots, uint32_t chunk, uint32_t& i, uint32_t lane) {
   constexpr uint32_t kChunksPerSeg = kSegSize / kBlock;
   const uint32_t s = chunk / kChunksPerSeg, sub = chunk % kChunksPerSeg;
-  const uint32_t e = sub * kBlock + threadIdx.x;
+  const uint32_t e = sub * kBlock + lane;
   if (kUseList) {
     if (e >= seg[s]) return false;
     i = list[s * kSegSize + e];
@@ -398,6 +415,12 @@ __device__ __forceinline__ bool chunk_entry(const uint32_t* __restrict__ list, c
   }
   i = s * kSegSize + e;
   return i < n_slots;
+}
+
+template <bool kUseList, int kSegSize = kSeg>
+__device__ __forceinline__ bool chunk_entry(const uint32_t* __restrict__ list, const uint32_t* __restrict__ seg,
+                                            uint32_t n_slots, uint32_t chunk, uint32_t& i) {
+  return chunk_entry<kUseList, kSegSize>(list, seg, n_slots, chunk, i, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -507,13 +530,14 @@ __device__ __forceinline__ bool merge_decide(const Surfels& S, const FrameCtx& c
 }
 
 template <bool kUseList>
-__global__ void __launch_bounds__(kBlock)
-k_merge_decide(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<const float2> normals,
-               Lists L, uint8_t* __restrict__ merge_flag, const DevState* st) {
+__device__ __forceinline__ void merge_decide_chunks(const Surfels& S, const FrameCtx& c, const Scratch& sc,
+                                                    const Img<const uint16_t>& depth, const Img<const float2>& normals,
+                                                    const Lists& L, uint8_t* __restrict__ merge_flag, const DevState* st,
+                                                    uint32_t first_chunk, uint32_t chunk_stride, uint32_t lane) {
   const uint32_t n_slots = st->surfel_count, n_chunks = (n_slots + kBlock - 1) / kBlock;
-  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  for (uint32_t chunk = first_chunk; chunk < n_chunks; chunk += chunk_stride) {
     uint32_t i;
-    if (!chunk_entry<kUseList>(L.vis_list, L.vis_seg, n_slots, chunk, i)) continue;
+    if (!chunk_entry<kUseList>(L.vis_list, L.vis_seg, n_slots, chunk, i, lane)) continue;
     const float4 p4 = *S.group(kGroupP, i), n4 = *S.group(kGroupN, i);
     const float r2 = n4.w;
     if (!(r2 >= 0)) continue;  // :2017
@@ -523,6 +547,12 @@ k_merge_decide(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img
     const Vec3 gn = {n4.x, n4.y, n4.z};
     if (merge_decide(S, c, sc, depth, normals, p, i, gn, r2)) merge_flag[i] = 1;
   }
+}
+template <bool kUseList>
+__global__ void __launch_bounds__(kBlock)
+k_merge_decide(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<const float2> normals,
+               Lists L, uint8_t* __restrict__ merge_flag, const DevState* st) {
+  merge_decide_chunks<kUseList>(S, c, sc, depth, normals, L, merge_flag, st, blockIdx.x, gridDim.x, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -610,9 +640,11 @@ __device__ __forceinline__ int small_div(int q, float inv_d) { return (int)(((fl
 constexpr int kBlendTile = 32;
 constexpr int kBlendThreads = 1024;  // 16 wavefronts advance the rings of one tile
 constexpr int kBlendMaxHalo = 16;    // radius <= 17 uses this kernel (<= 64 KB LDS), larger radii the multi-launch path
-__global__ void __launch_bounds__(kBlendThreads)
-k_blend_fused(int radius, float term, float ds, Img<uint16_t> depth, Scratch sc, int W, int H) {
-  extern __shared__ __align__(16) unsigned char blend_lds[];
+// `depth` is only read; the blended depths of the tile interior go to `out` (a tile that has nothing to blend copies its
+// interior), so tiles never see each other's results and the kernel can share a launch with other readers of `depth`.
+__device__ __forceinline__ void blend_tile(unsigned char* blend_lds, int tile_x, int tile_y, int radius, float term, float ds,
+                                           const Img<const uint16_t>& depth, const Img<uint16_t>& out, const Scratch& sc,
+                                           int W, int H) {
   const int halo = radius - 1;
   const int rw = kBlendTile + 2 * halo;          // region width == height
   const int cells = rw * rw;
@@ -623,7 +655,7 @@ k_blend_fused(int radius, float term, float ds, Img<uint16_t> depth, Scratch sc,
   uint8_t* dist = reinterpret_cast<uint8_t*>(newdep + cells);
   uint8_t* ndist = dist + cells;
   uint8_t* flag = ndist + cells;                  // bit 0: supporting surfel valid, bit 1: processed pixel
-  const int x0 = blockIdx.x * kBlendTile - halo, y0 = blockIdx.y * kBlendTile - halo;
+  const int x0 = tile_x * kBlendTile - halo, y0 = tile_y * kBlendTile - halo;
   const float inv_rw = 1.0f / (float)rw;
   for (int k = threadIdx.x; k < cells; k += kBlendThreads) {
     const int ry = small_div(k, inv_rw), rx = k - ry * rw;
@@ -667,8 +699,9 @@ k_blend_fused(int radius, float term, float ds, Img<uint16_t> depth, Scratch sc,
     }
     newdep[k] = nd;
   }
-  // no measurement / surfel border anywhere in tile + halo: the blend changes nothing here
-  if (!__syncthreads_or(any)) return;
+  // no measurement / surfel border anywhere in tile + halo: the blend changes nothing here (dep = the input depths)
+  const bool blend_here = __syncthreads_or(any) != 0;
+  if (blend_here) {
   for (int k = threadIdx.x; k < cells; k += kBlendThreads) dep[k] = newdep[k];
   __syncthreads();
   // iteration kernels, :647-708.  Ring `it` is only needed (and only exact) up to halo - it pixels outside
@@ -716,10 +749,32 @@ k_blend_fused(int radius, float term, float ds, Img<uint16_t> depth, Scratch sc,
     // a ring that assigned nothing leaves no frontier: all later rings are empty too
     if (!__syncthreads_or(changed)) break;
   }
+  }
   for (int k = threadIdx.x; k < kBlendTile * kBlendTile; k += kBlendThreads) {
     const int ty = k / kBlendTile, tx = k - ty * kBlendTile;
-    const int x = blockIdx.x * kBlendTile + tx, y = blockIdx.y * kBlendTile + ty;
-    if (x < W && y < H) depth(y, x) = dep[(ty + halo) * rw + (tx + halo)];
+    const int x = tile_x * kBlendTile + tx, y = tile_y * kBlendTile + ty;
+    if (x < W && y < H) out(y, x) = dep[(ty + halo) * rw + (tx + halo)];
+  }
+}
+
+// MergeSurfelsCUDA's decisions and BlendMeasurementsCUDA in ONE launch: both only read the association images and the
+// (unblended) depth, neither reads what the other writes (merge flags / the blended copy), and on the frame-to-frame
+// critical path a launch boundary costs more than either kernel's tail.  The first n_blend_blocks workgroups are blend
+// tiles; the others walk the visible list, four 256-entry chunks per 1024-lane workgroup.
+template <bool kUseList>
+__global__ void __launch_bounds__(kBlendThreads)
+k_merge_and_blend(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<const float2> normals, Lists L,
+                  uint8_t* __restrict__ merge_flag, const DevState* st, int radius, float term, float ds,
+                  Img<uint16_t> blended, int tiles_x, uint32_t n_blend_blocks) {
+  extern __shared__ __align__(16) unsigned char blend_lds[];
+  if (blockIdx.x < n_blend_blocks) {
+    blend_tile(blend_lds, (int)(blockIdx.x % (uint32_t)tiles_x), (int)(blockIdx.x / (uint32_t)tiles_x), radius, term, ds, depth,
+               blended, sc, c.W, c.H);
+  } else {
+    constexpr uint32_t kChunksPerBlock = kBlendThreads / kBlock;
+    const uint32_t mb = blockIdx.x - n_blend_blocks, n_mb = gridDim.x - n_blend_blocks;
+    merge_decide_chunks<kUseList>(S, c, sc, depth, normals, L, merge_flag, st, mb * kChunksPerBlock + (threadIdx.x / kBlock),
+                                  n_mb * kChunksPerBlock, threadIdx.x % kBlock);
   }
 }
 
@@ -882,7 +937,7 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
       *S.group(kGroupP, i) = R.P; *S.group(kGroupN, i) = R.N; *S.group(kGroupC, i) = R.C;
       if (R.replaced) {
         S.f(kSmoothX, i) = R.new_smooth.x; S.f(kSmoothY, i) = R.new_smooth.y; S.f(kSmoothZ, i) = R.new_smooth.z;
-        *reinterpret_cast<uint4*>(S.group(kGroupT, i)) = make_uint4(kInvalid, kInvalid, kInvalid, kInvalid);
+        S.set_neighbors(i, make_uint4(kInvalid, kInvalid, kInvalid, kInvalid));
       }
     }
     // stamp and detach flag may have changed: refresh the flag table entry
@@ -978,7 +1033,7 @@ __device__ __forceinline__ void update_neighbors_body(const Surfels& S, const Fr
       }
     }
     if (ni[0] != t4.x || ni[1] != t4.y || ni[2] != t4.z || ni[3] != t4.w)
-      *reinterpret_cast<uint4*>(S.group(kGroupT, i)) = make_uint4(ni[0], ni[1], ni[2], ni[3]);
+      S.set_neighbors(i, make_uint4(ni[0], ni[1], ni[2], ni[3]));
   }
 }
 
@@ -991,9 +1046,12 @@ __device__ __forceinline__ void update_neighbors_body(const Surfels& S, const Fr
 constexpr int kScanPxPerThread = 4;
 constexpr int kScanPxPerBlock = kBlock * kScanPxPerThread;
 
+// With copy_back the blended depths (k_merge_and_blend's output) are stored into the caller's depth buffer on the way --
+// Integrate mutates its depth argument like the reference (kernels.cu:610, 681, 704) -- and used for the flags.
 __global__ void __launch_bounds__(kBlock)
-k_new_flags_scan(Img<const uint16_t> depth, Scratch sc, int W, int H, uint8_t* __restrict__ flags,
-                 uint32_t* __restrict__ local_rank, uint32_t* __restrict__ block_sums, DevState* st) {
+k_new_flags_scan(Img<const uint16_t> depth, Img<uint16_t> depth_out, int copy_back, Scratch sc, int W, int H,
+                 uint8_t* __restrict__ flags, uint32_t* __restrict__ local_rank, uint32_t* __restrict__ block_sums,
+                 DevState* st) {
   __shared__ uint32_t wave_tot[kBlock / 64];
   const int P = W * H;
   const int k0 = (blockIdx.x * kBlock + threadIdx.x) * kScanPxPerThread;
@@ -1005,7 +1063,9 @@ k_new_flags_scan(Img<const uint16_t> depth, Scratch sc, int W, int H, uint8_t* _
     bool fl = false;
     if (k < P) {
       const int y = k / W, x = k - y * W;
-      fl = x >= 1 && y >= 1 && x < W - 1 && y < H - 1 && depth(y, x) > 0 &&
+      const uint16_t d = depth(y, x);
+      if (copy_back) depth_out(y, x) = d;
+      fl = x >= 1 && y >= 1 && x < W - 1 && y < H - 1 && d > 0 &&
            sc.supporting[k] == kInvalid && sc.confl_key[k] == kInvalid;
       flags[k] = fl ? 1 : 0;
     }
@@ -1111,6 +1171,7 @@ __device__ __forceinline__ void new_create_body(const Surfels& S, const FrameCtx
     S.f(kRadiusSq, i) = r2;
     Vec3 sum = {0, 0, 0};
     int count_plus_1 = 1;
+    uint32_t nbs[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       const int kk = (y + kDY[d]) * W + (x + kDX[d]);
@@ -1131,8 +1192,9 @@ __device__ __forceinline__ void new_create_body(const Surfels& S, const FrameCtx
           if (ad2 <= c.rf2 * r2) nb = base + nrank;
         }
       }
-      S.u(kNeighbor0 + d, i) = nb;
+      nbs[d] = nb;
     }
+    S.set_neighbors(i, make_uint4(nbs[0], nbs[1], nbs[2], nbs[3]));
     S.f(kSmoothX, i) = (gp.x + sum.x) / (float)count_plus_1;  // :227-229
     S.f(kSmoothY, i) = (gp.y + sum.y) / (float)count_plus_1;
     S.f(kSmoothZ, i) = (gp.z + sum.z) / (float)count_plus_1;
@@ -1202,7 +1264,7 @@ k_neighbor_scan(Surfels S, int stats, Lists L, uint8_t* __restrict__ inwin8, uin
         const uint32_t rel = nb - base;
         const uint32_t f = (rel < (uint32_t)kSegB) ? lflags[rel] : L.flags8[nb];
         if (kDetach && i < detach_limit && (f & 2u)) {  // :1430-1433
-          S.u(kNeighbor0 + q, i) = kInvalid;
+          S.set_neighbor(i, q, kInvalid);
           continue;
         }
         ++edges;
@@ -1238,11 +1300,13 @@ k_neighbor_scan(Surfels S, int stats, Lists L, uint8_t* __restrict__ inwin8, uin
 // atomics are the slowest thing this chip does, so the terms travel three ways, all of which end in the same
 // exact integer sum (the three gradient components quantised to 2^-22 m, the weights counted per sender class and
 // multiplied out in 2^-32 fixed point by the reader -- integer addition: the split cannot change the result):
-//   1. the target lists the source back at slot k (5 of 6 edges): the term is STORED, without any atomic, into
+//   1. target inside the workgroup's own segment (3 of 4 edges): summed in LDS, stored once per target, coalesced
+//      (grad_local); the words hold (gx | gy) and (gz | sender class counts) as signed 32-bit halves (pack_pair);
+//   2. otherwise, the target lists the source back at slot k: the term is STORED, without any atomic, into
 //      inbox[target][k] -- a slot only this source writes, stamped with the call's epoch; k_reg_step converts it;
-//   2. otherwise, target inside the workgroup's own segment: summed in LDS, stored once per target (grad_local);
-//   3. otherwise: TWO 64-bit global atomics per term (grad_acc): the words hold (gx | gy) and (gz | sender
-//      class counts) as signed 32-bit halves (pack_pair in smx_common.hpp).
+//   3. otherwise: TWO 64-bit global atomics per term (grad_acc), same packing.
+// (Round 1 preferred the inbox to the LDS sums: 16-byte stores into random lines cost more than LDS atomics --
+// reg_accumulate 67 -> 57 us alone, +2 % frames/s, profiles/r02p_ab.txt.)
 constexpr int kSegAcc = 1024;     // slots per accumulation workgroup (16 KB of LDS sums)
 constexpr int kBlockAcc = 512;
 static_assert(kSegAcc % kSegB == 0 && kSegAcc % kBlockAcc == 0, "segment sizes must nest");
@@ -1288,8 +1352,10 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
     int back_slot[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 ts = *S.group(kGroupS, (gmask & (1u << q)) ? nb[q] : i);
-      const uint4 tt = *reinterpret_cast<const uint4*>(S.group(kGroupT, (mask & (1u << q)) ? nb[q] : i));
+      // one 32-byte record per link: the neighbour's smooth position and (the copy of) its own links
+      const float4* st = S.group(kGroupS, (gmask & (1u << q)) ? nb[q] : i);
+      const float4 ts = st[0];
+      const uint4 tt = *reinterpret_cast<const uint4*>(st + 1);
       np[q].x = ts.x; np[q].y = ts.y; np[q].z = ts.z;
       back_slot[q] = tt.x == i ? 0 : tt.y == i ? 1 : tt.z == i ? 2 : tt.w == i ? 3 : -1;
     }
@@ -1314,7 +1380,12 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
         bool once = true;
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (k != q && (mask & (1u << k)) && nb[k] == nb[q]) once = false;
-        if (back_slot[q] >= 0 && once) {
+        const uint32_t rel = nb[q] - base;
+        if (rel < (uint32_t)kSegAcc) {
+          // component-major LDS layout: consecutive lanes (consecutive targets) hit consecutive banks
+          atomicAdd(&lacc[rel], pack_pair(q22_from_float(term.x), q22_from_float(term.y)));
+          atomicAdd(&lacc[kSegAcc + rel], pack_pair(q22_from_float(term.z), 1 << (8 * (neighbor_count - 1))));
+        } else if (back_slot[q] >= 0 && once) {
           // w carries (call epoch, neighbour count) instead of weight / count: the reader recomputes the quotient
           // and ignores slots of older calls, so nobody has to clear the inbox
           inbox[4 * (size_t)nb[q] + back_slot[q]] =
@@ -1323,19 +1394,12 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
           // two packed words per term: (gx | gy) and (gz | one count in the byte of the sender's class)
           const unsigned long long w0 = pack_pair(q22_from_float(term.x), q22_from_float(term.y));
           const unsigned long long w1 = pack_pair(q22_from_float(term.z), 1 << (8 * (neighbor_count - 1)));
-          const uint32_t rel = nb[q] - base;
-          if (rel < (uint32_t)kSegAcc) {
-            // component-major LDS layout: consecutive lanes (consecutive targets) hit consecutive banks
-            atomicAdd(&lacc[rel], w0);
-            atomicAdd(&lacc[kSegAcc + rel], w1);
-          } else {
-            unsigned long long* a = reinterpret_cast<unsigned long long*>(&grad_acc[2 * (size_t)nb[q]]);
-            atomicAdd(&a[0], w0);
-            atomicAdd(&a[1], w1);
-          }
+          unsigned long long* a = reinterpret_cast<unsigned long long*>(&grad_acc[2 * (size_t)nb[q]]);
+          atomicAdd(&a[0], w0);
+          atomicAdd(&a[1], w1);
         }
         const float d2 = t.x * t.x + t.y * t.y + t.z * t.z;
-        if (d2 > rf2 * r2) { S.u(kNeighbor0 + q, i) = kInvalid; pruned = true; }  // :2190-2192
+        if (d2 > rf2 * r2) { S.set_neighbor(i, q, kInvalid); pruned = true; }  // :2190-2192
       }
       // the slot's own regulariser term (RegularizeSurfelsCUDAKernel :2238-2256 sees the row after the pruning
       // above): same neighbour positions, same n.t product, so it is formed here and k_reg_step gathers nothing
@@ -1518,7 +1582,7 @@ k_pack_rows(Surfels S, RowList rl, float* __restrict__ out, uint32_t count) {
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock)
     for (int k = 0; k < rl.n; ++k) {
       const int g = row_group(rl.rows[k]), sub = row_sub(rl.rows[k]);
-      out[(size_t)k * count + i] = g < 0 ? 0.0f : S.base[((size_t)g * S.pitch + i) * 4 + sub];
+      out[(size_t)k * count + i] = g < 0 ? 0.0f : S.base[S.quad(g, i) * 4 + sub];
     }
 }
 __global__ void __launch_bounds__(kBlock)
@@ -1526,7 +1590,8 @@ k_unpack_rows(Surfels S, RowList rl, const float* __restrict__ in, uint32_t coun
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock)
     for (int k = 0; k < rl.n; ++k) {
       const int g = row_group(rl.rows[k]), sub = row_sub(rl.rows[k]);
-      if (g >= 0) S.base[((size_t)g * S.pitch + i) * 4 + sub] = in[(size_t)k * count + i];
+      if (g >= 0) S.base[S.quad(g, i) * 4 + sub] = in[(size_t)k * count + i];
+      if (g == kGroupT) reinterpret_cast<float*>(S.tcopy(i))[sub] = in[(size_t)k * count + i];   // (T lives twice)
     }
 }
 
@@ -1696,7 +1761,8 @@ struct smx_recon_s {
   int table_window;
   int stats_enabled;
   int blend_multi_launch;   // A/B switch: 1 = the reference's start + iteration launches instead of the fused kernel
-  Scratch sc;
+  Scratch sc;               // the association images
+  uint16_t* blended_depth;  // [H][W] output of the fused blend (stored into the caller's depth by k_new_flags_scan)
   BlendBufs bb;
   uint8_t* new_flags;
   uint32_t* new_ranks;
@@ -1732,7 +1798,7 @@ struct smx_recon_s {
   // caller's stream after the pending regulariser, so the API keeps its one-stream semantics.
   int overlap_enabled;
   hipStream_t reg_stream;     // high priority: the frame-to-frame critical path
-  hipEvent_t ev_mid, ev_reg, ev_front;
+  hipEvent_t ev_mid, ev_reg;
   bool reg_pending;
   uint8_t* flags_buf[2];    // the flag table is double-buffered by frame (L.flags8 = the current frame's)
   bool have_frame;          // an Integrate call has been made since creation / the last state upload
@@ -1863,7 +1929,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
 #define SMX_TRY(x) do { rc = (x); if (rc != SMX_OK) { (void)smx_recon_destroy(r); return rc; } } while (0)  /* (no leak on a failed allocation) */
   // cuda_surfel_reconstruction.cc:59 -- 25 rows x max_surfel_count (zero-filled here so that the
   // padded tail of every row is defined)
-  SMX_TRY(dev_alloc(&r->S.base, (size_t)kGroups * 4 * r->S.pitch, true));
+  SMX_TRY(dev_alloc(&r->S.base, (size_t)kQuadsPerSlot * 4 * r->S.pitch, true));
   SMX_TRY(dev_alloc(&r->grad_acc, 2 * ((size_t)r->S.pitch + kSegAcc), true));
   SMX_TRY(dev_alloc(&r->grad_local, 2 * ((size_t)r->S.pitch + kSegAcc), true));
   SMX_TRY(dev_alloc(&r->inbox, 4 * ((size_t)r->S.pitch + kSegAcc), true));
@@ -1885,6 +1951,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->sc.depth_sums, P, false));
   SMX_TRY(dev_alloc(&r->sc.confl_key, P, false));
   SMX_TRY(dev_alloc(&r->sc.first_depth, P, false));
+  SMX_TRY(dev_alloc(&r->blended_depth, P, true));
   SMX_TRY(dev_alloc(&r->bb.distance_map, P, true));
   SMX_TRY(dev_alloc(&r->bb.new_distance_map, P, true));
   SMX_TRY(dev_alloc(&r->bb.deltas, P, true));
@@ -1905,9 +1972,10 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
     SMX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     SMX_HIP(hipStreamCreateWithPriority(&r->reg_stream, hipStreamNonBlocking, hi));
   }
-  SMX_HIP(hipEventCreateWithFlags(&r->ev_front, hipEventDisableTiming));
-  SMX_HIP(hipEventCreateWithFlags(&r->ev_mid, hipEventDisableTiming));
-  SMX_HIP(hipEventCreateWithFlags(&r->ev_reg, hipEventDisableTiming));
+  // (device-scope release: these events order GPU streams, the host never reads data behind them)
+  const unsigned evf = hipEventDisableTiming | hipEventReleaseToDevice;
+  SMX_HIP(hipEventCreateWithFlags(&r->ev_mid, evf));
+  SMX_HIP(hipEventCreateWithFlags(&r->ev_reg, evf));
   SMX_HIP(hipEventCreateWithFlags(&r->ev_staging, hipEventDisableTiming));
   r->overlap_enabled = 1;
   r->prof_slot = -1;
@@ -1925,12 +1993,10 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
 int smx_recon_destroy(smx_recon r) {
   if (!r) return SMX_OK;
   SMX_ON_DEVICE(r->device);
-  void* ptrs[] = {r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->flags_buf[0], r->flags_buf[1],
-                  r->merge_flag, r->inwin8, r->need_seg, r->sc.supporting, r->sc.counts,
-                  r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth, r->bb.distance_map, r->bb.new_distance_map,
+  void* ptrs[] = {r->sc.supporting, r->sc.counts, r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth, r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->flags_buf[0], r->flags_buf[1],
+                  r->merge_flag, r->inwin8, r->need_seg, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->block_offsets, r->st};
   if (r->reg_stream) { (void)hipStreamSynchronize(r->reg_stream); (void)hipStreamDestroy(r->reg_stream); }
-  if (r->ev_front) (void)hipEventDestroy(r->ev_front);
   if (r->ev_mid) (void)hipEventDestroy(r->ev_mid);
   if (r->ev_reg) (void)hipEventDestroy(r->ev_reg);
   if (r->ev_staging) (void)hipEventDestroy(r->ev_staging);
@@ -2056,20 +2122,24 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   // the flag table of the previous frame stays readable for the regulariser that may still be running
   const uint8_t* flags_prev = r->L.flags8;
   r->L.flags8 = (r->L.flags8 == r->flags_buf[0]) ? r->flags_buf[1] : r->flags_buf[0];
-  // Streams.  Pipelined: the kernels that only read surfel state (clear .. blend) stay on the caller's stream,
-  // everything on the frame-to-frame critical path (integrate .. regulariser) goes to the internal high-priority
-  // stream sH, where frame f+1 simply queues behind frame f.  The caller's stream is released once the frame has
-  // created its surfels (ev_mid), so the next call's first kernels run beside this frame's regulariser.
+  // Streams.  Everything on the frame-to-frame critical cycle -- clear, pass A, associate, merge + blend, flags,
+  // integrate, update + create; frame f + 1 needs the positions and slots frame f wrote -- stays on the CALLER's
+  // stream, in order.  The regulariser chain (pass B, edges, step) is forked to the internal stream after update +
+  // create and runs beside the NEXT call's clear .. flags, which read only P / N records and the other copy of the flag
+  // table; the next call's integrate kernel waits for it (a wait that has normally been satisfied long before).  Not
+  // pipelined: the same launches, all on the caller's stream.  (Measured against round 1's arrangement -- integrate ..
+  // regulariser on the internal stream, an event hand-off in each direction -- it is a tie, profiles/r03c_matrix.txt;
+  // this one needs one hand-off instead of two and leaves the caller's stream free as soon as its buffers are consumed.)
   const bool pipelined = r->overlap_enabled != 0;
-  const hipStream_t sF = st;
-  const hipStream_t sH = pipelined ? r->reg_stream : st;
-  if (!pipelined) {
-    const int rcj = join_regularizer(r, st);
-    if (rcj != SMX_OK) return rcj;
-  }
+  const hipStream_t sF = st, sC = st;
+  const hipStream_t sR = pipelined ? r->reg_stream : st;
+  if (r->stats_enabled) hipLaunchKernelGGL(k_reset_frame_stats, dim3(1), dim3(1), 0, sF, r->st);
   if (tm) SMX_HIP(hipEventRecord(r->ev[0], sF));
+  // The association images are re-initialised right in front of pass A, on the critical stream: clearing them on the
+  // side stream (three sets in rotation) takes 8 us off the chain but leaves the lines cold for the z-buffer and
+  // association atomics that follow -- pass A 36 -> 53 us, -2 % frames/s (profiles/r03b_matrix.txt).
   { SlotTimer t(r, sF, kSlotClear);
-    hipLaunchKernelGGL(k_clear_assoc, gpx, b, 0, sF, r->sc, r->bb, P, r->st); }
+    hipLaunchKernelGGL(k_clear_assoc, gpx, b, 0, sF, r->sc, P); }
   { SlotTimer t(r, sF, kSlotScanVisible);
     hipLaunchKernelGGL(k_scan_visible, gs, b, 0, sF, r->S, c, r->sc, r->L, flags_prev, r->st);
     r->table_valid = true; r->table_frame = frame_index; r->table_window = c.reg_window; }
@@ -2077,76 +2147,84 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     if (r->scan_mode) hipLaunchKernelGGL((k_associate<false>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->st);
     else hipLaunchKernelGGL((k_associate<true>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->st); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[1], sF)); SMX_HIP(hipEventRecord(r->ev[2], sF)); }
-  { SlotTimer t(r, sF, kSlotMergeDecide);
-    if (r->scan_mode) hipLaunchKernelGGL((k_merge_decide<false>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st);
-    else hipLaunchKernelGGL((k_merge_decide<true>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st); }
-  if (tm) { SMX_HIP(hipEventRecord(r->ev[3], sF)); SMX_HIP(hipEventRecord(r->ev[4], sF)); }
-  if (p->do_blending) {
-    SlotTimer t(r, sF, kSlotBlend);
-    const float ds = 1.0f / c.inv_depth_scaling;  // kernels.cc:179
-    const float term = 1.0f / ((float)p->measurement_blending_radius - 1.0f);  // kernels.cc:196
-    const int halo = p->measurement_blending_radius - 1;
-    if (halo <= kBlendMaxHalo && !r->blend_multi_launch) {
-      const int rw = kBlendTile + 2 * halo;
-      const size_t lds = (size_t)rw * rw * 15;
-      hipLaunchKernelGGL(k_blend_fused, dim3(div_up(r->W, kBlendTile), div_up(r->H, kBlendTile)), dim3(kBlendThreads), lds, sF,
-                         p->measurement_blending_radius, term, ds, depth_rw, r->sc, r->W, r->H);
-    } else {
+  const int halo = p->measurement_blending_radius - 1;
+  const bool fused_blend = p->do_blending && halo <= kBlendMaxHalo && !r->blend_multi_launch;
+  const float ds = 1.0f / c.inv_depth_scaling;  // kernels.cc:179
+  const float term = p->do_blending ? 1.0f / ((float)p->measurement_blending_radius - 1.0f) : 0.0f;  // kernels.cc:196
+  const Img<uint16_t> blended = {r->blended_depth, r->H, r->W, (size_t)r->W * sizeof(uint16_t)};
+  if (fused_blend) {
+    // merge decisions + blending in one launch (the stage times of GetTimings: merging = the launch, blending = 0)
+    SlotTimer t(r, sF, kSlotMergeDecide);
+    const int rw = kBlendTile + 2 * halo;
+    const size_t lds = (size_t)rw * rw * 15;
+    const int tiles_x = div_up(r->W, kBlendTile);
+    const uint32_t n_blend = (uint32_t)(tiles_x * div_up(r->H, kBlendTile));
+    const dim3 g(n_blend + (uint32_t)(r->grid_list / (kBlendThreads / kBlock)));
+    if (r->scan_mode) hipLaunchKernelGGL((k_merge_and_blend<false>), g, dim3(kBlendThreads), lds, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st, p->measurement_blending_radius, term, ds, blended, tiles_x, n_blend);
+    else hipLaunchKernelGGL((k_merge_and_blend<true>), g, dim3(kBlendThreads), lds, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st, p->measurement_blending_radius, term, ds, blended, tiles_x, n_blend);
+    if (tm) { SMX_HIP(hipEventRecord(r->ev[3], sF)); SMX_HIP(hipEventRecord(r->ev[4], sF)); SMX_HIP(hipEventRecord(r->ev[5], sF)); }
+  } else {
+    { SlotTimer t(r, sF, kSlotMergeDecide);
+      if (r->scan_mode) hipLaunchKernelGGL((k_merge_decide<false>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st);
+      else hipLaunchKernelGGL((k_merge_decide<true>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st); }
+    if (tm) { SMX_HIP(hipEventRecord(r->ev[3], sF)); SMX_HIP(hipEventRecord(r->ev[4], sF)); }
+    if (p->do_blending) {
+      // the reference's own sequence (2 clears + start + iterations, kernels.cc:165-205), in place on the caller's depth
+      SlotTimer t(r, sF, kSlotBlend);
+      SMX_HIP(hipMemsetAsync(r->bb.distance_map, 0, (size_t)P, sF));
+      SMX_HIP(hipMemsetAsync(r->bb.new_distance_map, 0, (size_t)P, sF));
       hipLaunchKernelGGL(k_blend_start, gimg, b, 0, sF, ds, depth_rw, r->sc, r->bb, r->W, r->H);
       for (int it = 2; it < p->measurement_blending_radius; ++it)
         hipLaunchKernelGGL(k_blend_iter, gimg, b, 0, sF, it, term, ds, depth_rw, r->sc, r->bb, r->W, r->H);
     }
+    if (tm) SMX_HIP(hipEventRecord(r->ev[5], sF));
   }
-  if (tm) SMX_HIP(hipEventRecord(r->ev[5], sF));
   // Which pixels spawn a surfel depends only on the association images and the blended depth: the flag + rank
-  // kernel of CreateNewSurfelsCUDA runs here, off the frame-to-frame critical path.
+  // kernel of CreateNewSurfelsFUDA; with the fused blend it also stores the blended depths into the caller's buffer.
   { SlotTimer t(r, sF, kSlotNewFlagsScan);
-    hipLaunchKernelGGL(k_new_flags_scan, dim3(r->n_scan_blocks), b, 0, sF, in.depth, r->sc, r->W, r->H, r->new_flags,
-                       r->new_ranks, r->block_sums, r->st); }
-  if (pipelined) {
-    SMX_HIP(hipEventRecord(r->ev_front, sF));
-    SMX_HIP(hipStreamWaitEvent(sH, r->ev_front, 0));
-  }
-  if (tm) SMX_HIP(hipEventRecord(r->ev[6], sH));
+    hipLaunchKernelGGL(k_new_flags_scan, dim3(r->n_scan_blocks), b, 0, sF,
+                       fused_blend ? Img<const uint16_t>{r->blended_depth, r->H, r->W, (size_t)r->W * sizeof(uint16_t)} : in.depth,
+                       depth_rw, fused_blend ? 1 : 0, r->sc, r->W, r->H, r->new_flags, r->new_ranks, r->block_sums, r->st); }
   // Everything up to here only read P and N records; from here on they (and T, S) are written, so the previous
-  // frame's regulariser has to be done: it precedes these kernels in the critical stream's own order.
-  { SlotTimer t(r, sH, kSlotIntegrate);
-    if (r->scan_mode) hipLaunchKernelGGL((k_integrate<false>), gl, b, 0, sH, r->S, c, r->sc, in, r->L, r->merge_flag, r->st);
-    else hipLaunchKernelGGL((k_integrate<true>), gl, b, 0, sH, r->S, c, r->sc, in, r->L, r->merge_flag, r->st); }
-  if (tm) { SMX_HIP(hipEventRecord(r->ev[7], sH)); SMX_HIP(hipEventRecord(r->ev[8], sH)); }
-  { SlotTimer t(r, sH, kSlotUpdateNeighbors);
+  // call's regulariser has to be done.
+  if (pipelined && r->reg_pending) SMX_HIP(hipStreamWaitEvent(sC, r->ev_reg, 0));
+  if (tm) SMX_HIP(hipEventRecord(r->ev[6], sC));
+  { SlotTimer t(r, sC, kSlotIntegrate);
+    if (r->scan_mode) hipLaunchKernelGGL((k_integrate<false>), gl, b, 0, sC, r->S, c, r->sc, in, r->L, r->merge_flag, r->st);
+    else hipLaunchKernelGGL((k_integrate<true>), gl, b, 0, sC, r->S, c, r->sc, in, r->L, r->merge_flag, r->st); }
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[7], sC)); SMX_HIP(hipEventRecord(r->ev[8], sC)); }
+  { SlotTimer t(r, sC, kSlotUpdateNeighbors);
     CreateArgs ca;
     ca.flags = r->new_flags; ca.ranks = r->new_ranks; ca.block_sums = r->block_sums; ca.block_offsets_out = r->block_offsets;
     ca.n_scan_blocks = r->n_scan_blocks; ca.max_surfels = r->max_surfels; ca.flags8 = r->L.flags8; ca.dirty8 = r->L.dirty8;
     const uint32_t ncb = (uint32_t)div_up(P, kBlock);
     const dim3 guc(ncb + (uint32_t)r->grid_list);
     const size_t lds = (size_t)r->n_scan_blocks * sizeof(uint32_t);
-    if (r->scan_mode) hipLaunchKernelGGL((k_update_and_create<false>), guc, b, lds, sH, r->S, c, r->sc, in, r->L, ca, ncb, r->st);
-    else hipLaunchKernelGGL((k_update_and_create<true>), guc, b, lds, sH, r->S, c, r->sc, in, r->L, ca, ncb, r->st); }
+    if (r->scan_mode) hipLaunchKernelGGL((k_update_and_create<false>), guc, b, lds, sC, r->S, c, r->sc, in, r->L, ca, ncb, r->st);
+    else hipLaunchKernelGGL((k_update_and_create<true>), guc, b, lds, sC, r->S, c, r->sc, in, r->L, ca, ncb, r->st); }
   // (the detach half of UpdateNeighborsCUDA runs fused into pass B below)
-  if (tm) { SMX_HIP(hipEventRecord(r->ev[9], sH)); SMX_HIP(hipEventRecord(r->ev[10], sH)); }
-  if (tm) { SMX_HIP(hipEventRecord(r->ev[11], sH)); SMX_HIP(hipEventRecord(r->ev[12], sH)); }
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[9], sC)); SMX_HIP(hipEventRecord(r->ev[10], sC)); }
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[11], sC)); SMX_HIP(hipEventRecord(r->ev[12], sC)); }
   SMX_LAUNCH_CHECK();
   int rc = SMX_OK;
   const int iters = p->regularization_iterations_per_integration_iteration;
-  hipStream_t rs = sH;
   if (pipelined) {
-    // the caller's buffers are free from here on, and the next frame's read-only kernels may start
-    SMX_HIP(hipEventRecord(r->ev_mid, sH));
-    SMX_HIP(hipStreamWaitEvent(st, r->ev_mid, 0));
+    // fork: the caller's stream is free again (its buffers have been consumed), the regulariser runs on the side
+    SMX_HIP(hipEventRecord(r->ev_mid, sC));
+    SMX_HIP(hipStreamWaitEvent(sR, r->ev_mid, 0));
   }
   if (iters == 0) {
-    rc = enqueue_regularize(r, rs, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
+    rc = enqueue_regularize(r, sR, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
                             p->regularization_frame_window_size, true, true);
   } else {
     for (int k = 0; k < iters && rc == SMX_OK; ++k)
-      rc = enqueue_regularize(r, rs, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
+      rc = enqueue_regularize(r, sR, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
                               p->regularization_frame_window_size, k == 0, false);
   }
   if (rc != SMX_OK) return rc;
-  if (tm) { SMX_HIP(hipEventRecord(r->ev[13], rs)); r->have_timings = true; }
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[13], sR)); r->have_timings = true; }
   if (pipelined) {
-    SMX_HIP(hipEventRecord(r->ev_reg, sH));
+    SMX_HIP(hipEventRecord(r->ev_reg, sR));
     r->reg_pending = true;
   }
   return SMX_OK;

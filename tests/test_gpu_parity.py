@@ -112,6 +112,35 @@ def test_depth_stage_edge_cases(smx):
 
 # ---- CUDABuffer -----------------------------------------------------------------------------
 @pytest.mark.parametrize("w,h", [(160, 120), (203, 77), (640, 480)])
+def test_fused_erode_normals_radii_bit_exact(smx, w, h):
+    """smx_erode_normals_radii (one launch, intermediate images in LDS tiles) leaves exactly the final depth, normals and
+    radii of the oracle's three stages, for every erosion radius (0 = border copy) and sizes that are not tile multiples;
+    the radius buffer keeps its old value where the depth is dropped (cu:777-780)."""
+    s = small_stream(w, h)
+    pre = small_pre(w)
+    raw = s.frame(4)[0]
+    o = orc.bilateral_filter_and_cutoff(raw, max_depth=pre.max_depth_u16(), depth_valid_region_radius=pre.depth_valid_region_radius)
+    rng = np.random.default_rng(3)
+    o[rng.random(o.shape) < 0.02] = 0                      # holes: exercises every validity test
+    A, B = smx.CUDABuffer(h, w, np.uint16), smx.CUDABuffer(h, w, np.uint16)
+    N, R = smx.CUDABuffer(h, w, np.float32, 2), smx.CUDABuffer(h, w, np.float32)
+    A.UploadAsync(None, o)
+    for radius in (0, 1, 2, 3):
+        R.Clear(-7.0)
+        smx.ErodeNormalsRadiiCUDA(None, radius, 85.0, 1.5, float("inf"), 5000.0, s.fx, s.fy, s.cx, s.cy, A, B, N, R)
+        oe = orc.erode_depth_map(o, radius)
+        on_d, on = orc.compute_normals_and_drop_bad_pixels(oe, s.fx, s.fy, s.cx, s.cy)
+        or_d, orad = orc.compute_point_radii_and_remove_isolated_pixels(on_d, s.fx, s.fy, s.cx, s.cy,
+                                                                       radius_init=np.full((h, w), -7.0, np.float32))
+        assert np.array_equal(B.Download(), or_d), radius
+        assert np.array_equal(N.Download().view(np.uint32), on.view(np.uint32)), radius
+        assert np.array_equal(R.Download().view(np.uint32), orad.view(np.uint32)), radius
+        assert (or_d > 0).sum() > 100
+    with pytest.raises(smx.SmxError):
+        smx.ErodeNormalsRadiiCUDA(None, 4, 85.0, 1.5, float("inf"), 5000.0, s.fx, s.fy, s.cx, s.cy, A, B, N, R)
+
+
+@pytest.mark.parametrize("w,h", [(160, 120), (203, 77), (640, 480)])
 def test_median_filter_and_densify_bit_exact(smx, w, h):
     """The reference's CPU MedianFilterAndDensifyDepthMap (APP/main.cc:206-252) on the GPU: two iterations, sparse
     input (45 % holes), odd sizes, borders."""
@@ -564,6 +593,26 @@ def test_state_injection_roundtrip(smx):
     for p in (po, pg2):
         p.process(f, s.outlier_frames(f), s.others_TR_reference(f), s.pose(f))
     _compare_state(po, pg2)
+
+
+def test_row_upload_download_roundtrip_every_row(smx):
+    """The debug row accessors convert between the reference's 25-row layout and the grouped records: every row with
+    storage comes back bit for bit (distinct values per row and slot, so that a write into a neighbouring record shows),
+    the rows without storage (14-16 Accum*, 23 GradientCount) read as 0 and are ignored on upload; counts that are and
+    are not multiples of the segment size."""
+    cam = smx.PinholeCamera4f(160, 120, 130.0, 130.0, 80.0, 60.0)
+    for n, cap in ((1000, 60000), (70001, 100000), (1_300_000, 1_500_000)):
+        r = smx.CUDASurfelReconstruction(cap, cam)
+        rows = (np.arange(25, dtype=np.uint32)[:, None] * np.uint32(50_000_000) + np.arange(n, dtype=np.uint32)[None, :] + np.uint32(7)).view(np.float32)
+        r.debug_upload_surfels(np.ascontiguousarray(rows), 3)
+        assert r.surfels_size() == n and r.surfel_count() == n - 3
+        back = r.debug_download_surfels(n)
+        for k in range(25):
+            if k in (14, 15, 16, 23):
+                assert not back[k].view(np.uint32).any(), k
+            else:
+                assert np.array_equal(back[k].view(np.uint32), rows[k].view(np.uint32)), k
+        r.close()
 
 
 def test_invalid_arguments_raise(smx):
