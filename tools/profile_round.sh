@@ -7,12 +7,12 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out
 mkdir -p $OUT
 rm -f $OUT/pmc_traffic.json
-CMD="python bench.py --steps 300 --warmup 20 --cpu-frames 0 --quiet"
+CMD="python bench.py --steps 300 --warmup 20 --cpu-frames 0 --host-frames 0 --quiet"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_trace -o run -- $CMD > $OUT/${TAG}_bench.log 2>&1
 python tools/prof_summary.py /tmp/prof_trace $OUT/${TAG}_bench_timed_region_summary.md > /dev/null
 python tools/prof_timeline.py /tmp/prof_trace 2 $OUT/${TAG}_timeline_two_frames.md > /dev/null
 cp "$(ls /tmp/prof_trace/*/*kernel_stats.csv /tmp/prof_trace/*kernel_stats.csv 2>/dev/null | tail -1)" $OUT/${TAG}_bench_kernel_stats.csv 2>/dev/null
-CMDS="python bench.py --steps 20 --warmup 5 --cpu-frames 0 --quiet"
+CMDS="python bench.py --steps 20 --warmup 5 --cpu-frames 0 --host-frames 0 --quiet"
 for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum"; do
   N=$(echo $C | cut -d' ' -f1)
   rm -rf /tmp/prof_pmc
