@@ -262,6 +262,8 @@ def main():
                     help="frames of the extra pass whose inputs arrive from page-locked host memory (0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the full-size GPU-vs-oracle check")
     ap.add_argument("--no-overlap", action="store_true", help="A/B: no frame pipelining inside Integrate")
+    ap.add_argument("--run-ahead", action="store_true", help="A/B: preprocessing two steps ahead, waits routed off the caller's stream")
+    ap.add_argument("--bilateral-variant", type=int, default=0, help="A/B: 1 = one tap per instruction")
     ap.add_argument("--dry-run", action="store_true", help="rank path only (no GPU, gloo): see the module docstring")
     ap.add_argument("--quiet", action="store_true")
     args = ap.parse_args()
@@ -324,6 +326,10 @@ def run_integrate(args):
 
     rec = wl.pipe.reconstruction
     rec.set_stats_enabled(False)   # the distribution counters are single-address atomics: off while timing
+    if args.run_ahead:
+        wl.pipe.set_run_ahead(True)
+    if args.bilateral_variant:
+        _lib.check(_lib.load().smx_debug_set_bilateral_variant(args.bilateral_variant))
     wl.pipe.run_array(*wl.steps(plan[:W]))
     # short calibration pass with HIP events around every kernel: which Integrate kernel dominates the frame?
     # (frame pipelining off here and in the per-kernel pass below, so that kernels are timed one at a time)

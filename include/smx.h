@@ -109,6 +109,9 @@ int smx_bilateral_filtering_and_depth_cutoff(
     smx_stream s, float sigma_xy, float sigma_value_factor, uint16_t value_to_ignore,
     float radius_factor, uint16_t max_depth, float depth_valid_region_radius,
     const smx_buffer_desc* input_depth /*u16*/, const smx_buffer_desc* output_depth /*u16*/);
+/* A/B switch (process-wide; same results): 0 = the filter forms two taps' weights per packed instruction (default),
+ * 1 = one tap per instruction. */
+int smx_debug_set_bilateral_variant(int32_t variant);
 /* OutlierDepthMapFusionCUDA<count,u16>, both overloads (cu:229-285 and :399-455):
  * other_count = count-1 in {2,4,6,8}; required_count < 0 selects the
  * all-must-agree overload.  others_TR_reference: other_count row-major 3x4. */
@@ -310,6 +313,18 @@ int smx_recon_set_scan_mode(smx_recon r, int32_t mode);
  * Every entry point that takes a stream first orders that stream after the pending regulariser, so the
  * one-stream semantics of CUDASurfelReconstruction are kept; results are identical on and off. */
 int smx_recon_set_overlap(smx_recon r, int32_t enabled);
+/* Dependency routing for a caller that runs its own pipeline around Integrate (smx_driver does: preprocessing of
+ * later frames on a second stream).  An event record or wait costs a stream 6 - 8 us on this hardware, and the
+ * caller's stream carries the frame-to-frame critical chain; these two hooks move one record and one wait per frame
+ * from it to the internal stream.  Both are one-shot: they apply to the NEXT smx_recon_integrate call (also when
+ * that call fails); either may be null.
+ *   inputs_consumed  is recorded at the point from which that call no longer reads its four input images.
+ *   chain_after      must have been recorded already; the call's internal completion mark waits for it.  The next
+ *                    call orders its integration kernels -- and so every call after that all of its kernels -- after
+ *                    that mark: work covered by chain_after is complete before the call AFTER the next one starts to
+ *                    read its inputs, without any wait on the caller's stream.
+ * With pipelining off both act on the caller's stream at the same points. */
+int smx_recon_integrate_hooks(smx_recon r, smx_event inputs_consumed, smx_event chain_after);
 
 /* ---- radius-neighbor search (replaces CompressedOctree::FindNearestSurfelsWithinRadius,
  * APP/octree.h:470-477, APP/octree.cc:313-470, for batched queries) ---- */

@@ -71,11 +71,16 @@ typedef struct {
 } smx_driver_host_frame;
 int smx_driver_run_streamed(smx_driver d, smx_stream s, const smx_driver_step* steps,
                             const smx_driver_host_frame* uploads, int32_t n);
-/* Overlap of the depth preprocessing of frame f+1 (own stream, second set of work images) with Integrate(f);
+/* Overlap of the depth preprocessing of later frames (own stream, further sets of work images) with Integrate(f);
  * default on.  Results are identical either way. */
 int smx_driver_set_overlap(smx_driver d, int32_t enabled);
 /* A/B switch: erosion + normals + radii as one fused launch (default) or as the reference's three calls; same images. */
 int smx_driver_set_fused_tail(smx_driver d, int32_t enabled);
+/* smx_driver_run with overlap on (default OFF, results identical; measured 1 % slower than the plain loop, see
+ * profiles/r04c_runahead_ab.txt: the extra wait lands on the internal stream, which is the longer chain): the preprocessing runs two steps ahead of Integrate
+ * (three sets of work images) and its dependencies are routed through smx_recon_integrate_hooks, so that from the third
+ * step of a call on the caller's stream carries one event record and one wait per frame instead of two and two. */
+int smx_driver_set_run_ahead(smx_driver d, int32_t enabled);
 /* Working buffers after the last frame: final (blended) depth, normals, radius. */
 int smx_driver_work_descs(smx_driver d, smx_buffer_desc* depth, smx_buffer_desc* normals, smx_buffer_desc* radius);
 

@@ -178,6 +178,162 @@ k_bilateral_r(float denom_xy, float sigma_value_factor, uint16_t value_to_ignore
   }
 }
 
+// The same filter with two taps per instruction.  Alone on the chip the kernel above runs at the VALU issue limit
+// (23 instructions per tap, one wavefront per SIMD issuing back to back), so the way to make it cheaper is fewer
+// instructions: gfx950 executes v_pk_{mul,add,fma}_f32 -- two independent IEEE single-precision operations per lane --
+// at the rate of the scalar forms, and every step of a tap's weight except its final select is such an operation.
+//   - Taps are paired so that both have the same spatial term: (-dx, dy) with (+dx, dy), and the centre column's
+//     (0, -dy) with (0, +dy).  The weights are formed pairwise, the two sums still add them one at a time in the
+//     reference's tap order (row by row, left to right), so every rounding is the one the scalar kernel performs.
+//   - The tile is staged as floats (no conversion per tap; the two taps of a pair arrive in one ds_read2_b32, already
+//     an aligned register pair).  Cells to ignore and cells outside the image hold -1e30: their squared difference
+//     overflows to +inf, the exponent to -inf, and the "x < -86 -> 0" select every tap has anyway turns the weight into
+//     0 -- no separate test.  (0 * -1e30 = -0 is added to a sum that is +0 or positive: no change.)
+//   - round-to-nearest-integer of t = x * log2(e) as (t + 1.5 * 2^23) - 1.5 * 2^23 (two packed adds instead of
+//     v_rndne_f32, exact for |t| < 2^22; a larger |t| has x < -86 and is discarded); the integer sits in the low
+//     mantissa bits of the intermediate, so 2^n is one shift-add and the final scaling a packed multiplication
+//     (exact: the result is a normal number whenever it is kept).
+// 13.5 VALU instructions per tap instead of 23.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+// (N independent pairs advance together, one step of the evaluation at a time: with one wavefront per SIMD nothing else
+// hides the latency of a dependent packed operation, and the compiler keeps the order it is given)
+template <int N>
+__device__ __forceinline__ void det_expf_nonpositive2(const f32x2 (&x)[N], f32x2 (&e)[N]) {
+  const f32x2 magic = splat2(12582912.0f);
+  f32x2 tm[N], n[N], r[N], p[N], r2[N], y[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) tm[k] = x[k] * splat2(1.44269504088896341f);
+#pragma unroll
+  for (int k = 0; k < N; ++k) tm[k] = tm[k] + magic;
+#pragma unroll
+  for (int k = 0; k < N; ++k) n[k] = tm[k] - magic;
+#pragma unroll
+  for (int k = 0; k < N; ++k) r[k] = __builtin_elementwise_fma(n[k], splat2(-0.693359375f), x[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) r[k] = __builtin_elementwise_fma(n[k], splat2(2.12194440e-4f), r[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) p[k] = __builtin_elementwise_fma(splat2(1.9875691500e-4f), r[k], splat2(1.3981999507e-3f));
+#pragma unroll
+  for (int k = 0; k < N; ++k) p[k] = __builtin_elementwise_fma(p[k], r[k], splat2(8.3334519073e-3f));
+#pragma unroll
+  for (int k = 0; k < N; ++k) p[k] = __builtin_elementwise_fma(p[k], r[k], splat2(4.1665795894e-2f));
+#pragma unroll
+  for (int k = 0; k < N; ++k) p[k] = __builtin_elementwise_fma(p[k], r[k], splat2(1.6666665459e-1f));
+#pragma unroll
+  for (int k = 0; k < N; ++k) p[k] = __builtin_elementwise_fma(p[k], r[k], splat2(5.0000001201e-1f));
+#pragma unroll
+  for (int k = 0; k < N; ++k) r2[k] = r[k] * r[k];
+#pragma unroll
+  for (int k = 0; k < N; ++k) y[k] = __builtin_elementwise_fma(p[k], r2[k], r[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) y[k] = y[k] + splat2(1.0f);
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const i32x2 scale_bits = (__builtin_bit_cast(i32x2, tm[k]) << 23) + 0x3F800000;
+    e[k] = y[k] * __builtin_bit_cast(f32x2, scale_bits);
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    e[k].x = (x[k].x < -86.0f) ? 0.0f : e[k].x;
+    e[k].y = (x[k].y < -86.0f) ? 0.0f : e[k].y;
+  }
+}
+constexpr float kBilIgnore = -1.0e30f;
+constexpr int bil_half_width(int R, int dy) {
+  int hw = 0;
+  while ((hw + 1) * (hw + 1) + dy * dy <= R * R) ++hw;
+  return hw;
+}
+
+template <int R>
+__global__ void __launch_bounds__(kThreads)
+k_bilateral_p(float denom_xy, float sigma_value_factor, uint16_t value_to_ignore, uint16_t max_depth, float region_r2,
+              Img<const uint16_t> in, Img<uint16_t> out, int tiles_x, int n_tiles) {
+  constexpr int TW = kBilTileW + 2 * R, TH = kBilTileH + 2 * R;
+  __shared__ float tile[TH * TW];
+  __shared__ float spatial[R * R + 1];
+  const int W = out.width, H = out.height;
+  for (int g2 = threadIdx.x; g2 <= R * R; g2 += kThreads) spatial[g2] = (float)(-g2) / denom_xy;
+  __syncthreads();
+  float sp[R * R + 1];  // (constant indices after unrolling: the entries in use live in registers)
+#pragma unroll
+  for (int g2 = 0; g2 <= R * R; ++g2) sp[g2] = spatial[g2];
+  const float fmax_depth = (float)max_depth;
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int bx = t % tiles_x, by = t / tiles_x;
+    __syncthreads();  // (the previous tile's readers are done)
+    const int x0 = bx * kBilTileW - R, y0 = by * kBilTileH - R;
+    for (int i = threadIdx.x; i < TW * TH; i += kThreads) {
+      const int ty = i / TW, tx = i - ty * TW;
+      const int gx = x0 + tx, gy = y0 + ty;
+      // cells outside the image read as "ignore": the reference's clamped loop bounds never visit them
+      uint16_t v = value_to_ignore;
+      if (gx >= 0 && gy >= 0 && gx < W && gy < H) v = in(gy, gx);
+      tile[i] = (v == value_to_ignore) ? kBilIgnore : (float)v;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & (kBilTileW - 1), ly = threadIdx.x / kBilTileW;
+    const int x = bx * kBilTileW + lx, y = by * kBilTileH + ly;
+    if (x >= W || y >= H) continue;
+    const unsigned half_w = (unsigned)(W / 2), half_h = (unsigned)(H / 2);
+    const unsigned dxc = (unsigned)x - half_w, dyc = (unsigned)y - half_h;
+    const float center_distance_squared = (float)(dxc * dxc + dyc * dyc);
+    if (center_distance_squared > region_r2) { out(y, x) = value_to_ignore; continue; }
+    const float* tc = &tile[(ly + R) * TW + (lx + R)];
+    const float fcenter = tc[0];
+    if (fcenter < 0.0f || fcenter > fmax_depth) { out(y, x) = value_to_ignore; continue; }
+    const float adapted_sigma_value = fcenter * sigma_value_factor;
+    const float adapted_denom_value = 2.0f * adapted_sigma_value * adapted_sigma_value;
+    const f32x2 inv_denom_value = splat2(1.0f / adapted_denom_value);
+    const f32x2 fcenter2 = splat2(fcenter);
+    float sum = 0, weight = 0;
+    float wc[R + 1], pc[R + 1];   // centre-column taps (0, +dy), formed together with (0, -dy) and added when row +dy is
+#pragma unroll
+    for (int dy = -R; dy <= R; ++dy) {
+      const int hw = bil_half_width(R, dy);   // (a constant in every unrolled copy)
+      const float* row = tc + dy * TW;
+      // the row's pairs: slot 0 = the centre column's (0, dy) with (0, -dy) [rows dy <= 0], slot dx = (-dx, dy) with (+dx, dy)
+      f32x2 f[R + 1], x[R + 1], w[R + 1], p[R + 1];
+#pragma unroll
+      for (int dx = 0; dx <= R; ++dx) {
+        f[dx] = (dx == 0) ? f32x2{row[0], tc[-dy * TW]} : (dx <= hw) ? f32x2{row[-dx], row[dx]} : splat2(0.0f);
+      }
+#pragma unroll
+      for (int dx = 0; dx <= R; ++dx) {
+        f32x2 vd = fcenter2 - f[dx];   // integers below 2^16 (or the -1e30 mark): exact
+        vd = vd * vd;
+        x[dx] = splat2(sp[(dx <= hw ? dx * dx : 0) + dy * dy]) + (-vd) * inv_denom_value;
+      }
+      // (unused slots -- beyond the disc, the centre pair of rows dy > 0 -- are dead code after unrolling)
+      det_expf_nonpositive2<R + 1>(x, w);
+#pragma unroll
+      for (int dx = 0; dx <= R; ++dx) p[dx] = w[dx] * f[dx];
+      float w0, p0;
+      if (dy <= 0) {
+        w0 = w[0].x; p0 = p[0].x;
+        wc[-dy] = w[0].y; pc[-dy] = p[0].y;
+      } else {
+        w0 = wc[dy]; p0 = pc[dy];
+      }
+      // the two sums, in the reference's order: dx = -hw .. hw
+#pragma unroll
+      for (int dx = R; dx >= 1; --dx) {
+        if (dx > hw) continue;
+        sum += p[dx].x; weight += w[dx].x;
+      }
+      sum += p0; weight += w0;
+#pragma unroll
+      for (int dx = 1; dx <= R; ++dx) {
+        if (dx > hw) continue;
+        sum += p[dx].y; weight += w[dx].y;
+      }
+    }
+    out(y, x) = (weight == 0) ? value_to_ignore : f2u16(sum / weight + 0.5f);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Multi-frame outlier cull.  Reference: OutlierDepthMapFusionCUDAKernel (both overloads),
 // cuda_depth_processing.cu:168-227 and :337-397.  Matrices and image descriptors travel in the
@@ -551,6 +707,14 @@ inline dim3 grid_rows(int W, int H) { return dim3(div_up(W, kTileW), div_up(H, k
 
 extern "C" {
 
+// A/B switch (process-wide, results identical): 0 = two taps per instruction (k_bilateral_p), 1 = k_bilateral_r
+static int g_bilateral_variant = 0;
+int smx_debug_set_bilateral_variant(int32_t variant) {
+  SMX_CHECK_ARG(variant == 0 || variant == 1);
+  g_bilateral_variant = variant;
+  return SMX_OK;
+}
+
 int smx_bilateral_filtering_and_depth_cutoff(
     smx_stream s, float sigma_xy, float sigma_value_factor, uint16_t value_to_ignore,
     float radius_factor, uint16_t max_depth, float depth_valid_region_radius,
@@ -568,8 +732,14 @@ int smx_bilateral_filtering_and_depth_cutoff(
   const Img<const uint16_t> src = as_img<const uint16_t>(input_depth);
   const Img<uint16_t> dst = as_img<uint16_t>(output_depth);
 #define SMX_BILATERAL(R)                                                                                          \
-  case R: hipLaunchKernelGGL(k_bilateral_r<R>, grid, dim3(kThreads), 0, (hipStream_t)s, denom_xy, sigma_value_factor, \
-                             value_to_ignore, max_depth, region_r2, src, dst, tiles_x, n_tiles); break
+  case R:                                                                                                         \
+    if (g_bilateral_variant == 0)                                                                                 \
+      hipLaunchKernelGGL(k_bilateral_p<R>, grid, dim3(kThreads), 0, (hipStream_t)s, denom_xy, sigma_value_factor, \
+                         value_to_ignore, max_depth, region_r2, src, dst, tiles_x, n_tiles);                      \
+    else                                                                                                          \
+      hipLaunchKernelGGL(k_bilateral_r<R>, grid, dim3(kThreads), 0, (hipStream_t)s, denom_xy, sigma_value_factor, \
+                         value_to_ignore, max_depth, region_r2, src, dst, tiles_x, n_tiles);                      \
+    break
   switch (radius) {
     SMX_BILATERAL(1); SMX_BILATERAL(2); SMX_BILATERAL(3); SMX_BILATERAL(4);
     SMX_BILATERAL(5); SMX_BILATERAL(6); SMX_BILATERAL(7); SMX_BILATERAL(8);

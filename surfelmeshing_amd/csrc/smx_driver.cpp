@@ -17,8 +17,8 @@ struct Frame {
   Frame(int h, int w) : depth(h, w), color(h, w) {}
 };
 
-// The per-frame work images (main.cc:801-812).  Two sets: the preprocessing of frame f+1 runs on its own stream
-// while Integrate(f) still reads the other set.
+// The per-frame work images (main.cc:801-812).  Three sets: the preprocessing of frames f+1 and f+2 runs on its own
+// stream while Integrate(f) still reads its set.
 struct WorkSet {
   CUDABuffer<u16> filtered_depth_buffer_A, filtered_depth_buffer_B;
   CUDABuffer<float2_> normals_buffer;
@@ -39,18 +39,21 @@ struct smx_driver_s {
   smx_driver_config cfg;
   PinholeCamera4f camera;
   CUDASurfelReconstruction reconstruction;
-  WorkSet work0, work1;
+  WorkSet work0, work1, work2;
   WorkSet* last;
+  WorkSet* prev;            // the set of the step before `last`
+  WorkSet* set(unsigned long long k) { return (k % 3 == 0) ? &work0 : (k % 3 == 1) ? &work1 : &work2; }
   std::map<u32, std::unique_ptr<Frame>> frames;
   cudaStream_t pre_stream = nullptr;   // depth preprocessing of the next frame
   smx_event run_start = nullptr;
   bool overlap = true;
+  bool run_ahead = false;  // smx_driver_run: preprocessing two steps ahead, dependencies routed off the caller's stream (A/B: -1 %)
   bool fuse_tail = true;   // erosion + normals + radii as one launch (A/B: smx_driver_set_fused_tail)
   unsigned long long frame_counter = 0;
 
   explicit smx_driver_s(const smx_driver_config& c, const float* intr)
       : cfg(c), camera(c.width, c.height, intr), reconstruction(c.max_surfel_count, camera),
-        work0(c.height, c.width), work1(c.height, c.width), last(&work0) {
+        work0(c.height, c.width), work1(c.height, c.width), work2(c.height, c.width), last(&work0), prev(&work0) {
     // preprocessing runs ahead of the frame loop: it only has to keep up, so it yields to the surfel kernels
     SMX_SHIM_CHECK(smx_stream_create_with_priority(&pre_stream, -1));
     SMX_SHIM_CHECK(smx_event_create(&run_start));
@@ -223,8 +226,7 @@ static int upload_on(smx_driver d, cudaStream_t stream, const smx_driver_host_fr
   if (f->last_reader != 0) {
     // readers: the last enqueued step (its event), or older ones (the other work set's event covers every step
     // before the last)
-    WorkSet* other = (d->last == &d->work0) ? &d->work1 : &d->work0;
-    WorkSet* w = (f->last_reader >= d->frame_counter) ? d->last : other;
+    WorkSet* w = (f->last_reader >= d->frame_counter) ? d->last : d->prev;
     if (w->used) SMX_SHIM_CHECK(smx_stream_wait_event(stream, w->integrated));
   }
   f->depth.UploadAsync(stream, u.depth);
@@ -240,9 +242,9 @@ static int run_one(smx_driver d, smx_stream s, const smx_driver_step& step, cons
     rc = upload_on(d, d->overlap ? d->pre_stream : (cudaStream_t)s, *arriving);
     if (rc != SMX_OK) return rc;
   }
-  WorkSet* ws = (d->frame_counter++ & 1) ? &d->work1 : &d->work0;
+  WorkSet* ws = d->set(d->frame_counter++);
   if (d->overlap) {
-    // preprocessing(f) on its own stream: it may start as soon as Integrate(f-2) has released this work set,
+    // preprocessing(f) on its own stream: it may start as soon as Integrate(f-3) has released this work set,
     // i.e. it overlaps Integrate(f-1); Integrate(f) then waits for it.
     if (ws->used) SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, ws->integrated));
     rc = preprocess_frame(d, d->pre_stream, step, ws);
@@ -257,7 +259,50 @@ static int run_one(smx_driver d, smx_stream s, const smx_driver_step& step, cons
   if (rc != SMX_OK) return rc;
   SMX_SHIM_CHECK(smx_event_record(ws->integrated, s));
   ws->used = true;
+  d->prev = d->last;
   d->last = ws;
+  return SMX_OK;
+}
+
+// Preprocessing of one step on the preprocessing stream, into the next work set in rotation.
+static int preprocess_ahead(smx_driver d, const smx_driver_step& step, WorkSet** out) {
+  WorkSet* ws = d->set(d->frame_counter++);
+  if (ws->used) SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, ws->integrated));
+  const int rc = preprocess_frame(d, d->pre_stream, step, ws);
+  if (rc != SMX_OK) return rc;
+  SMX_SHIM_CHECK(smx_event_record(ws->preprocessed, d->pre_stream));
+  *out = ws;
+  return SMX_OK;
+}
+
+// The frame loop over frames that are resident, with the preprocessing two steps ahead of Integrate.  The caller's
+// stream carries the frame-to-frame critical chain (Integrate(f + 1) needs the map Integrate(f) leaves), and every
+// event record or wait in it costs 6 - 8 us of a 300 us frame.  The dependencies on the preprocessing stream are
+// therefore routed through the reconstruction's internal stream (smx_recon_integrate_hooks): "work set free again"
+// is recorded there, and its completion mark for step i -- which Integrate(i + 1) waits for anyway -- also waits for
+// the preprocessing of step i + 2.  Steps 0 and 1 of a call wait on the caller's stream as before.
+static int run_ahead(smx_driver d, smx_stream s, const smx_driver_step* steps, int32_t n) {
+  WorkSet* ring[3] = {nullptr, nullptr, nullptr};
+  int rc;
+  for (int i = 0; i < n && i < 2; ++i)
+    if ((rc = preprocess_ahead(d, steps[i], &ring[i % 3])) != SMX_OK) return rc;
+  for (int i = 0; i < n; ++i) {
+    smx_event chain = nullptr;
+    if (i + 2 < n) {
+      if ((rc = preprocess_ahead(d, steps[i + 2], &ring[(i + 2) % 3])) != SMX_OK) return rc;
+      chain = ring[(i + 2) % 3]->preprocessed;
+    }
+    WorkSet* ws = ring[i % 3];
+    if (i < 2) SMX_SHIM_CHECK(smx_stream_wait_event(s, ws->preprocessed));
+    SMX_SHIM_CHECK(smx_recon_integrate_hooks(d->reconstruction.handle(), ws->integrated, chain));
+    if ((rc = integrate_frame(d, s, steps[i], ws)) != SMX_OK) {
+      (void)smx_recon_integrate_hooks(d->reconstruction.handle(), nullptr, nullptr);
+      return rc;
+    }
+    ws->used = true;
+    d->prev = d->last;
+    d->last = ws;
+  }
   return SMX_OK;
 }
 
@@ -267,6 +312,7 @@ int smx_driver_run(smx_driver d, smx_stream s, const smx_driver_step* steps, int
   if (d->overlap) {
     SMX_SHIM_CHECK(smx_event_record(d->run_start, s));
     SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, d->run_start));
+    if (d->run_ahead) return run_ahead(d, s, steps, n);
   }
   for (int i = 0; i < n; ++i) {
     const int rc = run_one(d, s, steps[i], nullptr);
@@ -292,6 +338,12 @@ int smx_driver_run_streamed(smx_driver d, smx_stream s, const smx_driver_step* s
 int smx_driver_set_overlap(smx_driver d, int32_t enabled) {
   if (!d) return fail("null argument");
   d->overlap = enabled != 0;
+  return SMX_OK;
+}
+
+int smx_driver_set_run_ahead(smx_driver d, int32_t enabled) {
+  if (!d) return fail("null argument");
+  d->run_ahead = enabled != 0;
   return SMX_OK;
 }
 

@@ -1760,6 +1760,7 @@ struct smx_recon_s {
   uint32_t table_frame;
   int table_window;
   int stats_enabled;
+  hipEvent_t hook_consumed, hook_chain;   // smx_recon_integrate_hooks: one-shot, taken by the next Integrate call
   int blend_multi_launch;   // A/B switch: 1 = the reference's start + iteration launches instead of the fused kernel
   Scratch sc;               // the association images
   uint16_t* blended_depth;  // [H][W] output of the fused blend (stored into the caller's depth by k_new_flags_scan)
@@ -2085,6 +2086,8 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
                         const float global_T_local[12], const smx_integrate_params* p) {
   SMX_CHECK_ARG(r && depth && normals && radius && color && global_T_local && p);
   SMX_ON_DEVICE(r->device);
+  const hipEvent_t hook_consumed = r->hook_consumed, hook_chain = r->hook_chain;   // one-shot, also when the call fails
+  r->hook_consumed = nullptr; r->hook_chain = nullptr;
   SMX_CHECK_ARG(depth->width == r->W && depth->height == r->H && normals->width == r->W && normals->height == r->H);
   SMX_CHECK_ARG(radius->width == r->W && radius->height == r->H && color->width == r->W && color->height == r->H);
   // (the radius is only read when blending is on: do_blending is an independent flag, APP/main.cc:348-354)
@@ -2213,6 +2216,9 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     SMX_HIP(hipEventRecord(r->ev_mid, sC));
     SMX_HIP(hipStreamWaitEvent(sR, r->ev_mid, 0));
   }
+  // (smx_recon_integrate_hooks) the input images are free from here on; marked on the side so that the caller's stream
+  // carries one record per call, not two
+  if (hook_consumed) SMX_HIP(hipEventRecord(hook_consumed, sR));
   if (iters == 0) {
     rc = enqueue_regularize(r, sR, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
                             p->regularization_frame_window_size, true, true);
@@ -2223,10 +2229,20 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   }
   if (rc != SMX_OK) return rc;
   if (tm) { SMX_HIP(hipEventRecord(r->ev[13], sR)); r->have_timings = true; }
+  // (smx_recon_integrate_hooks) whatever this event covers is complete before the regulariser counts as complete,
+  // i.e. before the second half of the next call and all of the call after it
+  if (hook_chain) SMX_HIP(hipStreamWaitEvent(sR, hook_chain, 0));
   if (pipelined) {
     SMX_HIP(hipEventRecord(r->ev_reg, sR));
     r->reg_pending = true;
   }
+  return SMX_OK;
+}
+
+int smx_recon_integrate_hooks(smx_recon r, smx_event inputs_consumed, smx_event chain_after) {
+  SMX_CHECK_ARG(r != nullptr);
+  r->hook_consumed = (hipEvent_t)inputs_consumed;
+  r->hook_chain = (hipEvent_t)chain_after;
   return SMX_OK;
 }
 

@@ -643,15 +643,18 @@ def test_streams_with_priority_and_explicit_stream(smx):
     st.close()
 
 
-def test_native_driver_matches_oracle(smx):
+@pytest.mark.parametrize("run_ahead", [False, True])
+def test_native_driver_matches_oracle(smx, run_ahead):
     """The C++ frame loop (include/smx_driver.h, written against the shim classes of smx_shim.hpp) produces the
-    same state as the oracle; many frames are enqueued by one call."""
+    same state as the oracle; many frames are enqueued by one call.  run_ahead: the preprocessing two steps ahead with
+    its dependencies routed through smx_recon_integrate_hooks."""
     from surfelmeshing_amd.pipeline import NativeFramePipeline
     from surfelmeshing_amd._lib import IntegrateParams
     s = small_stream(obstacle_until=8)
     pre = small_pre(s.width)
     po = OraclePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, 60000, pre)
     pn = NativeFramePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, 60000, pre, IntegrateParams.defaults())
+    pn.set_run_ahead(run_ahead)
     frames = list(range(4, 20))
     for f in range(0, 24):
         d, c = s.frame(f)

@@ -18,6 +18,11 @@ def run(n):
         api.BilateralFilteringAndDepthCutoffCUDA(None, p.bilateral_filter_sigma_xy, p.bilateral_filter_sigma_depth_factor, 0,
                                                  p.bilateral_filter_radius_factor, p.max_depth_u16(), p.depth_valid_region_radius, src, dst)
     api.StreamSynchronize(None)
-run(20)
-t = time.perf_counter(); run(500); dt = time.perf_counter() - t
-print('bilateral: %.1f us per call' % (dt / 500 * 1e6))
+outs = []
+for variant in (0, 1):
+    _lib.check(_lib.load().smx_debug_set_bilateral_variant(variant))
+    run(20)
+    t = time.perf_counter(); run(500); dt = time.perf_counter() - t
+    print('bilateral variant %d (%s): %.1f us per call' % (variant, 'two taps per instruction' if variant == 0 else 'one tap per instruction', dt / 500 * 1e6))
+    outs.append(dst.Download())
+print('results identical:', bool(np.array_equal(outs[0], outs[1])))

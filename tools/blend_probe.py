@@ -9,7 +9,7 @@ from surfelmeshing_amd.pipeline import FramePipeline
 from surfelmeshing_amd._lib import IntegrateParams
 _lib.require_gpu()
 s = small_stream(640, 480, obstacle_until=6)
-for radius in (3, 6, 12, 17):
+for radius in (2, 3, 6, 9, 12, 17):
     pg = FramePipeline(640, 480, s.fx, s.fy, s.cx, s.cy, 2_000_000, small_pre(640), IntegrateParams.defaults(measurement_blending_radius=radius))
     for f in range(0, 30):
         d, c = s.frame(f); pg.upload(f, d, c)
@@ -22,5 +22,5 @@ for radius in (3, 6, 12, 17):
     for f in range(14, 24):
         pg.process(f, s.outlier_frames(f), s.others_TR_reference(f), s.pose(f))
         acc += np.array(rec.kernel_times_ms())
-    print('radius %2d: blend %.1f us  (clear %.1f, merge %.1f)' % (radius, acc[names.index('blend')] * 100, acc[names.index('clear_assoc')] * 100, acc[names.index('merge_decide')] * 100))
+    print('radius %2d: blend slot %.1f us, merge(+blend when fused) slot %.1f us, clear %.1f' % (radius, acc[names.index('blend')] * 100, acc[names.index('merge_decide')] * 100, acc[names.index('clear_assoc')] * 100))
     pg.reconstruction.close()
