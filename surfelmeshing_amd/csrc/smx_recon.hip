@@ -218,7 +218,13 @@ constexpr int kSeg = 1024;
 // hundred slots apart), i.e. the fewer 64-bit global atomics remain.
 constexpr int kSegB = 1024;
 constexpr int kBlockB = kSegB / 4;
+// The non-empty 256-entry chunks of a segmented list, appended by the pass that builds the list (one atomic per
+// non-empty segment): descriptor = chunk id (segment * chunks-per-segment + sub-chunk) | (entries - 1) << 24.  The list
+// kernels walk these instead of probing every chunk of every segment: on the frame's binding cycle each dependent
+// memory round trip costs microseconds, and a probe that finds an empty chunk is one (profiles/r04_critical_cycle_notes.md).
+struct Chunks { uint32_t* desc; uint32_t* count; };
 struct Lists {
+  Chunks vis_chunks, rec_chunks;
   uint32_t* vis_list;     // slots that project into the image this frame
   float* seg_box;         // per pass-A segment: min xyz, max xyz, covered slot count (u32), newest stamp (u32)
   uint32_t* vis_seg;
@@ -228,6 +234,17 @@ struct Lists {
   uint8_t* dirty8;        // delta tracking (null = off): 1 = a transferred attribute of the slot changed since the
                           // last smx_recon_transfer_changed_to_cpu
 };
+
+// (thread 0 of the workgroup that built a segment's list)
+__device__ __forceinline__ void emit_chunks(const Chunks& ch, uint32_t segment, uint32_t total, uint32_t chunks_per_segment) {
+  if (total == 0) return;
+  const uint32_t nc = (total + kBlock - 1) / kBlock;
+  const uint32_t pos = atomicAdd(ch.count, nc);
+  for (uint32_t k = 0; k < nc; ++k) {
+    const uint32_t in_chunk = min((uint32_t)kBlock, total - k * kBlock);
+    ch.desc[pos + k] = (segment * chunks_per_segment + k) | ((in_chunk - 1u) << 24);
+  }
+}
 
 __device__ __forceinline__ bool stamp_outside_window(uint32_t stamp, uint32_t frame, int window) {
   return (int)stamp < (int)(frame - (uint32_t)window);  // kernels.cu:2132
@@ -266,8 +283,9 @@ struct BlendBufs {
 };
 
 __global__ void __launch_bounds__(kBlock)
-k_clear_assoc(Scratch sc, int P) {
+k_clear_assoc(Scratch sc, int P, uint32_t* __restrict__ vis_chunk_count) {
   const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k == 0) *vis_chunk_count = 0;   // pass A, the next launch, appends the visible list's chunks
   if (k < P) {
     sc.supporting[k] = kInvalid;
     sc.counts[k] = 0;
@@ -386,6 +404,7 @@ k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, const uint8_t* __rest
     if (vis_bits & (1u << j)) L.vis_list[off++] = i0 + j;
   if (threadIdx.x == 0) {
     L.vis_seg[blockIdx.x] = total;
+    emit_chunks(L.vis_chunks, blockIdx.x, total, kSeg / kBlock);
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     int ns = (int)0x80000000;
     for (int w = 0; w < kBlock / 64; ++w) {
@@ -399,28 +418,33 @@ k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, const uint8_t* __rest
   }
 }
 
-// List kernels walk the segmented list in chunks of kBlock entries (one entry per lane), grid-striding
-// over the chunk ids so that the visible slots -- which cluster in a few segments -- still spread over the
-// whole chip.  In the A/B "scan mode" every slot of the chunk is visited instead of the list entries.
+// List kernels walk the list's chunk descriptors (one entry per lane), grid-striding so that the visible slots --
+// which cluster in a few segments -- still spread over the whole chip.  In the A/B "scan mode" every slot is visited
+// instead, in chunks of kBlock slots.
+// number of walk steps; the first descriptor is requested together with the count (the array is long enough for any
+// index a walk can form)
+template <bool kUseList>
+__device__ __forceinline__ uint32_t walk_begin(const Chunks& ch, uint32_t n_slots_scan, uint32_t first, uint32_t& desc) {
+  if (kUseList) { desc = ch.desc[first]; return *ch.count; }
+  desc = 0;
+  return (n_slots_scan + kBlock - 1) / kBlock;
+}
+template <bool kUseList>
+__device__ __forceinline__ uint32_t walk_next(const Chunks& ch, uint32_t c, uint32_t n_steps) {
+  return (kUseList && c < n_steps) ? ch.desc[c] : 0u;
+}
 template <bool kUseList, int kSegSize = kSeg>
-__device__ __forceinline__ bool chunk_entry(const uint32_t* __restrict__ list, const uint32_t* __restrict__ seg,
-                                            uint32_t n_slots, uint32_t chunk, uint32_t& i, uint32_t lane) {
-  constexpr uint32_t kChunksPerSeg = kSegSize / kBlock;
-  const uint32_t s = chunk / kChunksPerSeg, sub = chunk % kChunksPerSeg;
-  const uint32_t e = sub * kBlock + lane;
+__device__ __forceinline__ bool walk_entry(const uint32_t* __restrict__ list, uint32_t desc, uint32_t c, uint32_t n_slots_scan,
+                                           uint32_t lane, uint32_t& i) {
   if (kUseList) {
-    if (e >= seg[s]) return false;
-    i = list[s * kSegSize + e];
+    constexpr uint32_t kChunksPerSeg = kSegSize / kBlock;
+    const uint32_t chunk = desc & 0x00FFFFFFu;
+    if (lane > (desc >> 24)) return false;
+    i = list[(chunk / kChunksPerSeg) * kSegSize + (chunk % kChunksPerSeg) * kBlock + lane];
     return true;
   }
-  i = s * kSegSize + e;
-  return i < n_slots;
-}
-
-template <bool kUseList, int kSegSize = kSeg>
-__device__ __forceinline__ bool chunk_entry(const uint32_t* __restrict__ list, const uint32_t* __restrict__ seg,
-                                            uint32_t n_slots, uint32_t chunk, uint32_t& i) {
-  return chunk_entry<kUseList, kSegSize>(list, seg, n_slots, chunk, i, threadIdx.x);
+  i = c * kBlock + lane;
+  return i < n_slots_scan;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -465,10 +489,14 @@ template <bool kUseList>
 __global__ void __launch_bounds__(kBlock)
 k_associate(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<const float2> normals,
             Lists L, const DevState* st) {
-  const uint32_t n_slots = st->surfel_count, n_chunks = (n_slots + kBlock - 1) / kBlock;
-  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  const uint32_t n_scan = kUseList ? 0u : st->surfel_count;
+  uint32_t desc;
+  const uint32_t n_steps = walk_begin<kUseList>(L.vis_chunks, n_scan, blockIdx.x, desc);
+  for (uint32_t w = blockIdx.x; w < n_steps; w += gridDim.x) {
+    const uint32_t cur = desc;
+    desc = walk_next<kUseList>(L.vis_chunks, w + gridDim.x, n_steps);   // (the next step's descriptor travels while this one is worked on)
     uint32_t i;
-    if (!chunk_entry<kUseList>(L.vis_list, L.vis_seg, n_slots, chunk, i)) continue;
+    if (!walk_entry<kUseList>(L.vis_list, cur, w, n_scan, threadIdx.x, i)) continue;
     const float4 p4 = *S.group(kGroupP, i), n4 = *S.group(kGroupN, i);  // both records in flight together
     if (!is_active(__float_as_uint(p4.w), c.frame, c.window)) continue;
     Proj p;
@@ -534,10 +562,14 @@ __device__ __forceinline__ void merge_decide_chunks(const Surfels& S, const Fram
                                                     const Img<const uint16_t>& depth, const Img<const float2>& normals,
                                                     const Lists& L, uint8_t* __restrict__ merge_flag, const DevState* st,
                                                     uint32_t first_chunk, uint32_t chunk_stride, uint32_t lane) {
-  const uint32_t n_slots = st->surfel_count, n_chunks = (n_slots + kBlock - 1) / kBlock;
-  for (uint32_t chunk = first_chunk; chunk < n_chunks; chunk += chunk_stride) {
+  const uint32_t n_scan = kUseList ? 0u : st->surfel_count;
+  uint32_t desc;
+  const uint32_t n_steps = walk_begin<kUseList>(L.vis_chunks, n_scan, first_chunk, desc);
+  for (uint32_t w = first_chunk; w < n_steps; w += chunk_stride) {
+    const uint32_t cur = desc;
+    desc = walk_next<kUseList>(L.vis_chunks, w + chunk_stride, n_steps);   // (the next step's descriptor travels while this one is worked on)
     uint32_t i;
-    if (!chunk_entry<kUseList>(L.vis_list, L.vis_seg, n_slots, chunk, i, lane)) continue;
+    if (!walk_entry<kUseList>(L.vis_list, cur, w, n_scan, lane, i)) continue;
     const float4 p4 = *S.group(kGroupP, i), n4 = *S.group(kGroupN, i);
     const float r2 = n4.w;
     if (!(r2 >= 0)) continue;  // :2017
@@ -899,11 +931,15 @@ template <bool kUseList>
 __global__ void __launch_bounds__(kBlock)
 k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
             uint8_t* __restrict__ merge_flag, DevState* st) {
-  const uint32_t n_slots = st->surfel_count, n_chunks = (n_slots + kBlock - 1) / kBlock;
+  const uint32_t n_scan = kUseList ? 0u : st->surfel_count;
   uint32_t merged_here = 0;
-  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  uint32_t desc;
+  const uint32_t n_steps = walk_begin<kUseList>(L.vis_chunks, n_scan, blockIdx.x, desc);
+  for (uint32_t w = blockIdx.x; w < n_steps; w += gridDim.x) {
+    const uint32_t cur = desc;
+    desc = walk_next<kUseList>(L.vis_chunks, w + gridDim.x, n_steps);   // (the next step's descriptor travels while this one is worked on)
     uint32_t i;
-    if (!chunk_entry<kUseList>(L.vis_list, L.vis_seg, n_slots, chunk, i)) continue;
+    if (!walk_entry<kUseList>(L.vis_list, cur, w, n_scan, threadIdx.x, i)) continue;
     if (merge_flag[i]) {
       // apply the merge marks, kernels.cu:1987-1989 (decided in k_merge_decide)
       merge_flag[i] = 0;
@@ -959,10 +995,16 @@ __device__ __forceinline__ void update_neighbors_body(const Surfels& S, const Fr
                                                       const Lists& L, const DevState* st, uint32_t block, uint32_t n_blocks) {
   const int kDX[4] = {-1, 1, 0, 0}, kDY[4] = {0, 0, -1, 1};
   // (the slot count BEFORE this frame's creation: the creating workgroups of the same launch advance surfel_count)
-  const uint32_t n_slots = st->create_base_next, n_chunks = (n_slots + kBlock - 1) / kBlock;
-  for (uint32_t chunk = block; chunk < n_chunks; chunk += n_blocks) {
+  const uint32_t n_scan = kUseList ? 0u : st->create_base_next;
+  // (this launch precedes the regulariser's pass B on every path through Integrate: its chunk counter starts at zero)
+  if (block == 0 && threadIdx.x == 0) *L.rec_chunks.count = 0;
+  uint32_t desc;
+  const uint32_t n_steps = walk_begin<kUseList>(L.vis_chunks, n_scan, block, desc);
+  for (uint32_t w = block; w < n_steps; w += n_blocks) {
+    const uint32_t cur = desc;
+    desc = walk_next<kUseList>(L.vis_chunks, w + n_blocks, n_steps);   // (the next step's descriptor travels while this one is worked on)
     uint32_t i;
-    if (!chunk_entry<kUseList>(L.vis_list, L.vis_seg, n_slots, chunk, i)) continue;
+    if (!walk_entry<kUseList>(L.vis_list, cur, w, n_scan, threadIdx.x, i)) continue;
     // the slot's three records in flight together (P: position + stamp, N: normal + r^2, T: neighbour ids)
     const float4 p4 = *S.group(kGroupP, i), n4 = *S.group(kGroupN, i);
     const uint4 t4 = *reinterpret_cast<const uint4*>(S.group(kGroupT, i));
@@ -1286,6 +1328,7 @@ k_neighbor_scan(Surfels S, int stats, Lists L, uint8_t* __restrict__ inwin8, uin
   const int any = __syncthreads_or(need);
   if (threadIdx.x == 0) {
     L.recent_seg[blockIdx.x] = total;
+    emit_chunks(L.rec_chunks, blockIdx.x, total, kSegB / kBlock);
     if (kAccumulate) need_seg[blockIdx.x] = (any || total) ? 1u : 0u;  // k_reg_accumulate also serves recent slots
     if (stats && total) atomicAdd(&st->recent_count, total);
   }
@@ -1434,10 +1477,13 @@ k_rebuild_flags(Surfels S, uint32_t frame, int reg_window, uint8_t* __restrict__
 __global__ void __launch_bounds__(kBlock)
 k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long* __restrict__ grad_local,
            const float4* __restrict__ inbox, Lists L, DevState* st, uint32_t epoch) {
-  const uint32_t n_slots = st->surfel_count, n_chunks = (n_slots + kBlock - 1) / kBlock;
-  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  uint32_t desc;
+  const uint32_t n_steps = walk_begin<true>(L.rec_chunks, 0u, blockIdx.x, desc);
+  for (uint32_t w = blockIdx.x; w < n_steps; w += gridDim.x) {
+    const uint32_t cur = desc;
+    desc = walk_next<true>(L.rec_chunks, w + gridDim.x, n_steps);   // (the next step's descriptor travels while this one is worked on)
     uint32_t i;
-    if (!chunk_entry<true, kSegB>(L.recent_list, L.recent_seg, n_slots, chunk, i)) continue;
+    if (!walk_entry<true, kSegB>(L.recent_list, cur, w, 0u, threadIdx.x, i)) continue;
     const Vec3 mp = {S.f(kX, i), S.f(kY, i), S.f(kZ, i)};
     const Vec3 sp = {S.f(kSmoothX, i), S.f(kSmoothY, i), S.f(kSmoothZ, i)};
     // exact fixed-point sums: contributions from other segments (global atomics) + from the own segment
@@ -1500,10 +1546,13 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long*
 // RegularizeSurfelsCUDACopyOnlyKernel (:2310-2327), over the recent list.
 __global__ void __launch_bounds__(kBlock)
 k_reg_copy_raw(Surfels S, Lists L, const DevState* st) {
-  const uint32_t n_slots = st->surfel_count, n_chunks = (n_slots + kBlock - 1) / kBlock;
-  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  uint32_t desc;
+  const uint32_t n_steps = walk_begin<true>(L.rec_chunks, 0u, blockIdx.x, desc);
+  for (uint32_t w = blockIdx.x; w < n_steps; w += gridDim.x) {
+    const uint32_t cur = desc;
+    desc = walk_next<true>(L.rec_chunks, w + gridDim.x, n_steps);   // (the next step's descriptor travels while this one is worked on)
     uint32_t i;
-    if (!chunk_entry<true, kSegB>(L.recent_list, L.recent_seg, n_slots, chunk, i)) continue;
+    if (!walk_entry<true, kSegB>(L.recent_list, cur, w, 0u, threadIdx.x, i)) continue;
     if (L.dirty8) L.dirty8[i] = 1;
     S.f(kSmoothX, i) = S.f(kX, i);
     S.f(kSmoothY, i) = S.f(kY, i);
@@ -1511,7 +1560,10 @@ k_reg_copy_raw(Surfels S, Lists L, const DevState* st) {
   }
 }
 
-__global__ void k_reset_recent(DevState* st) { st->recent_count = 0; st->n_edges = 0; st->n_window_edges = 0; st->n_contributors = 0; }
+__global__ void k_reset_recent(DevState* st, int stats, uint32_t* rec_chunk_count) {
+  if (stats) { st->recent_count = 0; st->n_edges = 0; st->n_window_edges = 0; st->n_contributors = 0; }
+  if (rec_chunk_count) *rec_chunk_count = 0;
+}
 
 // ---- changed-surfel delta for the mesher ---------------------------------------------------------
 // Three small kernels over the dirty bytes: per-segment counts, one-workgroup scan of the counts, gather of
@@ -1841,8 +1893,10 @@ int join_regularizer(smx_recon r, hipStream_t st) {
   return SMX_OK;
 }
 
+// zero_chunks: pass B appends to the recent list's chunk descriptors; inside Integrate the launch in front of it
+// (k_update_and_create) has reset their counter, everywhere else it is done here.
 int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, float weight, int window,
-                       bool detach, bool copy_only) {
+                       bool detach, bool copy_only, bool zero_chunks) {
   const dim3 g(r->nsegB), bB(kBlockB), gl(r->grid_list), b(kBlock);
   const float rf2 = rf * rf;
   if (!r->table_valid || r->table_frame != frame || r->table_window != window) {
@@ -1852,7 +1906,7 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
   const int stats = r->stats_enabled;
   {
     SlotTimer t(r, st, kSlotNeighborScan);
-    if (stats) hipLaunchKernelGGL(k_reset_recent, dim3(1), dim3(1), 0, st, r->st);
+    if (stats || zero_chunks) hipLaunchKernelGGL(k_reset_recent, dim3(1), dim3(1), 0, st, r->st, stats, zero_chunks ? r->L.rec_chunks.count : nullptr);
     if (copy_only) {
       if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, false>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st);
       else hipLaunchKernelGGL((k_neighbor_scan<false, false>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st);
@@ -1941,6 +1995,11 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->L.vis_seg, (size_t)r->nseg, true));
   SMX_TRY(dev_alloc(&r->L.seg_box, (size_t)r->nseg * 8, true));
   SMX_TRY(dev_alloc(&r->L.recent_seg, (size_t)r->nsegB, true));
+  // chunk descriptors: every chunk of every segment in the worst case, + room for the index a walk forms first
+  SMX_TRY(dev_alloc(&r->L.vis_chunks.desc, (size_t)r->nseg * (kSeg / kBlock) + 65536, true));
+  SMX_TRY(dev_alloc(&r->L.rec_chunks.desc, (size_t)r->nsegB * (kSegB / kBlock) + 65536, true));
+  SMX_TRY(dev_alloc(&r->L.vis_chunks.count, 1, true));
+  SMX_TRY(dev_alloc(&r->L.rec_chunks.count, 1, true));
   SMX_TRY(dev_alloc(&r->flags_buf[0], (size_t)r->nsegB * kSegB, true));
   SMX_TRY(dev_alloc(&r->flags_buf[1], (size_t)r->nsegB * kSegB, true));
   r->L.flags8 = r->flags_buf[0];
@@ -1994,7 +2053,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
 int smx_recon_destroy(smx_recon r) {
   if (!r) return SMX_OK;
   SMX_ON_DEVICE(r->device);
-  void* ptrs[] = {r->sc.supporting, r->sc.counts, r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth, r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->flags_buf[0], r->flags_buf[1],
+  void* ptrs[] = {r->sc.supporting, r->sc.counts, r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth, r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.vis_chunks.count, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1],
                   r->merge_flag, r->inwin8, r->need_seg, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->block_offsets, r->st};
   if (r->reg_stream) { (void)hipStreamSynchronize(r->reg_stream); (void)hipStreamDestroy(r->reg_stream); }
@@ -2142,7 +2201,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   // side stream (three sets in rotation) takes 8 us off the chain but leaves the lines cold for the z-buffer and
   // association atomics that follow -- pass A 36 -> 53 us, -2 % frames/s (profiles/r03b_matrix.txt).
   { SlotTimer t(r, sF, kSlotClear);
-    hipLaunchKernelGGL(k_clear_assoc, gpx, b, 0, sF, r->sc, P); }
+    hipLaunchKernelGGL(k_clear_assoc, gpx, b, 0, sF, r->sc, P, r->L.vis_chunks.count); }
   { SlotTimer t(r, sF, kSlotScanVisible);
     hipLaunchKernelGGL(k_scan_visible, gs, b, 0, sF, r->S, c, r->sc, r->L, flags_prev, r->st);
     r->table_valid = true; r->table_frame = frame_index; r->table_window = c.reg_window; }
@@ -2221,11 +2280,11 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   if (hook_consumed) SMX_HIP(hipEventRecord(hook_consumed, sR));
   if (iters == 0) {
     rc = enqueue_regularize(r, sR, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
-                            p->regularization_frame_window_size, true, true);
+                            p->regularization_frame_window_size, true, true, false);
   } else {
     for (int k = 0; k < iters && rc == SMX_OK; ++k)
       rc = enqueue_regularize(r, sR, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
-                              p->regularization_frame_window_size, k == 0, false);
+                              p->regularization_frame_window_size, k == 0, false, k > 0);
   }
   if (rc != SMX_OK) return rc;
   if (tm) { SMX_HIP(hipEventRecord(r->ev[13], sR)); r->have_timings = true; }
@@ -2252,7 +2311,7 @@ int smx_recon_regularize(smx_recon r, smx_stream s, uint32_t frame_index, float 
   SMX_ON_DEVICE(r->device);
   { const int rcj = join_regularizer(r, (hipStream_t)s); if (rcj != SMX_OK) return rcj; }
   return enqueue_regularize(r, (hipStream_t)s, frame_index, radius_factor_for_regularization_neighbors,
-                            regularizer_weight, regularization_frame_window_size, false, false);
+                            regularizer_weight, regularization_frame_window_size, false, false, true);
 }
 
 int smx_recon_counts(smx_recon r, smx_stream s, uint32_t* surfel_count, uint32_t* surfels_size) {
@@ -2522,6 +2581,8 @@ static int invalidate_derived(smx_recon r, hipStream_t st) {
   SMX_HIP(hipMemsetAsync(r->L.vis_seg, 0, (size_t)r->nseg * 4, st));
   SMX_HIP(hipMemsetAsync(r->L.seg_box, 0, (size_t)r->nseg * 8 * sizeof(float), st));
   SMX_HIP(hipMemsetAsync(r->L.recent_seg, 0, (size_t)r->nsegB * 4, st));
+  SMX_HIP(hipMemsetAsync(r->L.vis_chunks.count, 0, 4, st));
+  SMX_HIP(hipMemsetAsync(r->L.rec_chunks.count, 0, 4, st));
   hipLaunchKernelGGL(k_rebuild_flags, dim3(r->grid_surfels), dim3(kBlock), 0, st, r->S, 0u, 0x7FFFFFFF, r->L.flags8, r->st);
   SMX_LAUNCH_CHECK();
   r->table_valid = false;
