@@ -284,6 +284,11 @@ struct BlendBufs {
 
 __global__ void __launch_bounds__(kBlock)
 k_clear_assoc(Scratch sc, int P, uint32_t* __restrict__ vis_chunk_count) {
+  // Only the first Integrate call after creation launches this.  In the frame loop the re-initialisation rides on
+  // kernels that are there anyway, over two sets of images in alternation: k_update_and_create of call f writes the
+  // z-buffer of call f + 1 (and zeroes its chunk counter), pass A of call f + 1 writes the other four images while it
+  // scans -- a slice per workgroup, in front of the launches whose atomics land on them.  As a launch of its own on
+  // the caller's stream the 8 MB of stores took 31 us of every frame beside the regulariser's pass B (7 us alone).
   const int k = blockIdx.x * kBlock + threadIdx.x;
   if (k == 0) *vis_chunk_count = 0;   // pass A, the next launch, appends the visible list's chunks
   if (k < P) {
@@ -308,9 +313,18 @@ __device__ __forceinline__ void min_depth_at(float* first_depth, int W, int x, i
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, const uint8_t* __restrict__ flags_prev, DevState* st) {
+k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, const uint8_t* __restrict__ flags_prev, DevState* st,
+               int clear_assoc) {
   __shared__ uint32_t wave_tot[kBlock / 64];
   __shared__ float box_part[kBlock / 64][8];
+  if (clear_assoc) {
+    // side job (see k_clear_assoc): this workgroup's slice of the four images the association atomics land on
+    const uint32_t P = (uint32_t)(c.W * c.H), per = (P + gridDim.x - 1) / gridDim.x;
+    for (uint32_t k = threadIdx.x; k < per; k += kBlock) {
+      const uint32_t px = blockIdx.x * per + k;
+      if (px < P) { sc.supporting[px] = kInvalid; sc.counts[px] = 0; sc.depth_sums[px] = 0; sc.confl_key[px] = kInvalid; }
+    }
+  }
   __shared__ int skip_segment;
   const uint32_t N = st->surfel_count;
   const uint32_t base = blockIdx.x * kSeg;
@@ -1147,6 +1161,8 @@ k_new_flags_scan(Img<const uint16_t> depth, Img<uint16_t> depth_out, int copy_ba
 struct CreateArgs {
   const uint8_t* flags; const uint32_t* ranks; const uint32_t* block_sums; uint32_t* block_offsets_out;
   int n_scan_blocks; uint32_t max_surfels; uint8_t* flags8; uint8_t* dirty8;
+  // the NEXT call's association images (the other set): this launch re-initialises its z-buffer and its chunk counter
+  float* next_first_depth; uint32_t* next_vis_chunk_count; int n_pixels;
 };
 __device__ __forceinline__ void new_create_body(const Surfels& S, const FrameCtx& c, const Scratch& sc, const FrameIn& in,
                                                 const CreateArgs& a, DevState* st, uint32_t block, uint32_t n_blocks) {
@@ -1250,8 +1266,20 @@ template <bool kUseList>
 __global__ void __launch_bounds__(kBlock)
 k_update_and_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, CreateArgs a, uint32_t n_create_blocks,
                     DevState* st) {
-  if (blockIdx.x < n_create_blocks) new_create_body(S, c, sc, in, a, st, blockIdx.x, n_create_blocks);
-  else update_neighbors_body<kUseList>(S, c, sc, in, L, st, blockIdx.x - n_create_blocks, gridDim.x - n_create_blocks);
+  if (blockIdx.x < n_create_blocks) {
+    new_create_body(S, c, sc, in, a, st, blockIdx.x, n_create_blocks);
+  } else {
+    // Side job (see k_clear_assoc): pass A of the next call follows this launch and min-reduces into the other set's
+    // z-buffer; a slice of it per workgroup, written here, is still in L2 when those atomics arrive.
+    const uint32_t block = blockIdx.x - n_create_blocks, n_blocks = gridDim.x - n_create_blocks;
+    const uint32_t per = ((uint32_t)a.n_pixels + n_blocks - 1) / n_blocks;
+    for (uint32_t k = threadIdx.x; k < per; k += kBlock) {
+      const uint32_t px = block * per + k;
+      if (px < (uint32_t)a.n_pixels) a.next_first_depth[px] = __builtin_inff();
+    }
+    if (block == 0 && threadIdx.x == 0) *a.next_vis_chunk_count = 0;
+    update_neighbors_body<kUseList>(S, c, sc, in, L, st, block, n_blocks);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1814,7 +1842,11 @@ struct smx_recon_s {
   int stats_enabled;
   hipEvent_t hook_consumed, hook_chain;   // smx_recon_integrate_hooks: one-shot, taken by the next Integrate call
   int blend_multi_launch;   // A/B switch: 1 = the reference's start + iteration launches instead of the fused kernel
-  Scratch sc;               // the association images
+  Scratch sc;               // the association images of the current call (= sc_set[sc_cur])
+  Scratch sc_set[2];
+  uint32_t* vis_count_set[2];
+  int sc_cur;
+  bool next_set_ready;      // the other set's z-buffer and chunk counter were re-initialised by the last k_update_and_create
   uint16_t* blended_depth;  // [H][W] output of the fused blend (stored into the caller's depth by k_new_flags_scan)
   BlendBufs bb;
   uint8_t* new_flags;
@@ -1998,7 +2030,6 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   // chunk descriptors: every chunk of every segment in the worst case, + room for the index a walk forms first
   SMX_TRY(dev_alloc(&r->L.vis_chunks.desc, (size_t)r->nseg * (kSeg / kBlock) + 65536, true));
   SMX_TRY(dev_alloc(&r->L.rec_chunks.desc, (size_t)r->nsegB * (kSegB / kBlock) + 65536, true));
-  SMX_TRY(dev_alloc(&r->L.vis_chunks.count, 1, true));
   SMX_TRY(dev_alloc(&r->L.rec_chunks.count, 1, true));
   SMX_TRY(dev_alloc(&r->flags_buf[0], (size_t)r->nsegB * kSegB, true));
   SMX_TRY(dev_alloc(&r->flags_buf[1], (size_t)r->nsegB * kSegB, true));
@@ -2006,11 +2037,16 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->merge_flag, r->S.pitch, true));
   SMX_TRY(dev_alloc(&r->inwin8, (size_t)r->nsegB * kSegB, true));
   SMX_TRY(dev_alloc(&r->need_seg, (size_t)r->nsegB + kSegAcc / kSegB, true));
-  SMX_TRY(dev_alloc(&r->sc.supporting, P, false));
-  SMX_TRY(dev_alloc(&r->sc.counts, P, false));
-  SMX_TRY(dev_alloc(&r->sc.depth_sums, P, false));
-  SMX_TRY(dev_alloc(&r->sc.confl_key, P, false));
-  SMX_TRY(dev_alloc(&r->sc.first_depth, P, false));
+  for (int k = 0; k < 2; ++k) {
+    SMX_TRY(dev_alloc(&r->sc_set[k].supporting, P, false));
+    SMX_TRY(dev_alloc(&r->sc_set[k].counts, P, false));
+    SMX_TRY(dev_alloc(&r->sc_set[k].depth_sums, P, false));
+    SMX_TRY(dev_alloc(&r->sc_set[k].confl_key, P, false));
+    SMX_TRY(dev_alloc(&r->sc_set[k].first_depth, P, false));
+    SMX_TRY(dev_alloc(&r->vis_count_set[k], 1, true));
+  }
+  r->sc = r->sc_set[0];
+  r->L.vis_chunks.count = r->vis_count_set[0];
   SMX_TRY(dev_alloc(&r->blended_depth, P, true));
   SMX_TRY(dev_alloc(&r->bb.distance_map, P, true));
   SMX_TRY(dev_alloc(&r->bb.new_distance_map, P, true));
@@ -2053,7 +2089,9 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
 int smx_recon_destroy(smx_recon r) {
   if (!r) return SMX_OK;
   SMX_ON_DEVICE(r->device);
-  void* ptrs[] = {r->sc.supporting, r->sc.counts, r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth, r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.vis_chunks.count, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1],
+  void* ptrs[] = {r->sc_set[0].supporting, r->sc_set[0].counts, r->sc_set[0].depth_sums, r->sc_set[0].confl_key, r->sc_set[0].first_depth,
+                  r->sc_set[1].supporting, r->sc_set[1].counts, r->sc_set[1].depth_sums, r->sc_set[1].confl_key, r->sc_set[1].first_depth,
+                  r->vis_count_set[0], r->vis_count_set[1], r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1],
                   r->merge_flag, r->inwin8, r->need_seg, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->block_offsets, r->st};
   if (r->reg_stream) { (void)hipStreamSynchronize(r->reg_stream); (void)hipStreamDestroy(r->reg_stream); }
@@ -2197,13 +2235,21 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   const hipStream_t sR = pipelined ? r->reg_stream : st;
   if (r->stats_enabled) hipLaunchKernelGGL(k_reset_frame_stats, dim3(1), dim3(1), 0, sF, r->st);
   if (tm) SMX_HIP(hipEventRecord(r->ev[0], sF));
-  // The association images are re-initialised right in front of pass A, on the critical stream: clearing them on the
-  // side stream (three sets in rotation) takes 8 us off the chain but leaves the lines cold for the z-buffer and
-  // association atomics that follow -- pass A 36 -> 53 us, -2 % frames/s (profiles/r03b_matrix.txt).
-  { SlotTimer t(r, sF, kSlotClear);
-    hipLaunchKernelGGL(k_clear_assoc, gpx, b, 0, sF, r->sc, P, r->L.vis_chunks.count); }
+  // The association images: two sets in alternation.  The previous call's k_update_and_create has re-initialised this
+  // call's z-buffer and chunk counter, pass A does the other four images on the way (k_clear_assoc explains; each
+  // image is written right in front of the launch whose atomics land on it -- clearing early on a side stream left
+  // the lines cold, pass A 36 -> 53 us, profiles/r03b_matrix.txt).  Only a first call clears with a launch of its own.
+  r->sc_cur ^= 1;
+  r->sc = r->sc_set[r->sc_cur];
+  r->L.vis_chunks.count = r->vis_count_set[r->sc_cur];
+  const bool set_ready = r->next_set_ready;
+  r->next_set_ready = false;
+  if (!set_ready) {
+    SlotTimer t(r, sF, kSlotClear);
+    hipLaunchKernelGGL(k_clear_assoc, gpx, b, 0, sF, r->sc, P, r->L.vis_chunks.count);
+  }
   { SlotTimer t(r, sF, kSlotScanVisible);
-    hipLaunchKernelGGL(k_scan_visible, gs, b, 0, sF, r->S, c, r->sc, r->L, flags_prev, r->st);
+    hipLaunchKernelGGL(k_scan_visible, gs, b, 0, sF, r->S, c, r->sc, r->L, flags_prev, r->st, set_ready ? 1 : 0);
     r->table_valid = true; r->table_frame = frame_index; r->table_window = c.reg_window; }
   { SlotTimer t(r, sF, kSlotAssociate);
     if (r->scan_mode) hipLaunchKernelGGL((k_associate<false>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->st);
@@ -2259,6 +2305,8 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     CreateArgs ca;
     ca.flags = r->new_flags; ca.ranks = r->new_ranks; ca.block_sums = r->block_sums; ca.block_offsets_out = r->block_offsets;
     ca.n_scan_blocks = r->n_scan_blocks; ca.max_surfels = r->max_surfels; ca.flags8 = r->L.flags8; ca.dirty8 = r->L.dirty8;
+    ca.next_first_depth = r->sc_set[r->sc_cur ^ 1].first_depth; ca.next_vis_chunk_count = r->vis_count_set[r->sc_cur ^ 1];
+    ca.n_pixels = P;
     const uint32_t ncb = (uint32_t)div_up(P, kBlock);
     const dim3 guc(ncb + (uint32_t)r->grid_list);
     const size_t lds = (size_t)r->n_scan_blocks * sizeof(uint32_t);
@@ -2268,6 +2316,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   if (tm) { SMX_HIP(hipEventRecord(r->ev[9], sC)); SMX_HIP(hipEventRecord(r->ev[10], sC)); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[11], sC)); SMX_HIP(hipEventRecord(r->ev[12], sC)); }
   SMX_LAUNCH_CHECK();
+  r->next_set_ready = true;   // (k_update_and_create has prepared the other set of association images)
   int rc = SMX_OK;
   const int iters = p->regularization_iterations_per_integration_iteration;
   if (pipelined) {
@@ -2581,7 +2630,8 @@ static int invalidate_derived(smx_recon r, hipStream_t st) {
   SMX_HIP(hipMemsetAsync(r->L.vis_seg, 0, (size_t)r->nseg * 4, st));
   SMX_HIP(hipMemsetAsync(r->L.seg_box, 0, (size_t)r->nseg * 8 * sizeof(float), st));
   SMX_HIP(hipMemsetAsync(r->L.recent_seg, 0, (size_t)r->nsegB * 4, st));
-  SMX_HIP(hipMemsetAsync(r->L.vis_chunks.count, 0, 4, st));
+  SMX_HIP(hipMemsetAsync(r->vis_count_set[0], 0, 4, st));
+  SMX_HIP(hipMemsetAsync(r->vis_count_set[1], 0, 4, st));
   SMX_HIP(hipMemsetAsync(r->L.rec_chunks.count, 0, 4, st));
   hipLaunchKernelGGL(k_rebuild_flags, dim3(r->grid_surfels), dim3(kBlock), 0, st, r->S, 0u, 0x7FFFFFFF, r->L.flags8, r->st);
   SMX_LAUNCH_CHECK();
