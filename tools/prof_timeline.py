@@ -21,8 +21,8 @@ def main():
     marks = [r for r in rows if "k_smx_marker" in r["Kernel_Name"]]
     lo, hi = (marks[0]["_e"], marks[1]["_s"]) if len(marks) >= 2 else (rows[0]["_s"], rows[-1]["_e"])
     sel = [r for r in rows if r["_s"] >= lo and r["_e"] <= hi]
-    # frames are delimited by k_clear_assoc dispatches
-    clears = [i for i, r in enumerate(sel) if "k_clear_assoc" in r["Kernel_Name"]]
+    # frames are delimited by the dispatches of pass A (k_scan_visible), the first launch of an Integrate call
+    clears = [i for i, r in enumerate(sel) if "k_scan_visible" in r["Kernel_Name"]]
     mid = len(clears) // 2
     a, b = clears[mid], clears[min(mid + nfr, len(clears) - 1)]
     t0 = sel[a]["_s"]
