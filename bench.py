@@ -527,9 +527,12 @@ def bilateral_valu_roofline(wl, api, torch, frame):
     depth.close()
     out.close()
     tf = flops / (ms * 1e-3) / 1e12
-    return {"bound": "valu_fp32", "kernel": "k_bilateral_r<%d>" % radius, "achieved": tf, "peak": VALU_PEAK_TFLOPS,
+    return {"bound": "valu_fp32", "kernel": "k_bilateral_p<%d>" % radius, "achieved": tf, "peak": VALU_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS, "flop_per_launch": flops, "taps": taps,
-            "avg_launch_ms_alone": ms, "note": "timed alone, back to back; inside the frame it shares the chip with two other chains"}
+            "avg_launch_ms_alone": ms,
+            "note": "timed alone, back to back; inside the frame it shares the chip with two other chains.  28 flop per "
+                    "tap is the algorithm's count; the kernel issues 13.5 VALU instructions per tap (two taps per packed "
+                    "fp32 instruction wherever the ISA has one), peak = packed FMA rate"}
 
 
 def cpu_baseline(wl, plan, W, frames, state0, merge0, cap, check, log):

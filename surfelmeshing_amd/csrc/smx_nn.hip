@@ -459,7 +459,6 @@ struct QueryArgs {
   unsigned long long* stat;    // optional: [0] tiles, [1] staged candidates, [2] distance tests, [3] results
   const float* self_r2;        // kSelf: per-point r^2 (indexed by point index) times self_factor, or NULL: r^2 = self_factor
   float self_factor;
-  int debug;                   // experiments: bit 0 = no row writes, bit 1 = count only (no insertion), bit 2 = no lookups/scan
 };
 
 __device__ __forceinline__ bool before(float d2a, uint32_t ia, float d2b, uint32_t ib) {
@@ -709,7 +708,7 @@ k_query_stream(QueryArgs a) {
     float my_d2 = __builtin_inff();
     uint32_t my_idx = kInvalid;
     unsigned long long n_tests = 0;
-    if (ball && !(a.debug & 4)) {   // (uniform: one query per wave)
+    if (ball) {   // (uniform: one query per wave)
       const int blo[3] = {lo[0] >> kBrickShift, lo[1] >> kBrickShift, lo[2] >> kBrickShift};
       const int bn[3] = {(hi[0] >> kBrickShift) - blo[0] + 1, (hi[1] >> kBrickShift) - blo[1] + 1, (hi[2] >> kBrickShift) - blo[2] + 1};
       unsigned long long nbricks = (unsigned long long)bn[0] * bn[1] * bn[2];
@@ -746,7 +745,6 @@ k_query_stream(QueryArgs a) {
               if (ok && a.state != nullptr && (a.state[idx] & a.skip_mask)) ok = false;
             }
             unsigned long long m = __ballot(ok);
-            if (a.debug & 2) { count += __popcll(m); if (count > K) count = K; m = 0; }
             while (m) {
               const int src = __ffsll((long long)m) - 1;
               m &= m - 1;
@@ -769,7 +767,7 @@ k_query_stream(QueryArgs a) {
         }
       }
     }
-    if ((int)lane < count && !(a.debug & 1)) {
+    if ((int)lane < count) {
       a.out_idx[(size_t)qq * K + lane] = my_idx;
       a.out_d2[(size_t)qq * K + lane] = my_d2;
     }
@@ -905,7 +903,6 @@ int smx_nn_create(int32_t device_id, smx_nn* out) {
   smx_nn_s* nn = new smx_nn_s();
   memset(nn, 0, sizeof(*nn));
   nn->device = device;
-  { const char* qm = getenv("SMX_NN_QUERY_MODE"); nn->query_mode = (qm && qm[0] == '1') ? 1 : 0; }   // (A/B measurements)
   hipDeviceProp_t prop;
   SMX_HIP(hipGetDeviceProperties(&prop, device));
   const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1074,7 +1071,6 @@ int smx_nn_query_batch(smx_nn nn, smx_stream s, uint32_t nq, const float* qx, co
   hipLaunchKernelGGL(k_tile_starts, dim3(grid), dim3(kBlock), 0, st, nn->qflags, nq, total, nn->qtile_start);
   a.qorder = nn->qvals[cur]; a.tile_start = nn->qtile_start; a.n_tiles = total;
   a.stat = nn->stats_enabled ? nn->stat : nullptr;
-  { const char* dbg = getenv("SMX_NN_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
   const unsigned blocks = (unsigned)std::min<size_t>((size_t)nn->grid_blocks, ((size_t)nq + 15) / 16 + 1);
   if (nn->query_mode == 1) {
     const unsigned sb = (unsigned)std::min<size_t>(((size_t)nq + 3) / 4, 65536);
