@@ -264,6 +264,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="A/B: no frame pipelining inside Integrate")
     ap.add_argument("--run-ahead", action="store_true", help="A/B: preprocessing two steps ahead, waits routed off the caller's stream")
     ap.add_argument("--bilateral-variant", type=int, default=0, help="A/B: 1 = one tap per instruction")
+    ap.add_argument("--scan-mode", type=int, default=0, help="A/B: smx_recon_set_scan_mode bits (1 = all-slot scans, 2 = multi-launch blend)")
     ap.add_argument("--dry-run", action="store_true", help="rank path only (no GPU, gloo): see the module docstring")
     ap.add_argument("--quiet", action="store_true")
     args = ap.parse_args()
@@ -330,6 +331,8 @@ def run_integrate(args):
         wl.pipe.set_run_ahead(True)
     if args.bilateral_variant:
         _lib.check(_lib.load().smx_debug_set_bilateral_variant(args.bilateral_variant))
+    if args.scan_mode:
+        rec.set_scan_mode(args.scan_mode)
     wl.pipe.run_array(*wl.steps(plan[:W]))
     # short calibration pass with HIP events around every kernel: which Integrate kernel dominates the frame?
     # (frame pipelining off here and in the per-kernel pass below, so that kernels are timed one at a time)

@@ -319,7 +319,8 @@ k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, const uint8_t* __rest
   __shared__ float box_part[kBlock / 64][8];
   if (clear_assoc) {
     // side job (see k_clear_assoc): this workgroup's slice of the four images the association atomics land on
-    const uint32_t P = (uint32_t)(c.W * c.H), per = (P + gridDim.x - 1) / gridDim.x;
+    // (slices of whole 64-pixel runs: every store instruction of a wavefront covers whole cache lines)
+    const uint32_t P = (uint32_t)(c.W * c.H), per = ((P + gridDim.x - 1) / gridDim.x + 63u) & ~63u;
     for (uint32_t k = threadIdx.x; k < per; k += kBlock) {
       const uint32_t px = blockIdx.x * per + k;
       if (px < P) { sc.supporting[px] = kInvalid; sc.counts[px] = 0; sc.depth_sums[px] = 0; sc.confl_key[px] = kInvalid; }
@@ -1272,7 +1273,7 @@ k_update_and_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, Crea
     // Side job (see k_clear_assoc): pass A of the next call follows this launch and min-reduces into the other set's
     // z-buffer; a slice of it per workgroup, written here, is still in L2 when those atomics arrive.
     const uint32_t block = blockIdx.x - n_create_blocks, n_blocks = gridDim.x - n_create_blocks;
-    const uint32_t per = ((uint32_t)a.n_pixels + n_blocks - 1) / n_blocks;
+    const uint32_t per = (((uint32_t)a.n_pixels + n_blocks - 1) / n_blocks + 63u) & ~63u;   // (whole cache lines)
     for (uint32_t k = threadIdx.x; k < per; k += kBlock) {
       const uint32_t px = block * per + k;
       if (px < (uint32_t)a.n_pixels) a.next_first_depth[px] = __builtin_inff();
