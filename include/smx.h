@@ -370,8 +370,10 @@ typedef struct {
  * kernels on s, no allocation, no synchronisation. */
 int smx_nn_query_self(smx_nn nn, smx_stream s, const float* radius_squared, float factor, int32_t k,
                       const uint8_t* state, uint8_t skip_mask, uint32_t* out_idx, float* out_d2, int32_t* out_count);
-/* A/B switch of the query kernel (results are identical): 0 = the brick tiles staged in LDS (default), 1 = one wavefront
- * per query reading the same brick ranges through L1 / L2. */
+/* A/B switch of the query kernel (results are identical): 2 = one LANE per query over the brick tiles staged in LDS,
+ * queries it cannot hold (more than 32 matches, very large regions) answered by kernel 0 afterwards (default);
+ * 0 = one wavefront per query over the same staged tiles; 1 = one wavefront per query reading the brick ranges
+ * through L1 / L2. */
 int smx_nn_set_query_mode(smx_nn nn, int32_t mode);
 int smx_nn_set_stats_enabled(smx_nn nn, smx_stream s, int32_t enabled);
 int smx_nn_get_stats(smx_nn nn, smx_stream s, smx_nn_stats* out);

@@ -459,6 +459,11 @@ struct QueryArgs {
   unsigned long long* stat;    // optional: [0] tiles, [1] staged candidates, [2] distance tests, [3] results
   const float* self_r2;        // kSelf: per-point r^2 (indexed by point index) times self_factor, or NULL: r^2 = self_factor
   float self_factor;
+  // k_query_lanes answers the common case and marks what it cannot (out_count = -1, *redo_flag = 1); k_query_tiles
+  // with redo = 1 then answers exactly the marked queries (and returns at once if nothing was marked)
+  int redo;
+  uint32_t* redo_flag;
+  uint8_t* tile_redo;          // per tile (kSelf: per table slot): 1 = some query of it is marked
 };
 
 __device__ __forceinline__ bool before(float d2a, uint32_t ia, float d2b, uint32_t ib) {
@@ -493,6 +498,7 @@ k_query_tiles(QueryArgs a) {
   const Grid& g = a.g;
   const uint32_t n_tiles = kSelf ? a.mask + 1u : *a.n_tiles;
   const int K = a.K;
+  if (a.redo && *a.redo_flag == 0u) return;   // (uniform) k_query_lanes answered everything
   for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     uint32_t sub_begin, sub_end;
     if (kSelf) {
@@ -502,9 +508,10 @@ k_query_tiles(QueryArgs a) {
     } else {
       sub_begin = a.tile_start[t]; sub_end = a.tile_start[t + 1];
     }
+    if (a.redo && !a.tile_redo[t]) continue;   // (uniform) nothing of this tile was marked
    for (uint32_t j0 = sub_begin; j0 < sub_end; j0 += 64) {   // (general tiles hold <= 64 queries: one pass)
     const uint32_t nt = min(sub_end - j0, 64u);
-    const bool have = lane < nt;
+    bool have = lane < nt;
     uint32_t q = 0;
     float px = 0, py = 0, pz = 0, r2 = -1.0f;
     if (have) {
@@ -515,6 +522,12 @@ k_query_tiles(QueryArgs a) {
       } else {
         const float4 qr = a.qrec[j0 + lane]; q = a.qorder[j0 + lane]; px = qr.x; py = qr.y; pz = qr.z; r2 = qr.w;
       }
+    }
+    if (a.redo) {
+      // only the queries k_query_lanes marked; the others keep the rows they have
+      have = have && a.out_count[q] == -1;
+      if (!have) r2 = -1.0f;
+      if (!__syncthreads_or(have ? 1 : 0)) continue;   // (uniform)
     }
     // the lane's cell range (clamped to the grid), empty for r^2 < 0 / NaN
     int lo[3] = {0, 0, 0}, hi[3] = {-1, -1, -1};
@@ -678,6 +691,206 @@ k_query_tiles(QueryArgs a) {
   }
 }
 
+// One LANE per query (the default, smx_nn_set_query_mode 2).  k_query_tiles spends a wavefront's 64 lanes on one query at
+// a time: at the candidate counts of a surfel cloud (81 distance tests and 7 results per query at C5) most of its
+// instructions are cross-lane bookkeeping -- readlane broadcasts of the query, ballots, the insertion network.  Here the
+// tile's candidates are staged the same way, and then every lane walks ALL of them for its own query: the read of a
+// candidate is one broadcast LDS load for the whole wavefront, the test is eight VALU instructions with no cross-lane
+// traffic, a match is appended to the lane's private list in LDS (lane-major, odd stride: conflict-free).  The lists are
+// sorted by (dist^2, index) lane-privately and written out a row at a time, coalesced.  Same candidates, same
+// arithmetic, same total order: the rows are identical to k_query_tiles'.  What does not fit the simple shape --
+// more than kLaneCap matches, a region of more than 64 bricks or more than kStageL points -- is marked and answered
+// by k_query_tiles afterwards (same launch sequence, no host round trip).
+constexpr int kStageL = 768;     // staged points per tile (12 KB); a surfel surface holds ~300 around a brick at cell = 1.5 x spacing
+constexpr int kLaneCap = 32;     // entries of a lane's private list (positions in the stage: 2 bytes each)
+constexpr int kLaneStride = kLaneCap + 2;   // (in 16-bit units: an odd number of 32-bit words per lane)
+template <bool kSelf>
+__global__ void __launch_bounds__(64)
+k_query_lanes(QueryArgs a) {
+  __shared__ float4 stage[kStageL];
+  __shared__ uint16_t l_pos[64 * kLaneStride];
+  __shared__ uint32_t seg_end[64], seg_src[64];
+  const uint32_t lane = threadIdx.x;
+  const Grid& g = a.g;
+  const uint32_t n_tiles = kSelf ? a.mask + 1u : *a.n_tiles;
+  const int K = a.K;
+  for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    uint32_t sub_begin, sub_end;
+    if (kSelf) {
+      const uint4 slot = *reinterpret_cast<const uint4*>(&a.table[t]);
+      if ((slot.x | slot.y) == 0u) continue;   // (uniform) empty slot
+      sub_begin = slot.z; sub_end = slot.w;
+    } else {
+      sub_begin = a.tile_start[t]; sub_end = a.tile_start[t + 1];
+    }
+    bool tile_marked = false;
+    for (uint32_t j0 = sub_begin; j0 < sub_end; j0 += 64) {
+      const uint32_t nt = min(sub_end - j0, 64u);
+      const bool have = lane < nt;
+      uint32_t q = 0;
+      float px = 0, py = 0, pz = 0, r2 = -1.0f;
+      if (have) {
+        if (kSelf) {
+          const float4 rec = a.sorted[j0 + lane];
+          q = __float_as_uint(rec.w); px = rec.x; py = rec.y; pz = rec.z;
+          r2 = a.self_r2 ? a.self_r2[q] * a.self_factor : a.self_factor;
+        } else {
+          const float4 qr = a.qrec[j0 + lane]; q = a.qorder[j0 + lane]; px = qr.x; py = qr.y; pz = qr.z; r2 = qr.w;
+        }
+      }
+      // the lane's cell range (clamped to the grid), empty for r^2 < 0 / NaN -- as in k_query_tiles
+      int lo[3] = {0, 0, 0}, hi[3] = {-1, -1, -1};
+      bool ball = have && (r2 >= 0);
+      if (ball) {
+        const float qp[3] = {px, py, pz};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float rad = cover_radius(r2, qp[k]);
+          const float flo = floorf((qp[k] - rad - g.min[k]) / g.cell), fhi = floorf((qp[k] + rad - g.min[k]) / g.cell);
+          lo[k] = flo >= 0.0f ? (flo < (float)g.dim[k] ? (int)flo : g.dim[k]) : 0;
+          hi[k] = fhi >= 0.0f ? (fhi < (float)g.dim[k] ? (int)fhi : g.dim[k] - 1) : -1;
+          if (!(lo[k] <= hi[k])) ball = false;
+        }
+      }
+      if (!ball) r2 = -1.0f;
+      int rlo[3], rhi[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        int mn = ball ? lo[k] : 0x7FFFFFFF, mx = ball ? hi[k] : -1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { mn = min(mn, __shfl_xor(mn, off)); mx = max(mx, __shfl_xor(mx, off)); }
+        rlo[k] = mn; rhi[k] = mx;
+      }
+      bool redo = false;      // the lane's query goes to k_query_tiles
+      uint32_t cnt = 0;       // matches of the lane's query (the first kLaneCap of them are in its list)
+      unsigned long long n_tests = 0, n_staged = 0;
+      if (rhi[0] >= rlo[0]) {   // (uniform) at least one lane has a ball
+        const int blo[3] = {rlo[0] >> kBrickShift, rlo[1] >> kBrickShift, rlo[2] >> kBrickShift};
+        const int bn[3] = {(rhi[0] >> kBrickShift) - blo[0] + 1, (rhi[1] >> kBrickShift) - blo[1] + 1, (rhi[2] >> kBrickShift) - blo[2] + 1};
+        const unsigned long long nbricks = (unsigned long long)bn[0] * bn[1] * bn[2];
+        if (nbricks > 64ull) {
+          redo = ball;
+        } else {
+          uint32_t s = 0, e = 0;
+          int clo[3] = {0, 0, 0}, chi[3] = {-1, -1, -1};
+          if ((unsigned long long)lane < nbricks) {
+            const int bx = blo[0] + (int)(lane % (uint32_t)bn[0]);
+            const int by = blo[1] + (int)((lane / (uint32_t)bn[0]) % (uint32_t)bn[1]);
+            const int bz = blo[2] + (int)(lane / ((uint32_t)bn[0] * (uint32_t)bn[1]));
+            if (!find_brick(a.table, a.mask, brick_index(g, bx, by, bz), s, e)) { s = 0; e = 0; }
+            clo[0] = bx << kBrickShift; clo[1] = by << kBrickShift; clo[2] = bz << kBrickShift;
+            chi[0] = clo[0] + kBrickCells - 1; chi[1] = clo[1] + kBrickCells - 1; chi[2] = clo[2] + kBrickCells - 1;
+          }
+          const uint32_t len = e - s;
+          uint32_t incl = len;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) { const uint32_t tv = __shfl_up(incl, off); if (lane >= (uint32_t)off) incl += tv; }
+          const uint32_t total = lane_u(incl, 63);
+          if (total > (uint32_t)kStageL) {
+            redo = ball;
+          } else if (total > 0) {
+            __syncthreads();   // (the previous tile's readers are done)
+            seg_end[lane] = incl;               // the range of lane L fills flat positions [seg_end[L] - len, seg_end[L])
+            seg_src[lane] = s - (incl - len);   // source index = seg_src[L] + flat position (mod 2^32)
+            __syncthreads();
+            uint32_t cur = 0;
+            for (uint32_t k0 = 0; k0 < total; k0 += 64) {
+              const uint32_t k = min(k0 + lane, total - 1u);
+              while (k >= seg_end[cur]) ++cur;
+              const float4 v = a.sorted[seg_src[cur] + k];
+              if (k0 + lane < total) stage[k0 + lane] = v;
+            }
+            __syncthreads();
+            n_staged = total;
+            unsigned long long segs = __ballot(len > 0);
+            while (segs) {
+              const int sg = __ffsll((long long)segs) - 1;
+              segs &= segs - 1;
+              const uint32_t seg_len = lane_u(len, sg), seg_flat = lane_u(incl - len, sg);
+              const int s0 = __builtin_amdgcn_readlane(clo[0], sg), e0 = __builtin_amdgcn_readlane(chi[0], sg);
+              const int s1 = __builtin_amdgcn_readlane(clo[1], sg), e1 = __builtin_amdgcn_readlane(chi[1], sg);
+              const int s2 = __builtin_amdgcn_readlane(clo[2], sg), e2 = __builtin_amdgcn_readlane(chi[2], sg);
+              // only the bricks the lane's own cell range overlaps (most queries need one or two of the staged ones)
+              const bool ov = ball && s0 <= hi[0] && e0 >= lo[0] && s1 <= hi[1] && e1 >= lo[1] && s2 <= hi[2] && e2 >= lo[2];
+              const unsigned long long ovm = __ballot(ov);
+              if (!ovm) continue;   // (uniform)
+              n_tests += (unsigned long long)__popcll(ovm) * seg_len;
+              // Four candidates per step, all four LDS reads (one address for the whole wavefront: broadcasts) issued
+              // before the first test; a match is appended without a branch (a list that is full keeps overwriting its
+              // spare last entry; cnt keeps counting and marks the query for the other kernel afterwards).
+              const uint32_t lbase = lane * kLaneStride;
+              for (uint32_t k0 = 0; k0 < seg_len; k0 += 4) {
+                float4 rec[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rec[u] = stage[seg_flat + min(k0 + u, seg_len - 1u)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  const float dx = rec[u].x - px, dy = rec[u].y - py, dz = rec[u].z - pz;
+                  const float d2 = dx * dx + dy * dy + dz * dz;
+                  bool ok = ov && (k0 + u < seg_len) && d2 <= r2;
+                  if (a.state != nullptr) {   // (uniform; the filter is the rare case)
+                    if (ok && (a.state[__float_as_uint(rec[u].w)] & a.skip_mask)) ok = false;
+                  }
+                  if (ok) {
+                    l_pos[lbase + min(cnt, (uint32_t)kLaneCap)] = (uint16_t)(seg_flat + k0 + u);
+                    ++cnt;
+                  }
+                }
+              }
+            }
+            if (cnt > (uint32_t)kLaneCap) redo = true;
+          }
+        }
+      }
+      // Rows out, one query at a time: lane e takes the query's e-th match (recomputed from the stage: the same
+      // subtraction and sum as in the test above), finds its rank in the (dist^2, index) order by comparing with all
+      // matches (broadcasts from registers, no sorting network, no data movement) and stores it at that position of the
+      // output row -- the row's entries leave the wavefront together.
+      const uint32_t n = redo ? 0u : cnt;
+      const uint32_t n_out = min(n, (uint32_t)K);
+      __syncthreads();
+      for (uint32_t ql = 0; ql < nt; ++ql) {
+        const uint32_t nm = lane_u(n, (int)ql);
+        if (nm == 0) continue;   // (uniform)
+        const uint32_t qq = lane_u(q, (int)ql);
+        const float qx = lane_f(px, (int)ql), qy = lane_f(py, (int)ql), qz = lane_f(pz, (int)ql);
+        float my_d2 = __builtin_inff();
+        uint32_t my_idx = kInvalid;
+        if (lane < nm) {
+          const float4 rec = stage[l_pos[ql * kLaneStride + lane]];
+          const float dx = rec.x - qx, dy = rec.y - qy, dz = rec.z - qz;
+          my_d2 = dx * dx + dy * dy + dz * dz;
+          my_idx = __float_as_uint(rec.w);
+        }
+        uint32_t rank = 0;
+        for (uint32_t e = 0; e < nm; ++e) {
+          const float ed2 = lane_f(my_d2, (int)e);
+          const uint32_t eidx = lane_u(my_idx, (int)e);
+          rank += before(ed2, eidx, my_d2, my_idx) ? 1u : 0u;
+        }
+        if (lane < nm && rank < (uint32_t)K) {
+          a.out_idx[(size_t)qq * K + rank] = my_idx;
+          a.out_d2[(size_t)qq * K + rank] = my_d2;
+        }
+      }
+      if (have) a.out_count[q] = redo ? -1 : (int32_t)n_out;
+      if (__ballot(redo)) { tile_marked = true; if (lane == 0) *a.redo_flag = 1u; }
+      if (a.stat) {
+        uint32_t csum = have ? n_out : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) csum += __shfl_xor(csum, off);
+        if (lane == 0) {
+          atomicAdd(&a.stat[0], 1ull);
+          atomicAdd(&a.stat[1], n_staged); atomicAdd(&a.stat[2], n_tests);
+          atomicAdd(&a.stat[3], (unsigned long long)csum);
+        }
+      }
+      __syncthreads();
+    }
+    if (lane == 0) a.tile_redo[t] = tile_marked ? 1 : 0;
+  }
+}
+
 // The same search without the LDS stage (A/B partner of k_query_tiles, smx_nn_set_query_mode): one wavefront per query,
 // queries still in brick order, so the bricks a query needs were read by its neighbours a moment ago and come from
 // L1 / L2.  No shared memory, no barriers, 8 wavefronts per SIMD.
@@ -804,13 +1017,15 @@ struct smx_nn_s {
   unsigned long long* qkeys[2];
   uint32_t* qvals[2];
   uint32_t *qflags, *qtile_start;
+  uint8_t *tile_redo_q, *tile_redo_self;   // k_query_lanes' per-tile marks: one per query tile / per table slot
   float* qrows;         // upload target for host queries [4][cap]
   float4* qrec;         // queries in brick order
   uint8_t* dstate; size_t cap_state;
   uint32_t* didx; float* dd2; int32_t* dcnt; size_t cap_out;   // staging for host outputs [nq * k]
   unsigned long long* stat;   // 4 counters (device), filled while stats_enabled
   int stats_enabled;
-  int query_mode;       // 0 = LDS-staged brick tiles (k_query_tiles), 1 = one wavefront per query from L1 / L2 (k_query_stream)
+  int query_mode;       // 2 = one lane per query (k_query_lanes; default), 0 = one wavefront per query over LDS-staged brick tiles
+                        // (k_query_tiles), 1 = one wavefront per query from L1 / L2 (k_query_stream)
   int grid_blocks;      // persistent grid of the tile kernel
 };
 
@@ -818,7 +1033,7 @@ namespace {
 
 void nn_free(smx_nn nn) {
   void* ptrs[] = {nn->keys[0], nn->keys[1], nn->vals[0], nn->vals[1], nn->rows, nn->sorted, nn->hist, nn->table, nn->bbox,
-                  nn->partial, nn->counts, nn->qkeys[0], nn->qkeys[1], nn->qvals[0], nn->qvals[1], nn->qflags,
+                  nn->partial, nn->counts, nn->qkeys[0], nn->qkeys[1], nn->qvals[0], nn->qvals[1], nn->qflags, nn->tile_redo_q, nn->tile_redo_self,
                   nn->qtile_start, nn->qrows, nn->qrec, nn->dstate, nn->didx, nn->dd2, nn->dcnt, nn->stat};
   for (void* p : ptrs) if (p) (void)hipFree(p);
 }
@@ -865,6 +1080,7 @@ int ensure_queries(smx_nn nn, size_t nq) {
   int rc = SMX_OK;
   for (int k = 0; k < 2 && rc == SMX_OK; ++k) { rc = grow(&nn->qkeys[k], cap); if (rc == SMX_OK) rc = grow(&nn->qvals[k], cap); }
   if (rc == SMX_OK) rc = grow(&nn->qflags, cap + 1);
+  if (rc == SMX_OK) rc = grow(&nn->tile_redo_q, cap + 1);
   if (rc == SMX_OK) rc = grow(&nn->qtile_start, cap + 2);
   if (rc == SMX_OK) rc = grow(&nn->qrows, 4 * cap);
   if (rc == SMX_OK) rc = grow(&nn->qrec, cap);
@@ -906,13 +1122,14 @@ int smx_nn_create(int32_t device_id, smx_nn* out) {
   hipDeviceProp_t prop;
   SMX_HIP(hipGetDeviceProperties(&prop, device));
   const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  nn->query_mode = 2;           // lane per query, k_query_tiles for what it marks
   nn->grid_blocks = cus * 12;   // persistent grid of the tile kernel: 6 workgroups (24 wavefronts) fit a CU, two rounds
   int rc = grow(&nn->bbox, 6);
   if (rc == SMX_OK) rc = grow(&nn->partial, 6 * 2048);
   if (rc == SMX_OK) rc = grow(&nn->counts, 1);
-  if (rc == SMX_OK) rc = grow(&nn->stat, 4);
+  if (rc == SMX_OK) rc = grow(&nn->stat, 5);   // [4]: k_query_lanes' redo flag
   if (rc != SMX_OK) { nn_free(nn); delete nn; return rc; }
-  SMX_HIP(hipMemset(nn->stat, 0, 4 * sizeof(unsigned long long)));
+  SMX_HIP(hipMemset(nn->stat, 0, 5 * sizeof(unsigned long long)));
   *out = nn;
   return SMX_OK;
 }
@@ -991,6 +1208,7 @@ int smx_nn_build(smx_nn nn, smx_stream s, const float* x, const float* y, const 
   while (slots < (size_t)h.n_bricks * 2) slots <<= 1;
   if (slots > nn->table_slots) {
     rc = grow(&nn->table, slots);
+    if (rc == SMX_OK) rc = grow(&nn->tile_redo_self, slots);
     nn->table_slots = rc == SMX_OK ? slots : 0;
     if (rc != SMX_OK) return rc;
   }
@@ -1075,7 +1293,15 @@ int smx_nn_query_batch(smx_nn nn, smx_stream s, uint32_t nq, const float* qx, co
   if (nn->query_mode == 1) {
     const unsigned sb = (unsigned)std::min<size_t>(((size_t)nq + 3) / 4, 65536);
     hipLaunchKernelGGL(k_query_stream, dim3(sb), dim3(kBlock), 0, st, a);
+  } else if (nn->query_mode == 0) {
+    hipLaunchKernelGGL(k_query_tiles<false>, dim3(blocks), dim3(64 * kTileWaves), 0, st, a);
   } else {
+    a.redo_flag = reinterpret_cast<uint32_t*>(nn->stat + 4);
+    a.tile_redo = nn->tile_redo_q;
+    SMX_HIP(hipMemsetAsync(a.redo_flag, 0, 4, st));
+    const unsigned lb = (unsigned)std::min<size_t>((size_t)nn->grid_blocks * 4, (size_t)nq + 1);
+    hipLaunchKernelGGL(k_query_lanes<false>, dim3(lb), dim3(64), 0, st, a);
+    a.redo = 1;
     hipLaunchKernelGGL(k_query_tiles<false>, dim3(blocks), dim3(64 * kTileWaves), 0, st, a);
   }
   SMX_LAUNCH_CHECK();
@@ -1106,13 +1332,21 @@ int smx_nn_query_self(smx_nn nn, smx_stream s, const float* radius_squared, floa
   a.self_r2 = radius_squared; a.self_factor = factor;
   a.stat = nn->stats_enabled ? nn->stat : nullptr;
   const unsigned blocks = (unsigned)std::min<size_t>((size_t)nn->grid_blocks, nn->table_slots);
+  if (nn->query_mode == 2) {
+    a.redo_flag = reinterpret_cast<uint32_t*>(nn->stat + 4);
+    a.tile_redo = nn->tile_redo_self;
+    SMX_HIP(hipMemsetAsync(a.redo_flag, 0, 4, st));
+    const unsigned lb = (unsigned)std::min<size_t>((size_t)nn->grid_blocks * 4, nn->table_slots);
+    hipLaunchKernelGGL(k_query_lanes<true>, dim3(lb), dim3(64), 0, st, a);
+    a.redo = 1;
+  }
   hipLaunchKernelGGL(k_query_tiles<true>, dim3(blocks), dim3(64 * kTileWaves), 0, st, a);
   SMX_LAUNCH_CHECK();
   return SMX_OK;
 }
 
 int smx_nn_set_query_mode(smx_nn nn, int32_t mode) {
-  SMX_CHECK_ARG(nn != nullptr && (mode == 0 || mode == 1));
+  SMX_CHECK_ARG(nn != nullptr && mode >= 0 && mode <= 2);
   nn->query_mode = mode;
   return SMX_OK;
 }

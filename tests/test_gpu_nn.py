@@ -285,11 +285,18 @@ def test_self_queries_and_kernel_modes_agree(smx):
         cs, ds, is_ = nn.FindNearestOfIndexedPoints(n, 64, radius_squared=r2, factor=1.0, state=st, skip_mask=mask)
         assert np.all(cs[nanrows] == 0)
         rows = {}
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             nn.set_query_mode(mode)
             rows[mode] = nn.FindNearestSurfelsWithinRadius(pts, r2, 64, state=st, skip_mask=mask)
+        # the self-query entry point under the other tile kernel as well (the first call ran the default, mode 2:
+        # one lane per query, with the dense clump's queries -- more than 32 matches -- redone by the tile kernel)
         nn.set_query_mode(0)
-        for mode in (0, 1):
+        c0, d0, i0 = nn.FindNearestOfIndexedPoints(n, 64, radius_squared=r2, factor=1.0, state=st, skip_mask=mask)
+        nn.set_query_mode(2)
+        m0 = np.arange(64)[None, :] < cs[:, None]
+        assert np.array_equal(c0, cs) and np.array_equal(i0[m0], is_[m0]) and np.array_equal(d0[m0].view(np.uint32), ds[m0].view(np.uint32))
+        assert (cs > 32).sum() > 100 and (cs < 32).sum() > 1000        # both paths of mode 2 were taken
+        for mode in (0, 1, 2):
             cb, db, ib = rows[mode]
             assert np.all(cb[nanrows] == 0)                             # NaN query: empty ball
             assert np.array_equal(cb, cs), mode
