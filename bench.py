@@ -482,6 +482,10 @@ def roofline_block(st, P, dominant, dom_ms, dom_n, kernel_ms, ms_per_step):
     pmc, why = pmc_file()
     traffic = raw = frame = None
     if pmc is not None:
+        at = pmc.get("_meta", {}).get("surfel_slots")
+        if not at or abs(at - st["surfels_size"]) > 0.1 * st["surfels_size"]:
+            pmc, why = None, "collected at %s surfel slots, this run has %d" % (at, st["surfels_size"])
+    if pmc is not None:
         k = pmc.get(SLOT_KERNEL.get(dominant, ""), {})
         traffic = pmc_bytes(k)
         raw = {"FETCH_SIZE_KB": k.get("FETCH_SIZE"), "WRITE_SIZE_KB": k.get("WRITE_SIZE"),
