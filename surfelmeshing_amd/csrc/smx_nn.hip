@@ -704,6 +704,41 @@ k_query_tiles(QueryArgs a) {
 constexpr int kStageL = 768;     // staged points per tile (12 KB); a surfel surface holds ~300 around a brick at cell = 1.5 x spacing
 constexpr int kLaneCap = 32;     // entries of a lane's private list (positions in the stage: 2 bytes each)
 constexpr int kLaneStride = kLaneCap + 2;   // (in 16-bit units: an odd number of 32-bit words per lane)
+
+// The lane's matches, sorted in registers by Batcher's odd-even merge network over 64-bit keys (dist^2 bits << 32 |
+// index: a non-negative float orders like its bit pattern, so one unsigned 64-bit compare is the (dist^2, index) order),
+// then parked lane-major in LDS (`o_key`, stride N + 1 words of 8 bytes) for the coalesced row output.  Every lane of
+// the wavefront sorts its own list at the same time: N = 16 costs 63 compare-exchanges for all 64 queries together,
+// where ranking the matches of one query after the other costs about as much per QUERY.
+template <int N>
+__device__ __forceinline__ void sort_lane_matches(const float4* __restrict__ stage, const uint16_t* __restrict__ l_pos, uint32_t lbase,
+                                                  uint32_t n, float px, float py, float pz, unsigned long long (&key)[N]) {
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    key[e] = ~0ull;
+    if ((uint32_t)e < n) {
+      const float4 rec = stage[l_pos[lbase + e]];
+      const float dx = rec.x - px, dy = rec.y - py, dz = rec.z - pz;
+      const float d2 = dx * dx + dy * dy + dz * dz;   // (the same subtraction and sum as in the test that accepted it)
+      key[e] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)__float_as_uint(rec.w);
+    }
+  }
+#pragma unroll
+  for (int p = 1; p < N; p <<= 1)
+#pragma unroll
+    for (int k = p; k >= 1; k >>= 1)
+#pragma unroll
+      for (int j = k % p; j + k < N; j += 2 * k)
+#pragma unroll
+        for (int i = 0; i < k; ++i) {
+          if (i + j + k < N && (i + j) / (2 * p) == (i + j + k) / (2 * p)) {
+            const unsigned long long a0 = key[i + j], b0 = key[i + j + k];
+            const bool sw = b0 < a0;
+            key[i + j] = sw ? b0 : a0;
+            key[i + j + k] = sw ? a0 : b0;
+          }
+        }
+}
 template <bool kSelf>
 __global__ void __launch_bounds__(64)
 k_query_lanes(QueryArgs a) {
@@ -842,13 +877,46 @@ k_query_lanes(QueryArgs a) {
           }
         }
       }
+      const uint32_t n = redo ? 0u : cnt;
+      const uint32_t n_out = min(n, (uint32_t)K);
+      uint32_t n_max = n;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, off));
+      __syncthreads();
+      if (n_max <= 16u) {   // (uniform) the usual case: every lane sorts its own matches in registers
+        constexpr int kOutStride = 17;
+        unsigned long long* o_key = reinterpret_cast<unsigned long long*>(stage);   // (the stage is free once the keys are formed)
+        static_assert(sizeof(unsigned long long) * 64 * kOutStride <= sizeof(float4) * kStageL, "the output rows fit the stage");
+        if (n_max <= 8u) {
+          unsigned long long key[8];
+          sort_lane_matches<8>(stage, l_pos, lane * kLaneStride, n, px, py, pz, key);
+          __syncthreads();
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o_key[lane * kOutStride + e] = key[e];
+        } else {
+          unsigned long long key[16];
+          sort_lane_matches<16>(stage, l_pos, lane * kLaneStride, n, px, py, pz, key);
+          __syncthreads();
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o_key[lane * kOutStride + e] = key[e];
+        }
+        __syncthreads();
+        // rows out, one query at a time: lane e writes entry e (one contiguous piece of each output row)
+        for (uint32_t ql = 0; ql < nt; ++ql) {
+          const uint32_t nq = lane_u(n_out, (int)ql);
+          if (nq == 0) continue;   // (uniform)
+          const uint32_t qq = lane_u(q, (int)ql);
+          if (lane < nq) {
+            const unsigned long long kv = o_key[ql * kOutStride + lane];
+            a.out_idx[(size_t)qq * K + lane] = (uint32_t)kv;
+            a.out_d2[(size_t)qq * K + lane] = __uint_as_float((uint32_t)(kv >> 32));
+          }
+        }
+      } else {
       // Rows out, one query at a time: lane e takes the query's e-th match (recomputed from the stage: the same
       // subtraction and sum as in the test above), finds its rank in the (dist^2, index) order by comparing with all
       // matches (broadcasts from registers, no sorting network, no data movement) and stores it at that position of the
       // output row -- the row's entries leave the wavefront together.
-      const uint32_t n = redo ? 0u : cnt;
-      const uint32_t n_out = min(n, (uint32_t)K);
-      __syncthreads();
       for (uint32_t ql = 0; ql < nt; ++ql) {
         const uint32_t nm = lane_u(n, (int)ql);
         if (nm == 0) continue;   // (uniform)
@@ -872,6 +940,7 @@ k_query_lanes(QueryArgs a) {
           a.out_idx[(size_t)qq * K + rank] = my_idx;
           a.out_d2[(size_t)qq * K + rank] = my_d2;
         }
+      }
       }
       if (have) a.out_count[q] = redo ? -1 : (int32_t)n_out;
       if (__ballot(redo)) { tile_marked = true; if (lane == 0) *a.redo_flag = 1u; }
