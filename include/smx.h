@@ -306,7 +306,8 @@ enum {
 int smx_recon_debug_download_scratch(smx_recon r, smx_stream s, int32_t which, void* dst);
 /* A/B switches; results are identical in every mode.  bit 0: every surfel kernel scans all slots like
  * the reference does instead of the compacted lists; bit 1: measurement blending as the reference's
- * start + iteration launches instead of the fused LDS kernel. */
+ * start + iteration launches instead of the fused LDS kernel; bit 2: the regulariser's link scan gathers the flag byte
+ * of every far link (no hot-group filter). */
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode);
 /* Frame pipelining (default on): the regulariser of a frame runs on an internal stream beside the first
  * kernels of the next smx_recon_integrate call (which only read what the regulariser does not write).

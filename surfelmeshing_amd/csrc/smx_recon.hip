@@ -233,7 +233,16 @@ struct Lists {
   uint8_t* flags8;        // per slot: bit 0 = stamp inside the regulariser window, bit 1 = detach request
   uint8_t* dirty8;        // delta tracking (null = off): 1 = a transferred attribute of the slot changed since the
                           // last smx_recon_transfer_changed_to_cpu
+  // "Hot" groups (pass B's filter for its far flag gathers, see k_neighbor_scan): per group of slots the number
+  // (mod 256) of the last Integrate call in which the group held a slot inside the regulariser window (pass A) or a
+  // flag byte / link record of it was written.  `epoch` = this call's number.  (At C2 a group is 2048 slots, at C3 8192.)
+  uint8_t* hot_epoch;
+  uint32_t n_hot_groups;
+  uint32_t epoch;
+  int hot_shift;          // slots per group = 1 << hot_shift: the smallest power of two >= 1024 that keeps the table <= 4 KB
 };
+// hot = active in this call or the previous one (or, seen from the pass B that runs beside it, in the next one)
+__device__ __forceinline__ bool group_is_hot(uint32_t last, uint32_t epoch) { return ((epoch - last + 1u) & 255u) <= 2u; }
 
 // (thread 0 of the workgroup that built a segment's list)
 __device__ __forceinline__ void emit_chunks(const Chunks& ch, uint32_t segment, uint32_t total, uint32_t chunks_per_segment) {
@@ -357,6 +366,7 @@ k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, const uint8_t* __rest
     return;  // (vis_seg stays 0, the box stays as it is)
   }
   uint32_t vis_bits = 0;
+  bool lane_recent = false;
   float bmin[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bmax[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
   uint32_t newest = 0;   // in the wrap-around order of stamp_outside_window: compared as signed
   bool have_stamp = false;
@@ -394,7 +404,10 @@ k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, const uint8_t* __rest
       }
     }
     *reinterpret_cast<uchar4*>(&L.flags8[i0]) = make_uchar4(new_flags[0], new_flags[1], new_flags[2], new_flags[3]);
+    lane_recent = ((new_flags[0] | new_flags[1] | new_flags[2] | new_flags[3]) & 1u) != 0;
   }
+  // (a slot inside the regulariser window: the group is hot -- same value from every writer, one byte store per wavefront)
+  if (__ballot(lane_recent) && (threadIdx.x & 63) == 0) L.hot_epoch[base >> L.hot_shift] = (uint8_t)L.epoch;
   // the segment's bounding box and newest stamp (wave shuffles, then one partial per wavefront through LDS)
   int newest_s = have_stamp ? (int)newest : (int)0x80000000;
 #pragma unroll
@@ -963,6 +976,7 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
       const uint32_t col = (S.u(kColor, i) & 0x00FFFFFFu) | 0x01000000u;
       S.u(kColor, i) = col;
       L.flags8[i] = make_flags(0u, col, c.frame, c.reg_window);
+      L.hot_epoch[i >> L.hot_shift] = (uint8_t)L.epoch;
       if (L.dirty8) L.dirty8[i] = 1;
       ++merged_here;
       continue;  // r^2 < 0: the integrate kernel does nothing for it (:1050-1052)
@@ -984,6 +998,7 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
     integrate_or_conflict(R, c, px0, true, p.px, p.py, p.l, i, st);
     integrate_or_conflict(R, c, px1, second, ox, oy, p.l, i, st);
     if (R.dirty) {
+      L.hot_epoch[i >> L.hot_shift] = (uint8_t)L.epoch;   // (stamp / colour mark may have changed, a replacement drops the links)
       if (L.dirty8) L.dirty8[i] = 1;
       *S.group(kGroupP, i) = R.P; *S.group(kGroupN, i) = R.N; *S.group(kGroupC, i) = R.C;
       if (R.replaced) {
@@ -1089,8 +1104,10 @@ __device__ __forceinline__ void update_neighbors_body(const Surfels& S, const Fr
         for (int q = 0; q < 4; ++q) if (q == best_n) { ni[q] = nb; nd2[q] = d2; }
       }
     }
-    if (ni[0] != t4.x || ni[1] != t4.y || ni[2] != t4.z || ni[3] != t4.w)
+    if (ni[0] != t4.x || ni[1] != t4.y || ni[2] != t4.z || ni[3] != t4.w) {
       S.set_neighbors(i, make_uint4(ni[0], ni[1], ni[2], ni[3]));
+      L.hot_epoch[i >> L.hot_shift] = (uint8_t)L.epoch;   // (new links)
+    }
   }
 }
 
@@ -1164,6 +1181,7 @@ struct CreateArgs {
   int n_scan_blocks; uint32_t max_surfels; uint8_t* flags8; uint8_t* dirty8;
   // the NEXT call's association images (the other set): this launch re-initialises its z-buffer and its chunk counter
   float* next_first_depth; uint32_t* next_vis_chunk_count; int n_pixels;
+  uint8_t* hot_epoch; uint32_t epoch; int hot_shift;   // Lists::hot_epoch, epoch, hot_shift
 };
 __device__ __forceinline__ void new_create_body(const Surfels& S, const FrameCtx& c, const Scratch& sc, const FrameIn& in,
                                                 const CreateArgs& a, DevState* st, uint32_t block, uint32_t n_blocks) {
@@ -1225,6 +1243,7 @@ __device__ __forceinline__ void new_create_body(const Surfels& S, const FrameCtx
     S.u(kCreationStamp, i) = c.frame;
     S.u(kLastUpdateStamp, i) = c.frame;
     flags8[i] = make_flags(c.frame, 0u, c.frame, c.reg_window);
+    a.hot_epoch[i >> a.hot_shift] = (uint8_t)a.epoch;
     if (a.dirty8) a.dirty8[i] = 1;
     const float r2 = in.radius(y, x);
     S.f(kRadiusSq, i) = r2;
@@ -1293,8 +1312,9 @@ k_update_and_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, Crea
 // accumulators are zero between calls (k_reg_step zeroes what it consumes).
 template <bool kDetach, bool kAccumulate>
 __global__ void __launch_bounds__(kBlockB)
-k_neighbor_scan(Surfels S, int stats, Lists L, uint8_t* __restrict__ inwin8, uint32_t* __restrict__ need_seg,
+k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict__ inwin8, uint32_t* __restrict__ need_seg,
                 DevState* st) {
+  extern __shared__ __align__(16) uint8_t lhot[];   // the hot-group table (n_hot_groups bytes, padded to 16)
   // B1: pure streaming.  Per slot: detach (:1430-1433), which of its neighbours lie inside the regulariser
   // window (4-bit mask -> inwin8), membership in the recent list.  No LDS accumulators here, so the
   // occupancy stays high; the accumulation itself runs in k_reg_accumulate on the few segments that need it.
@@ -1306,6 +1326,19 @@ k_neighbor_scan(Surfels S, int stats, Lists L, uint8_t* __restrict__ inwin8, uin
   // The reference detaches BEFORE it creates new surfels (kernels.cc:333-339 precedes cc:264-286), so
   // slots created in this frame keep links to flagged surfels until the next frame.
   const uint32_t detach_limit = st->create_base;
+  // The far flag gathers (a link that leaves the segment: one random byte from the 5 MB table, 4.6 M per frame at C2,
+  // 21 of this kernel's 55 us alone) are skipped where their result is known.  The flag byte of the target matters in
+  // two ways: bit 0 (inside the window) -- zero if the target's group is not hot, because pass A found no such slot in
+  // it and nothing stamped one since; bit 1 (detach request) -- of consequence only while a link to the marked slot
+  // still exists: a mark set in call g removes the links that exist then in pass B of call g (or g + 1 for sources
+  // created in g), and a link created in a later call h is examined in pass B of h (or h + 1); in all of those passes
+  // the target's or the source's group is hot (mark or link written in the call or the one before) and the gather takes
+  // place.  So with BOTH groups cold the byte cannot change anything.  The table (one byte per group: <= 4 KB)
+  // is copied to LDS, so the test itself is an LDS read, not another gather.  (use_hot = 0 for two calls whenever
+  // flags or links were written outside Integrate.)
+  if (use_hot)
+    for (uint32_t g = threadIdx.x * 16; g < L.n_hot_groups; g += kBlockB * 16)
+      *reinterpret_cast<uint4*>(&lhot[g]) = *reinterpret_cast<const uint4*>(&L.hot_epoch[g]);
   const uint32_t i0 = base + threadIdx.x * 4;
   uint32_t recent_bits = 0;
   int need = 0;
@@ -1318,6 +1351,7 @@ k_neighbor_scan(Surfels S, int stats, Lists L, uint8_t* __restrict__ inwin8, uin
   }
   *reinterpret_cast<uchar4*>(&lflags[threadIdx.x * 4]) = own;
   __syncthreads();
+  const bool quiet = use_hot && !group_is_hot(lhot[base >> L.hot_shift], L.epoch);
   if (i0 < N) {
     const uint8_t ownf[4] = {own.x, own.y, own.z, own.w};
     uint8_t inw[4] = {0, 0, 0, 0};
@@ -1333,7 +1367,10 @@ k_neighbor_scan(Surfels S, int stats, Lists L, uint8_t* __restrict__ inwin8, uin
         if (nb == kInvalid) continue;
         // three of four links stay inside the segment: those flags come from the LDS copy
         const uint32_t rel = nb - base;
-        const uint32_t f = (rel < (uint32_t)kSegB) ? lflags[rel] : L.flags8[nb];
+        uint32_t f;
+        if (rel < (uint32_t)kSegB) f = lflags[rel];
+        else if (quiet && !group_is_hot(lhot[nb >> L.hot_shift], L.epoch)) f = 0;   // (both bits are of no consequence)
+        else f = L.flags8[nb];
         if (kDetach && i < detach_limit && (f & 2u)) {  // :1430-1433
           S.set_neighbor(i, q, kInvalid);
           continue;
@@ -1847,6 +1884,8 @@ struct smx_recon_s {
   Scratch sc_set[2];
   uint32_t* vis_count_set[2];
   int sc_cur;
+  int hot_holdoff;          // > 0: pass B does not use the hot-group table (decremented per Integrate call)
+  int hot_filter_enabled;   // A/B switch (smx_recon_set_scan_mode bit 2 clears it)
   bool next_set_ready;      // the other set's z-buffer and chunk counter were re-initialised by the last k_update_and_create
   uint16_t* blended_depth;  // [H][W] output of the fused blend (stored into the caller's depth by k_new_flags_scan)
   BlendBufs bb;
@@ -1935,17 +1974,20 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
   if (!r->table_valid || r->table_frame != frame || r->table_window != window) {
     hipLaunchKernelGGL(k_rebuild_flags, dim3(r->grid_surfels), b, 0, st, r->S, frame, window, r->L.flags8, r->st);
     r->table_valid = true; r->table_frame = frame; r->table_window = window;
+    r->hot_holdoff = 3;   // (the flags were rewritten outside pass A: this pass and those of the next two calls gather everything)
   }
   const int stats = r->stats_enabled;
+  const int use_hot = (r->hot_holdoff == 0 && !r->scan_mode && r->hot_filter_enabled) ? 1 : 0;
+  const size_t hot_lds = ((size_t)r->L.n_hot_groups + 15) & ~(size_t)15;
   {
     SlotTimer t(r, st, kSlotNeighborScan);
     if (stats || zero_chunks) hipLaunchKernelGGL(k_reset_recent, dim3(1), dim3(1), 0, st, r->st, stats, zero_chunks ? r->L.rec_chunks.count : nullptr);
     if (copy_only) {
-      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, false>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st);
-      else hipLaunchKernelGGL((k_neighbor_scan<false, false>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st);
+      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, false>), g, bB, hot_lds, st, r->S, stats, use_hot, r->L, r->inwin8, r->need_seg, r->st);
+      else hipLaunchKernelGGL((k_neighbor_scan<false, false>), g, bB, hot_lds, st, r->S, stats, use_hot, r->L, r->inwin8, r->need_seg, r->st);
     } else {
-      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, true>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st);
-      else hipLaunchKernelGGL((k_neighbor_scan<false, true>), g, bB, 0, st, r->S, stats, r->L, r->inwin8, r->need_seg, r->st);
+      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, true>), g, bB, hot_lds, st, r->S, stats, use_hot, r->L, r->inwin8, r->need_seg, r->st);
+      else hipLaunchKernelGGL((k_neighbor_scan<false, true>), g, bB, hot_lds, st, r->S, stats, use_hot, r->L, r->inwin8, r->need_seg, r->st);
     }
   }
   if (!copy_only) {
@@ -2035,6 +2077,13 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->flags_buf[0], (size_t)r->nsegB * kSegB, true));
   SMX_TRY(dev_alloc(&r->flags_buf[1], (size_t)r->nsegB * kSegB, true));
   r->L.flags8 = r->flags_buf[0];
+  r->L.hot_shift = 10;
+  while ((((size_t)r->nseg * kSeg) >> r->L.hot_shift) + 1 > 4096) ++r->L.hot_shift;
+  r->L.n_hot_groups = (uint32_t)((((size_t)r->nseg * kSeg) >> r->L.hot_shift) + 1);
+  SMX_TRY(dev_alloc(&r->L.hot_epoch, (size_t)r->L.n_hot_groups + 64, true));   // (zeros: "last active in call 0")
+  r->L.epoch = 128;   // (far from the zeros)
+  r->hot_filter_enabled = 1;
+  r->hot_holdoff = 3;
   SMX_TRY(dev_alloc(&r->merge_flag, r->S.pitch, true));
   SMX_TRY(dev_alloc(&r->inwin8, (size_t)r->nsegB * kSegB, true));
   SMX_TRY(dev_alloc(&r->need_seg, (size_t)r->nsegB + kSegAcc / kSegB, true));
@@ -2092,7 +2141,7 @@ int smx_recon_destroy(smx_recon r) {
   SMX_ON_DEVICE(r->device);
   void* ptrs[] = {r->sc_set[0].supporting, r->sc_set[0].counts, r->sc_set[0].depth_sums, r->sc_set[0].confl_key, r->sc_set[0].first_depth,
                   r->sc_set[1].supporting, r->sc_set[1].counts, r->sc_set[1].depth_sums, r->sc_set[1].confl_key, r->sc_set[1].first_depth,
-                  r->vis_count_set[0], r->vis_count_set[1], r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1],
+                  r->vis_count_set[0], r->vis_count_set[1], r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1], r->L.hot_epoch,
                   r->merge_flag, r->inwin8, r->need_seg, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->block_offsets, r->st};
   if (r->reg_stream) { (void)hipStreamSynchronize(r->reg_stream); (void)hipStreamDestroy(r->reg_stream); }
@@ -2171,10 +2220,11 @@ int smx_recon_set_overlap(smx_recon r, int32_t enabled) {
 }
 
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
-  SMX_CHECK_ARG(r != nullptr && mode >= 0 && mode <= 3);
+  SMX_CHECK_ARG(r != nullptr && mode >= 0 && mode <= 7);
   SMX_ON_DEVICE(r->device);
   r->scan_mode = mode & 1;
   r->blend_multi_launch = (mode >> 1) & 1;
+  r->hot_filter_enabled = ((mode >> 2) & 1) ? 0 : 1;
   return SMX_OK;
 }
 
@@ -2223,6 +2273,8 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   // the flag table of the previous frame stays readable for the regulariser that may still be running
   const uint8_t* flags_prev = r->L.flags8;
   r->L.flags8 = (r->L.flags8 == r->flags_buf[0]) ? r->flags_buf[1] : r->flags_buf[0];
+  r->L.epoch = (r->L.epoch + 1u) & 255u;
+  if (r->hot_holdoff > 0) --r->hot_holdoff;
   // Streams.  Everything on the frame-to-frame critical cycle -- clear, pass A, associate, merge + blend, flags,
   // integrate, update + create; frame f + 1 needs the positions and slots frame f wrote -- stays on the CALLER's
   // stream, in order.  The regulariser chain (pass B, edges, step) is forked to the internal stream after update +
@@ -2307,7 +2359,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     ca.flags = r->new_flags; ca.ranks = r->new_ranks; ca.block_sums = r->block_sums; ca.block_offsets_out = r->block_offsets;
     ca.n_scan_blocks = r->n_scan_blocks; ca.max_surfels = r->max_surfels; ca.flags8 = r->L.flags8; ca.dirty8 = r->L.dirty8;
     ca.next_first_depth = r->sc_set[r->sc_cur ^ 1].first_depth; ca.next_vis_chunk_count = r->vis_count_set[r->sc_cur ^ 1];
-    ca.n_pixels = P;
+    ca.n_pixels = P; ca.hot_epoch = r->L.hot_epoch; ca.epoch = r->L.epoch; ca.hot_shift = r->L.hot_shift;
     const uint32_t ncb = (uint32_t)div_up(P, kBlock);
     const dim3 guc(ncb + (uint32_t)r->grid_list);
     const size_t lds = (size_t)r->n_scan_blocks * sizeof(uint32_t);
@@ -2637,6 +2689,7 @@ static int invalidate_derived(smx_recon r, hipStream_t st) {
   hipLaunchKernelGGL(k_rebuild_flags, dim3(r->grid_surfels), dim3(kBlock), 0, st, r->S, 0u, 0x7FFFFFFF, r->L.flags8, r->st);
   SMX_LAUNCH_CHECK();
   r->table_valid = false;
+  r->hot_holdoff = 3;     // (flags and links may have been rewritten: pass B gathers everything for two calls)
   r->have_frame = false;  // (the boxes are gone, so any frame index may follow)
   return SMX_OK;
 }
