@@ -41,7 +41,7 @@ VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 (vector)
 ALG_BYTES = {
     # P records + flag bytes of the segments that are read, 2 flag bytes per slot of the culled ones, list + z-buffer
     "scan_visible": lambda st, P: 18.0 * (st["surfels_size"] - 1024.0 * st.get("n_segments_skipped", 0))
-                                  + 2.0 * 1024.0 * st.get("n_segments_skipped", 0) + 24.0 * st["n_visible"],
+                                  + 2.0 * 1024.0 * st.get("n_segments_skipped", 0) + (4.0 + 1.9 * 8.0) * st["n_visible"],
     "neighbor_scan": lambda st, P: 18.0 * st["surfels_size"] + 1.0 * st["n_edges"] + 4.0 * st["n_recent"],
     # slots served: contributors and recent slots (mostly the same slots): 50 B own records each; 48 B per link into
     # the window (target S + T records, 16 B inbox/accumulator store); 16 B own-term record per recent slot
@@ -50,13 +50,13 @@ ALG_BYTES = {
     # P, S, r^2, own-term record, three accumulator channels (32 + 32 + 64 B), S store, inbox re-zeroing
     "reg_step": lambda st, P: 224.0 * st["n_recent"],
     "reg_update": lambda st, P: 36.0 * st["n_recent"],
-    "associate": lambda st, P: 90.0 * st["n_visible"],
-    # (one launch with the measurement blending since round 2: the slot "blend" is only timed in the multi-launch fallback)
-    "merge_decide": lambda st, P: 60.0 * st["n_visible"] + 26.0 * P,
+    # association tiles: per pair (~1.9 per visible slot) 8 B + the slot's P and N records (32 B); per pixel the
+    # measurement (10 B) and the five images written (24 B); the merge phase's supported-surfel records (32 B per visible slot)
+    "assoc_tiles": lambda st, P: 1.9 * 40.0 * st["n_visible"] + 34.0 * P + 32.0 * st["n_visible"],
     "integrate": lambda st, P: 160.0 * st["n_visible"],
     "update_neighbors+create": lambda st, P: 190.0 * st["n_visible"] + 6.0 * P + 122.0 * st["n_new"],
-    "blend": lambda st, P: 26.0 * P,
-    "clear_assoc": lambda st, P: 26.0 * P,
+    # blend tiles: depth + supporting per region cell (54 x 54 cells per 32 x 32 tile at radius 12) + the blended depth
+    "blend": lambda st, P: 6.0 * (54.0 * 54.0 / 1024.0) * P + 2.0 * P,
     "new_flags_scan": lambda st, P: 15.0 * P,
 }
 
@@ -436,9 +436,9 @@ def run_integrate(args):
 
 # kernel-slot name -> kernel name in rocprofv3 output
 SLOT_KERNEL = {"reg_accumulate": "k_reg_accumulate", "reg_step": "k_reg_step", "neighbor_scan": "k_neighbor_scan<true, true>",
-               "scan_visible": "k_scan_visible", "associate": "k_associate<true>", "merge_decide": "k_merge_and_blend<true>",
+               "scan_visible": "k_scan_visible", "assoc_tiles": "k_assoc_tiles", "blend": "k_blend_tiles",
                "integrate": "k_integrate<true>", "update_neighbors+create": "k_update_and_create<true>",
-               "blend": "k_blend_start", "clear_assoc": "k_clear_assoc", "new_flags_scan": "k_new_flags_scan"}
+               "new_flags_scan": "k_new_flags_scan"}
 
 
 def pmc_file():

@@ -281,6 +281,9 @@ typedef struct {
                                     * of one neighbour-count class; smooth positions may then deviate from the
                                     * reference.  Terms are 2 * regularizer_weight / count * (n . d) * n: with
                                     * neighbour distances of centimetres any weight below ~100 is far inside. */
+  uint32_t n_pairs;            /* (slot, pixel) pairs pass A appended to the association tiles' bins */
+  uint32_t n_overflow_pairs;   /* ... of which went through the overflow list (a tile's bin was full) */
+  uint32_t max_tile_pairs;     /* pairs of the fullest tile */
 } smx_recon_stats;
 int smx_recon_get_stats(smx_recon r, smx_stream s, smx_recon_stats* out);
 /* The n_* counters above are single-address atomics; they are collected only while enabled
@@ -307,7 +310,8 @@ int smx_recon_debug_download_scratch(smx_recon r, smx_stream s, int32_t which, v
 /* A/B switches; results are identical in every mode.  bit 0: every surfel kernel scans all slots like
  * the reference does instead of the compacted lists; bit 1: measurement blending as the reference's
  * start + iteration launches instead of the fused LDS kernel; bit 2: the regulariser's link scan gathers the flag byte
- * of every far link (no hot-group filter). */
+ * of every far link (no hot-group filter); bit 3: association bins of 16 pairs per tile, so that most pairs travel
+ * through the overflow list. */
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode);
 /* Frame pipelining (default on): the regulariser of a frame runs on an internal stream beside the first
  * kernels of the next smx_recon_integrate call (which only read what the regulariser does not write).
@@ -326,6 +330,11 @@ int smx_recon_set_overlap(smx_recon r, int32_t enabled);
  *                    read its inputs, without any wait on the caller's stream.
  * With pipelining off both act on the caller's stream at the same points. */
 int smx_recon_integrate_hooks(smx_recon r, smx_event inputs_consumed, smx_event chain_after);
+/* A third hook of the same kind (one-shot, may be null): `inputs_ready` must have been recorded already (e.g. at the end of
+ * the preprocessing of the frame, on the caller's preprocessing stream); the NEXT smx_recon_integrate call waits for it
+ * on the caller's stream itself, AFTER its first kernel -- the all-slot scan, which does not read the four input images --
+ * instead of the caller waiting in front of the call. */
+int smx_recon_integrate_inputs_ready(smx_recon r, smx_event inputs_ready);
 
 /* ---- radius-neighbor search (replaces CompressedOctree::FindNearestSurfelsWithinRadius,
  * APP/octree.h:470-477, APP/octree.cc:313-470, for batched queries) ---- */

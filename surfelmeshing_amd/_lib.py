@@ -64,7 +64,7 @@ class ReconStats(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in
                 ("surfels_size", "merge_count", "n_visible", "n_new", "n_merged", "n_recent", "n_edges",
                  "n_integrated", "n_replaced", "n_conflict_hits", "capacity_clamped", "n_window_edges", "n_contributors",
-                 "n_segments_skipped", "regularizer_saturated")]
+                 "n_segments_skipped", "regularizer_saturated", "n_pairs", "n_overflow_pairs", "max_tile_pairs")]
 
 
 class NNStats(C.Structure):
@@ -91,7 +91,7 @@ EXPORTS = [
     "smx_recon_kernel_slot_count", "smx_recon_kernel_slot_name", "smx_recon_get_kernel_timings",
     "smx_recon_profile_begin", "smx_recon_profile_end",
     "smx_recon_debug_download_surfels", "smx_recon_debug_upload_surfels", "smx_recon_debug_download_scratch",
-    "smx_debug_set_bilateral_variant", "smx_recon_set_scan_mode", "smx_recon_set_overlap", "smx_recon_integrate_hooks",
+    "smx_debug_set_bilateral_variant", "smx_recon_set_scan_mode", "smx_recon_set_overlap", "smx_recon_integrate_hooks", "smx_recon_integrate_inputs_ready",
     "smx_nn_create", "smx_nn_destroy", "smx_nn_build", "smx_nn_query_batch", "smx_nn_query_self", "smx_nn_set_query_mode", "smx_nn_set_stats_enabled", "smx_nn_get_stats",
     "smx_synth_render_room",
 ]

@@ -250,14 +250,24 @@ static int run_one(smx_driver d, smx_stream s, const smx_driver_step& step, cons
     rc = preprocess_frame(d, d->pre_stream, step, ws);
     if (rc != SMX_OK) return rc;
     SMX_SHIM_CHECK(smx_event_record(ws->preprocessed, d->pre_stream));
-    SMX_SHIM_CHECK(smx_stream_wait_event(s, ws->preprocessed));
+    // Both dependencies are routed through Integrate itself: it waits for the preprocessed images behind its all-slot
+    // scan (which does not read them), and marks "images consumed" on its internal stream -- the caller's stream, which
+    // carries the front chain of the frame, gets neither a wait in front of the call nor a record behind it.
+    SMX_SHIM_CHECK(smx_recon_integrate_inputs_ready(d->reconstruction.handle(), ws->preprocessed));
+    SMX_SHIM_CHECK(smx_recon_integrate_hooks(d->reconstruction.handle(), ws->integrated, nullptr));
+    rc = integrate_frame(d, s, step, ws);
+    if (rc != SMX_OK) {
+      (void)smx_recon_integrate_hooks(d->reconstruction.handle(), nullptr, nullptr);
+      (void)smx_recon_integrate_inputs_ready(d->reconstruction.handle(), nullptr);
+      return rc;
+    }
   } else {
     rc = preprocess_frame(d, s, step, ws);
     if (rc != SMX_OK) return rc;
+    rc = integrate_frame(d, s, step, ws);
+    if (rc != SMX_OK) return rc;
+    SMX_SHIM_CHECK(smx_event_record(ws->integrated, s));
   }
-  rc = integrate_frame(d, s, step, ws);
-  if (rc != SMX_OK) return rc;
-  SMX_SHIM_CHECK(smx_event_record(ws->integrated, s));
   ws->used = true;
   d->prev = d->last;
   d->last = ws;

@@ -32,6 +32,7 @@
 #include "smx_common.hpp"
 
 using namespace smx;
+namespace smx { extern int g_exp_timed_region; }
 
 namespace {
 
@@ -55,6 +56,7 @@ struct DevState {
   uint32_t n_window_edges, n_contributors;
   uint32_t n_segments_skipped;
   uint32_t reg_saturated;  // sticky: a regulariser term hit the +-16 m clamp or a sender-class counter came near its byte
+  uint32_t n_pairs, n_overflow_pairs, max_tile_pairs;   // statistics of the association tiles' bins
 };
 
 // HBM layout of the surfel attributes.  The reference keeps 25 separate rows (SoA, kernels.cuh:49-78); that is
@@ -244,6 +246,56 @@ struct Lists {
 // hot = active in this call or the previous one (or, seen from the pass B that runs beside it, in the next one)
 __device__ __forceinline__ bool group_is_hot(uint32_t last, uint32_t epoch) { return ((epoch - last + 1u) & 255u) <= 2u; }
 
+// Phase stamps inside a kernel (builds with -DSMX_STAMPS only; tools/stamps.py): lane 0 of every workgroup stores the
+// shader clock at marked points, the host averages the differences.
+#ifdef SMX_PRIO
+#define SMX_SETPRIO() __builtin_amdgcn_s_setprio(SMX_PRIO)
+#else
+#define SMX_SETPRIO() do { } while (0)
+#endif
+#ifdef SMX_STAMPS
+#define SMX_STAMP(buf, k) do { if ((buf) && threadIdx.x == 0) (buf)[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SMX_STAMP(buf, k) do { } while (0)
+#endif
+
+// ---- association tiles ------------------------------------------------------------------------------------------
+// The per-pixel association state of a frame (z-buffer minimum, supporting surfel, count, depth sum, conflict key) is
+// built per image TILE in LDS by k_assoc_tiles instead of with device-scope atomics on five dense images: pass A
+// appends one (slot, pixel) PAIR per pixel a visible slot touches (<= 2) to the bin of the pixel's tile; the tile's
+// workgroup reduces its pairs with LDS atomics (all of the reductions are order-independent and exact: min, integer
+// add) and writes the five images with plain stores.  Nothing is cleared per frame.
+constexpr int kTileW = 32, kTileH = 8, kTilePx = kTileW * kTileH;   // one 256-lane workgroup per tile
+// pair code: bits 0-7 pixel inside the tile (row-major, kTileW wide); bit 8: the slot's second ("quadrant") pixel;
+// bit 9: the slot is active for integration (kernels.cu:77-87) -- inactive visible slots still take part in the merge phase
+constexpr uint32_t kPairSecond = 1u << 8, kPairActive = 1u << 9;
+constexpr uint32_t kCountStride = 32;     // one pair counter per 128-byte line: atomics on one line serialise, whatever word they hit
+constexpr uint32_t kTileBinCap = 8192;   // pairs per bin (64 KB): 32 per pixel before a tile spills to the overflow list
+struct TileBins {
+  uint2* pairs;          // [n_tiles][cap]: (slot, code)
+  uint32_t* count;       // [n_tiles * kCountStride]: pairs appended in this call (zeroed again by the tile's workgroup); may exceed cap,
+  uint4* ovf;            // in which case the rest went to this list: (tile, slot, code, -), room for 2 pairs per slot
+  uint32_t* ovf_count;   // this call's overflow counter (two in alternation: the tile kernel zeroes the next call's)
+  uint32_t cap;
+  int tiles_x;
+  uint32_t n_tiles;
+  int exp;   // EXPERIMENT switch (timing only)
+};
+
+// Pass A appends its pairs (<= 8 per lane: 4 slots x 2 pixels; key = tile << 10 | code, kNoPair = none) with ONE
+// returning device-scope atomic per (workgroup, tile): every pair takes a rank from an LDS counter of its tile (the
+// table is direct-mapped: n_tiles words), the pair that drew rank 0 reserves the workgroup's run in the tile's bin, and
+// after a barrier every pair is stored at base + rank.  The cost does not depend on how many tiles a workgroup touches
+// (a first version agreed on one tile after the other by wave ballots: fine on average, 100 us for the wavefronts whose
+// 512 pairs fell into a hundred tiles -- profiles/r08_pass_a_append.md).
+constexpr uint32_t kNoPair = 0xFFFFFFFFu;
+constexpr uint32_t kMaxTilesLds = 8192;   // 64 KB for the two tables; larger images fall back to one atomic per pair
+__device__ __forceinline__ void pair_store(const TileBins& tb, uint32_t key, uint32_t slot, uint32_t pos) {
+  const uint32_t tile = key >> 10, code = key & 1023u;
+  if (pos < tb.cap) tb.pairs[(size_t)tile * tb.cap + pos] = make_uint2(slot, code);
+  else tb.ovf[atomicAdd(tb.ovf_count, 1u)] = make_uint4(tile, slot, code, 0u);
+}
+
 // (thread 0 of the workgroup that built a segment's list)
 __device__ __forceinline__ void emit_chunks(const Chunks& ch, uint32_t segment, uint32_t total, uint32_t chunks_per_segment) {
   if (total == 0) return;
@@ -284,61 +336,48 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t mine, uint32_t* wav
   return wave_off + incl - mine;
 }
 
+// "These loads travel together": pins loaded values at this point of the program, so that every load issued above is in
+// flight before the first of them is waited for.  Without it the compiler sinks independent loads below the branches
+// that follow (it cannot know that a dependent round trip costs microseconds on the frame's latency chain and a wasted
+// 16-byte load nothing): tools/isa_phases.py counts the waits per kernel.
+__device__ __forceinline__ void keep(uint32_t v) { asm volatile("" :: "v"(v)); }
+__device__ __forceinline__ void keep(int v) { asm volatile("" :: "v"(v)); }
+__device__ __forceinline__ void keep(float v) { asm volatile("" :: "v"(v)); }
+__device__ __forceinline__ void keep(const float2& v) { keep(v.x); keep(v.y); }
+__device__ __forceinline__ void keep(const float4& v) { keep(v.x); keep(v.y); keep(v.z); keep(v.w); }
+__device__ __forceinline__ void keep(const uint4& v) { keep(v.x); keep(v.y); keep(v.z); keep(v.w); }
+
 // ---------------------------------------------------------------------------------------------
-// 5 clears (cuda_surfel_reconstruction.cc:134-138) + the 2 clears of BlendMeasurementsCUDA
-// (kernels.cc:165-166) in one launch + per-frame counter reset.
+// The reference's 5 clears (cuda_surfel_reconstruction.cc:134-138) have no counterpart: k_assoc_tiles writes every pixel
+// of the association images with plain stores.  The maps of the multi-launch blend fallback (kernels.cc:165-166):
 struct BlendBufs {
   uint8_t* distance_map; uint8_t* new_distance_map; float* deltas; float* new_deltas;
 };
 
-__global__ void __launch_bounds__(kBlock)
-k_clear_assoc(Scratch sc, int P, uint32_t* __restrict__ vis_chunk_count) {
-  // Only the first Integrate call after creation launches this.  In the frame loop the re-initialisation rides on
-  // kernels that are there anyway, over two sets of images in alternation: k_update_and_create of call f writes the
-  // z-buffer of call f + 1 (and zeroes its chunk counter), pass A of call f + 1 writes the other four images while it
-  // scans -- a slice per workgroup, in front of the launches whose atomics land on them.  As a launch of its own on
-  // the caller's stream the 8 MB of stores took 31 us of every frame beside the regulariser's pass B (7 us alone).
-  const int k = blockIdx.x * kBlock + threadIdx.x;
-  if (k == 0) *vis_chunk_count = 0;   // pass A, the next launch, appends the visible list's chunks
-  if (k < P) {
-    sc.supporting[k] = kInvalid;
-    sc.counts[k] = 0;
-    sc.depth_sums[k] = 0;
-    sc.confl_key[k] = kInvalid;
-    sc.first_depth[k] = __builtin_inff();
-  }
-}
 __global__ void k_reset_frame_stats(DevState* st) {   // (value-distribution counters: only while statistics are on)
   st->n_visible = 0; st->n_merged = 0; st->n_integrated = 0; st->n_replaced = 0; st->n_conflict_hits = 0;
   st->n_segments_skipped = 0;
+  st->n_pairs = 0; st->n_overflow_pairs = 0; st->max_tile_pairs = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pass A.  RenderMinDepthCUDAKernel (kernels.cu:1466-1557) fused with the construction of the
-// visible list and the refresh of the "recent" bit of the flag table.  One workgroup per segment of
-// kSeg slots; rows 18,0,1,2 are streamed with 16-byte lane loads (4 slots per lane).
-__device__ __forceinline__ void min_depth_at(float* first_depth, int W, int x, int y, float z) {
-  atomicMin(reinterpret_cast<int*>(&first_depth[(size_t)y * W + x]), __float_as_int(z));  // :1463
-}
-
+// Pass A.  The all-slot half of RenderMinDepthCUDAKernel (kernels.cu:1466-1557): which slots project into the image and
+// onto which pixels -- fused with the construction of the visible list and the refresh of the "recent" bit of the flag
+// table.  One workgroup per segment of kSeg slots; rows 18,0,1,2 are streamed with 16-byte lane loads (4 slots per
+// lane).  The z-buffer minimum itself (:1463) is formed by k_assoc_tiles from the pairs appended here.
 __global__ void __launch_bounds__(kBlock)
-k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, const uint8_t* __restrict__ flags_prev, DevState* st,
-               int clear_assoc) {
+k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, const uint8_t* __restrict__ flags_prev, DevState* st) {
   __shared__ uint32_t wave_tot[kBlock / 64];
   __shared__ float box_part[kBlock / 64][8];
-  if (clear_assoc) {
-    // side job (see k_clear_assoc): this workgroup's slice of the four images the association atomics land on
-    // (slices of whole 64-pixel runs: every store instruction of a wavefront covers whole cache lines)
-    const uint32_t P = (uint32_t)(c.W * c.H), per = ((P + gridDim.x - 1) / gridDim.x + 63u) & ~63u;
-    for (uint32_t k = threadIdx.x; k < per; k += kBlock) {
-      const uint32_t px = blockIdx.x * per + k;
-      if (px < P) { sc.supporting[px] = kInvalid; sc.counts[px] = 0; sc.depth_sums[px] = 0; sc.confl_key[px] = kInvalid; }
-    }
-  }
   __shared__ int skip_segment;
+  extern __shared__ uint32_t tile_lds[];   // [n_tiles] pairs of this workgroup per tile, [n_tiles] base of its run in the tile's bin
+  SMX_SETPRIO();
+  const bool lds_tables = tb.n_tiles <= kMaxTilesLds;
   const uint32_t N = st->surfel_count;
   const uint32_t base = blockIdx.x * kSeg;
   if (base >= N) return;  // uniform per workgroup
+  if (lds_tables)
+    for (uint32_t k = threadIdx.x; k < tb.n_tiles; k += kBlock) tile_lds[k] = 0;   // (visible before the ranks are drawn: the barrier below)
   const uint32_t i0 = base + threadIdx.x * 4;
   const uint32_t in_seg = (N - base < (uint32_t)kSeg) ? N - base : (uint32_t)kSeg;
   // Segment culling.  The box below was formed from every slot of the segment the last time it was read; it is still
@@ -370,6 +409,10 @@ k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, const uint8_t* __rest
   float bmin[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bmax[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
   uint32_t newest = 0;   // in the wrap-around order of stamp_outside_window: compared as signed
   bool have_stamp = false;
+  // the pairs of the lane's four slots: entry 2 j = slot j's own pixel, 2 j + 1 = its quadrant pixel
+  uint32_t key[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) key[j] = kNoPair;
   if (i0 < N) {
     // four consecutive P records (X, Y, Z, stamp) = 64 contiguous bytes per lane; the group arrays are
     // padded to a multiple of 64 slots, so the loads stay inside the array
@@ -395,16 +438,26 @@ k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, const uint8_t* __rest
       }
       if (i < N && maybe_in_image(g, c) && project_pos(g, c, p)) {
         vis_bits |= 1u << j;
-        if (is_active(stamps[j], c.frame, c.window)) {
-          if (c.stats) atomicAdd(&st->n_visible, 1u);
-          min_depth_at(sc.first_depth, c.W, p.px, p.py, p.l.z);
-          int ox, oy;
-          if (quadrant(p, c, ox, oy)) min_depth_at(sc.first_depth, c.W, ox, oy, p.l.z);
-        }
+        const bool active = is_active(stamps[j], c.frame, c.window);
+        if (active && c.stats) atomicAdd(&st->n_visible, 1u);
+        const uint32_t act = active ? kPairActive : 0u;
+        key[2 * j] = (((uint32_t)(p.py / kTileH) * (uint32_t)tb.tiles_x + (uint32_t)(p.px / kTileW)) << 10) |
+                     (uint32_t)((p.py % kTileH) * kTileW + (p.px % kTileW)) | act;
+        int ox, oy;
+        if (active && quadrant(p, c, ox, oy))   // (:1506-1549: the second z-buffer pixel, active slots only)
+          key[2 * j + 1] = (((uint32_t)(oy / kTileH) * (uint32_t)tb.tiles_x + (uint32_t)(ox / kTileW)) << 10) |
+                           (uint32_t)((oy % kTileH) * kTileW + (ox % kTileW)) | act | kPairSecond;
       }
     }
     *reinterpret_cast<uchar4*>(&L.flags8[i0]) = make_uchar4(new_flags[0], new_flags[1], new_flags[2], new_flags[3]);
     lane_recent = ((new_flags[0] | new_flags[1] | new_flags[2] | new_flags[3]) & 1u) != 0;
+  }
+  // ranks inside the workgroup's run of each tile (LDS atomics; the barrier inside the scan below completes them)
+  uint32_t rank[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    rank[j] = 0;
+    if (key[j] != kNoPair && lds_tables) rank[j] = atomicAdd(&tile_lds[key[j] >> 10], 1u);
   }
   // (a slot inside the regulariser window: the group is hot -- same value from every writer, one byte store per wavefront)
   if (__ballot(lane_recent) && (threadIdx.x & 63) == 0) L.hot_epoch[base >> L.hot_shift] = (uint8_t)L.epoch;
@@ -427,9 +480,37 @@ k_scan_visible(Surfels S, FrameCtx c, Scratch sc, Lists L, const uint8_t* __rest
   }
   uint32_t total;
   uint32_t off = base + block_excl_scan((uint32_t)__popc(vis_bits), wave_tot, total);  // (synchronises)
+  // the pair that drew rank 0 reserves the run of its (workgroup, tile); all reservations of the workgroup are in
+  // flight together (the tile number goes through an opaque VGPR: with a visibly uniform address the compiler's atomic
+  // optimizer wraps the operation in a wave reduction + readfirstlane, i.e. a wait for each result in turn)
+  if (lds_tables) {
+    uint32_t got[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      got[j] = 0;
+      if (key[j] != kNoPair && rank[j] == 0) {
+        uint32_t tv = key[j] >> 10;
+        asm volatile("" : "+v"(tv));
+        got[j] = atomicAdd(&tb.count[tv * kCountStride], tile_lds[tv]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (key[j] != kNoPair && rank[j] == 0) tile_lds[tb.n_tiles + (key[j] >> 10)] = got[j];
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     if (vis_bits & (1u << j)) L.vis_list[off++] = i0 + j;
+  if (lds_tables) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (key[j] != kNoPair) pair_store(tb, key[j], i0 + (uint32_t)(j >> 1), tile_lds[tb.n_tiles + (key[j] >> 10)] + rank[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (key[j] != kNoPair) pair_store(tb, key[j], i0 + (uint32_t)(j >> 1), atomicAdd(&tb.count[(key[j] >> 10) * kCountStride], 1u));
+  }
   if (threadIdx.x == 0) {
     L.vis_seg[blockIdx.x] = total;
     emit_chunks(L.vis_chunks, blockIdx.x, total, kSeg / kBlock);
@@ -476,143 +557,214 @@ __device__ __forceinline__ bool walk_entry(const uint32_t* __restrict__ list, ui
 }
 
 // ---------------------------------------------------------------------------------------------
-// AssociateSurfelsCUDAKernel / ConsiderSurfelAssociationToPixel, kernels.cu:1586-1808.
-struct AssocPixel { uint16_t depth; float first; float2 nxy; };
-__device__ __forceinline__ AssocPixel load_assoc_pixel(const FrameCtx& c, const Scratch& sc, const Img<const uint16_t>& depth,
-                                                       const Img<const float2>& normals, int x, int y) {
-  AssocPixel a;
-  a.depth = depth(y, x); a.first = sc.first_depth[(size_t)y * c.W + x]; a.nxy = normals(y, x);
-  return a;
+// k_assoc_tiles: the per-pixel halves of RenderMinDepthCUDAKernel (kernels.cu:1463), AssociateSurfelsCUDAKernel /
+// ConsiderSurfelAssociationToPixel (:1586-1808) and MergeSurfelsCUDAKernel / ConsiderSurfelMergeAtPixel (:1857-2052),
+// one workgroup per image tile over the pairs pass A appended to the tile's bin.  Three phases separated by workgroup
+// barriers, as the reference separates them by kernel launches: z-buffer minimum; association (supporting surfel =
+// lowest qualifying index, count, exact fixed-point depth sum, associate-phase conflict key); merge decisions (read the
+// final supporting surfel; merge-phase conflict key).  All reductions are LDS atomics on order-independent exact
+// operations, so the result does not depend on the order of the pairs in the bin.  Merge decisions have snapshot
+// semantics: this kernel only records them (merge_flag); the marks (:1987-1989) are applied at the top of k_integrate.
+struct PairRec { uint32_t i, code; Vec3 g, l, gn; float r2; };
+__device__ __forceinline__ PairRec fetch_pair(const Surfels& S, const FrameCtx& c, uint32_t i, uint32_t code) {
+  const float4 p4 = *S.group(kGroupP, i), n4 = *S.group(kGroupN, i);   // both records in flight together
+  PairRec r;
+  r.i = i; r.code = code;
+  r.g = Vec3{p4.x, p4.y, p4.z};
+  r.l = mul(c.L, r.g);   // == project_pos(...).l: the z every kernel compares with first_depth
+  r.gn = Vec3{n4.x, n4.y, n4.z};
+  r.r2 = n4.w;
+  return r;
 }
-__device__ __forceinline__ void associate_at(const FrameCtx& c, const Scratch& sc, const AssocPixel& px,
-                                             int x, int y, const Proj& p, uint32_t i, const Vec3& gn, float r2) {
-  const size_t k = (size_t)y * c.W + x;
-  const float measurement_depth = c.inv_depth_scaling * (float)px.depth;
+struct TileLds {
+  int zmin[kTilePx];                  // float bits of the smallest camera-space z (positive floats order like ints)
+  uint32_t sup[kTilePx], cnt[kTilePx], confl[kTilePx];
+  unsigned long long sum[kTilePx];
+  float2 nrm[kTilePx];
+  uint16_t depth[kTilePx];
+};
+// ConsiderSurfelAssociationToPixel, :1586-1695
+__device__ __forceinline__ void assoc_stage(TileLds& t, const FrameCtx& c, const PairRec& r) {
+  if (!(r.code & kPairActive)) return;
+  const uint32_t k = r.code & 255u;
+  const float measurement_depth = c.inv_depth_scaling * (float)t.depth[k];
   if (measurement_depth <= 0) return;
-  const float first = px.first;
+  const float first = __int_as_float(t.zmin[k]);
   if (first < (1 - c.sensor_noise_factor) * measurement_depth) {
     // :1615 racing plain store -> deterministic: associate-phase writers carry class bit 31
-    if (first == p.l.z) atomicMin(&sc.confl_key[k], 0x80000000u | i);
+    if (first == r.l.z) atomicMin(&t.confl[k], 0x80000000u | r.i);
     return;
   }
   const float occlusion_depth = (1 + c.sensor_noise_factor) * measurement_depth;
-  if (p.l.z > occlusion_depth) return;
-  const float surfel_distance = sqrtf(p.l.x * p.l.x + p.l.y * p.l.y + p.l.z * p.l.z);
-  const Vec3 ln = rotate(c.L, gn);
-  const float dot_angle = (1.0f / surfel_distance) * (p.l.x * ln.x + p.l.y * ln.y + p.l.z * ln.z);
+  if (r.l.z > occlusion_depth) return;
+  const float surfel_distance = sqrtf(r.l.x * r.l.x + r.l.y * r.l.y + r.l.z * r.l.z);
+  const Vec3 ln = rotate(c.L, r.gn);
+  const float dot_angle = (1.0f / surfel_distance) * (r.l.x * ln.x + r.l.y * ln.y + r.l.z * ln.z);
   if (dot_angle > 0) return;
-  if (measurement_depth < p.l.z) {
-    const float2 n = px.nxy;
+  if (measurement_depth < r.l.z) {
+    const float2 n = t.nrm[k];
     const float nz = meas_normal_z(n.x, n.y);
     const float d = ln.x * n.x + ln.y * n.y + ln.z * nz;
     if (d < c.cos_normal_compat) return;
   }
-  if (r2 <= 0) return;  // :1674
-  atomicMin(&sc.supporting[k], i);      // :1688 first-wins CAS -> lowest index
-  atomicAdd(&sc.counts[k], 1u);
-  atomicAdd(reinterpret_cast<unsigned long long*>(&sc.depth_sums[k]), (unsigned long long)q_from_float(p.l.z));
+  if (r.r2 <= 0) return;  // :1674
+  atomicMin(&t.sup[k], r.i);      // :1688 first-wins CAS -> lowest index
+  atomicAdd(&t.cnt[k], 1u);
+  atomicAdd(&t.sum[k], (unsigned long long)q_from_float(r.l.z));   // :1694, exact in 2^-32 fixed point
 }
-
-template <bool kUseList>
-__global__ void __launch_bounds__(kBlock)
-k_associate(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<const float2> normals,
-            Lists L, const DevState* st) {
-  const uint32_t n_scan = kUseList ? 0u : st->surfel_count;
-  uint32_t desc;
-  const uint32_t n_steps = walk_begin<kUseList>(L.vis_chunks, n_scan, blockIdx.x, desc);
-  for (uint32_t w = blockIdx.x; w < n_steps; w += gridDim.x) {
-    const uint32_t cur = desc;
-    desc = walk_next<kUseList>(L.vis_chunks, w + gridDim.x, n_steps);   // (the next step's descriptor travels while this one is worked on)
-    uint32_t i;
-    if (!walk_entry<kUseList>(L.vis_list, cur, w, n_scan, threadIdx.x, i)) continue;
-    const float4 p4 = *S.group(kGroupP, i), n4 = *S.group(kGroupN, i);  // both records in flight together
-    if (!is_active(__float_as_uint(p4.w), c.frame, c.window)) continue;
-    Proj p;
-    const Vec3 g = {p4.x, p4.y, p4.z};
-    if (!project_pos(g, c, p)) continue;
-    const Vec3 gn = {n4.x, n4.y, n4.z};
-    int ox = p.px, oy = p.py;
-    const bool second = quadrant(p, c, ox, oy);
-    const AssocPixel a0 = load_assoc_pixel(c, sc, depth, normals, p.px, p.py);
-    const AssocPixel a1 = load_assoc_pixel(c, sc, depth, normals, ox, oy);  // both pixels' reads in flight together
-    associate_at(c, sc, a0, p.px, p.py, p, i, gn, n4.w);
-    if (second) associate_at(c, sc, a1, ox, oy, p, i, gn, n4.w);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// MergeSurfelsCUDAKernel / ConsiderSurfelMergeAtPixel, kernels.cu:1857-2052.  Snapshot
-// semantics: this kernel only records decisions (merge_flag); the marks (:1987-1989) are applied
-// at the top of k_integrate, after every decision has read pre-merge state.
-__device__ __forceinline__ bool merge_decide(const Surfels& S, const FrameCtx& c, const Scratch& sc,
-                                             const Img<const uint16_t>& depth, const Img<const float2>& normals,
-                                             const Proj& p, uint32_t i, const Vec3& gn, float r2) {
-  const int x = p.px, y = p.py;
-  const size_t k = (size_t)y * c.W + x;
-  const float measurement_depth = c.inv_depth_scaling * (float)depth(y, x);
-  if (measurement_depth <= 0) return false;
-  const float first = sc.first_depth[k];
+// ConsiderSurfelMergeAtPixel, :1857-1990 (the slot's own pixel only; any visible slot with r^2 >= 0, :2017)
+// First half: the pixel-side tests; returns the supporting surfel the slot has to be compared with (kInvalid: none).
+__device__ __forceinline__ uint32_t merge_candidate(TileLds& t, const FrameCtx& c, const PairRec& r) {
+  if (r.code & kPairSecond) return kInvalid;
+  if (!(r.r2 >= 0)) return kInvalid;  // :2017
+  const uint32_t k = r.code & 255u;
+  const float measurement_depth = c.inv_depth_scaling * (float)t.depth[k];
+  if (measurement_depth <= 0) return kInvalid;
+  const float first = __int_as_float(t.zmin[k]);
   if (first < (1 - c.sensor_noise_factor) * measurement_depth) {
     // :1887 plain store issued after the associate kernel: merge-phase writers win (class 0)
-    if (first == p.l.z) atomicMin(&sc.confl_key[k], i);
-    return false;
+    if (first == r.l.z) atomicMin(&t.confl[k], r.i);
+    return kInvalid;
   }
   const float occlusion_depth = (1 + c.sensor_noise_factor) * measurement_depth;
-  if (p.l.z > occlusion_depth) return false;
-  const float surfel_distance = sqrtf(p.l.x * p.l.x + p.l.y * p.l.y + p.l.z * p.l.z);
-  const Vec3 ln = rotate(c.L, gn);
-  float dot_angle = (1.0f / surfel_distance) * (p.l.x * ln.x + p.l.y * ln.y + p.l.z * ln.z);
-  if (dot_angle > 0) return false;
-  if (measurement_depth < p.l.z) {
-    const float2 n = normals(y, x);
+  if (r.l.z > occlusion_depth) return kInvalid;
+  const float surfel_distance = sqrtf(r.l.x * r.l.x + r.l.y * r.l.y + r.l.z * r.l.z);
+  const Vec3 ln = rotate(c.L, r.gn);
+  const float dot_angle = (1.0f / surfel_distance) * (r.l.x * ln.x + r.l.y * ln.y + r.l.z * ln.z);
+  if (dot_angle > 0) return kInvalid;
+  if (measurement_depth < r.l.z) {
+    const float2 n = t.nrm[k];
     const float nz = meas_normal_z(n.x, n.y);
     const float d = ln.x * n.x + ln.y * n.y + ln.z * nz;
-    if (d < c.cos_normal_compat) return false;
+    if (d < c.cos_normal_compat) return kInvalid;
   }
-  const uint32_t s = sc.supporting[k];
-  if (s == i || s == kInvalid) return false;  // :1950-1953
-  const float4 sp4 = *S.group(kGroupP, s), sn4 = *S.group(kGroupN, s);  // the supported surfel's two records
+  const uint32_t s = t.sup[k];
+  if (s == r.i || s == kInvalid) return kInvalid;  // :1950-1953
+  return s;
+}
+// ... second half: the supporting surfel's two records against the slot's, :1955-1990
+__device__ __forceinline__ void merge_decide(const PairRec& r, const float4& sp4, const float4& sn4, uint8_t* __restrict__ merge_flag) {
   const float other_r2 = sn4.w;
-  const float radius_diff = r2 / other_r2;
+  const float radius_diff = r.r2 / other_r2;
   const float kT = 1.2f * 1.2f;
-  if (radius_diff > kT || radius_diff < 1 / kT) return false;
-  const float dx = p.g.x - sp4.x, dy = p.g.y - sp4.y, dz = p.g.z - sp4.z;
+  if (radius_diff > kT || radius_diff < 1 / kT) return;
+  const float dx = r.g.x - sp4.x, dy = r.g.y - sp4.y, dz = r.g.z - sp4.z;
   const float d2 = dx * dx + dy * dy + dz * dz;
   const float kDist = 0.5f * (0.25f * 0.25f);
-  if (d2 > kDist * (r2 + other_r2)) return false;
-  dot_angle = gn.x * sn4.x + gn.y * sn4.y + gn.z * sn4.z;
-  if (dot_angle < 0.93969f) return false;
-  return true;
+  if (d2 > kDist * (r.r2 + other_r2)) return;
+  const float dot_angle = r.gn.x * sn4.x + r.gn.y * sn4.y + r.gn.z * sn4.z;
+  if (dot_angle < 0.93969f) return;
+  merge_flag[r.i] = 1;
+}
+__device__ __forceinline__ void merge_stage(TileLds& t, const Surfels& S, const FrameCtx& c, const PairRec& r,
+                                            uint8_t* __restrict__ merge_flag) {
+  const uint32_t s = merge_candidate(t, c, r);
+  if (s == kInvalid) return;
+  const float4 sp4 = *S.group(kGroupP, s), sn4 = *S.group(kGroupN, s);  // the supported surfel's two records
+  keep(sp4); keep(sn4);
+  merge_decide(r, sp4, sn4, merge_flag);
 }
 
-template <bool kUseList>
-__device__ __forceinline__ void merge_decide_chunks(const Surfels& S, const FrameCtx& c, const Scratch& sc,
-                                                    const Img<const uint16_t>& depth, const Img<const float2>& normals,
-                                                    const Lists& L, uint8_t* __restrict__ merge_flag, const DevState* st,
-                                                    uint32_t first_chunk, uint32_t chunk_stride, uint32_t lane) {
-  const uint32_t n_scan = kUseList ? 0u : st->surfel_count;
-  uint32_t desc;
-  const uint32_t n_steps = walk_begin<kUseList>(L.vis_chunks, n_scan, first_chunk, desc);
-  for (uint32_t w = first_chunk; w < n_steps; w += chunk_stride) {
-    const uint32_t cur = desc;
-    desc = walk_next<kUseList>(L.vis_chunks, w + chunk_stride, n_steps);   // (the next step's descriptor travels while this one is worked on)
-    uint32_t i;
-    if (!walk_entry<kUseList>(L.vis_list, cur, w, n_scan, lane, i)) continue;
-    const float4 p4 = *S.group(kGroupP, i), n4 = *S.group(kGroupN, i);
-    const float r2 = n4.w;
-    if (!(r2 >= 0)) continue;  // :2017
-    Proj p;
-    const Vec3 g = {p4.x, p4.y, p4.z};
-    if (!project_pos(g, c, p)) continue;
-    const Vec3 gn = {n4.x, n4.y, n4.z};
-    if (merge_decide(S, c, sc, depth, normals, p, i, gn, r2)) merge_flag[i] = 1;
+constexpr int kPairCache = 4;   // pairs per lane kept in registers across the three phases (a tile holds ~600 at C2)
+template <class F>
+__device__ __forceinline__ void for_uncached_pairs(const Surfels& S, const FrameCtx& c, const TileBins& tb, uint32_t tile,
+                                                   uint32_t n_binned, bool overflowed, uint32_t n_ovf, F f) {
+  for (uint32_t k = kPairCache * kTilePx + threadIdx.x; k < n_binned; k += kTilePx) {
+    const uint2 pr = tb.pairs[(size_t)tile * tb.cap + k];
+    f(fetch_pair(S, c, pr.x, pr.y));
   }
+  if (overflowed)   // (a bin that ran full: the rest of its pairs is somewhere in the overflow list)
+    for (uint32_t e = threadIdx.x; e < n_ovf; e += kTilePx) {
+      const uint4 o = tb.ovf[e];
+      if (o.x == tile) f(fetch_pair(S, c, o.y, o.z));
+    }
 }
-template <bool kUseList>
-__global__ void __launch_bounds__(kBlock)
-k_merge_decide(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<const float2> normals,
-               Lists L, uint8_t* __restrict__ merge_flag, const DevState* st) {
-  merge_decide_chunks<kUseList>(S, c, sc, depth, normals, L, merge_flag, st, blockIdx.x, gridDim.x, threadIdx.x);
+
+__global__ void __launch_bounds__(kTilePx)
+k_assoc_tiles(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<const float2> normals, TileBins tb,
+              uint32_t* __restrict__ next_ovf_count, uint8_t* __restrict__ merge_flag, DevState* st,
+              unsigned long long* stamps) {
+  __shared__ TileLds t;
+  SMX_SETPRIO();
+  SMX_STAMP(stamps, 0);
+  const uint32_t tile = blockIdx.x, lane = threadIdx.x;
+  const int x = (int)(tile % (uint32_t)tb.tiles_x) * kTileW + (int)(lane % kTileW);
+  const int y = (int)(tile / (uint32_t)tb.tiles_x) * kTileH + (int)(lane / kTileW);
+  const bool in_image = x < c.W && y < c.H;
+  const uint32_t n_total = tb.count[tile * kCountStride];
+  const uint32_t n_ovf = *tb.ovf_count;
+  const uint32_t n_binned = n_total < tb.cap ? n_total : tb.cap;
+  const bool overflowed = n_total > tb.cap;
+  // the first pairs of every lane, their surfel records and the tile's measurements: all requested up front
+  uint2 pr[kPairCache];
+  bool have[kPairCache];
+#pragma unroll
+  for (int q = 0; q < kPairCache; ++q) {
+    const uint32_t k = q * kTilePx + lane;
+    have[q] = k < n_binned;
+    pr[q] = tb.pairs[(size_t)tile * tb.cap + (have[q] ? k : 0u)];   // (no branch around the load: they all travel together)
+  }
+#pragma unroll
+  for (int q = 0; q < kPairCache; ++q) { keep(pr[q].x); keep(pr[q].y); if (!have[q]) pr[q] = make_uint2(0u, 0u); }
+  const uint16_t own_depth = in_image ? depth(y, x) : (uint16_t)0;
+  const float2 own_normal = in_image ? normals(y, x) : make_float2(0.f, 0.f);
+  PairRec rec[kPairCache];
+#pragma unroll
+  for (int q = 0; q < kPairCache; ++q) rec[q] = fetch_pair(S, c, pr[q].x, pr[q].y);   // (slot 0 stands in for "no pair")
+  t.zmin[lane] = 0x7F800000;   // +inf
+  t.sup[lane] = kInvalid; t.cnt[lane] = 0; t.confl[lane] = kInvalid; t.sum[lane] = 0;
+  t.depth[lane] = own_depth; t.nrm[lane] = own_normal;
+  __syncthreads();
+  SMX_STAMP(stamps, 1);
+  // phase 1: z-buffer minimum over the active pairs (:1463)
+  auto zmin_stage = [&](const PairRec& r) { if (r.code & kPairActive) atomicMin(&t.zmin[r.code & 255u], __float_as_int(r.l.z)); };
+#pragma unroll
+  for (int q = 0; q < kPairCache; ++q) if (have[q]) zmin_stage(rec[q]);
+  for_uncached_pairs(S, c, tb, tile, n_binned, overflowed, n_ovf, zmin_stage);
+  __syncthreads();
+  SMX_STAMP(stamps, 2);
+  // (every lane has read the counters: ready for the next call's pass A)
+  if (lane == 0) {
+    tb.count[tile * kCountStride] = 0;
+    if (tile == 0) *next_ovf_count = 0;
+    if (c.stats) {
+      atomicAdd(&st->n_pairs, n_total);
+      atomicMax(&st->max_tile_pairs, n_total);
+      if (tile == 0) st->n_overflow_pairs = n_ovf;
+    }
+  }
+  // phase 2: association
+#pragma unroll
+  for (int q = 0; q < kPairCache; ++q) if (have[q]) assoc_stage(t, c, rec[q]);
+  for_uncached_pairs(S, c, tb, tile, n_binned, overflowed, n_ovf, [&](const PairRec& r) { assoc_stage(t, c, r); });
+  __syncthreads();
+  SMX_STAMP(stamps, 3);
+  // phase 3: merge decisions (the supported surfels' records of all cached pairs are gathered together)
+  uint32_t cand[kPairCache];
+  float4 cp4[kPairCache], cn4[kPairCache];
+#pragma unroll
+  for (int q = 0; q < kPairCache; ++q) cand[q] = have[q] ? merge_candidate(t, c, rec[q]) : kInvalid;
+#pragma unroll
+  for (int q = 0; q < kPairCache; ++q) {
+    const uint32_t g = cand[q] == kInvalid ? 0u : cand[q];   // (slot 0 stands in)
+    cp4[q] = *S.group(kGroupP, g); cn4[q] = *S.group(kGroupN, g);
+  }
+#pragma unroll
+  for (int q = 0; q < kPairCache; ++q) { keep(cp4[q]); keep(cn4[q]); }
+#pragma unroll
+  for (int q = 0; q < kPairCache; ++q) if (cand[q] != kInvalid) merge_decide(rec[q], cp4[q], cn4[q], merge_flag);
+  for_uncached_pairs(S, c, tb, tile, n_binned, overflowed, n_ovf, [&](const PairRec& r) { merge_stage(t, S, c, r, merge_flag); });
+  __syncthreads();
+  SMX_STAMP(stamps, 4);
+  if (in_image) {
+    const size_t k = (size_t)y * c.W + x;
+    sc.first_depth[k] = __int_as_float(t.zmin[lane]);
+    sc.supporting[k] = t.sup[lane];
+    sc.counts[k] = t.cnt[lane];
+    sc.depth_sums[k] = (long long)t.sum[lane];
+    sc.confl_key[k] = t.confl[lane];
+  }
+  SMX_STAMP(stamps, 5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -691,151 +843,182 @@ k_blend_iter(int it, float term, float ds, Img<uint16_t> depth, Scratch sc, Blen
 // Fused form of the whole BlendMeasurementsCUDA sequence (start kernel + radius-2 iteration kernels,
 // 13 launches in the reference incl. the clears): one launch, one workgroup per 32x32 pixel tile.  A ring of
 // BFS distance d depends only on pixels within d+1 of it, so a halo of radius-1 pixels makes the tile
-// interior exact; depth, both distance maps and both delta maps of tile + halo live in LDS, the rings
-// advance with workgroup barriers, and only the interior depths are written back.
-// q / d for 0 <= q < 2^16, 0 < d <= 2^8 with one multiplication: (q + 0.5) / d is at least 1 / (2 d) away from every
-// integer, far more than the float rounding error, so truncation gives the exact quotient (the AMD ISA has no integer
-// divide: the generic expansion is ~30 instructions, and the ring loops below did one per cell per ring).
-__device__ __forceinline__ int small_div(int q, float inv_d) { return (int)(((float)q + 0.5f) * inv_d); }
+// interior exact; the depths and both delta maps of tile + halo live in LDS, the rings advance with one workgroup
+// barrier each, and only the interior depths are written back.
+//
+// The two distance maps of the reference are kept as BIT MASKS, one 64-bit word per region row (the region is at most
+// 64 cells wide): the current frontier (cells assigned in the previous ring) and the cells still unassigned.  The cells a
+// ring assigns are `unassigned & dilate3x3(frontier)` -- three shifts and ORs per row -- and only those cells read their
+// neighbours' deltas, in the reference's window order; a ring costs what it changes instead of nine LDS reads for every
+// cell of the region (profiles/r04g: the ring loop was 47 of the old kernel's 66 us).
 constexpr int kBlendTile = 32;
-constexpr int kBlendThreads = 1024;  // 16 wavefronts advance the rings of one tile
-constexpr int kBlendMaxHalo = 16;    // radius <= 17 uses this kernel (<= 64 KB LDS), larger radii the multi-launch path
-// `depth` is only read; the blended depths of the tile interior go to `out` (a tile that has nothing to blend copies its
-// interior), so tiles never see each other's results and the kernel can share a launch with other readers of `depth`.
-__device__ __forceinline__ void blend_tile(unsigned char* blend_lds, int tile_x, int tile_y, int radius, float term, float ds,
-                                           const Img<const uint16_t>& depth, const Img<uint16_t>& out, const Scratch& sc,
-                                           int W, int H) {
+constexpr int kBlendThreads = 1024;  // 64 region rows x 16 lanes, 4 cells per lane
+constexpr int kBlendMaxHalo = 16;    // radius <= 17 uses this kernel (region <= 64 x 64), larger radii the multi-launch path
+struct BlendMasks {
+  unsigned long long any[32];       // workgroup-wide OR, one word per use (ring): written before that ring's barrier, read after it
+  unsigned long long zero[64];      // measured depth == 0 (or outside the image)
+  unsigned long long supp[64];      // pixel has a supporting surfel
+  unsigned long long elig[64];      // kBorder = 1 rule of both kernels (:576-577, :660-661) and not on the region rim
+  unsigned long long un_m[64];      // measurement-border map: cells at distance 255 (not reached yet)
+  unsigned long long un_n[64];      // surfel-border map: measured cells without a supporting surfel, not reached yet
+  unsigned long long fr_m[3][64];   // frontier (cells assigned by ring `it`) at [it % 3]
+  unsigned long long fr_n[3][64];
+};
+__device__ __forceinline__ unsigned long long dilate_row(unsigned long long m) { return m | (m << 1) | (m >> 1); }
+// __syncthreads_or with ONE barrier: every wavefront in which the predicate holds somewhere stores 1 to the word of this
+// use, then the barrier, then everybody reads it (the library's version takes three barriers and an LDS reduction; with 16
+// wavefronts and ten rings the barriers were most of the kernel).
+__device__ __forceinline__ bool block_any(unsigned long long* word, bool pred) {
+  if (__ballot(pred) != 0 && (threadIdx.x & 63) == 0) *word = 1;
+  __syncthreads();
+  return *word != 0;
+}
+
+__global__ void __launch_bounds__(kBlendThreads)
+k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<uint16_t> out, Scratch sc, int W, int H,
+              int tiles_x, unsigned long long* stamps) {
+  extern __shared__ __align__(16) unsigned char blend_lds[];
+  SMX_SETPRIO();
+  SMX_STAMP(stamps, 0);
   const int halo = radius - 1;
-  const int rw = kBlendTile + 2 * halo;          // region width == height
+  const int rw = kBlendTile + 2 * halo;          // region width == height (<= 64)
   const int cells = rw * rw;
-  float* delta = reinterpret_cast<float*>(blend_lds);
+  BlendMasks& M = *reinterpret_cast<BlendMasks*>(blend_lds);
+  float* delta = reinterpret_cast<float*>(blend_lds + sizeof(BlendMasks));
   float* ndelta = delta + cells;
   uint16_t* dep = reinterpret_cast<uint16_t*>(ndelta + cells);
-  uint16_t* newdep = dep + cells;
-  uint8_t* dist = reinterpret_cast<uint8_t*>(newdep + cells);
-  uint8_t* ndist = dist + cells;
-  uint8_t* flag = ndist + cells;                  // bit 0: supporting surfel valid, bit 1: processed pixel
+  const int tile_x = (int)(blockIdx.x % (uint32_t)tiles_x), tile_y = (int)(blockIdx.x / (uint32_t)tiles_x);
   const int x0 = tile_x * kBlendTile - halo, y0 = tile_y * kBlendTile - halo;
-  const float inv_rw = 1.0f / (float)rw;
-  for (int k = threadIdx.x; k < cells; k += kBlendThreads) {
-    const int ry = small_div(k, inv_rw), rx = k - ry * rw;
-    const int x = x0 + rx, y = y0 + ry;
-    uint16_t d = 0; uint8_t f = 0;
-    if (x >= 0 && y >= 0 && x < W && y < H) {
-      d = depth(y, x);
-      if (sc.supporting[(size_t)y * W + x] != kInvalid) f |= 1;
-      // kBorder = 1 rule of both kernels (:576-577, :660-661); cells on the region rim cannot be
-      // evaluated (their 3x3 window leaves the region) and are not needed
-      if (x >= 1 && y >= 1 && x < W - 1 && y < H - 1 && rx >= 1 && ry >= 1 && rx < rw - 1 && ry < rw - 1) f |= 2;
-    }
-    dep[k] = d; flag[k] = f; dist[k] = 0; ndist[k] = 0; delta[k] = 0; ndelta[k] = 0;
+  // Loading: this lane's row and its four columns cg, cg + 16, cg + 32, cg + 48 (16 lanes read 16 consecutive cells).
+  const int r = (int)(threadIdx.x >> 4), cg = (int)(threadIdx.x & 15);
+  auto row_bits = [cg](uint32_t bits) -> unsigned long long {   // the lane's four bits at their columns of the row mask
+    return ((unsigned long long)((bits & 1u) | ((bits & 2u) << 15)) << cg) |
+           ((unsigned long long)(((bits >> 2) & 1u) | ((bits & 8u) << 13)) << (cg + 32));
+  };
+  // ---- load: depth and "has a supporting surfel" of the lane's four cells (all requested before the first use)
+  uint32_t dv[4], sv[4];
+  bool inside[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int cx = cg + 16 * b, x = x0 + cx, y = y0 + r;
+    inside[b] = r < rw && cx < rw && x >= 0 && y >= 0 && x < W && y < H;
+    const int xc = min(max(x, 0), W - 1), yc = min(max(y, 0), H - 1);
+    dv[b] = depth(yc, xc);
+    sv[b] = sc.supporting[(size_t)yc * W + xc];
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) { keep(dv[b]); keep(sv[b]); }
+  {
+    unsigned long long* mz = reinterpret_cast<unsigned long long*>(&M);
+    for (int k = threadIdx.x; k < (int)(sizeof(BlendMasks) / 8); k += kBlendThreads) mz[k] = 0;
   }
   __syncthreads();
-  // start kernel, :563-615 (decisions read the unmodified depths; the new depths are applied afterwards)
-  int any = 0;
-  for (int k = threadIdx.x; k < cells; k += kBlendThreads) {
-    uint16_t nd = dep[k];
-    if ((flag[k] & 2) && dep[k] != 0 && (flag[k] & 1)) {
-      bool mb = false, sb = false;
-      for (int wy = -1; wy <= 1; ++wy)
-        for (int wx = -1; wx <= 1; ++wx) {
-          const int kk = k + wy * rw + wx;
-          if (dep[kk] == 0) mb = true;
-          else if (!(flag[kk] & 1)) sb = true;
-        }
-      const int ry = small_div(k, inv_rw), rx = k - ry * rw;
-      const size_t g = (size_t)(y0 + ry) * W + (x0 + rx);
+  SMX_STAMP(stamps, 1);
+  uint32_t zb = 0, sb0 = 0, eb = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int cx = cg + 16 * b, x = x0 + cx, y = y0 + r;
+    const uint32_t d = inside[b] ? dv[b] : 0u;
+    if (r < rw && cx < rw) {
+      dep[r * rw + cx] = (uint16_t)d;
+      delta[r * rw + cx] = 0; ndelta[r * rw + cx] = 0;
+    }
+    if (d == 0) zb |= 1u << b;
+    if (inside[b] && sv[b] != kInvalid) sb0 |= 1u << b;
+    // cells on the region rim cannot be evaluated (their 3x3 window leaves the region) and are not needed
+    if (inside[b] && x >= 1 && y >= 1 && x < W - 1 && y < H - 1 && cx >= 1 && r >= 1 && cx < rw - 1 && r < rw - 1) eb |= 1u << b;
+  }
+  atomicOr(&M.zero[r], row_bits(zb));
+  if (sb0) atomicOr(&M.supp[r], row_bits(sb0));
+  if (eb) atomicOr(&M.elig[r], row_bits(eb));
+  __syncthreads();
+  SMX_STAMP(stamps, 2);
+  // ---- start kernel, :563-615 (decisions read the unmodified depths: the zero mask was formed from them)
+  // From here on FOUR wavefronts work (one per SIMD), a lane per quarter row: rr = its row, its cells the columns
+  // qq, qq + 4, qq + 8, ...  (Interleaved: the cells a ring assigns come in runs along a border, and a lane walks its
+  // set bits one after the other.)  Every lane of the other twelve wavefronts would form the same row masks again --
+  // at four cycles per wave instruction that redundancy, not the barriers, was most of a ring; they only join the barriers.
+  const bool ring_lane = threadIdx.x < 256;
+  const int rr = (int)(threadIdx.x >> 2), qq = (int)(threadIdx.x & 3);
+  const unsigned long long mine = 0x1111111111111111ull << qq;
+  bool started = false;
+  if (ring_lane && rr >= 1 && rr < rw - 1) {
+    const unsigned long long zu = M.zero[rr - 1], zr = M.zero[rr], zd = M.zero[rr + 1];
+    const unsigned long long su = M.supp[rr - 1], sr = M.supp[rr], sd = M.supp[rr + 1];
+    const unsigned long long el = M.elig[rr];
+    const unsigned long long cand = el & ~zr & sr;
+    const unsigned long long mb = cand & (dilate_row(zu) | dilate_row(zr) | dilate_row(zd)) & mine;            // a window cell without measurement
+    const unsigned long long sbm = cand & (dilate_row(~zu & ~su) | dilate_row(~zr & ~sr) | dilate_row(~zd & ~sd)) & mine;  // ... measured, without surfel
+    const unsigned long long un_m = cand & ~mb & mine, un_n = el & ~zr & ~sr & mine;
+    for (unsigned long long todo = mb | sbm; todo; todo &= todo - 1) {
+      const int col = __ffsll((long long)todo) - 1, k = rr * rw + col;
+      const size_t g = (size_t)(y0 + rr) * W + (x0 + col);
       const float own = (float)dep[k];
-      if (sb) { ndist[k] = 1; ndelta[k] = depth_sum_avg(sc, g) - own / ds; any = 1; }
-      if (mb) {
-        dist[k] = 1;
-        const float avg = depth_sum_avg(sc, g);
+      const float avg = depth_sum_avg(sc, g);
+      if ((sbm >> col) & 1ull) ndelta[k] = avg - own / ds;
+      if ((mb >> col) & 1ull) {
         delta[k] = avg - own / ds;
-        nd = f2u16(ds * avg + 0.5f);  // :610
-        any = 1;
-      } else {
-        dist[k] = 255;
+        dep[k] = f2u16(ds * avg + 0.5f);  // :610
       }
     }
-    newdep[k] = nd;
+    if (mb) atomicOr(&M.fr_m[1][rr], mb);
+    if (sbm) atomicOr(&M.fr_n[1][rr], sbm);
+    if (un_m) atomicOr(&M.un_m[rr], un_m);
+    if (un_n) atomicOr(&M.un_n[rr], un_n);
+    started = (mb | sbm) != 0;
   }
   // no measurement / surfel border anywhere in tile + halo: the blend changes nothing here (dep = the input depths)
-  const bool blend_here = __syncthreads_or(any) != 0;
-  if (blend_here) {
-  for (int k = threadIdx.x; k < cells; k += kBlendThreads) dep[k] = newdep[k];
-  __syncthreads();
-  // iteration kernels, :647-708.  Ring `it` is only needed (and only exact) up to halo - it pixels outside
-  // the tile, so the evaluated square shrinks by one pixel per ring.
-  for (int it = 2; it < radius; ++it) {
-    const float f = (float)(it - 1) * term;
-    const int side = kBlendTile + 2 * (halo - it);
-    const float inv_side = 1.0f / (float)side;
-    int changed = 0;
-    for (int q = threadIdx.x; q < side * side; q += kBlendThreads) {
-      const int qy = small_div(q, inv_side), qx = q - qy * side;
-      const int k = (qy + it) * rw + (qx + it);
-      if (!(flag[k] & 2)) continue;
-      if (dist[k] == 255) {
-        float delta_sum = 0; int count = 0;
-        for (int wy = -1; wy <= 1; ++wy)
-          for (int wx = -1; wx <= 1; ++wx) {
-            const int kk = k + wy * rw + wx;
-            if (dist[kk] == it - 1) { delta_sum += delta[kk]; ++count; }
+  const bool any_start = block_any(&M.any[1], started);
+  SMX_STAMP(stamps, 3);
+  if (any_start) {
+    // ---- iteration kernels, :647-708.  Ring `it` is only needed (and only exact) up to halo - it pixels outside
+    // the tile, so the evaluated square shrinks by one pixel per ring.
+    for (int it = 2; it < radius; ++it) {
+      const float f = (float)(it - 1) * term;
+      const int cur = (it - 1) % 3, nxt = it % 3, clr = (it + 1) % 3;
+      const int lo = it, hi = rw - it;
+      bool assigned = false;
+      if (ring_lane && rr >= lo && rr < hi) {
+        const unsigned long long cm = (((1ull << (hi - lo)) - 1ull) << lo) & mine;
+        const unsigned long long mu = M.fr_m[cur][rr - 1], mc = M.fr_m[cur][rr], md = M.fr_m[cur][rr + 1];
+        const unsigned long long nu = M.fr_n[cur][rr - 1], nc = M.fr_n[cur][rr], nd = M.fr_n[cur][rr + 1];
+        const unsigned long long reach_m = M.un_m[rr] & (dilate_row(mu) | dilate_row(mc) | dilate_row(md)) & cm;
+        const unsigned long long reach_n = M.un_n[rr] & (dilate_row(nu) | dilate_row(nc) | dilate_row(nd)) & cm;
+        // (a cell belongs to one map only -- supported cells to the measurement-border map, unsupported ones to the
+        // surfel-border map -- so one code path serves both)
+        for (unsigned long long todo = reach_m | reach_n; todo; todo &= todo - 1) {
+          const int col = __ffsll((long long)todo) - 1, k = rr * rw + col;
+          const bool second = ((reach_n >> col) & 1ull) != 0;
+          const unsigned long long fu = second ? nu : mu, fc = second ? nc : mc, fd = second ? nd : md;
+          float* dl = second ? ndelta : delta;
+          float delta_sum = 0; int count = 0;
+#pragma unroll
+          for (int wy = -1; wy <= 1; ++wy) {
+            const unsigned long long fw = wy < 0 ? fu : wy == 0 ? fc : fd;
+#pragma unroll
+            for (int wx = -1; wx <= 1; ++wx)
+              if ((fw >> (col + wx)) & 1ull) { delta_sum += dl[k + wy * rw + wx]; ++count; }
           }
-        if (count > 0) {
-          dist[k] = (uint8_t)it;
-          const float avg = delta_sum / (float)count;
-          delta[k] = avg;
-          dep[k] = f2u16((float)dep[k] + (ds * (1 - f) * avg + 0.5f));  // :681
-          changed = 1;
+          const float avg = delta_sum / (float)count;   // (count > 0: the cell is in the frontier's dilation)
+          dl[k] = avg;
+          dep[k] = f2u16((float)dep[k] + (ds * (1 - f) * avg + 0.5f));  // :681 / :704
         }
+        if (reach_m) { atomicOr(&M.fr_m[nxt][rr], reach_m); atomicAnd(&M.un_m[rr], ~reach_m); }
+        if (reach_n) { atomicOr(&M.fr_n[nxt][rr], reach_n); atomicAnd(&M.un_n[rr], ~reach_n); }
+        assigned = (reach_m | reach_n) != 0;
       }
-      if (dep[k] != 0 && !(flag[k] & 1) && ndist[k] == 0) {
-        float delta_sum = 0; int count = 0;
-        for (int wy = -1; wy <= 1; ++wy)
-          for (int wx = -1; wx <= 1; ++wx) {
-            const int kk = k + wy * rw + wx;
-            if (ndist[kk] == it - 1) { delta_sum += ndelta[kk]; ++count; }
-          }
-        if (count > 0) {
-          ndist[k] = (uint8_t)it;
-          const float avg = delta_sum / (float)count;
-          ndelta[k] = avg;
-          dep[k] = f2u16((float)dep[k] + (ds * (1 - f) * avg + 0.5f));  // :704
-          changed = 1;
-        }
-      }
+      if (ring_lane && qq == 0) { M.fr_m[clr][rr] = 0; M.fr_n[clr][rr] = 0; }   // (last read one ring ago, next written one ring ahead)
+      // a ring that assigned nothing leaves no frontier: all later rings are empty too
+      if (!block_any(&M.any[it], assigned)) break;
     }
-    // a ring that assigned nothing leaves no frontier: all later rings are empty too
-    if (!__syncthreads_or(changed)) break;
   }
-  }
+  SMX_STAMP(stamps, 4);
   for (int k = threadIdx.x; k < kBlendTile * kBlendTile; k += kBlendThreads) {
     const int ty = k / kBlendTile, tx = k - ty * kBlendTile;
     const int x = tile_x * kBlendTile + tx, y = tile_y * kBlendTile + ty;
     if (x < W && y < H) out(y, x) = dep[(ty + halo) * rw + (tx + halo)];
   }
-}
-
-// MergeSurfelsCUDA's decisions and BlendMeasurementsCUDA in ONE launch: both only read the association images and the
-// (unblended) depth, neither reads what the other writes (merge flags / the blended copy), and on the frame-to-frame
-// critical path a launch boundary costs more than either kernel's tail.  The first n_blend_blocks workgroups are blend
-// tiles; the others walk the visible list, four 256-entry chunks per 1024-lane workgroup.
-template <bool kUseList>
-__global__ void __launch_bounds__(kBlendThreads)
-k_merge_and_blend(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<const float2> normals, Lists L,
-                  uint8_t* __restrict__ merge_flag, const DevState* st, int radius, float term, float ds,
-                  Img<uint16_t> blended, int tiles_x, uint32_t n_blend_blocks) {
-  extern __shared__ __align__(16) unsigned char blend_lds[];
-  if (blockIdx.x < n_blend_blocks) {
-    blend_tile(blend_lds, (int)(blockIdx.x % (uint32_t)tiles_x), (int)(blockIdx.x / (uint32_t)tiles_x), radius, term, ds, depth,
-               blended, sc, c.W, c.H);
-  } else {
-    constexpr uint32_t kChunksPerBlock = kBlendThreads / kBlock;
-    const uint32_t mb = blockIdx.x - n_blend_blocks, n_mb = gridDim.x - n_blend_blocks;
-    merge_decide_chunks<kUseList>(S, c, sc, depth, normals, L, merge_flag, st, mb * kChunksPerBlock + (threadIdx.x / kBlock),
-                                  n_mb * kChunksPerBlock, threadIdx.x % kBlock);
-  }
+  SMX_STAMP(stamps, 5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1014,7 +1197,7 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
   for (int off = 32; off > 0; off >>= 1) merged_here += __shfl_xor(merged_here, off);
   if ((threadIdx.x & 63) == 0 && merged_here) {
     atomicAdd(&st->merge_count, merged_here);
-    atomicAdd(&st->n_merged, merged_here);
+    if (c.stats) atomicAdd(&st->n_merged, merged_here);   // (per-call statistic: reset by k_reset_frame_stats while statistics are on)
   }
 }
 
@@ -1131,16 +1314,25 @@ k_new_flags_scan(Img<const uint16_t> depth, Img<uint16_t> depth_out, int copy_ba
   const int k0 = (blockIdx.x * kBlock + threadIdx.x) * kScanPxPerThread;
   uint32_t f[kScanPxPerThread];
   uint32_t mine = 0;
+  // (all loads of the lane first: written as `d > 0 && supporting == .. && key == ..` per pixel they come one by one)
+  uint32_t dv[kScanPxPerThread], sv[kScanPxPerThread], cv[kScanPxPerThread];
+#pragma unroll
+  for (int j = 0; j < kScanPxPerThread; ++j) {
+    const int k = min(k0 + j, P - 1);
+    const int y = k / W, x = k - y * W;
+    dv[j] = depth(y, x); sv[j] = sc.supporting[k]; cv[j] = sc.confl_key[k];
+  }
+#pragma unroll
+  for (int j = 0; j < kScanPxPerThread; ++j) { keep(dv[j]); keep(sv[j]); keep(cv[j]); }
 #pragma unroll
   for (int j = 0; j < kScanPxPerThread; ++j) {
     const int k = k0 + j;
     bool fl = false;
     if (k < P) {
       const int y = k / W, x = k - y * W;
-      const uint16_t d = depth(y, x);
+      const uint16_t d = (uint16_t)dv[j];
       if (copy_back) depth_out(y, x) = d;
-      fl = x >= 1 && y >= 1 && x < W - 1 && y < H - 1 && d > 0 &&
-           sc.supporting[k] == kInvalid && sc.confl_key[k] == kInvalid;
+      fl = x >= 1 && y >= 1 && x < W - 1 && y < H - 1 && d > 0 && sv[j] == kInvalid && cv[j] == kInvalid;
       flags[k] = fl ? 1 : 0;
     }
     f[j] = fl ? 1u : 0u;
@@ -1179,8 +1371,8 @@ k_new_flags_scan(Img<const uint16_t> depth, Img<uint16_t> depth_out, int copy_ba
 struct CreateArgs {
   const uint8_t* flags; const uint32_t* ranks; const uint32_t* block_sums; uint32_t* block_offsets_out;
   int n_scan_blocks; uint32_t max_surfels; uint8_t* flags8; uint8_t* dirty8;
-  // the NEXT call's association images (the other set): this launch re-initialises its z-buffer and its chunk counter
-  float* next_first_depth; uint32_t* next_vis_chunk_count; int n_pixels;
+  uint32_t* next_vis_chunk_count;   // the NEXT call's chunk counter of the visible list: reset by this launch
+  int n_pixels;
   uint8_t* hot_epoch; uint32_t epoch; int hot_shift;   // Lists::hot_epoch, epoch, hot_shift
 };
 __device__ __forceinline__ void new_create_body(const Surfels& S, const FrameCtx& c, const Scratch& sc, const FrameIn& in,
@@ -1289,14 +1481,8 @@ k_update_and_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, Crea
   if (blockIdx.x < n_create_blocks) {
     new_create_body(S, c, sc, in, a, st, blockIdx.x, n_create_blocks);
   } else {
-    // Side job (see k_clear_assoc): pass A of the next call follows this launch and min-reduces into the other set's
-    // z-buffer; a slice of it per workgroup, written here, is still in L2 when those atomics arrive.
     const uint32_t block = blockIdx.x - n_create_blocks, n_blocks = gridDim.x - n_create_blocks;
-    const uint32_t per = (((uint32_t)a.n_pixels + n_blocks - 1) / n_blocks + 63u) & ~63u;   // (whole cache lines)
-    for (uint32_t k = threadIdx.x; k < per; k += kBlock) {
-      const uint32_t px = block * per + k;
-      if (px < (uint32_t)a.n_pixels) a.next_first_depth[px] = __builtin_inff();
-    }
+    // (pass A of the next call, which follows this launch, appends to the other chunk counter)
     if (block == 0 && threadIdx.x == 0) *a.next_vis_chunk_count = 0;
     update_neighbors_body<kUseList>(S, c, sc, in, L, st, block, n_blocks);
   }
@@ -1435,51 +1621,85 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
 #pragma unroll
   for (int k = 0; k < kSegAcc * 2 / kBlockAcc; ++k) lacc[k * kBlockAcc + threadIdx.x] = 0;
   __syncthreads();
+  // Both slots of a lane travel together through three levels of loads, every load of a level requested before the
+  // first one is used: (1) mask + flag bytes, (2) the slots' own T, S, N records, (3) one 32-byte record per link.
+  // The link records are read whole and compared without branches: a chain of `a == i ? 0 : b == i ? 1 : ...` makes the
+  // compiler fetch the second half of a record lazily, word by word, three dependent round trips per link
+  // (tools/isa_phases.py: 28 waits on this kernel's path before, 4 now).
+  constexpr int kSub = kSegAcc / kBlockAcc;
+  uint32_t idx[kSub], mask[kSub];
+  bool rec[kSub], act[kSub];
 #pragma unroll
-  for (int sub = 0; sub < kSegAcc / kBlockAcc; ++sub) {
-    const uint32_t i = base + sub * kBlockAcc + threadIdx.x;
-    const uint32_t mask = (i < N) ? inwin8[i] : 0u;
-    const bool rec = (i < N) && (flags8[i] & 1u);
-    if (!mask && !rec) continue;
-    // all loads are issued before the first use: the slot's own records, then per edge the target's S record
-    // (smooth position) and, for edges into the window, its T record (its neighbour ids); unused slots read
-    // the slot's own data
-    const uint4 own_t = *reinterpret_cast<const uint4*>(S.group(kGroupT, i));
-    const uint32_t nb[4] = {own_t.x, own_t.y, own_t.z, own_t.w};
-    const float4 own_s = *S.group(kGroupS, i), own_n = *S.group(kGroupN, i);
-    const Vec3 sp = {own_s.x, own_s.y, own_s.z};
-    const Vec3 nrm = {own_n.x, own_n.y, own_n.z};
-    const float r2 = own_n.w;
+  for (int sub = 0; sub < kSub; ++sub) {
+    idx[sub] = base + sub * kBlockAcc + threadIdx.x;
+    const bool in = idx[sub] < N;
+    const uint32_t m8 = in ? (uint32_t)inwin8[idx[sub]] : 0u, f8 = in ? (uint32_t)flags8[idx[sub]] : 0u;
+    mask[sub] = m8;
+    rec[sub] = (f8 & 1u) != 0;
+  }
+  uint4 own_t[kSub];
+  float4 own_s[kSub], own_n[kSub];
+#pragma unroll
+  for (int sub = 0; sub < kSub; ++sub) {
+    act[sub] = mask[sub] != 0 || rec[sub];
+    const uint32_t i = act[sub] ? idx[sub] : base;   // (idle lanes read the segment's first slot: no branch around the loads)
+    own_t[sub] = *reinterpret_cast<const uint4*>(S.group(kGroupT, i));
+    own_s[sub] = *S.group(kGroupS, i);
+    own_n[sub] = *S.group(kGroupN, i);
+  }
+  uint32_t gmask[kSub];
+  float4 ts[kSub][4];
+  uint4 tt[kSub][4];
+#pragma unroll
+  for (int sub = 0; sub < kSub; ++sub) {
+    const uint32_t nb[4] = {own_t[sub].x, own_t[sub].y, own_t[sub].z, own_t[sub].w};
     // a recent slot needs every valid neighbour (its own step term, :2238-2256), any other slot only the
     // neighbours inside the window (the terms it pushes)
-    uint32_t gmask = mask;
-    if (rec) {
+    uint32_t gm = act[sub] ? mask[sub] : 0u;
+    if (act[sub] && rec[sub]) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) if (nb[q] != kInvalid) gmask |= 1u << q;
+      for (int q = 0; q < 4; ++q) if (nb[q] != kInvalid) gm |= 1u << q;
     }
+    gmask[sub] = gm;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      // one 32-byte record per link: the neighbour's smooth position and (the copy of) its own links; unused links
+      // read the slot's own record
+      const float4* lr = S.group(kGroupS, (gm & (1u << q)) ? nb[q] : (act[sub] ? idx[sub] : base));
+      ts[sub][q] = lr[0];
+      tt[sub][q] = *reinterpret_cast<const uint4*>(lr + 1);
+    }
+  }
+#pragma unroll
+  for (int sub = 0; sub < kSub; ++sub) {
+    if (!act[sub]) continue;
+    const uint32_t i = idx[sub];
+    const uint32_t nb[4] = {own_t[sub].x, own_t[sub].y, own_t[sub].z, own_t[sub].w};
+    const uint32_t msk = mask[sub];
+    const Vec3 sp = {own_s[sub].x, own_s[sub].y, own_s[sub].z};
+    const Vec3 nrm = {own_n[sub].x, own_n[sub].y, own_n[sub].z};
+    const float r2 = own_n[sub].w;
     Vec3 np[4];
     int back_slot[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      // one 32-byte record per link: the neighbour's smooth position and (the copy of) its own links
-      const float4* st = S.group(kGroupS, (gmask & (1u << q)) ? nb[q] : i);
-      const float4 ts = st[0];
-      const uint4 tt = *reinterpret_cast<const uint4*>(st + 1);
-      np[q].x = ts.x; np[q].y = ts.y; np[q].z = ts.z;
-      back_slot[q] = tt.x == i ? 0 : tt.y == i ? 1 : tt.z == i ? 2 : tt.w == i ? 3 : -1;
+      np[q].x = ts[sub][q].x; np[q].y = ts[sub][q].y; np[q].z = ts[sub][q].z;
+      const uint32_t eq = (tt[sub][q].x == i ? 1u : 0u) | (tt[sub][q].y == i ? 2u : 0u) | (tt[sub][q].z == i ? 4u : 0u) |
+                          (tt[sub][q].w == i ? 8u : 0u);
+      back_slot[q] = eq ? (int)__builtin_ctz(eq) : -1;   // (the first position that lists the source back)
     }
-    const int neighbor_count = mask ? __popc(mask) : 1;
+    const int neighbor_count = msk ? __popc(msk) : 1;
     const float factor = 2 * weight / (float)neighbor_count;  // :2153
     const float wk = weight / (float)neighbor_count;          // :2182
     int own_count = 0;
     Vec3 rg = {0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (!(gmask & (1u << q))) continue;
+      if (!(gmask[sub] & (1u << q))) continue;
       const Vec3 t = {np[q].x - sp.x, np[q].y - sp.y, np[q].z - sp.z};
       const float nd = nrm.x * t.x + nrm.y * t.y + nrm.z * t.z;
       bool pruned = false;
-      if (mask & (1u << q)) {
+      if (msk & (1u << q)) {
         const float f = factor * nd;
         const float4 term = make_float4(f * nrm.x, f * nrm.y, f * nrm.z, wk);
         // the fixed-point channel carries |component| < 16 m (q22_from_float clamps): a huge regularizer_weight or a
@@ -1488,7 +1708,7 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
         // the exclusive inbox slot is only usable if this source has ONE in-window edge to that target
         bool once = true;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (k != q && (mask & (1u << k)) && nb[k] == nb[q]) once = false;
+        for (int k = 0; k < 4; ++k) if (k != q && (msk & (1u << k)) && nb[k] == nb[q]) once = false;
         const uint32_t rel = nb[q] - base;
         if (rel < (uint32_t)kSegAcc) {
           // component-major LDS layout: consecutive lanes (consecutive targets) hit consecutive banks
@@ -1512,12 +1732,12 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
       }
       // the slot's own regulariser term (RegularizeSurfelsCUDAKernel :2238-2256 sees the row after the pruning
       // above): same neighbour positions, same n.t product, so it is formed here and k_reg_step gathers nothing
-      if (rec && !pruned) {
+      if (rec[sub] && !pruned) {
         ++own_count;
         rg.x = rg.x - nd * nrm.x; rg.y = rg.y - nd * nrm.y; rg.z = rg.z - nd * nrm.z;
       }
     }
-    if (rec) *S.group(kGroupG, i) = make_float4(rg.x, rg.y, rg.z, __int_as_float(own_count));
+    if (rec[sub]) *S.group(kGroupG, i) = make_float4(rg.x, rg.y, rg.z, __int_as_float(own_count));
   }
   __syncthreads();
   // store the in-segment sums (only this workgroup writes the grad_local entries of its segment)
@@ -1879,14 +2099,18 @@ struct smx_recon_s {
   int table_window;
   int stats_enabled;
   hipEvent_t hook_consumed, hook_chain;   // smx_recon_integrate_hooks: one-shot, taken by the next Integrate call
+  hipEvent_t hook_ready;                  // smx_recon_integrate_inputs_ready: likewise
   int blend_multi_launch;   // A/B switch: 1 = the reference's start + iteration launches instead of the fused kernel
-  Scratch sc;               // the association images of the current call (= sc_set[sc_cur])
-  Scratch sc_set[2];
-  uint32_t* vis_count_set[2];
+  Scratch sc;               // the association images (every pixel is rewritten by k_assoc_tiles in every call)
+  TileBins tb;              // pass A's pairs, binned by association tile
+  uint32_t* ovf_count_set[2];   // overflow counters, alternating by call (the tile kernel zeroes the next call's)
+  unsigned long long* stamps;   // -DSMX_STAMPS builds: [2][8192 workgroups][16] shader clocks (tile kernel, blend kernel)
+  int exp_env;              // EXPERIMENT switch from the environment, active inside bench.py's timed region only
+  uint32_t bin_cap_full;    // the bins' allocated capacity (tb.cap is lowered by the A/B switch that forces overflows)
+  uint32_t* vis_count_set[2];   // chunk counters of the visible list, alternating by call (k_update_and_create zeroes the next call's)
   int sc_cur;
   int hot_holdoff;          // > 0: pass B does not use the hot-group table (decremented per Integrate call)
   int hot_filter_enabled;   // A/B switch (smx_recon_set_scan_mode bit 2 clears it)
-  bool next_set_ready;      // the other set's z-buffer and chunk counter were re-initialised by the last k_update_and_create
   uint16_t* blended_depth;  // [H][W] output of the fused blend (stored into the caller's depth by k_new_flags_scan)
   BlendBufs bb;
   uint8_t* new_flags;
@@ -1922,9 +2146,12 @@ struct smx_recon_s {
   // regulariser does not write, and a second copy of the flag table).  Every entry point first orders the
   // caller's stream after the pending regulariser, so the API keeps its one-stream semantics.
   int overlap_enabled;
-  hipStream_t reg_stream;     // high priority: the frame-to-frame critical path
-  hipEvent_t ev_mid, ev_reg;
+  hipStream_t reg_stream;     // high priority: the frame-to-frame critical path (integrate .. regulariser)
+  hipEvent_t ev_front;        // caller's stream: pass A .. flags of a call are enqueued
+  hipEvent_t ev_upd;          // internal stream: update + create of a call are enqueued (the inputs are consumed, the map is ready for the next pass A)
+  hipEvent_t ev_reg;          // internal stream: end of the work enqueued so far (recorded on demand by join_regularizer)
   bool reg_pending;
+  hipStream_t last_stream;    // the caller's stream of the last Integrate call
   uint8_t* flags_buf[2];    // the flag table is double-buffered by frame (L.flags8 = the current frame's)
   bool have_frame;          // an Integrate call has been made since creation / the last state upload
   uint32_t last_frame;      // its frame_index: the segment culling of pass A presumes that it never decreases
@@ -1932,13 +2159,13 @@ struct smx_recon_s {
 
 // kernel slots of one Integrate call (launch order)
 enum : int {
-  kSlotClear = 0, kSlotScanVisible, kSlotAssociate, kSlotMergeDecide, kSlotBlend, kSlotIntegrate,
+  kSlotScanVisible = 0, kSlotAssocTiles, kSlotBlend, kSlotIntegrate,
   kSlotUpdateNeighbors, kSlotNewFlagsScan, kSlotNeighborScan,
   kSlotRegAccumulate, kSlotRegStep,
   kSlotRegUpdate, kSlotCount
 };
 static const char* const kSlotNames[kSlotCount] = {
-  "clear_assoc", "scan_visible", "associate", "merge_decide", "blend", "integrate", "update_neighbors+create",
+  "scan_visible", "assoc_tiles", "blend", "integrate", "update_neighbors+create",
   "new_flags_scan", "neighbor_scan", "reg_accumulate", "reg_step", "reg_update"};
 
 struct SlotTimer {
@@ -1960,8 +2187,12 @@ namespace {
 // Orders stream st after the regulariser that may still run on the internal stream.
 int join_regularizer(smx_recon r, hipStream_t st) {
   // (the flag stays set: a later call may come with another stream, which has to be ordered as well; waiting on a
-  // completed event costs nothing on the device)
-  if (r->reg_pending) SMX_HIP(hipStreamWaitEvent(st, r->ev_reg, 0));
+  // completed event costs nothing on the device.  The mark is recorded here, on demand: the frame loop itself never
+  // needs it, and every event operation on the internal stream sits on the frame-to-frame critical chain.)
+  if (r->reg_pending) {
+    SMX_HIP(hipEventRecord(r->ev_reg, r->reg_stream));
+    SMX_HIP(hipStreamWaitEvent(st, r->ev_reg, 0));
+  }
   return SMX_OK;
 }
 
@@ -2087,16 +2318,29 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->merge_flag, r->S.pitch, true));
   SMX_TRY(dev_alloc(&r->inwin8, (size_t)r->nsegB * kSegB, true));
   SMX_TRY(dev_alloc(&r->need_seg, (size_t)r->nsegB + kSegAcc / kSegB, true));
+  SMX_TRY(dev_alloc(&r->sc.supporting, P, true));
+  SMX_TRY(dev_alloc(&r->sc.counts, P, true));
+  SMX_TRY(dev_alloc(&r->sc.depth_sums, P, true));
+  SMX_TRY(dev_alloc(&r->sc.confl_key, P, true));
+  SMX_TRY(dev_alloc(&r->sc.first_depth, P, true));
   for (int k = 0; k < 2; ++k) {
-    SMX_TRY(dev_alloc(&r->sc_set[k].supporting, P, false));
-    SMX_TRY(dev_alloc(&r->sc_set[k].counts, P, false));
-    SMX_TRY(dev_alloc(&r->sc_set[k].depth_sums, P, false));
-    SMX_TRY(dev_alloc(&r->sc_set[k].confl_key, P, false));
-    SMX_TRY(dev_alloc(&r->sc_set[k].first_depth, P, false));
     SMX_TRY(dev_alloc(&r->vis_count_set[k], 1, true));
+    SMX_TRY(dev_alloc(&r->ovf_count_set[k], 1, true));
   }
-  r->sc = r->sc_set[0];
   r->L.vis_chunks.count = r->vis_count_set[0];
+  // Association tiles: one bin of kTileBinCap pairs per tile (a tile of 256 pixels holds ~600 pairs at C2; pairs
+  // beyond the capacity go to the overflow list, which has room for every pair a call can produce: 2 per slot).
+  r->tb.tiles_x = div_up(width, kTileW);
+  r->tb.n_tiles = (uint32_t)(r->tb.tiles_x * div_up(height, kTileH));
+  r->tb.cap = r->bin_cap_full = kTileBinCap;
+  SMX_TRY(dev_alloc(&r->tb.pairs, (size_t)r->tb.n_tiles * kTileBinCap, false));
+  SMX_TRY(dev_alloc(&r->tb.count, (size_t)r->tb.n_tiles * kCountStride, true));
+  SMX_TRY(dev_alloc(&r->tb.ovf, 2 * (size_t)r->S.pitch + 64, false));
+  r->tb.ovf_count = r->ovf_count_set[0];
+  r->exp_env = getenv("SMX_EXP") ? atoi(getenv("SMX_EXP")) : 0;
+#ifdef SMX_STAMPS
+  SMX_TRY(dev_alloc(&r->stamps, (size_t)2 * 16 * 8192, true));
+#endif
   SMX_TRY(dev_alloc(&r->blended_depth, P, true));
   SMX_TRY(dev_alloc(&r->bb.distance_map, P, true));
   SMX_TRY(dev_alloc(&r->bb.new_distance_map, P, true));
@@ -2120,7 +2364,8 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   }
   // (device-scope release: these events order GPU streams, the host never reads data behind them)
   const unsigned evf = hipEventDisableTiming | hipEventReleaseToDevice;
-  SMX_HIP(hipEventCreateWithFlags(&r->ev_mid, evf));
+  SMX_HIP(hipEventCreateWithFlags(&r->ev_front, evf));
+  SMX_HIP(hipEventCreateWithFlags(&r->ev_upd, evf));
   SMX_HIP(hipEventCreateWithFlags(&r->ev_reg, evf));
   SMX_HIP(hipEventCreateWithFlags(&r->ev_staging, hipEventDisableTiming));
   r->overlap_enabled = 1;
@@ -2139,13 +2384,14 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
 int smx_recon_destroy(smx_recon r) {
   if (!r) return SMX_OK;
   SMX_ON_DEVICE(r->device);
-  void* ptrs[] = {r->sc_set[0].supporting, r->sc_set[0].counts, r->sc_set[0].depth_sums, r->sc_set[0].confl_key, r->sc_set[0].first_depth,
-                  r->sc_set[1].supporting, r->sc_set[1].counts, r->sc_set[1].depth_sums, r->sc_set[1].confl_key, r->sc_set[1].first_depth,
+  void* ptrs[] = {r->sc.supporting, r->sc.counts, r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth,
+                  r->tb.pairs, r->tb.count, r->tb.ovf, r->ovf_count_set[0], r->ovf_count_set[1],
                   r->vis_count_set[0], r->vis_count_set[1], r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1], r->L.hot_epoch,
                   r->merge_flag, r->inwin8, r->need_seg, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->block_offsets, r->st};
   if (r->reg_stream) { (void)hipStreamSynchronize(r->reg_stream); (void)hipStreamDestroy(r->reg_stream); }
-  if (r->ev_mid) (void)hipEventDestroy(r->ev_mid);
+  if (r->ev_front) (void)hipEventDestroy(r->ev_front);
+  if (r->ev_upd) (void)hipEventDestroy(r->ev_upd);
   if (r->ev_reg) (void)hipEventDestroy(r->ev_reg);
   if (r->ev_staging) (void)hipEventDestroy(r->ev_staging);
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -2220,11 +2466,12 @@ int smx_recon_set_overlap(smx_recon r, int32_t enabled) {
 }
 
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
-  SMX_CHECK_ARG(r != nullptr && mode >= 0 && mode <= 7);
+  SMX_CHECK_ARG(r != nullptr && mode >= 0 && mode <= 15);
   SMX_ON_DEVICE(r->device);
   r->scan_mode = mode & 1;
   r->blend_multi_launch = (mode >> 1) & 1;
   r->hot_filter_enabled = ((mode >> 2) & 1) ? 0 : 1;
+  r->tb.cap = ((mode >> 3) & 1) ? 16u : r->bin_cap_full;   // 16 pairs per bin: most pairs travel through the overflow list
   return SMX_OK;
 }
 
@@ -2234,8 +2481,8 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
                         const float global_T_local[12], const smx_integrate_params* p) {
   SMX_CHECK_ARG(r && depth && normals && radius && color && global_T_local && p);
   SMX_ON_DEVICE(r->device);
-  const hipEvent_t hook_consumed = r->hook_consumed, hook_chain = r->hook_chain;   // one-shot, also when the call fails
-  r->hook_consumed = nullptr; r->hook_chain = nullptr;
+  const hipEvent_t hook_consumed = r->hook_consumed, hook_chain = r->hook_chain, hook_ready = r->hook_ready;   // one-shot, also when the call fails
+  r->hook_consumed = nullptr; r->hook_chain = nullptr; r->hook_ready = nullptr;
   SMX_CHECK_ARG(depth->width == r->W && depth->height == r->H && normals->width == r->W && normals->height == r->H);
   SMX_CHECK_ARG(radius->width == r->W && radius->height == r->H && color->width == r->W && color->height == r->H);
   // (the radius is only read when blending is on: do_blending is an independent flag, APP/main.cc:348-354)
@@ -2275,110 +2522,106 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   r->L.flags8 = (r->L.flags8 == r->flags_buf[0]) ? r->flags_buf[1] : r->flags_buf[0];
   r->L.epoch = (r->L.epoch + 1u) & 255u;
   if (r->hot_holdoff > 0) --r->hot_holdoff;
-  // Streams.  Everything on the frame-to-frame critical cycle -- clear, pass A, associate, merge + blend, flags,
-  // integrate, update + create; frame f + 1 needs the positions and slots frame f wrote -- stays on the CALLER's
-  // stream, in order.  The regulariser chain (pass B, edges, step) is forked to the internal stream after update +
-  // create and runs beside the NEXT call's clear .. flags, which read only P / N records and the other copy of the flag
-  // table; the next call's integrate kernel waits for it (a wait that has normally been satisfied long before).  Not
-  // pipelined: the same launches, all on the caller's stream.  (Measured against round 1's arrangement -- integrate ..
-  // regulariser on the internal stream, an event hand-off in each direction -- it is a tie, profiles/r03c_matrix.txt;
-  // this one needs one hand-off instead of two and leaves the caller's stream free as soon as its buffers are consumed.)
+  // Streams.  The frame-to-frame critical cycle is integrate(f) -> update + create(f) -> pass B -> edges -> step ->
+  // integrate(f + 1): the regulariser of frame f has to finish before frame f + 1 rewrites positions and links, and it
+  // is longer than the front of frame f + 1 (pass A, association tiles, blend, flags), which only reads P / N records
+  // and the other copy of the flag table.  That cycle runs on the INTERNAL stream, in order, with no event wait of its
+  // own inside it; the front runs on the caller's stream beside the previous call's regulariser and hands over to the
+  // internal stream once (ev_front).  The caller's stream then waits for update + create (ev_upd): its buffers are
+  // consumed, and the next call's pass A finds the map complete.  Both hand-offs sit on the shorter chain.  Every other
+  // entry point first orders its stream after the internal one (join_regularizer), which keeps the reference's
+  // one-stream semantics for anything that goes through the API.  Not pipelined: the same launches, all on the caller's
+  // stream.  (Rounds 1-2 kept integrate and update + create on the caller's stream and forked the regulariser: two
+  // hand-offs on the critical cycle, which then was about as long as the front chain -- profiles/r03c_matrix.txt.)
   const bool pipelined = r->overlap_enabled != 0;
-  const hipStream_t sF = st, sC = st;
+  const hipStream_t sF = st;
   const hipStream_t sR = pipelined ? r->reg_stream : st;
+  // (a caller that comes with another stream than last time: that stream has not waited for the previous call's map yet)
+  if (r->reg_pending && r->last_stream != st) { const int rcj = join_regularizer(r, st); if (rcj != SMX_OK) return rcj; }
+  r->last_stream = st;
   if (r->stats_enabled) hipLaunchKernelGGL(k_reset_frame_stats, dim3(1), dim3(1), 0, sF, r->st);
   if (tm) SMX_HIP(hipEventRecord(r->ev[0], sF));
-  // The association images: two sets in alternation.  The previous call's k_update_and_create has re-initialised this
-  // call's z-buffer and chunk counter, pass A does the other four images on the way (k_clear_assoc explains; each
-  // image is written right in front of the launch whose atomics land on it -- clearing early on a side stream left
-  // the lines cold, pass A 36 -> 53 us, profiles/r03b_matrix.txt).  Only a first call clears with a launch of its own.
+  // two chunk counters / overflow counters in alternation: the kernels of this call read theirs while they reset the
+  // next call's (k_update_and_create / k_assoc_tiles)
   r->sc_cur ^= 1;
-  r->sc = r->sc_set[r->sc_cur];
   r->L.vis_chunks.count = r->vis_count_set[r->sc_cur];
-  const bool set_ready = r->next_set_ready;
-  r->next_set_ready = false;
-  if (!set_ready) {
-    SlotTimer t(r, sF, kSlotClear);
-    hipLaunchKernelGGL(k_clear_assoc, gpx, b, 0, sF, r->sc, P, r->L.vis_chunks.count);
-  }
+  r->tb.ovf_count = r->ovf_count_set[r->sc_cur];
+  r->tb.exp = smx::g_exp_timed_region ? r->exp_env : 0;
   { SlotTimer t(r, sF, kSlotScanVisible);
-    hipLaunchKernelGGL(k_scan_visible, gs, b, 0, sF, r->S, c, r->sc, r->L, flags_prev, r->st, set_ready ? 1 : 0);
+    const size_t lds = r->tb.n_tiles <= kMaxTilesLds ? (size_t)r->tb.n_tiles * 8 : 0;
+    hipLaunchKernelGGL(k_scan_visible, gs, b, lds, sF, r->S, c, r->L, r->tb, flags_prev, r->st);
     r->table_valid = true; r->table_frame = frame_index; r->table_window = c.reg_window; }
-  { SlotTimer t(r, sF, kSlotAssociate);
-    if (r->scan_mode) hipLaunchKernelGGL((k_associate<false>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->st);
-    else hipLaunchKernelGGL((k_associate<true>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->st); }
-  if (tm) { SMX_HIP(hipEventRecord(r->ev[1], sF)); SMX_HIP(hipEventRecord(r->ev[2], sF)); }
+  // (smx_recon_integrate_inputs_ready) from here on the input images are read
+  if (hook_ready) SMX_HIP(hipStreamWaitEvent(sF, hook_ready, 0));
+  { SlotTimer t(r, sF, kSlotAssocTiles);
+    hipLaunchKernelGGL(k_assoc_tiles, dim3(r->tb.n_tiles), dim3(kTilePx), 0, sF, r->S, c, r->sc, in.depth, in.normals, r->tb,
+                       r->ovf_count_set[r->sc_cur ^ 1], r->merge_flag, r->st, r->stamps ? r->stamps : nullptr); }
+  // (the stage times of GetTimings: data association = pass A + the tile kernel, which also decides the merges)
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[1], sF)); SMX_HIP(hipEventRecord(r->ev[2], sF)); SMX_HIP(hipEventRecord(r->ev[3], sF)); SMX_HIP(hipEventRecord(r->ev[4], sF)); }
   const int halo = p->measurement_blending_radius - 1;
   const bool fused_blend = p->do_blending && halo <= kBlendMaxHalo && !r->blend_multi_launch;
   const float ds = 1.0f / c.inv_depth_scaling;  // kernels.cc:179
   const float term = p->do_blending ? 1.0f / ((float)p->measurement_blending_radius - 1.0f) : 0.0f;  // kernels.cc:196
   const Img<uint16_t> blended = {r->blended_depth, r->H, r->W, (size_t)r->W * sizeof(uint16_t)};
   if (fused_blend) {
-    // merge decisions + blending in one launch (the stage times of GetTimings: merging = the launch, blending = 0)
-    SlotTimer t(r, sF, kSlotMergeDecide);
+    SlotTimer t(r, sF, kSlotBlend);
     const int rw = kBlendTile + 2 * halo;
-    const size_t lds = (size_t)rw * rw * 15;
+    const size_t lds = sizeof(BlendMasks) + (size_t)rw * rw * 10;
     const int tiles_x = div_up(r->W, kBlendTile);
     const uint32_t n_blend = (uint32_t)(tiles_x * div_up(r->H, kBlendTile));
-    const dim3 g(n_blend + (uint32_t)(r->grid_list / (kBlendThreads / kBlock)));
-    if (r->scan_mode) hipLaunchKernelGGL((k_merge_and_blend<false>), g, dim3(kBlendThreads), lds, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st, p->measurement_blending_radius, term, ds, blended, tiles_x, n_blend);
-    else hipLaunchKernelGGL((k_merge_and_blend<true>), g, dim3(kBlendThreads), lds, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st, p->measurement_blending_radius, term, ds, blended, tiles_x, n_blend);
-    if (tm) { SMX_HIP(hipEventRecord(r->ev[3], sF)); SMX_HIP(hipEventRecord(r->ev[4], sF)); SMX_HIP(hipEventRecord(r->ev[5], sF)); }
-  } else {
-    { SlotTimer t(r, sF, kSlotMergeDecide);
-      if (r->scan_mode) hipLaunchKernelGGL((k_merge_decide<false>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st);
-      else hipLaunchKernelGGL((k_merge_decide<true>), gl, b, 0, sF, r->S, c, r->sc, in.depth, in.normals, r->L, r->merge_flag, r->st); }
-    if (tm) { SMX_HIP(hipEventRecord(r->ev[3], sF)); SMX_HIP(hipEventRecord(r->ev[4], sF)); }
-    if (p->do_blending) {
-      // the reference's own sequence (2 clears + start + iterations, kernels.cc:165-205), in place on the caller's depth
-      SlotTimer t(r, sF, kSlotBlend);
-      SMX_HIP(hipMemsetAsync(r->bb.distance_map, 0, (size_t)P, sF));
-      SMX_HIP(hipMemsetAsync(r->bb.new_distance_map, 0, (size_t)P, sF));
-      hipLaunchKernelGGL(k_blend_start, gimg, b, 0, sF, ds, depth_rw, r->sc, r->bb, r->W, r->H);
-      for (int it = 2; it < p->measurement_blending_radius; ++it)
-        hipLaunchKernelGGL(k_blend_iter, gimg, b, 0, sF, it, term, ds, depth_rw, r->sc, r->bb, r->W, r->H);
-    }
-    if (tm) SMX_HIP(hipEventRecord(r->ev[5], sF));
+    hipLaunchKernelGGL(k_blend_tiles, dim3(n_blend), dim3(kBlendThreads), lds, sF, p->measurement_blending_radius, term, ds,
+                       in.depth, blended, r->sc, r->W, r->H, tiles_x, r->stamps ? r->stamps + 16 * 8192 : nullptr);
+  } else if (p->do_blending) {
+    // the reference's own sequence (2 clears + start + iterations, kernels.cc:165-205), in place on the caller's depth
+    SlotTimer t(r, sF, kSlotBlend);
+    SMX_HIP(hipMemsetAsync(r->bb.distance_map, 0, (size_t)P, sF));
+    SMX_HIP(hipMemsetAsync(r->bb.new_distance_map, 0, (size_t)P, sF));
+    hipLaunchKernelGGL(k_blend_start, gimg, b, 0, sF, ds, depth_rw, r->sc, r->bb, r->W, r->H);
+    for (int it = 2; it < p->measurement_blending_radius; ++it)
+      hipLaunchKernelGGL(k_blend_iter, gimg, b, 0, sF, it, term, ds, depth_rw, r->sc, r->bb, r->W, r->H);
   }
+  if (tm) SMX_HIP(hipEventRecord(r->ev[5], sF));
   // Which pixels spawn a surfel depends only on the association images and the blended depth: the flag + rank
-  // kernel of CreateNewSurfelsFUDA; with the fused blend it also stores the blended depths into the caller's buffer.
+  // kernel of CreateNewSurfelsCUDA; with the fused blend it also stores the blended depths into the caller's buffer.
   { SlotTimer t(r, sF, kSlotNewFlagsScan);
     hipLaunchKernelGGL(k_new_flags_scan, dim3(r->n_scan_blocks), b, 0, sF,
                        fused_blend ? Img<const uint16_t>{r->blended_depth, r->H, r->W, (size_t)r->W * sizeof(uint16_t)} : in.depth,
                        depth_rw, fused_blend ? 1 : 0, r->sc, r->W, r->H, r->new_flags, r->new_ranks, r->block_sums, r->st); }
   // Everything up to here only read P and N records; from here on they (and T, S) are written, so the previous
-  // call's regulariser has to be done.
-  if (pipelined && r->reg_pending) SMX_HIP(hipStreamWaitEvent(sC, r->ev_reg, 0));
-  if (tm) SMX_HIP(hipEventRecord(r->ev[6], sC));
-  { SlotTimer t(r, sC, kSlotIntegrate);
-    if (r->scan_mode) hipLaunchKernelGGL((k_integrate<false>), gl, b, 0, sC, r->S, c, r->sc, in, r->L, r->merge_flag, r->st);
-    else hipLaunchKernelGGL((k_integrate<true>), gl, b, 0, sC, r->S, c, r->sc, in, r->L, r->merge_flag, r->st); }
-  if (tm) { SMX_HIP(hipEventRecord(r->ev[7], sC)); SMX_HIP(hipEventRecord(r->ev[8], sC)); }
-  { SlotTimer t(r, sC, kSlotUpdateNeighbors);
+  // call's regulariser has to be done: it is, by stream order -- the rest of the call follows it on the internal stream.
+  if (pipelined) {
+    SMX_HIP(hipEventRecord(r->ev_front, sF));
+    SMX_HIP(hipStreamWaitEvent(sR, r->ev_front, 0));
+  }
+  if (tm) SMX_HIP(hipEventRecord(r->ev[6], sR));
+  { SlotTimer t(r, sR, kSlotIntegrate);
+    if (r->scan_mode) hipLaunchKernelGGL((k_integrate<false>), gl, b, 0, sR, r->S, c, r->sc, in, r->L, r->merge_flag, r->st);
+    else hipLaunchKernelGGL((k_integrate<true>), gl, b, 0, sR, r->S, c, r->sc, in, r->L, r->merge_flag, r->st); }
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[7], sR)); SMX_HIP(hipEventRecord(r->ev[8], sR)); }
+  { SlotTimer t(r, sR, kSlotUpdateNeighbors);
     CreateArgs ca;
     ca.flags = r->new_flags; ca.ranks = r->new_ranks; ca.block_sums = r->block_sums; ca.block_offsets_out = r->block_offsets;
     ca.n_scan_blocks = r->n_scan_blocks; ca.max_surfels = r->max_surfels; ca.flags8 = r->L.flags8; ca.dirty8 = r->L.dirty8;
-    ca.next_first_depth = r->sc_set[r->sc_cur ^ 1].first_depth; ca.next_vis_chunk_count = r->vis_count_set[r->sc_cur ^ 1];
+    ca.next_vis_chunk_count = r->vis_count_set[r->sc_cur ^ 1];
     ca.n_pixels = P; ca.hot_epoch = r->L.hot_epoch; ca.epoch = r->L.epoch; ca.hot_shift = r->L.hot_shift;
     const uint32_t ncb = (uint32_t)div_up(P, kBlock);
     const dim3 guc(ncb + (uint32_t)r->grid_list);
     const size_t lds = (size_t)r->n_scan_blocks * sizeof(uint32_t);
-    if (r->scan_mode) hipLaunchKernelGGL((k_update_and_create<false>), guc, b, lds, sC, r->S, c, r->sc, in, r->L, ca, ncb, r->st);
-    else hipLaunchKernelGGL((k_update_and_create<true>), guc, b, lds, sC, r->S, c, r->sc, in, r->L, ca, ncb, r->st); }
+    if (r->scan_mode) hipLaunchKernelGGL((k_update_and_create<false>), guc, b, lds, sR, r->S, c, r->sc, in, r->L, ca, ncb, r->st);
+    else hipLaunchKernelGGL((k_update_and_create<true>), guc, b, lds, sR, r->S, c, r->sc, in, r->L, ca, ncb, r->st); }
   // (the detach half of UpdateNeighborsCUDA runs fused into pass B below)
-  if (tm) { SMX_HIP(hipEventRecord(r->ev[9], sC)); SMX_HIP(hipEventRecord(r->ev[10], sC)); }
-  if (tm) { SMX_HIP(hipEventRecord(r->ev[11], sC)); SMX_HIP(hipEventRecord(r->ev[12], sC)); }
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[9], sR)); SMX_HIP(hipEventRecord(r->ev[10], sR)); }
+  if (tm) { SMX_HIP(hipEventRecord(r->ev[11], sR)); SMX_HIP(hipEventRecord(r->ev[12], sR)); }
   SMX_LAUNCH_CHECK();
-  r->next_set_ready = true;   // (k_update_and_create has prepared the other set of association images)
   int rc = SMX_OK;
   const int iters = p->regularization_iterations_per_integration_iteration;
   if (pipelined) {
-    // fork: the caller's stream is free again (its buffers have been consumed), the regulariser runs on the side
-    SMX_HIP(hipEventRecord(r->ev_mid, sC));
-    SMX_HIP(hipStreamWaitEvent(sR, r->ev_mid, 0));
+    // the input images are free from here on, and the map is ready for the next call's pass A: the caller's stream
+    // continues behind this point (a device-side wait; the host does not block)
+    SMX_HIP(hipEventRecord(r->ev_upd, sR));
+    SMX_HIP(hipStreamWaitEvent(sF, r->ev_upd, 0));
   }
-  // (smx_recon_integrate_hooks) the input images are free from here on; marked on the side so that the caller's stream
-  // carries one record per call, not two
+  // (smx_recon_integrate_hooks) marked on the side so that the caller's stream does not carry the record
   if (hook_consumed) SMX_HIP(hipEventRecord(hook_consumed, sR));
   if (iters == 0) {
     rc = enqueue_regularize(r, sR, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
@@ -2393,17 +2636,30 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   // (smx_recon_integrate_hooks) whatever this event covers is complete before the regulariser counts as complete,
   // i.e. before the second half of the next call and all of the call after it
   if (hook_chain) SMX_HIP(hipStreamWaitEvent(sR, hook_chain, 0));
-  if (pipelined) {
-    SMX_HIP(hipEventRecord(r->ev_reg, sR));
-    r->reg_pending = true;
-  }
+  if (pipelined) r->reg_pending = true;
   return SMX_OK;
 }
+
+#ifdef SMX_STAMPS
+int smx_recon_debug_download_stamps(smx_recon r, unsigned long long* out) {   // [2][8192][16]
+  SMX_CHECK_ARG(r != nullptr && out != nullptr && r->stamps != nullptr);
+  SMX_ON_DEVICE(r->device);
+  SMX_HIP(hipDeviceSynchronize());
+  SMX_HIP(hipMemcpy(out, r->stamps, sizeof(unsigned long long) * 2 * 16 * 8192, hipMemcpyDeviceToHost));
+  return SMX_OK;
+}
+#endif
 
 int smx_recon_integrate_hooks(smx_recon r, smx_event inputs_consumed, smx_event chain_after) {
   SMX_CHECK_ARG(r != nullptr);
   r->hook_consumed = (hipEvent_t)inputs_consumed;
   r->hook_chain = (hipEvent_t)chain_after;
+  return SMX_OK;
+}
+
+int smx_recon_integrate_inputs_ready(smx_recon r, smx_event inputs_ready) {
+  SMX_CHECK_ARG(r != nullptr);
+  r->hook_ready = (hipEvent_t)inputs_ready;
   return SMX_OK;
 }
 
@@ -2443,6 +2699,7 @@ int smx_recon_get_stats(smx_recon r, smx_stream s, smx_recon_stats* out) {
   out->n_window_edges = h.n_window_edges; out->n_contributors = h.n_contributors;
   out->n_segments_skipped = h.n_segments_skipped;
   out->regularizer_saturated = h.reg_saturated;
+  out->n_pairs = h.n_pairs; out->n_overflow_pairs = h.n_overflow_pairs; out->max_tile_pairs = h.max_tile_pairs;
   return SMX_OK;
 }
 

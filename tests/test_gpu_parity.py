@@ -228,7 +228,7 @@ def test_cuda_buffer_roundtrips(smx):
 
 
 # ---- full pipeline --------------------------------------------------------------------------
-@pytest.mark.parametrize("scan_mode", [0, 1, 2, 3, 4])   # (4: pass B without its hot-group filter)
+@pytest.mark.parametrize("scan_mode", [0, 1, 2, 3, 4, 8])   # (4: pass B without its hot-group filter; 8: association bins of 16 pairs, the rest through the overflow list)
 def test_stream_parity_every_frame(smx, scan_mode):
     s = small_stream(obstacle_until=10)               # vanishing obstacle -> conflicts and replacements
     po, pg = _pipes(smx, s, 60000, scan_mode=scan_mode)

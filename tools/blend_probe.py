@@ -22,5 +22,5 @@ for radius in (2, 3, 6, 9, 12, 17):
     for f in range(14, 24):
         pg.process(f, s.outlier_frames(f), s.others_TR_reference(f), s.pose(f))
         acc += np.array(rec.kernel_times_ms())
-    print('radius %2d: blend slot %.1f us, merge(+blend when fused) slot %.1f us, clear %.1f' % (radius, acc[names.index('blend')] * 100, acc[names.index('merge_decide')] * 100, acc[names.index('clear_assoc')] * 100))
+    print('radius %2d: blend slot %.1f us, association tiles %.1f us' % (radius, acc[names.index('blend')] * 100, acc[names.index('assoc_tiles')] * 100))
     pg.reconstruction.close()
