@@ -53,11 +53,10 @@ ALG_BYTES = {
     # association tiles: per pair (~1.9 per visible slot) 8 B + the slot's P and N records (32 B); per pixel the
     # measurement (10 B) and the five images written (24 B); the merge phase's supported-surfel records (32 B per visible slot)
     "assoc_tiles": lambda st, P: 1.9 * 40.0 * st["n_visible"] + 34.0 * P + 32.0 * st["n_visible"],
-    "integrate": lambda st, P: 160.0 * st["n_visible"],
+    "integrate+new_flags": lambda st, P: 160.0 * st["n_visible"] + 15.0 * P,
     "update_neighbors+create": lambda st, P: 190.0 * st["n_visible"] + 6.0 * P + 122.0 * st["n_new"],
     # blend tiles: depth + supporting per region cell (54 x 54 cells per 32 x 32 tile at radius 12) + the blended depth
     "blend": lambda st, P: 6.0 * (54.0 * 54.0 / 1024.0) * P + 2.0 * P,
-    "new_flags_scan": lambda st, P: 15.0 * P,
 }
 
 CONFIGS = {
@@ -437,8 +436,7 @@ def run_integrate(args):
 # kernel-slot name -> kernel name in rocprofv3 output
 SLOT_KERNEL = {"reg_accumulate": "k_reg_accumulate", "reg_step": "k_reg_step", "neighbor_scan": "k_neighbor_scan<true, true>",
                "scan_visible": "k_scan_visible", "assoc_tiles": "k_assoc_tiles", "blend": "k_blend_tiles",
-               "integrate": "k_integrate<true>", "update_neighbors+create": "k_update_and_create<true>",
-               "new_flags_scan": "k_new_flags_scan"}
+               "integrate+new_flags": "k_integrate<true>", "update_neighbors+create": "k_update_and_create<true>",}
 
 
 def pmc_file():

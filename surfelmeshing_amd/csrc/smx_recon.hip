@@ -259,6 +259,16 @@ __device__ __forceinline__ bool group_is_hot(uint32_t last, uint32_t epoch) { re
 #define SMX_STAMP(buf, k) do { } while (0)
 #endif
 
+// Segment of a workgroup in the all-slot kernels: the LAST segments first.  Slots are never reordered, so the segments
+// that do real work in a frame -- recently created or updated surfels -- sit at the end of the slot range, behind
+// thousands of segments whose workgroups return after a test; dispatched in ascending order the heavy workgroups start
+// last and the kernel ends with their latency chains.
+#ifdef SMX_NO_REVERSE
+__device__ __forceinline__ uint32_t segment_of_block() { return blockIdx.x; }
+#else
+__device__ __forceinline__ uint32_t segment_of_block() { return gridDim.x - 1u - blockIdx.x; }
+#endif
+
 // ---- association tiles ------------------------------------------------------------------------------------------
 // The per-pixel association state of a frame (z-buffer minimum, supporting surfel, count, depth sum, conflict key) is
 // built per image TILE in LDS by k_assoc_tiles instead of with device-scope atomics on five dense images: pass A
@@ -367,6 +377,7 @@ __global__ void k_reset_frame_stats(DevState* st) {   // (value-distribution cou
 // lane).  The z-buffer minimum itself (:1463) is formed by k_assoc_tiles from the pairs appended here.
 __global__ void __launch_bounds__(kBlock)
 k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, const uint8_t* __restrict__ flags_prev, DevState* st) {
+  const uint32_t seg_id = segment_of_block();
   __shared__ uint32_t wave_tot[kBlock / 64];
   __shared__ float box_part[kBlock / 64][8];
   __shared__ int skip_segment;
@@ -374,7 +385,7 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, const uint8_t* __res
   SMX_SETPRIO();
   const bool lds_tables = tb.n_tiles <= kMaxTilesLds;
   const uint32_t N = st->surfel_count;
-  const uint32_t base = blockIdx.x * kSeg;
+  const uint32_t base = seg_id * kSeg;
   if (base >= N) return;  // uniform per workgroup
   if (lds_tables)
     for (uint32_t k = threadIdx.x; k < tb.n_tiles; k += kBlock) tile_lds[k] = 0;   // (visible before the ranks are drawn: the barrier below)
@@ -385,10 +396,10 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, const uint8_t* __res
   // moved, restamped, merged or replaced).  If it is out of view and its newest stamp has left the regulariser
   // window, this frame's result for the segment is known without reading its 16 KB of P records: nothing visible,
   // no recent bit.
-  float* box = &L.seg_box[8 * (size_t)blockIdx.x];
+  float* box = &L.seg_box[8 * (size_t)seg_id];
   if (threadIdx.x == 0) {
     int skip = 0;
-    if (__float_as_uint(box[6]) == in_seg && L.vis_seg[blockIdx.x] == 0 &&
+    if (__float_as_uint(box[6]) == in_seg && L.vis_seg[seg_id] == 0 &&
         stamp_outside_window(__float_as_uint(box[7]), c.frame, c.reg_window)) {
       const Vec3 lo = {box[0], box[1], box[2]}, hi = {box[3], box[4], box[5]};
       skip = box_out_of_view(lo, hi, c) ? 1 : 0;
@@ -512,8 +523,8 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, const uint8_t* __res
       if (key[j] != kNoPair) pair_store(tb, key[j], i0 + (uint32_t)(j >> 1), atomicAdd(&tb.count[(key[j] >> 10) * kCountStride], 1u));
   }
   if (threadIdx.x == 0) {
-    L.vis_seg[blockIdx.x] = total;
-    emit_chunks(L.vis_chunks, blockIdx.x, total, kSeg / kBlock);
+    L.vis_seg[seg_id] = total;
+    emit_chunks(L.vis_chunks, seg_id, total, kSeg / kBlock);
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     int ns = (int)0x80000000;
     for (int w = 0; w < kBlock / 64; ++w) {
@@ -843,35 +854,39 @@ k_blend_iter(int it, float term, float ds, Img<uint16_t> depth, Scratch sc, Blen
 // Fused form of the whole BlendMeasurementsCUDA sequence (start kernel + radius-2 iteration kernels,
 // 13 launches in the reference incl. the clears): one launch, one workgroup per 32x32 pixel tile.  A ring of
 // BFS distance d depends only on pixels within d+1 of it, so a halo of radius-1 pixels makes the tile
-// interior exact; the depths and both delta maps of tile + halo live in LDS, the rings advance with one workgroup
-// barrier each, and only the interior depths are written back.
+// interior exact; the depths and both delta maps of tile + halo live in LDS and only the interior depths are written back.
 //
-// The two distance maps of the reference are kept as BIT MASKS, one 64-bit word per region row (the region is at most
-// 64 cells wide): the current frontier (cells assigned in the previous ring) and the cells still unassigned.  The cells a
-// ring assigns are `unassigned & dilate3x3(frontier)` -- three shifts and ORs per row -- and only those cells read their
-// neighbours' deltas, in the reference's window order; a ring costs what it changes instead of nine LDS reads for every
-// cell of the region (profiles/r04g: the ring loop was 47 of the old kernel's 66 us).
+// WHICH cells a ring assigns does not depend on the delta values: the two distance maps of the reference are breadth-
+// first fronts over three per-pixel predicates (no measurement / has a supporting surfel / evaluable).  So the fronts are
+// computed first, as BIT MASKS -- one 64-bit word per region row (the region is at most 64 cells wide), ring `it` =
+// `unassigned & dilate3x3(ring it - 1)`, three shifts and ORs per row -- by ONE wavefront with a lane per row, which
+// needs no barrier at all (the rows above and below come by lane shuffles).  The rings of delta values then follow with
+// one workgroup barrier each; a lane finds its cells of the ring in the precomputed masks and only those cells read
+// their neighbours' deltas, in the reference's window order.  A ring costs what it changes, not nine LDS reads for
+// every cell of the region (profiles/r04g: that ring loop was 47 of the old kernel's 66 us), and the loop ends with the
+// last non-empty ring.
 constexpr int kBlendTile = 32;
-constexpr int kBlendThreads = 1024;  // 64 region rows x 16 lanes, 4 cells per lane
+constexpr int kBlendThreads = 1024;
 constexpr int kBlendMaxHalo = 16;    // radius <= 17 uses this kernel (region <= 64 x 64), larger radii the multi-launch path
+constexpr int kBlendMaxRings = kBlendMaxHalo + 2;
 struct BlendMasks {
-  unsigned long long any[32];       // workgroup-wide OR, one word per use (ring): written before that ring's barrier, read after it
   unsigned long long zero[64];      // measured depth == 0 (or outside the image)
   unsigned long long supp[64];      // pixel has a supporting surfel
   unsigned long long elig[64];      // kBorder = 1 rule of both kernels (:576-577, :660-661) and not on the region rim
-  unsigned long long un_m[64];      // measurement-border map: cells at distance 255 (not reached yet)
-  unsigned long long un_n[64];      // surfel-border map: measured cells without a supporting surfel, not reached yet
-  unsigned long long fr_m[3][64];   // frontier (cells assigned by ring `it`) at [it % 3]
-  unsigned long long fr_n[3][64];
+  // cells whose distance is `it` in the measurement-border map (supported cells) / the surfel-border map; it = 1: the
+  // start kernel's border cells
+  unsigned long long ring_m[kBlendMaxRings][64];
+  unsigned long long ring_n[kBlendMaxRings][64];
+  int last_ring;                    // the highest non-empty ring (0: nothing to blend in tile + halo)
 };
 __device__ __forceinline__ unsigned long long dilate_row(unsigned long long m) { return m | (m << 1) | (m >> 1); }
-// __syncthreads_or with ONE barrier: every wavefront in which the predicate holds somewhere stores 1 to the word of this
-// use, then the barrier, then everybody reads it (the library's version takes three barriers and an LDS reduction; with 16
-// wavefronts and ten rings the barriers were most of the kernel).
-__device__ __forceinline__ bool block_any(unsigned long long* word, bool pred) {
-  if (__ballot(pred) != 0 && (threadIdx.x & 63) == 0) *word = 1;
-  __syncthreads();
-  return *word != 0;
+__device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v) {   // lane r gets lane r - 1's value, lane 0 gets 0
+  const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, 1), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1);
+  return (threadIdx.x & 63) == 0 ? 0ull : ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long shfl_down64(unsigned long long v) {   // lane r gets lane r + 1's value, lane 63 gets 0
+  const uint32_t lo = (uint32_t)__shfl_down((int)(uint32_t)v, 1), hi = (uint32_t)__shfl_down((int)(uint32_t)(v >> 32), 1);
+  return (threadIdx.x & 63) == 63 ? 0ull : ((unsigned long long)hi << 32) | lo;
 }
 
 __global__ void __launch_bounds__(kBlendThreads)
@@ -889,13 +904,13 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
   uint16_t* dep = reinterpret_cast<uint16_t*>(ndelta + cells);
   const int tile_x = (int)(blockIdx.x % (uint32_t)tiles_x), tile_y = (int)(blockIdx.x / (uint32_t)tiles_x);
   const int x0 = tile_x * kBlendTile - halo, y0 = tile_y * kBlendTile - halo;
-  // Loading: this lane's row and its four columns cg, cg + 16, cg + 32, cg + 48 (16 lanes read 16 consecutive cells).
+  // ---- load.  This lane's row and its four columns cg, cg + 16, cg + 32, cg + 48 (16 lanes read 16 consecutive cells):
+  // depth and "has a supporting surfel", all requested before the first use
   const int r = (int)(threadIdx.x >> 4), cg = (int)(threadIdx.x & 15);
   auto row_bits = [cg](uint32_t bits) -> unsigned long long {   // the lane's four bits at their columns of the row mask
     return ((unsigned long long)((bits & 1u) | ((bits & 2u) << 15)) << cg) |
            ((unsigned long long)(((bits >> 2) & 1u) | ((bits & 8u) << 13)) << (cg + 32));
   };
-  // ---- load: depth and "has a supporting surfel" of the lane's four cells (all requested before the first use)
   uint32_t dv[4], sv[4];
   bool inside[4];
 #pragma unroll
@@ -908,10 +923,7 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
   }
 #pragma unroll
   for (int b = 0; b < 4; ++b) { keep(dv[b]); keep(sv[b]); }
-  {
-    unsigned long long* mz = reinterpret_cast<unsigned long long*>(&M);
-    for (int k = threadIdx.x; k < (int)(sizeof(BlendMasks) / 8); k += kBlendThreads) mz[k] = 0;
-  }
+  if (threadIdx.x < 3 * 64) M.zero[threadIdx.x] = 0;   // (zero, supp, elig are adjacent)
   __syncthreads();
   SMX_STAMP(stamps, 1);
   uint32_t zb = 0, sb0 = 0, eb = 0;
@@ -933,84 +945,115 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
   if (eb) atomicOr(&M.elig[r], row_bits(eb));
   __syncthreads();
   SMX_STAMP(stamps, 2);
-  // ---- start kernel, :563-615 (decisions read the unmodified depths: the zero mask was formed from them)
-  // From here on FOUR wavefronts work (one per SIMD), a lane per quarter row: rr = its row, its cells the columns
-  // qq, qq + 4, qq + 8, ...  (Interleaved: the cells a ring assigns come in runs along a border, and a lane walks its
-  // set bits one after the other.)  Every lane of the other twelve wavefronts would form the same row masks again --
-  // at four cycles per wave instruction that redundancy, not the barriers, was most of a ring; they only join the barriers.
-  const bool ring_lane = threadIdx.x < 256;
-  const int rr = (int)(threadIdx.x >> 2), qq = (int)(threadIdx.x & 3);
-  const unsigned long long mine = 0x1111111111111111ull << qq;
-  bool started = false;
-  if (ring_lane && rr >= 1 && rr < rw - 1) {
-    const unsigned long long zu = M.zero[rr - 1], zr = M.zero[rr], zd = M.zero[rr + 1];
-    const unsigned long long su = M.supp[rr - 1], sr = M.supp[rr], sd = M.supp[rr + 1];
-    const unsigned long long el = M.elig[rr];
-    const unsigned long long cand = el & ~zr & sr;
-    const unsigned long long mb = cand & (dilate_row(zu) | dilate_row(zr) | dilate_row(zd)) & mine;            // a window cell without measurement
-    const unsigned long long sbm = cand & (dilate_row(~zu & ~su) | dilate_row(~zr & ~sr) | dilate_row(~zd & ~sd)) & mine;  // ... measured, without surfel
-    const unsigned long long un_m = cand & ~mb & mine, un_n = el & ~zr & ~sr & mine;
-    for (unsigned long long todo = mb | sbm; todo; todo &= todo - 1) {
-      const int col = __ffsll((long long)todo) - 1, k = rr * rw + col;
-      const size_t g = (size_t)(y0 + rr) * W + (x0 + col);
-      const float own = (float)dep[k];
-      const float avg = depth_sum_avg(sc, g);
-      if ((sbm >> col) & 1ull) ndelta[k] = avg - own / ds;
-      if ((mb >> col) & 1ull) {
-        delta[k] = avg - own / ds;
-        dep[k] = f2u16(ds * avg + 0.5f);  // :610
+  // ---- the fronts of both maps, by the first wavefront: lane = region row
+  if (threadIdx.x < 64) {
+    const int row = (int)threadIdx.x;
+    const unsigned long long z = M.zero[row], s = M.supp[row], e = M.elig[row];
+    const unsigned long long zu = shfl_up64(z), zd = shfl_down64(z), su = shfl_up64(s), sd = shfl_down64(s);
+    // start kernel, :563-615 (the decisions read the unmodified depths: so does the zero mask)
+    const unsigned long long cand = e & ~z & s;
+    unsigned long long fm = cand & (dilate_row(zu) | dilate_row(z) | dilate_row(zd));                      // a window cell without measurement
+    unsigned long long fn = cand & (dilate_row(~zu & ~su) | dilate_row(~z & ~s) | dilate_row(~zd & ~sd));  // ... measured, without surfel
+    unsigned long long un_m = cand & ~fm;      // distance 255: supported, not reached yet
+    unsigned long long un_n = e & ~z & ~s;     // measured cells without a supporting surfel, not reached yet
+    M.ring_m[1][row] = fm; M.ring_n[1][row] = fn;
+    int last = __ballot((fm | fn) != 0) != 0 ? 1 : 0;
+    // iteration kernels, :647-708.  Ring `it` is only needed (and only exact) up to halo - it pixels outside the
+    // tile, so the evaluated square shrinks by one pixel per ring.
+    if (last)
+      for (int it = 2; it < radius; ++it) {
+        const int lo = it, hi = rw - it;
+        const unsigned long long cm = (row >= lo && row < hi) ? ((1ull << (hi - lo)) - 1ull) << lo : 0ull;
+        const unsigned long long mu = shfl_up64(fm), md = shfl_down64(fm), nu = shfl_up64(fn), nd = shfl_down64(fn);
+        fm = un_m & (dilate_row(mu) | dilate_row(fm) | dilate_row(md)) & cm;
+        fn = un_n & (dilate_row(nu) | dilate_row(fn) | dilate_row(nd)) & cm;
+        un_m &= ~fm; un_n &= ~fn;
+        // a ring that assigned nothing leaves no frontier: all later rings are empty too
+        if (__ballot((fm | fn) != 0) == 0) break;
+        M.ring_m[it][row] = fm; M.ring_n[it][row] = fn;
+        last = it;
       }
-    }
-    if (mb) atomicOr(&M.fr_m[1][rr], mb);
-    if (sbm) atomicOr(&M.fr_n[1][rr], sbm);
-    if (un_m) atomicOr(&M.un_m[rr], un_m);
-    if (un_n) atomicOr(&M.un_n[rr], un_n);
-    started = (mb | sbm) != 0;
+    if (row == 0) M.last_ring = last;
   }
-  // no measurement / surfel border anywhere in tile + halo: the blend changes nothing here (dep = the input depths)
-  const bool any_start = block_any(&M.any[1], started);
+  __syncthreads();
   SMX_STAMP(stamps, 3);
-  if (any_start) {
-    // ---- iteration kernels, :647-708.  Ring `it` is only needed (and only exact) up to halo - it pixels outside
-    // the tile, so the evaluated square shrinks by one pixel per ring.
-    for (int it = 2; it < radius; ++it) {
-      const float f = (float)(it - 1) * term;
-      const int cur = (it - 1) % 3, nxt = it % 3, clr = (it + 1) % 3;
-      const int lo = it, hi = rw - it;
-      bool assigned = false;
-      if (ring_lane && rr >= lo && rr < hi) {
-        const unsigned long long cm = (((1ull << (hi - lo)) - 1ull) << lo) & mine;
-        const unsigned long long mu = M.fr_m[cur][rr - 1], mc = M.fr_m[cur][rr], md = M.fr_m[cur][rr + 1];
-        const unsigned long long nu = M.fr_n[cur][rr - 1], nc = M.fr_n[cur][rr], nd = M.fr_n[cur][rr + 1];
-        const unsigned long long reach_m = M.un_m[rr] & (dilate_row(mu) | dilate_row(mc) | dilate_row(md)) & cm;
-        const unsigned long long reach_n = M.un_n[rr] & (dilate_row(nu) | dilate_row(nc) | dilate_row(nd)) & cm;
-        // (a cell belongs to one map only -- supported cells to the measurement-border map, unsupported ones to the
-        // surfel-border map -- so one code path serves both)
-        for (unsigned long long todo = reach_m | reach_n; todo; todo &= todo - 1) {
-          const int col = __ffsll((long long)todo) - 1, k = rr * rw + col;
-          const bool second = ((reach_n >> col) & 1ull) != 0;
-          const unsigned long long fu = second ? nu : mu, fc = second ? nc : mc, fd = second ? nd : md;
-          float* dl = second ? ndelta : delta;
-          float delta_sum = 0; int count = 0;
+  const int last_ring = M.last_ring;
+  // no measurement / surfel border anywhere in tile + halo: the blend changes nothing here (dep = the input depths)
+  if (last_ring >= 1) {
+    // From here on a lane owns the cells (r0 + 16 j, 4 cq + j), j = 0..3: four different rows and columns, so that the
+    // cells of one ring -- runs along a border, horizontal or vertical -- spread over as many lanes as possible (a lane
+    // walks its cells of a ring one after the other).
+    const int r0 = (int)(threadIdx.x >> 4), cq = (int)(threadIdx.x & 15);
+    // start kernel: the border cells' deltas from the association sums
+    {
+      uint32_t hit_m = 0, hit_n = 0;
 #pragma unroll
-          for (int wy = -1; wy <= 1; ++wy) {
-            const unsigned long long fw = wy < 0 ? fu : wy == 0 ? fc : fd;
-#pragma unroll
-            for (int wx = -1; wx <= 1; ++wx)
-              if ((fw >> (col + wx)) & 1ull) { delta_sum += dl[k + wy * rw + wx]; ++count; }
-          }
-          const float avg = delta_sum / (float)count;   // (count > 0: the cell is in the frontier's dilation)
-          dl[k] = avg;
-          dep[k] = f2u16((float)dep[k] + (ds * (1 - f) * avg + 0.5f));  // :681 / :704
-        }
-        if (reach_m) { atomicOr(&M.fr_m[nxt][rr], reach_m); atomicAnd(&M.un_m[rr], ~reach_m); }
-        if (reach_n) { atomicOr(&M.fr_n[nxt][rr], reach_n); atomicAnd(&M.un_n[rr], ~reach_n); }
-        assigned = (reach_m | reach_n) != 0;
+      for (int j = 0; j < 4; ++j) {
+        const int R = (r0 + 16 * j) & 63, C = 4 * cq + j;
+        hit_m |= (uint32_t)((M.ring_m[1][R] >> C) & 1ull) << j;
+        hit_n |= (uint32_t)((M.ring_n[1][R] >> C) & 1ull) << j;
       }
-      if (ring_lane && qq == 0) { M.fr_m[clr][rr] = 0; M.fr_n[clr][rr] = 0; }   // (last read one ring ago, next written one ring ahead)
-      // a ring that assigned nothing leaves no frontier: all later rings are empty too
-      if (!block_any(&M.any[it], assigned)) break;
+      if (hit_m | hit_n) {
+        long long bs[4]; uint32_t bc[4];   // depth sum and count of the lane's border cells, requested together
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int R = (r0 + 16 * j) & 63, C = 4 * cq + j;
+          const bool need = ((hit_m | hit_n) & (1u << j)) != 0;
+          const size_t g = need ? (size_t)(y0 + R) * W + (x0 + C) : (size_t)0;
+          bs[j] = sc.depth_sums[g]; bc[j] = sc.counts[g];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { keep((uint32_t)bs[j]); keep((uint32_t)(bs[j] >> 32)); keep(bc[j]); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (!((hit_m | hit_n) & (1u << j))) continue;
+          const int R = (r0 + 16 * j) & 63, C = 4 * cq + j, k = R * rw + C;
+          const float own = (float)dep[k];
+          const float avg = q_to_float(bs[j]) / (float)bc[j];   // depth_sum_avg
+          if (hit_n & (1u << j)) ndelta[k] = avg - own / ds;
+          if (hit_m & (1u << j)) {
+            delta[k] = avg - own / ds;
+            dep[k] = f2u16(ds * avg + 0.5f);  // :610
+          }
+        }
+      }
     }
+    for (int it = 2; it <= last_ring; ++it) {
+      __syncthreads();   // the deltas of ring it - 1 are complete
+      const float f = (float)(it - 1) * term;
+      uint32_t hit_m = 0, hit_n = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int R = (r0 + 16 * j) & 63, C = 4 * cq + j;
+        hit_m |= (uint32_t)((M.ring_m[it][R] >> C) & 1ull) << j;
+        hit_n |= (uint32_t)((M.ring_n[it][R] >> C) & 1ull) << j;
+      }
+      // (a cell belongs to one map only -- supported cells to the measurement-border map, unsupported ones to the
+      // surfel-border map -- so one code path serves both)
+      for (uint32_t todo = hit_m | hit_n; todo; todo &= todo - 1) {
+        const int j = __ffs((int)todo) - 1;
+        const int R = (r0 + 16 * j) & 63, C = 4 * cq + j, k = R * rw + C;
+        const bool second = (hit_n >> j) & 1u;
+        const unsigned long long* fr = second ? M.ring_n[it - 1] : M.ring_m[it - 1];
+        float* dl = second ? ndelta : delta;
+        const unsigned long long fu = fr[R - 1], fc = fr[R], fd = fr[R + 1];
+        // the nine neighbours' deltas, read unconditionally (no branch per window cell) and added in the reference's
+        // window order where the neighbour belongs to the previous ring
+        float w[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) w[q] = dl[k + (q / 3 - 1) * rw + (q % 3 - 1)];
+        float delta_sum = 0; int count = 0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          const unsigned long long fw = q < 3 ? fu : q < 6 ? fc : fd;
+          if ((fw >> (C + q % 3 - 1)) & 1ull) { delta_sum += w[q]; ++count; }
+        }
+        const float avg = delta_sum / (float)count;   // (count > 0: the cell is in the previous ring's dilation)
+        dl[k] = avg;
+        dep[k] = f2u16((float)dep[k] + (ds * (1 - f) * avg + 0.5f));  // :681 / :704
+      }
+    }
+    __syncthreads();
   }
   SMX_STAMP(stamps, 4);
   for (int k = threadIdx.x; k < kBlendTile * kBlendTile; k += kBlendThreads) {
@@ -1019,6 +1062,87 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
     if (x < W && y < H) out(y, x) = dep[(ty + halo) * rw + (tx + halo)];
   }
   SMX_STAMP(stamps, 5);
+}
+
+// ---------------------------------------------------------------------------------------------
+// CreateNewSurfelsCUDA, kernels.cc:37-146.  The u8 flag kernel (kernels.cu:90-111), the CUB
+// exclusive scan (kernels.cu:2506-2520) and the two D2H count reads are replaced by:
+//   k_new_flags_scan  flags + block-local exclusive ranks (wave64 ballot/popcount + LDS),
+//   k_new_create      scan of the <= a few hundred block totals (redundantly per workgroup; workgroup 0 advances
+//                     the device-side count) + the creation kernel (kernels.cu:133-231).
+constexpr int kScanPxPerThread = 4;
+constexpr int kScanPxPerBlock = kBlock * kScanPxPerThread;
+
+// With copy_back the blended depths (k_merge_and_blend's output) are stored into the caller's depth buffer on the way --
+// Integrate mutates its depth argument like the reference (kernels.cu:610, 681, 704) -- and used for the flags.
+struct NewFlagsArgs {
+  Img<const uint16_t> depth; Img<uint16_t> depth_out; int copy_back;
+  uint8_t* flags; uint32_t* local_rank; uint32_t* block_sums;
+};
+__device__ __forceinline__ void new_flags_scan_body(const NewFlagsArgs& a, const Scratch& sc, int W, int H, DevState* st, uint32_t block) {
+  const Img<const uint16_t>& depth = a.depth;
+  const Img<uint16_t>& depth_out = a.depth_out;
+  const int copy_back = a.copy_back;
+  uint8_t* __restrict__ flags = a.flags;
+  uint32_t* __restrict__ local_rank = a.local_rank;
+  uint32_t* __restrict__ block_sums = a.block_sums;
+  __shared__ uint32_t wave_tot[kBlock / 64];
+  const int P = W * H;
+  const int k0 = (block * kBlock + threadIdx.x) * kScanPxPerThread;
+  uint32_t f[kScanPxPerThread];
+  uint32_t mine = 0;
+  // (all loads of the lane first: written as `d > 0 && supporting == .. && key == ..` per pixel they come one by one)
+  uint32_t dv[kScanPxPerThread], sv[kScanPxPerThread], cv[kScanPxPerThread];
+#pragma unroll
+  for (int j = 0; j < kScanPxPerThread; ++j) {
+    const int k = min(k0 + j, P - 1);
+    const int y = k / W, x = k - y * W;
+    dv[j] = depth(y, x); sv[j] = sc.supporting[k]; cv[j] = sc.confl_key[k];
+  }
+#pragma unroll
+  for (int j = 0; j < kScanPxPerThread; ++j) { keep(dv[j]); keep(sv[j]); keep(cv[j]); }
+#pragma unroll
+  for (int j = 0; j < kScanPxPerThread; ++j) {
+    const int k = k0 + j;
+    bool fl = false;
+    if (k < P) {
+      const int y = k / W, x = k - y * W;
+      const uint16_t d = (uint16_t)dv[j];
+      if (copy_back) depth_out(y, x) = d;
+      fl = x >= 1 && y >= 1 && x < W - 1 && y < H - 1 && d > 0 && sv[j] == kInvalid && cv[j] == kInvalid;
+      flags[k] = fl ? 1 : 0;
+    }
+    f[j] = fl ? 1u : 0u;
+    mine += f[j];
+  }
+  // wave-level inclusive scan of per-lane counts
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off);
+    if (lane >= (uint32_t)off) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t wave_off = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    if ((uint32_t)w < wave) wave_off += wave_tot[w];
+    total += wave_tot[w];
+  }
+  uint32_t run = wave_off + incl - mine;
+#pragma unroll
+  for (int j = 0; j < kScanPxPerThread; ++j) {
+    const int k = k0 + j;
+    if (k < P) local_rank[k] = run;
+    run += f[j];
+  }
+  if (threadIdx.x == 0) {
+    block_sums[block] = total;
+    // (not create_base itself: the previous frame's pass B may still be reading that one)
+    if (block == 0) st->create_base_next = st->surfel_count;  // stable until k_new_create's workgroup 0 adds the new slots
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1138,17 +1262,24 @@ __device__ __forceinline__ void integrate_or_conflict(SurfelRegs& R, const Frame
   }
 }
 
+// The launch is shared with the flag + rank pass of CreateNewSurfelsCUDA (the first n_flag_blocks workgroups): both only
+// need the front of the frame (association images, blended depth) and neither reads what the other writes -- the
+// integration reads the blended depths from `in.depth`, which is the blend's own output image when the flag pass is the
+// one that stores them back into the caller's buffer -- and a launch of its own for 300 small workgroups cost the front
+// chain its 11 us plus a launch boundary.
 template <bool kUseList>
 __global__ void __launch_bounds__(kBlock)
 k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
-            uint8_t* __restrict__ merge_flag, DevState* st) {
+            uint8_t* __restrict__ merge_flag, DevState* st, NewFlagsArgs nf, uint32_t n_flag_blocks) {
+  if (blockIdx.x < n_flag_blocks) { new_flags_scan_body(nf, sc, c.W, c.H, st, blockIdx.x); return; }
+  const uint32_t block = blockIdx.x - n_flag_blocks, n_blocks = gridDim.x - n_flag_blocks;
   const uint32_t n_scan = kUseList ? 0u : st->surfel_count;
   uint32_t merged_here = 0;
   uint32_t desc;
-  const uint32_t n_steps = walk_begin<kUseList>(L.vis_chunks, n_scan, blockIdx.x, desc);
-  for (uint32_t w = blockIdx.x; w < n_steps; w += gridDim.x) {
+  const uint32_t n_steps = walk_begin<kUseList>(L.vis_chunks, n_scan, block, desc);
+  for (uint32_t w = block; w < n_steps; w += n_blocks) {
     const uint32_t cur = desc;
-    desc = walk_next<kUseList>(L.vis_chunks, w + gridDim.x, n_steps);   // (the next step's descriptor travels while this one is worked on)
+    desc = walk_next<kUseList>(L.vis_chunks, w + n_blocks, n_steps);   // (the next step's descriptor travels while this one is worked on)
     uint32_t i;
     if (!walk_entry<kUseList>(L.vis_list, cur, w, n_scan, threadIdx.x, i)) continue;
     if (merge_flag[i]) {
@@ -1295,79 +1426,7 @@ __device__ __forceinline__ void update_neighbors_body(const Surfels& S, const Fr
 }
 
 // ---------------------------------------------------------------------------------------------
-// CreateNewSurfelsCUDA, kernels.cc:37-146.  The u8 flag kernel (kernels.cu:90-111), the CUB
-// exclusive scan (kernels.cu:2506-2520) and the two D2H count reads are replaced by:
-//   k_new_flags_scan  flags + block-local exclusive ranks (wave64 ballot/popcount + LDS),
-//   k_new_create      scan of the <= a few hundred block totals (redundantly per workgroup; workgroup 0 advances
-//                     the device-side count) + the creation kernel (kernels.cu:133-231).
-constexpr int kScanPxPerThread = 4;
-constexpr int kScanPxPerBlock = kBlock * kScanPxPerThread;
-
-// With copy_back the blended depths (k_merge_and_blend's output) are stored into the caller's depth buffer on the way --
-// Integrate mutates its depth argument like the reference (kernels.cu:610, 681, 704) -- and used for the flags.
-__global__ void __launch_bounds__(kBlock)
-k_new_flags_scan(Img<const uint16_t> depth, Img<uint16_t> depth_out, int copy_back, Scratch sc, int W, int H,
-                 uint8_t* __restrict__ flags, uint32_t* __restrict__ local_rank, uint32_t* __restrict__ block_sums,
-                 DevState* st) {
-  __shared__ uint32_t wave_tot[kBlock / 64];
-  const int P = W * H;
-  const int k0 = (blockIdx.x * kBlock + threadIdx.x) * kScanPxPerThread;
-  uint32_t f[kScanPxPerThread];
-  uint32_t mine = 0;
-  // (all loads of the lane first: written as `d > 0 && supporting == .. && key == ..` per pixel they come one by one)
-  uint32_t dv[kScanPxPerThread], sv[kScanPxPerThread], cv[kScanPxPerThread];
-#pragma unroll
-  for (int j = 0; j < kScanPxPerThread; ++j) {
-    const int k = min(k0 + j, P - 1);
-    const int y = k / W, x = k - y * W;
-    dv[j] = depth(y, x); sv[j] = sc.supporting[k]; cv[j] = sc.confl_key[k];
-  }
-#pragma unroll
-  for (int j = 0; j < kScanPxPerThread; ++j) { keep(dv[j]); keep(sv[j]); keep(cv[j]); }
-#pragma unroll
-  for (int j = 0; j < kScanPxPerThread; ++j) {
-    const int k = k0 + j;
-    bool fl = false;
-    if (k < P) {
-      const int y = k / W, x = k - y * W;
-      const uint16_t d = (uint16_t)dv[j];
-      if (copy_back) depth_out(y, x) = d;
-      fl = x >= 1 && y >= 1 && x < W - 1 && y < H - 1 && d > 0 && sv[j] == kInvalid && cv[j] == kInvalid;
-      flags[k] = fl ? 1 : 0;
-    }
-    f[j] = fl ? 1u : 0u;
-    mine += f[j];
-  }
-  // wave-level inclusive scan of per-lane counts
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t incl = mine;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t t = __shfl_up(incl, off);
-    if (lane >= (uint32_t)off) incl += t;
-  }
-  if (lane == 63) wave_tot[wave] = incl;
-  __syncthreads();
-  uint32_t wave_off = 0, total = 0;
-#pragma unroll
-  for (int w = 0; w < kBlock / 64; ++w) {
-    if ((uint32_t)w < wave) wave_off += wave_tot[w];
-    total += wave_tot[w];
-  }
-  uint32_t run = wave_off + incl - mine;
-#pragma unroll
-  for (int j = 0; j < kScanPxPerThread; ++j) {
-    const int k = k0 + j;
-    if (k < P) local_rank[k] = run;
-    run += f[j];
-  }
-  if (threadIdx.x == 0) {
-    block_sums[blockIdx.x] = total;
-    // (not create_base itself: the previous frame's pass B may still be reading that one)
-    if (blockIdx.x == 0) st->create_base_next = st->surfel_count;  // stable until k_new_create's workgroup 0 adds the new slots
-  }
-}
-
+// (creation, second half: the flag + rank pass of CreateNewSurfelsCUDA is further up, next to the launch it shares)
 struct CreateArgs {
   const uint8_t* flags; const uint32_t* ranks; const uint32_t* block_sums; uint32_t* block_offsets_out;
   int n_scan_blocks; uint32_t max_surfels; uint8_t* flags8; uint8_t* dirty8;
@@ -1500,6 +1559,7 @@ template <bool kDetach, bool kAccumulate>
 __global__ void __launch_bounds__(kBlockB)
 k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict__ inwin8, uint32_t* __restrict__ need_seg,
                 DevState* st) {
+  const uint32_t seg_id = segment_of_block();
   extern __shared__ __align__(16) uint8_t lhot[];   // the hot-group table (n_hot_groups bytes, padded to 16)
   // B1: pure streaming.  Per slot: detach (:1430-1433), which of its neighbours lie inside the regulariser
   // window (4-bit mask -> inwin8), membership in the recent list.  No LDS accumulators here, so the
@@ -1507,7 +1567,7 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
   __shared__ uint32_t wave_tot[kBlockB / 64];
   __shared__ __attribute__((aligned(4))) uint8_t lflags[kSegB];  // the segment's own flag bytes
   const uint32_t N = st->surfel_count;
-  const uint32_t base = blockIdx.x * kSegB;
+  const uint32_t base = seg_id * kSegB;
   if (base >= N) return;
   // The reference detaches BEFORE it creates new surfels (kernels.cc:333-339 precedes cc:264-286), so
   // slots created in this frame keep links to flagged surfels until the next frame.
@@ -1579,9 +1639,9 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
     if (recent_bits & (1u << j)) L.recent_list[off++] = i0 + j;
   const int any = __syncthreads_or(need);
   if (threadIdx.x == 0) {
-    L.recent_seg[blockIdx.x] = total;
-    emit_chunks(L.rec_chunks, blockIdx.x, total, kSegB / kBlock);
-    if (kAccumulate) need_seg[blockIdx.x] = (any || total) ? 1u : 0u;  // k_reg_accumulate also serves recent slots
+    L.recent_seg[seg_id] = total;
+    emit_chunks(L.rec_chunks, seg_id, total, kSegB / kBlock);
+    if (kAccumulate) need_seg[seg_id] = (any || total) ? 1u : 0u;  // k_reg_accumulate also serves recent slots
     if (stats && total) atomicAdd(&st->recent_count, total);
   }
 }
@@ -1610,13 +1670,14 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
                  long long* __restrict__ grad_local, float4* __restrict__ inbox,
                  const uint8_t* __restrict__ inwin8, const uint8_t* __restrict__ flags8,
                  const uint32_t* __restrict__ need_seg, DevState* st, uint32_t epoch) {
+  const uint32_t seg_id = segment_of_block();
   __shared__ unsigned long long lacc[kSegAcc * 2];  // per target: (gx | gy), (gz | sender classes)
   const uint32_t N = st->surfel_count;
-  const uint32_t base = blockIdx.x * kSegAcc;
+  const uint32_t base = seg_id * kSegAcc;
   if (base >= N) return;
   uint32_t need = 0;
 #pragma unroll
-  for (int k = 0; k < kSegAcc / kSegB; ++k) need |= need_seg[blockIdx.x * (kSegAcc / kSegB) + k];
+  for (int k = 0; k < kSegAcc / kSegB; ++k) need |= need_seg[seg_id * (kSegAcc / kSegB) + k];
   if (!need) return;
 #pragma unroll
   for (int k = 0; k < kSegAcc * 2 / kBlockAcc; ++k) lacc[k * kBlockAcc + threadIdx.x] = 0;
@@ -2160,13 +2221,13 @@ struct smx_recon_s {
 // kernel slots of one Integrate call (launch order)
 enum : int {
   kSlotScanVisible = 0, kSlotAssocTiles, kSlotBlend, kSlotIntegrate,
-  kSlotUpdateNeighbors, kSlotNewFlagsScan, kSlotNeighborScan,
+  kSlotUpdateNeighbors, kSlotNeighborScan,
   kSlotRegAccumulate, kSlotRegStep,
   kSlotRegUpdate, kSlotCount
 };
 static const char* const kSlotNames[kSlotCount] = {
-  "scan_visible", "assoc_tiles", "blend", "integrate", "update_neighbors+create",
-  "new_flags_scan", "neighbor_scan", "reg_accumulate", "reg_step", "reg_update"};
+  "scan_visible", "assoc_tiles", "blend", "integrate+new_flags", "update_neighbors+create",
+  "neighbor_scan", "reg_accumulate", "reg_step", "reg_update"};
 
 struct SlotTimer {
   smx_recon r; hipStream_t st; int slot; bool kev, prof;
@@ -2581,12 +2642,15 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
       hipLaunchKernelGGL(k_blend_iter, gimg, b, 0, sF, it, term, ds, depth_rw, r->sc, r->bb, r->W, r->H);
   }
   if (tm) SMX_HIP(hipEventRecord(r->ev[5], sF));
-  // Which pixels spawn a surfel depends only on the association images and the blended depth: the flag + rank
-  // kernel of CreateNewSurfelsCUDA; with the fused blend it also stores the blended depths into the caller's buffer.
-  { SlotTimer t(r, sF, kSlotNewFlagsScan);
-    hipLaunchKernelGGL(k_new_flags_scan, dim3(r->n_scan_blocks), b, 0, sF,
-                       fused_blend ? Img<const uint16_t>{r->blended_depth, r->H, r->W, (size_t)r->W * sizeof(uint16_t)} : in.depth,
-                       depth_rw, fused_blend ? 1 : 0, r->sc, r->W, r->H, r->new_flags, r->new_ranks, r->block_sums, r->st); }
+  // Which pixels spawn a surfel depends only on the association images and the blended depth: the flag + rank pass of
+  // CreateNewSurfelsCUDA rides in the integration launch below; with the fused blend it also stores the blended depths
+  // into the caller's buffer, and the integration kernel reads them from the blend's output image.
+  NewFlagsArgs nf;
+  nf.depth = fused_blend ? Img<const uint16_t>{r->blended_depth, r->H, r->W, (size_t)r->W * sizeof(uint16_t)} : in.depth;
+  nf.depth_out = depth_rw; nf.copy_back = fused_blend ? 1 : 0;
+  nf.flags = r->new_flags; nf.local_rank = r->new_ranks; nf.block_sums = r->block_sums;
+  FrameIn in_integrate = in;
+  in_integrate.depth = nf.depth;
   // Everything up to here only read P and N records; from here on they (and T, S) are written, so the previous
   // call's regulariser has to be done: it is, by stream order -- the rest of the call follows it on the internal stream.
   if (pipelined) {
@@ -2595,8 +2659,10 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   }
   if (tm) SMX_HIP(hipEventRecord(r->ev[6], sR));
   { SlotTimer t(r, sR, kSlotIntegrate);
-    if (r->scan_mode) hipLaunchKernelGGL((k_integrate<false>), gl, b, 0, sR, r->S, c, r->sc, in, r->L, r->merge_flag, r->st);
-    else hipLaunchKernelGGL((k_integrate<true>), gl, b, 0, sR, r->S, c, r->sc, in, r->L, r->merge_flag, r->st); }
+    const uint32_t nfb = (uint32_t)r->n_scan_blocks;
+    const dim3 gi(nfb + (uint32_t)r->grid_list);
+    if (r->scan_mode) hipLaunchKernelGGL((k_integrate<false>), gi, b, 0, sR, r->S, c, r->sc, in_integrate, r->L, r->merge_flag, r->st, nf, nfb);
+    else hipLaunchKernelGGL((k_integrate<true>), gi, b, 0, sR, r->S, c, r->sc, in_integrate, r->L, r->merge_flag, r->st, nf, nfb); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[7], sR)); SMX_HIP(hipEventRecord(r->ev[8], sR)); }
   { SlotTimer t(r, sR, kSlotUpdateNeighbors);
     CreateArgs ca;
