@@ -262,7 +262,6 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="skip the full-size GPU-vs-oracle check")
     ap.add_argument("--no-overlap", action="store_true", help="A/B: no frame pipelining inside Integrate")
     ap.add_argument("--run-ahead", action="store_true", help="A/B: preprocessing two steps ahead, waits routed off the caller's stream")
-    ap.add_argument("--bilateral-variant", type=int, default=0, help="A/B: 1 = one tap per instruction")
     ap.add_argument("--scan-mode", type=int, default=0, help="A/B: smx_recon_set_scan_mode bits (1 = all-slot scans, 2 = multi-launch blend, 4 = no hot-group filter in pass B)")
     ap.add_argument("--dry-run", action="store_true", help="rank path only (no GPU, gloo): see the module docstring")
     ap.add_argument("--quiet", action="store_true")
@@ -314,9 +313,14 @@ def run_integrate(args):
     if log:
         print("# grown to %d live surfels in %d frames, %.1fs" % (n_live, g_end, time.time() - t0), file=sys.stderr)
 
-    # timed window: re-traverse the start of the trajectory (mapped area) with new frame indices
+    # timed window: re-traverse the start of the trajectory (mapped area) with new frame indices.  The first SETTLE frames
+    # of the re-traversal are untimed whatever --warmup says: the regulariser window (30 frames) and the integration
+    # window still hold the end of the growth phase when it begins, and a short warm-up would time a different regime
+    # (round 2: 4144 frames/s at --steps 20 --warmup 5 against 3873 at --steps 300 --warmup 20).
     first = g_end + 10
     cal, reps = 10, 20
+    SETTLE = 64
+    W_user, W = W, W + SETTLE
     total = W + cal + K
     do_host = args.host_frames if (rank == 0 and world == 1) else 0   # PCIe-inclusive pass: rank 0 at N = 1 only
     for j in range(-4, total + 1 + reps + do_host + 4):
@@ -328,8 +332,6 @@ def run_integrate(args):
     rec.set_stats_enabled(False)   # the distribution counters are single-address atomics: off while timing
     if args.run_ahead:
         wl.pipe.set_run_ahead(True)
-    if args.bilateral_variant:
-        _lib.check(_lib.load().smx_debug_set_bilateral_variant(args.bilateral_variant))
     if args.scan_mode:
         rec.set_scan_mode(args.scan_mode)
     wl.pipe.run_array(*wl.steps(plan[:W]))
@@ -339,10 +341,15 @@ def run_integrate(args):
     rec.set_timing_enabled(2)
     names = rec.kernel_time_names()
     cal_ms = np.zeros(len(names))
-    for j in range(W, W + cal):
+    for j in range(W, W + cal - 1):
         wl.pipe.run_array(*wl.steps(plan[j:j + 1]))
         cal_ms += np.array(rec.kernel_times_ms())
     rec.set_timing_enabled(0)
+    # value distributions of the frame in front of the timed window (counters on for this frame only)
+    rec.set_stats_enabled(True)
+    wl.pipe.run_array(*wl.steps(plan[W + cal - 1:W + cal]))
+    st_before = rec.stats()
+    rec.set_stats_enabled(False)
     rec.set_overlap(not args.no_overlap)
     dominant = names[int(np.argmax(cal_ms))]
     api.StreamSynchronize(None)
@@ -404,7 +411,7 @@ def run_integrate(args):
     result = {
         "metric": "RGB-D frames/s integrated @640x480, 5M live surfels; achieved HBM GB/s" if args.config == "C2" else
                   "RGB-D frames/s integrated @%dx%d, %dM surfel cap; achieved HBM GB/s" % (width, height, target_live // 1000000),
-        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W_user,
         "ms_per_step": 1e3 * elapsed / K, "host_enqueue_ms_per_step": 1e3 * enqueue_local / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: synthetic room stream %dx%d, full preprocessing + Integrate per frame, "
@@ -412,6 +419,9 @@ def run_integrate(args):
                                (args.config, width, height, live, st["surfels_size"]),
                    "max_surfel_count": cap, "streams": world, "parallelism": "1 independent stream per GPU"},
         "distributions": st,
+        "steady_state": {"settle_frames": SETTLE, "note": "untimed frames of the re-traversal in front of --warmup",
+                         "frame_before_timed_window": {k: st_before[k] for k in ("surfels_size", "n_visible", "n_recent", "n_new")},
+                         "frame_after_timed_window": {k: st[k] for k in ("surfels_size", "n_visible", "n_recent", "n_new")}},
         "stage_ms": dict(zip(["data_association", "surfel_merging", "measurement_blending", "integration",
                               "neighbor_update", "new_surfel_creation", "regularization"], [float(x) for x in stage_ms])),
         "reference_model_bytes_per_frame": ref_bytes,
@@ -421,7 +431,7 @@ def run_integrate(args):
 
     if rank == 0:
         result["roofline"] = roofline_block(st, P, dominant, dom_ms, dom_n, dict(zip(names, [float(x) for x in kernel_ms])),
-                                            1e3 * elapsed / K)
+                                            1e3 * elapsed / K, args.config)
         result["roofline_valu"] = bilateral_valu_roofline(wl, api, torch, plan[0][0])
         if host_pass is not None:
             result["host_frames"] = host_pass
@@ -439,13 +449,15 @@ SLOT_KERNEL = {"reg_accumulate": "k_reg_accumulate", "reg_step": "k_reg_step", "
                "integrate+new_flags": "k_integrate<true>", "update_neighbors+create": "k_update_and_create<true>",}
 
 
-def pmc_file():
-    """The committed rocprofv3 --pmc summary of this same command (profiles/pmc_traffic.json, written by
+def pmc_file(config="C2"):
+    """The committed rocprofv3 --pmc summary of this same command (profiles/pmc_traffic[_C3|_C5].json, written by
     tools/pmc_summary.py through tools/profile_round.sh, which stamps it with the hash of the kernel sources it was
-    collected on).  A file collected on other sources is REFUSED: (None, reason)."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    collected on and with the counts of the PMC runs themselves).  A file collected on other sources is REFUSED:
+    (None, reason)."""
+    name = "pmc_traffic.json" if config == "C2" else "pmc_traffic_%s.json" % config
+    path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
-        return None, "no profiles/pmc_traffic.json"
+        return None, "no profiles/" + name
     try:
         d = json.load(open(path))
     except (ValueError, OSError) as e:
@@ -465,7 +477,7 @@ def pmc_bytes(k):
     return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
 
 
-def roofline_block(st, P, dominant, dom_ms, dom_n, kernel_ms, ms_per_step):
+def roofline_block(st, P, dominant, dom_ms, dom_n, kernel_ms, ms_per_step, config="C2"):
     """Roofline of the dominant Integrate kernel: algorithmic bytes per launch (ALG_BYTES) / average launch
     duration measured with HIP events on the launch stream over the timed region; `frame` = all kernels of one frame
     (PMC bytes of the committed profile of the same build) / the measured frame time."""
@@ -477,7 +489,7 @@ def roofline_block(st, P, dominant, dom_ms, dom_n, kernel_ms, ms_per_step):
             b = ALG_BYTES[k](st, P)
             # the per-kernel pass brackets every launch with two event records (~6 us of overhead per kernel)
             per_kernel[k] = {"ms_with_event_overhead": ms, "algorithmic_MB": b / 1e6}
-    pmc, why = pmc_file()
+    pmc, why = pmc_file(config)
     traffic = raw = frame = None
     if pmc is not None:
         at = pmc.get("_meta", {}).get("surfel_slots")
@@ -486,8 +498,13 @@ def roofline_block(st, P, dominant, dom_ms, dom_n, kernel_ms, ms_per_step):
     if pmc is not None:
         k = pmc.get(SLOT_KERNEL.get(dominant, ""), {})
         traffic = pmc_bytes(k)
+        # like for like: the algorithmic bytes of the PMC run's own counts (its window differs from this run's)
+        own = pmc.get("_meta", {}).get("distributions_of_the_pmc_run") or {}
+        alg_own = ALG_BYTES[dominant](own, P) if all(x in own for x in ("surfels_size", "n_visible", "n_recent", "n_edges")) else None
         raw = {"FETCH_SIZE_KB": k.get("FETCH_SIZE"), "WRITE_SIZE_KB": k.get("WRITE_SIZE"),
-               "collected_at_surfel_slots": pmc.get("_meta", {}).get("surfel_slots")}
+               "collected_at_surfel_slots": pmc.get("_meta", {}).get("surfel_slots"),
+               "algorithmic_bytes_of_the_pmc_run": alg_own,
+               "traffic_over_algorithmic": (traffic / alg_own) if (traffic and alg_own) else None}
         total = sum(b for b in (pmc_bytes(v) for n, v in pmc.items() if n != "_meta") if b)
         frame = {"pmc_bytes_per_frame": total, "GBs": total / (ms_per_step * 1e-3) / 1e9,
                  "frac": total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -763,6 +780,24 @@ def run_c5(args):
     query_batch()
     t_batch = timed(query_batch, 2)
     build_bytes = 12.0 * n + 8.0 * n + 16.0 * info["n_bricks"]
+    # committed PMC profile of this command (profiles/pmc_traffic_C5.json): HBM traffic and the VALU issue-slot utilisation
+    c5_traffic = c5_valu = None
+    pmc, c5_why = pmc_file("C5")
+    if pmc is not None and pmc.get("_meta", {}).get("surfel_slots") != n:
+        pmc, c5_why = None, "collected at %s points, this run has %d" % (pmc.get("_meta", {}).get("surfel_slots"), n)
+    if pmc is not None:
+        k = pmc.get("k_query_lanes", {})
+        c5_traffic = pmc_bytes(k)
+        if "SQ_INSTS_VALU" in k:
+            # one wave64 VALU instruction occupies a SIMD for 4 cycles: a CU issues at most one per cycle
+            peak = 256 * 2.4e9
+            rate = k["SQ_INSTS_VALU"] / (ms_step * 1e-3)
+            c5_valu = {"bound": "valu-issue", "kernel": "k_query_lanes", "valu_wave_instructions_per_launch": k["SQ_INSTS_VALU"],
+                       "salu_wave_instructions_per_launch": k.get("SQ_INSTS_SALU"), "waves_per_launch": k.get("SQ_WAVES"),
+                       "valu_wave_instructions_per_query": k["SQ_INSTS_VALU"] / n,
+                       "achieved": rate / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s", "frac": rate / peak,
+                       "note": "SQ_INSTS_VALU of the committed PMC pass / this run's step time; peak = 256 CUs x 1 VALU "
+                               "wave-instruction per cycle x 2.4 GHz"}
     result = {
         "metric": "radius-neighbor queries/s, every one of 50M surfels queries its own neighbourhood, K=64 (BASELINE.json configs[4])",
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": ms_step,
@@ -773,11 +808,14 @@ def run_c5(args):
         "distributions": {"n_points": n, "n_bricks": info["n_bricks"], "grid_cells": info["dim"], "key_bits": info["key_bits"],
                           "mean_results": float(cnt1.mean()), "max_results": int(cnt1.max()), "tiles": st1["tiles"],
                           "staged_candidates_per_query": st1["staged_candidates"] / n, "distance_tests_per_query": st1["distance_tests"] / n},
-        "roofline": {"bound": "hbm", "kernel": "k_query_tiles<true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bytes_per_query * n,
+        "roofline": {"bound": "hbm", "kernel": "k_query_lanes", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": c5_traffic, "traffic_refused": c5_why,
+                     "algorithmic_bytes_per_launch": bytes_per_query * n,
                      "algorithmic_bytes_per_query": bytes_per_query, "avg_launch_ms": ms_step,
-                     "note": "one launch per step: the step time is the kernel time; the kernel is bound by cross-lane "
-                             "top-K insertion (VALU / DPP), not by bytes -- see DESIGN.md"},
+                     "note": "one step = k_query_lanes over all tiles (+ k_query_tiles, which returns at once unless a tile "
+                             "was marked for it): the step time is the kernel time; the kernel is bound by VALU issue, "
+                             "not by bytes -- roofline_valu, DESIGN.md"},
+        "roofline_valu": c5_valu,
         "index_build": {"ms": 1e3 * t_build, "algorithmic_bytes": build_bytes, "GBs": build_bytes / t_build / 1e9,
                         "frac": build_bytes / t_build / 1e9 / HBM_PEAK_GBS, "note": "12 N read + 8 N written + 16 B per occupied brick"},
         "radius_x2": {"queries_per_s": n / t_2r, "ms": 1e3 * t_2r, "mean_results": float(cnt2.mean()), "max_results": int(cnt2.max())},

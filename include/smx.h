@@ -76,7 +76,9 @@ int smx_stream_destroy(smx_stream s);
 int smx_stream_synchronize(smx_stream s);
 /* Events for cross-stream ordering (hipEvent_t, timing disabled): the frame driver overlaps depth
  * preprocessing of the next frame with the integration of the current one, as APP/main.cc overlaps uploads
- * (main.cc:902, 995). */
+ * (main.cc:902, 995).  An smx_event orders the streams of ONE device: it is created with a device-scope release
+ * (hipEventReleaseToDevice), so work behind it is visible to kernels and copies of that GPU; it is not meant to be
+ * waited for by the host or by another GPU (use smx_stream_synchronize for the host). */
 typedef void* smx_event;
 int smx_event_create(smx_event* out);
 int smx_event_destroy(smx_event e);
@@ -109,9 +111,6 @@ int smx_bilateral_filtering_and_depth_cutoff(
     smx_stream s, float sigma_xy, float sigma_value_factor, uint16_t value_to_ignore,
     float radius_factor, uint16_t max_depth, float depth_valid_region_radius,
     const smx_buffer_desc* input_depth /*u16*/, const smx_buffer_desc* output_depth /*u16*/);
-/* A/B switch (process-wide; same results): 0 = the filter forms two taps' weights per packed instruction (default),
- * 1 = one tap per instruction. */
-int smx_debug_set_bilateral_variant(int32_t variant);
 /* OutlierDepthMapFusionCUDA<count,u16>, both overloads (cu:229-285 and :399-455):
  * other_count = count-1 in {2,4,6,8}; required_count < 0 selects the
  * all-must-agree overload.  others_TR_reference: other_count row-major 3x4. */
@@ -201,10 +200,11 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
 int smx_recon_destroy(smx_recon r);
 /* Integrate, .h:59-77 / .cc:112-320.  depth is MUTATED by blending as in the
  * reference; global_T_local is row-major 3x4 (SE3f::matrix3x4()).
- * frame_index must not decrease from call to call (the reference's caller counts frames up, APP/main.cc:1015;
- * stamps are compared with it in windows, kernels.cu:77-87, 2132): pass A keeps, per 1024-slot segment, the newest
- * stamp it has seen and skips segments whose stamps have left the regulariser window, which presumes that time
- * moves forward.  A call with a smaller frame_index than the previous one is rejected (SMX_ERR_INVALID_ARGUMENT).
+ * frame_index normally counts up from call to call (the reference's caller does, APP/main.cc:1015; stamps are compared
+ * with it in windows, kernels.cu:77-87, 2132): pass A keeps, per 1024-slot segment, the newest stamp it has seen and
+ * skips segments whose stamps have left the regulariser window, which presumes that time moves forward.  A call with a
+ * smaller frame_index than the previous one is accepted like in the reference: it drops that cache (the call reads
+ * every segment again) and costs one stream join.
  * measurement_blending_radius is only read (and range-checked, 2..255) when do_blending != 0. */
 int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float depth_scaling,
                         const smx_buffer_desc* depth /*u16*/, const smx_buffer_desc* normals /*float2*/,

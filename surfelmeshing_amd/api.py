@@ -658,10 +658,12 @@ class SurfelNeighborIndex:
     def FindNearestOfIndexedPoints(self, n_points, max_result_count, radius_squared=None, factor=1.0, state=None,
                                    skip_mask=0, stream=None):
         """Every indexed point queries its own neighbourhood (smx_nn_query_self): r^2 = factor * radius_squared[i], or
-        r^2 = factor for all if radius_squared is None.  n_points = the number of points given to Build.  Returns
+        r^2 = factor for all if radius_squared is None.  n_points (optional check) = the number of points given to Build.  Returns
         (counts [n], dist2 [n,K], indices [n,K]); device staging is allocated here (the C entry point takes device
         pointers only)."""
-        n, k = int(n_points), int(max_result_count)
+        n, k = int(self.stats()["n_points"]), int(max_result_count)   # (the C entry point writes one row per point of the BUILD)
+        if n_points is not None and int(n_points) != n:
+            raise ValueError("n_points = %d, but the index was built over %d points" % (int(n_points), n))
         didx, dd2, dcnt = CUDABuffer(1, n * k, np.uint32), CUDABuffer(1, n * k, np.float32), CUDABuffer(1, n, np.int32)
         dr2 = dst = None
         if radius_squared is not None:

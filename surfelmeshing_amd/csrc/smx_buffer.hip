@@ -42,13 +42,9 @@ __global__ void k_fill(T* __restrict__ base, size_t pitch, int width, int height
 // tools/prof_summary.py can cut out the timed region of a benchmark run.
 __global__ void k_smx_marker(int id) { (void)id; }
 
-namespace smx { int g_exp_timed_region = 0; }   // EXPERIMENT (timing only): markers 1 / 2 delimit bench.py's timed region
-
 extern "C" {
 
 int smx_debug_marker(smx_stream s, int32_t id) {
-  if (id == 1) smx::g_exp_timed_region = 1;
-  if (id == 2) smx::g_exp_timed_region = 0;
   hipLaunchKernelGGL(k_smx_marker, dim3(1), dim3(64), 0, (hipStream_t)s, (int)id);
   SMX_LAUNCH_CHECK();
   return SMX_OK;

@@ -5,6 +5,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "smx_common.hpp"
 
 using namespace smx;
@@ -21,14 +23,15 @@ constexpr int kThreads = 256;
 // loads; the spatial exponent term -(dx^2+dy^2)/(2 sigma_xy^2) depends only on the tap offset and is
 // tabulated once per workgroup (same IEEE division, so the results are unchanged).  Out-of-image taps are
 // masked by coordinates, exactly like the reference's clamped loop bounds.
+// (per device: one process may drive several GPUs, one object and one host thread each)
 static int device_cu_count() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-              ? prop.multiProcessorCount : 256;
-  }
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+  if (dev >= 0 && dev < 64) { const int c = cache[dev].load(std::memory_order_relaxed); if (c > 0) return c; }
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+  if (dev >= 0 && dev < 64) cache[dev].store(cus, std::memory_order_relaxed);
   return cus;
 }
 
@@ -120,63 +123,6 @@ __device__ __forceinline__ float det_expf_nonpositive(float x) {
   return (x < -86.0f) ? 0.0f : e;
 }
 
-template <int R>
-__global__ void __launch_bounds__(kThreads)
-k_bilateral_r(float denom_xy, float sigma_value_factor, uint16_t value_to_ignore, uint16_t max_depth, float region_r2,
-              Img<const uint16_t> in, Img<uint16_t> out, int tiles_x, int n_tiles) {
-  constexpr int TW = kBilTileW + 2 * R, TH = kBilTileH + 2 * R;
-  __shared__ uint16_t tile[TH * TW];
-  __shared__ float spatial[R * R + 1];
-  const int W = out.width, H = out.height;
-  for (int g2 = threadIdx.x; g2 <= R * R; g2 += kThreads) spatial[g2] = (float)(-g2) / denom_xy;
-  __syncthreads();
-  float sp[R * R + 1];  // (constant indices after unrolling: the entries in use live in registers)
-#pragma unroll
-  for (int g2 = 0; g2 <= R * R; ++g2) sp[g2] = spatial[g2];
-  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const int bx = t % tiles_x, by = t / tiles_x;
-    __syncthreads();  // (the previous tile's readers are done)
-    const int x0 = bx * kBilTileW - R, y0 = by * kBilTileH - R;
-    for (int i = threadIdx.x; i < TW * TH; i += kThreads) {
-      const int ty = i / TW, tx = i - ty * TW;
-      const int gx = x0 + tx, gy = y0 + ty;
-      // cells outside the image read as "ignore": the reference's clamped loop bounds never visit them
-      tile[i] = (gx >= 0 && gy >= 0 && gx < W && gy < H) ? in(gy, gx) : value_to_ignore;
-    }
-    __syncthreads();
-    const int lx = threadIdx.x & (kBilTileW - 1), ly = threadIdx.x / kBilTileW;
-    const int x = bx * kBilTileW + lx, y = by * kBilTileH + ly;
-    if (x >= W || y >= H) continue;
-    const unsigned half_w = (unsigned)(W / 2), half_h = (unsigned)(H / 2);
-    const unsigned dxc = (unsigned)x - half_w, dyc = (unsigned)y - half_h;
-    const float center_distance_squared = (float)(dxc * dxc + dyc * dyc);
-    if (center_distance_squared > region_r2) { out(y, x) = value_to_ignore; continue; }
-    const uint16_t* tc = &tile[(ly + R) * TW + (lx + R)];
-    const uint16_t center_value = tc[0];
-    if (center_value == value_to_ignore || center_value > max_depth) { out(y, x) = value_to_ignore; continue; }
-    const float adapted_sigma_value = (float)center_value * sigma_value_factor;
-    const float adapted_denom_value = 2.0f * adapted_sigma_value * adapted_sigma_value;
-    const float inv_denom_value = 1.0f / adapted_denom_value;
-    float sum = 0, weight = 0;
-    const float fcenter = (float)center_value;
-#pragma unroll
-    for (int dy = -R; dy <= R; ++dy) {
-#pragma unroll
-      for (int dx = -R; dx <= R; ++dx) {
-        if (dx * dx + dy * dy > R * R) continue;  // (compile time)
-        const uint16_t sample = tc[dy * TW + dx];
-        const float fsample = (float)sample;
-        float vd = fcenter - fsample;   // == (float)((int)center - (int)sample): integers below 2^16, the difference is exact
-        vd *= vd;
-        float w = det_expf_nonpositive(sp[dx * dx + dy * dy] + (-vd) * inv_denom_value);
-        w = (sample == value_to_ignore) ? 0.0f : w;
-        sum += w * fsample;
-        weight += w;
-      }
-    }
-    out(y, x) = (weight == 0) ? value_to_ignore : f2u16(sum / weight + 0.5f);
-  }
-}
 
 // The same filter with two taps per instruction.  Alone on the chip the kernel above runs at the VALU issue limit
 // (23 instructions per tap, one wavefront per SIMD issuing back to back), so the way to make it cheaper is fewer
@@ -707,14 +653,6 @@ inline dim3 grid_rows(int W, int H) { return dim3(div_up(W, kTileW), div_up(H, k
 
 extern "C" {
 
-// A/B switch (process-wide, results identical): 0 = two taps per instruction (k_bilateral_p), 1 = k_bilateral_r
-static int g_bilateral_variant = 0;
-int smx_debug_set_bilateral_variant(int32_t variant) {
-  SMX_CHECK_ARG(variant == 0 || variant == 1);
-  g_bilateral_variant = variant;
-  return SMX_OK;
-}
-
 int smx_bilateral_filtering_and_depth_cutoff(
     smx_stream s, float sigma_xy, float sigma_value_factor, uint16_t value_to_ignore,
     float radius_factor, uint16_t max_depth, float depth_valid_region_radius,
@@ -726,19 +664,15 @@ int smx_bilateral_filtering_and_depth_cutoff(
   const int tiles_x = div_up(output_depth->width, kBilTileW), n_tiles = tiles_x * div_up(output_depth->height, kBilTileH);
   // Two workgroups per CU: the filter is ALU-bound and runs beside the surfel kernels (preprocessing of the next
   // frame overlaps Integrate); a launch that floods every CU slows those down more than it gains here.
-  static const int max_blocks = 2 * device_cu_count();
+  const int max_blocks = 2 * device_cu_count();
   const dim3 grid(n_tiles < max_blocks ? n_tiles : max_blocks);
   const float denom_xy = 2.0f * sigma_xy * sigma_xy, region_r2 = depth_valid_region_radius * depth_valid_region_radius;
   const Img<const uint16_t> src = as_img<const uint16_t>(input_depth);
   const Img<uint16_t> dst = as_img<uint16_t>(output_depth);
 #define SMX_BILATERAL(R)                                                                                          \
   case R:                                                                                                         \
-    if (g_bilateral_variant == 0)                                                                                 \
-      hipLaunchKernelGGL(k_bilateral_p<R>, grid, dim3(kThreads), 0, (hipStream_t)s, denom_xy, sigma_value_factor, \
-                         value_to_ignore, max_depth, region_r2, src, dst, tiles_x, n_tiles);                      \
-    else                                                                                                          \
-      hipLaunchKernelGGL(k_bilateral_r<R>, grid, dim3(kThreads), 0, (hipStream_t)s, denom_xy, sigma_value_factor, \
-                         value_to_ignore, max_depth, region_r2, src, dst, tiles_x, n_tiles);                      \
+    hipLaunchKernelGGL(k_bilateral_p<R>, grid, dim3(kThreads), 0, (hipStream_t)s, denom_xy, sigma_value_factor,   \
+                       value_to_ignore, max_depth, region_r2, src, dst, tiles_x, n_tiles);                        \
     break
   switch (radius) {
     SMX_BILATERAL(1); SMX_BILATERAL(2); SMX_BILATERAL(3); SMX_BILATERAL(4);

@@ -291,24 +291,34 @@ static int preprocess_ahead(smx_driver d, const smx_driver_step& step, WorkSet**
 // therefore routed through the reconstruction's internal stream (smx_recon_integrate_hooks): "work set free again"
 // is recorded there, and its completion mark for step i -- which Integrate(i + 1) waits for anyway -- also waits for
 // the preprocessing of step i + 2.  Steps 0 and 1 of a call wait on the caller's stream as before.
+// A step failed with work sets preprocessed but not integrated: bring the driver back to a state from which the next
+// run or upload is correct whatever it touches -- everything enqueued so far completes, no work set or frame counts as
+// in flight any more.
+static int abandon_run(smx_driver d, smx_stream s, int rc) {
+  (void)smx_recon_integrate_hooks(d->reconstruction.handle(), nullptr, nullptr);
+  (void)smx_recon_integrate_inputs_ready(d->reconstruction.handle(), nullptr);
+  (void)smx_stream_synchronize(d->pre_stream);
+  (void)smx_stream_synchronize(s);
+  d->work0.used = d->work1.used = d->work2.used = false;
+  for (auto& f : d->frames) f.second->last_reader = 0;
+  return rc;
+}
+
 static int run_ahead(smx_driver d, smx_stream s, const smx_driver_step* steps, int32_t n) {
   WorkSet* ring[3] = {nullptr, nullptr, nullptr};
   int rc;
   for (int i = 0; i < n && i < 2; ++i)
-    if ((rc = preprocess_ahead(d, steps[i], &ring[i % 3])) != SMX_OK) return rc;
+    if ((rc = preprocess_ahead(d, steps[i], &ring[i % 3])) != SMX_OK) return abandon_run(d, s, rc);
   for (int i = 0; i < n; ++i) {
     smx_event chain = nullptr;
     if (i + 2 < n) {
-      if ((rc = preprocess_ahead(d, steps[i + 2], &ring[(i + 2) % 3])) != SMX_OK) return rc;
+      if ((rc = preprocess_ahead(d, steps[i + 2], &ring[(i + 2) % 3])) != SMX_OK) return abandon_run(d, s, rc);
       chain = ring[(i + 2) % 3]->preprocessed;
     }
     WorkSet* ws = ring[i % 3];
     if (i < 2) SMX_SHIM_CHECK(smx_stream_wait_event(s, ws->preprocessed));
     SMX_SHIM_CHECK(smx_recon_integrate_hooks(d->reconstruction.handle(), ws->integrated, chain));
-    if ((rc = integrate_frame(d, s, steps[i], ws)) != SMX_OK) {
-      (void)smx_recon_integrate_hooks(d->reconstruction.handle(), nullptr, nullptr);
-      return rc;
-    }
+    if ((rc = integrate_frame(d, s, steps[i], ws)) != SMX_OK) return abandon_run(d, s, rc);
     ws->used = true;
     d->prev = d->last;
     d->last = ws;

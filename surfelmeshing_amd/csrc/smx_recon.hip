@@ -32,7 +32,6 @@
 #include "smx_common.hpp"
 
 using namespace smx;
-namespace smx { extern int g_exp_timed_region; }
 
 namespace {
 
@@ -248,11 +247,6 @@ __device__ __forceinline__ bool group_is_hot(uint32_t last, uint32_t epoch) { re
 
 // Phase stamps inside a kernel (builds with -DSMX_STAMPS only; tools/stamps.py): lane 0 of every workgroup stores the
 // shader clock at marked points, the host averages the differences.
-#ifdef SMX_PRIO
-#define SMX_SETPRIO() __builtin_amdgcn_s_setprio(SMX_PRIO)
-#else
-#define SMX_SETPRIO() do { } while (0)
-#endif
 #ifdef SMX_STAMPS
 #define SMX_STAMP(buf, k) do { if ((buf) && threadIdx.x == 0) (buf)[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -289,7 +283,6 @@ struct TileBins {
   uint32_t cap;
   int tiles_x;
   uint32_t n_tiles;
-  int exp;   // EXPERIMENT switch (timing only)
 };
 
 // Pass A appends its pairs (<= 8 per lane: 4 slots x 2 pixels; key = tile << 10 | code, kNoPair = none) with ONE
@@ -382,7 +375,6 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, const uint8_t* __res
   __shared__ float box_part[kBlock / 64][8];
   __shared__ int skip_segment;
   extern __shared__ uint32_t tile_lds[];   // [n_tiles] pairs of this workgroup per tile, [n_tiles] base of its run in the tile's bin
-  SMX_SETPRIO();
   const bool lds_tables = tb.n_tiles <= kMaxTilesLds;
   const uint32_t N = st->surfel_count;
   const uint32_t base = seg_id * kSeg;
@@ -696,7 +688,6 @@ k_assoc_tiles(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<
               uint32_t* __restrict__ next_ovf_count, uint8_t* __restrict__ merge_flag, DevState* st,
               unsigned long long* stamps) {
   __shared__ TileLds t;
-  SMX_SETPRIO();
   SMX_STAMP(stamps, 0);
   const uint32_t tile = blockIdx.x, lane = threadIdx.x;
   const int x = (int)(tile % (uint32_t)tb.tiles_x) * kTileW + (int)(lane % kTileW);
@@ -893,7 +884,6 @@ __global__ void __launch_bounds__(kBlendThreads)
 k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<uint16_t> out, Scratch sc, int W, int H,
               int tiles_x, unsigned long long* stamps) {
   extern __shared__ __align__(16) unsigned char blend_lds[];
-  SMX_SETPRIO();
   SMX_STAMP(stamps, 0);
   const int halo = radius - 1;
   const int rw = kBlendTile + 2 * halo;          // region width == height (<= 64)
@@ -2166,7 +2156,6 @@ struct smx_recon_s {
   TileBins tb;              // pass A's pairs, binned by association tile
   uint32_t* ovf_count_set[2];   // overflow counters, alternating by call (the tile kernel zeroes the next call's)
   unsigned long long* stamps;   // -DSMX_STAMPS builds: [2][8192 workgroups][16] shader clocks (tile kernel, blend kernel)
-  int exp_env;              // EXPERIMENT switch from the environment, active inside bench.py's timed region only
   uint32_t bin_cap_full;    // the bins' allocated capacity (tb.cap is lowered by the A/B switch that forces overflows)
   uint32_t* vis_count_set[2];   // chunk counters of the visible list, alternating by call (k_update_and_create zeroes the next call's)
   int sc_cur;
@@ -2398,7 +2387,6 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->tb.count, (size_t)r->tb.n_tiles * kCountStride, true));
   SMX_TRY(dev_alloc(&r->tb.ovf, 2 * (size_t)r->S.pitch + 64, false));
   r->tb.ovf_count = r->ovf_count_set[0];
-  r->exp_env = getenv("SMX_EXP") ? atoi(getenv("SMX_EXP")) : 0;
 #ifdef SMX_STAMPS
   SMX_TRY(dev_alloc(&r->stamps, (size_t)2 * 16 * 8192, true));
 #endif
@@ -2548,12 +2536,17 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   SMX_CHECK_ARG(radius->width == r->W && radius->height == r->H && color->width == r->W && color->height == r->H);
   // (the radius is only read when blending is on: do_blending is an independent flag, APP/main.cc:348-354)
   SMX_CHECK_ARG(!p->do_blending || (p->measurement_blending_radius >= 2 && p->measurement_blending_radius <= 255));
+  hipStream_t st = (hipStream_t)s;
   if (r->have_frame && (int32_t)(frame_index - r->last_frame) < 0) {
-    set_error("frame_index %u after %u: Integrate must be called with non-decreasing frame indices", frame_index, r->last_frame);
-    return SMX_ERR_INVALID_ARGUMENT;
+    // Time moves backwards (a sequence replayed on a live object, a loop-closure re-integration): the reference accepts
+    // any index.  What presumes forward time here is derived state only -- the segments' newest-stamp cache behind
+    // pass A's culling and the hot-group table behind pass B's filter -- so it is dropped: this call reads every segment.
+    { const int rcj = join_regularizer(r, st); if (rcj != SMX_OK) return rcj; }
+    SMX_HIP(hipMemsetAsync(r->L.vis_seg, 0, (size_t)r->nseg * 4, st));
+    SMX_HIP(hipMemsetAsync(r->L.seg_box, 0, (size_t)r->nseg * 8 * sizeof(float), st));
+    r->hot_holdoff = 3;
   }
   r->have_frame = true; r->last_frame = frame_index;
-  hipStream_t st = (hipStream_t)s;
   FrameCtx c;
   memcpy(c.G.m, global_T_local, sizeof(float) * 12);
   c.L = se3_inverse(global_T_local);  // cc:144
@@ -2607,7 +2600,6 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   r->sc_cur ^= 1;
   r->L.vis_chunks.count = r->vis_count_set[r->sc_cur];
   r->tb.ovf_count = r->ovf_count_set[r->sc_cur];
-  r->tb.exp = smx::g_exp_timed_region ? r->exp_env : 0;
   { SlotTimer t(r, sF, kSlotScanVisible);
     const size_t lds = r->tb.n_tiles <= kMaxTilesLds ? (size_t)r->tb.n_tiles * 8 : 0;
     hipLaunchKernelGGL(k_scan_visible, gs, b, lds, sF, r->S, c, r->L, r->tb, flags_prev, r->st);

@@ -643,6 +643,92 @@ def test_streams_with_priority_and_explicit_stream(smx):
     st.close()
 
 
+def test_two_objects_on_two_host_threads(smx):
+    """The 8-GPU code path minus the other seven GPUs: two host threads, each with its own native frame
+    driver (reconstruction object, streams, work sets) and its own synthetic stream, run CONCURRENTLY on the one GPU;
+    both maps equal the oracle's.  Shakes out state shared between objects (there must be none)."""
+    import threading
+    from surfelmeshing_amd.pipeline import NativeFramePipeline
+    from surfelmeshing_amd._lib import IntegrateParams
+    frames = list(range(4, 24))
+    jobs = []
+    for seed, until in ((1, 8), (7, 12)):
+        s = small_stream(obstacle_until=until, seed=seed)
+        pre = small_pre(s.width)
+        po = OraclePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, 60000, pre)
+        pn = NativeFramePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, 60000, pre, IntegrateParams.defaults())
+        for f in range(0, 28):
+            d, c = s.frame(f)
+            po.upload(f, d, c)
+            pn.upload(f, d, c)
+        steps = []
+        for f in frames:
+            others, T, pose = s.outlier_frames(f), s.others_TR_reference(f), s.pose(f)
+            po.process(f, others, T, pose)
+            steps.append(pn.make_step(f, others, T, pose))
+        jobs.append((po, pn, steps))
+    smx.StreamSynchronize(None)
+    errors = []
+
+    def work(pn, steps):
+        try:
+            st = smx.Stream()
+            pn.stream = st
+            for rep in range(3):                      # several enqueue calls per thread, interleaving with the other one
+                pn.run(steps[rep * 7:(rep + 1) * 7] if rep < 2 else steps[14:])
+            st.synchronize()
+            pn.stream = None
+            st.close()
+        except Exception as e:                         # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(pn, steps)) for _, pn, steps in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for po, pn, _ in jobs:
+        n = po.recon.surfels_size
+        assert n > 5000 and pn.reconstruction.surfels_size() == n
+        assert_surfels_match(pn.reconstruction.debug_download_surfels(n), po.recon.surfels(), n)
+    assert jobs[0][0].recon.surfels_size != jobs[1][0].recon.surfels_size   # (two different streams)
+
+
+def test_frame_index_may_decrease(smx):
+    """A sequence replayed on a live object (frame indices jump back): accepted like in the reference, same state as
+    the oracle -- the segment / hot-group caches that presume forward time are dropped for that call."""
+    s = small_stream(obstacle_until=8)
+    po, pg = _pipes(smx, s, 60000, params_kw=dict(regularization_frame_window_size=4))
+    run_both(po, pg, s, list(range(4, 16)), None)
+    _compare_state(po, pg)
+    run_both(po, pg, s, [8, 9, 10, 5, 6, 30], lambda f: _compare_state(po, pg))
+
+
+def test_get_timings_are_consistent(smx):
+    """GetTimings (cc:409-436): seven stage times of the last Integrate call; every stage that ran takes measurable
+    time, the sum is below the wall time of the call, and the per-kernel slots cover the same kernels."""
+    import time
+    s = small_stream(obstacle_until=8)
+    po, pg = _pipes(smx, s, 60000)
+    run_both(po, pg, s, list(range(4, 12)), None)
+    rec = pg.reconstruction
+    rec.set_timing_enabled(3)
+    smx.StreamSynchronize(None)
+    t0 = time.perf_counter()
+    run_both(po, pg, s, [12], None)
+    t = rec.GetTimings()
+    wall_ms = 1e3 * (time.perf_counter() - t0)
+    assert len(t) == 7 and all(x >= 0 for x in t)
+    assert t[0] > 0.001 and t[3] > 0.001 and t[4] > 0.001 and t[6] > 0.001, t    # association, integration, neighbours, regulariser
+    assert sum(t) < wall_ms, (t, wall_ms)
+    k = dict(zip(rec.kernel_time_names(), rec.kernel_times_ms()))
+    for name in ("scan_visible", "assoc_tiles", "blend", "integrate+new_flags", "update_neighbors+create", "neighbor_scan",
+                 "reg_accumulate", "reg_step"):
+        assert 0.0005 < k[name] < wall_ms, (name, k)
+    rec.set_timing_enabled(0)
+
+
 @pytest.mark.parametrize("run_ahead", [False, True])
 def test_native_driver_matches_oracle(smx, run_ahead):
     """The C++ frame loop (include/smx_driver.h, written against the shim classes of smx_shim.hpp) produces the

@@ -90,13 +90,22 @@ def test_depth_kernels_match_the_reference(ref, w, h):
     dict(do_blending=0, regularization_iterations_per_integration_iteration=0),
 ])
 def test_integrate_matches_the_reference_kernels_frame_by_frame(ref, kw):
-    w, h = 160, 120
+    _integrate_pin(ref, kw, 160, 120, list(range(4, 24)), 60000)
+
+
+def test_integrate_matches_the_reference_kernels_at_640x480(ref):
+    """The same pin at the bench's resolution (the 5 M-slot version is tests/tools/ref_pin_fullsize.py, whose result
+    is kept under profiles/)."""
+    _integrate_pin(ref, {}, 640, 480, list(range(4, 12)), 700000)
+
+
+def _integrate_pin(ref, kw, w, h, frames, cap):
+    scale = (w * h) // (160 * 120)                # pixel count relative to the small case: bounds on counts scale with it
     s = small_stream(w, h, obstacle_until=10)     # vanishing obstacle: conflicts, replacements, merges
     pre = small_pre(w)
     params = orc.IntegrateParams.defaults(**kw)
-    po = OraclePipeline(w, h, s.fx, s.fy, s.cx, s.cy, 60000, pre, params)
-    rr = ref.Recon(60000, w, h, s.fx, s.fy, s.cx, s.cy)
-    frames = list(range(4, 24))
+    po = OraclePipeline(w, h, s.fx, s.fy, s.cx, s.cy, cap, pre, params)
+    rr = ref.Recon(cap, w, h, s.fx, s.fy, s.cx, s.cy)
     for g in range(0, frames[-1] + 5):
         d, c = s.frame(g)
         po.upload(g, d, c)
@@ -129,7 +138,7 @@ def test_integrate_matches_the_reference_kernels_frame_by_frame(ref, kw):
         assert np.array_equal(so["first_depth"].view(np.uint32), sr["first_depth"].view(np.uint32))
         # blended depth: the reference's float atomicAdd depth sums depend on scheduling -> a stray LSB
         dd = po.depth_final.astype(np.int32) - depth_r.astype(np.int32)
-        assert np.abs(dd).max() <= 1 and np.count_nonzero(dd) <= 6, (g, np.count_nonzero(dd))
+        assert np.abs(dd).max() <= 1 and np.count_nonzero(dd) <= 6 * scale, (g, np.count_nonzero(dd))
         stray_depth += np.count_nonzero(dd)
         So, Sr = po.recon.surfels()[:, :n], rr.surfels(n)
         for row in INT_ROWS:
@@ -163,9 +172,9 @@ def test_integrate_matches_the_reference_kernels_frame_by_frame(ref, kw):
     pos_r, col_r = rr.export_vertices()
     assert np.array_equal(pos_o.view(np.uint32), pos_r.view(np.uint32)) and np.array_equal(col_o, col_r)   # (NaN = merged)
     rr.close()
-    assert po.recon.surfels_size > 12000 and applied > 1000
-    if not kw:
-        assert merges > 50 and replaced > 50 and stray_depth <= 25, (merges, replaced, stray_depth)
+    assert po.recon.surfels_size > 12000 * scale * len(frames) // 20 and applied > 1000
+    if not kw and len(frames) >= 20:
+        assert merges > 50 and replaced > 50 and stray_depth <= 25 * scale, (merges, replaced, stray_depth)
 
 
 def test_first_frame_without_any_race_is_identical(ref):

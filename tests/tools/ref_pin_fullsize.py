@@ -2,10 +2,12 @@
 (640x480) is handed to the reference's own kernels (oracle/_ref) and to the CPU oracle; per frame, both start from the
 same state, the oracle gets the reference run's race outcomes imposed, and everything is compared.
       python tests/tools/ref_pin_fullsize.py [frames]"""
-import sys, time
+import json, os, sys, time
 n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+out_json = sys.argv[2] if len(sys.argv) > 2 else None   # e.g. gpurun_out/rNN_ref_pin_fullsize.json (kept under profiles/)
 sys.argv = ['bench.py']
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import torch  # noqa
 import bench
@@ -39,6 +41,9 @@ for f in sorted(need):
     d, c = wl.pipe.download_frame(f)
     pf.upload(f, d, c); colors[f] = c
 params = orc.IntegrateParams.defaults()
+report = {"what": "reference kernels (oracle/_ref, compiled from /root/reference) vs the CPU oracle at the bench's size, "
+                  "same state and preprocessed frame per frame, the reference run's race outcomes imposed on the oracle",
+          "width": 640, "height": 480, "slots_at_start": int(S.shape[1]), "merged_at_start": int(merge0), "frames": []}
 for f, others, T, pose in plan:
     pf.preprocess(f, others, T)
     api.StreamSynchronize(None)
@@ -72,3 +77,20 @@ for f, others, T, pose in plan:
         neq = So[r_].view(np.uint32) != Sr[r_].view(np.uint32)
         if neq.any(): bad.append('row%d:%d(max|d| %.1e)' % (r_, neq.sum(), np.abs(So[r_] - Sr[r_])[neq].max()))
     print(line + ' | rows: ' + (' '.join(bad) if bad else 'ALL BIT-EQUAL') + ' | oracle %.1fs' % t)
+    smooth = [3, 4, 5]
+    report["frames"].append({
+        "frame": int(f), "slots": [int(n), int(cr['surfels_size'])], "merges": [int(po.merge_count), int(cr['merge_count'])],
+        "new": [int(po.stats()['n_new']), int(cr['n_new'])], "race_outcomes": {k: int(v) for k, v in ovr.items()},
+        "association_images_differing_pixels": {
+            "supporting": int((so['supporting'] != sr['supporting']).sum()), "counts": int((so['support_counts'] != sr['support_counts']).sum()),
+            "conflicting": int((so['conflicting'] != sr['conflicting']).sum()),
+            "first_depth": int((so['first_depth'].view(np.uint32) != sr['first_depth'].view(np.uint32)).sum())},
+        "blended_depth_differing_pixels": int((depth_o != depth_r).sum()),
+        "integer_rows_differing": {str(r_): int((So[r_].view(np.uint32) != Sr[r_].view(np.uint32)).sum()) for r_ in INT_ROWS
+                                   if (So[r_].view(np.uint32) != Sr[r_].view(np.uint32)).any()},
+        "float_rows_differing": {str(r_): {"count": int((So[r_].view(np.uint32) != Sr[r_].view(np.uint32)).sum()),
+                                           "max_abs_diff": float(np.abs(So[r_] - Sr[r_]).max())}
+                                 for r_ in FLOAT_ROWS if (So[r_].view(np.uint32) != Sr[r_].view(np.uint32)).any()},
+        "max_smooth_position_diff_m": float(max(np.abs(So[r_] - Sr[r_]).max() for r_ in smooth))})
+if out_json:
+    json.dump(report, open(out_json, 'w'), indent=1)

@@ -41,18 +41,24 @@ def main():
             cur = None
         if cur is not None:
             kernels[cur].append(line.strip())
+    # (one YAML block per kernel under amdhsa.kernels, keys in alphabetical order: collect a block, then file it by .name)
     meta = {}
-    name = None
+    block = {}
     for line in asm:
-        m = re.search(r"\.name:\s+(\S+)", line)
-        if m:
-            name = m.group(1)
-            meta[name] = {}
+        if re.match(r"\s+- \.", line) and ".args" in line or re.match(r"\s+- \.agpr_count", line):
+            if "name" in block:
+                meta[block["name"]] = block
+            block = {}
+        m = re.search(r"^\s+\.name:\s+(\S+)", line)
+        if m and "name" not in block:
+            block["name"] = m.group(1)
         for key in ("vgpr_count", "sgpr_count", "group_segment_fixed_size", "private_segment_fixed_size"):
             m2 = re.search(r"\." + key + r":\s+(\d+)", line)
-            if m2 and name:
-                meta[name][key] = int(m2.group(1))
-    print("%-44s %6s %6s %6s %7s %7s %6s %6s" % ("kernel", "loads", "phases", "atomic", "stores", "barrier", "vgpr", "lds"))
+            if m2:
+                block[key] = int(m2.group(1))
+    if "name" in block:
+        meta[block["name"]] = block
+    print("%-44s %6s %6s %6s %7s %7s %6s %6s %7s" % ("kernel", "loads", "phases", "atomic", "stores", "barrier", "vgpr", "lds", "scratch"))
     for k, body in kernels.items():
         short = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip()
         short = re.sub(r"\(anonymous namespace\)::", "", short).split("(")[0]
@@ -92,8 +98,9 @@ def main():
                 phases += 1
                 pending = False
         m = meta.get(k, {})
-        print("%-44s %6d %6d %6d %7d %7d %6s %6s" % (short[:44], loads, phases, atom, stores, barriers,
-                                                      m.get("vgpr_count", "?"), m.get("group_segment_fixed_size", "?")))
+        print("%-44s %6d %6d %6d %7d %7d %6s %6s %7s" % (short[:44], loads, phases, atom, stores, barriers,
+                                                          m.get("vgpr_count", "?"), m.get("group_segment_fixed_size", "?"),
+                                                          m.get("private_segment_fixed_size", "?")))
         if seq:
             out, prev, n = [], None, 0
             for t in trace + [None]:
