@@ -786,7 +786,7 @@ def run_c5(args):
     if pmc is not None and pmc.get("_meta", {}).get("surfel_slots") != n:
         pmc, c5_why = None, "collected at %s points, this run has %d" % (pmc.get("_meta", {}).get("surfel_slots"), n)
     if pmc is not None:
-        k = pmc.get("k_query_lanes", {})
+        k = next((v for name, v in pmc.items() if name.startswith("k_query_lanes")), {})
         c5_traffic = pmc_bytes(k)
         if "SQ_INSTS_VALU" in k:
             # one wave64 VALU instruction occupies a SIMD for 4 cycles: a CU issues at most one per cycle

@@ -208,6 +208,7 @@ __device__ __forceinline__ float meas_normal_z(float nx, float ny) {
 }
 
 constexpr int kBlock = 256;
+static_assert(kBlock / 64 == 4, "pass A sums four wavefronts' marks");
 static_assert(sizeof(uchar3) == 3, "uchar3 must be packed like the reference's Vec3u8");
 
 // Work lists are SEGMENTED: the slots [s*kSeg, (s+1)*kSeg) are scanned by one workgroup, which writes the
@@ -237,6 +238,8 @@ struct Lists {
   // "Hot" groups (pass B's filter for its far flag gathers, see k_neighbor_scan): per group of slots the number
   // (mod 256) of the last Integrate call in which the group held a slot inside the regulariser window (pass A) or a
   // flag byte / link record of it was written.  `epoch` = this call's number.  (At C2 a group is 2048 slots, at C3 8192.)
+  uint8_t* seg_act;       // per pass-A segment: 1 = pass A found visible or recently updated slots in it this frame
+  uint32_t descending;    // != 0: this call's all-slot kernels walk the segments downwards (segment_of_block)
   uint8_t* hot_epoch;
   uint32_t n_hot_groups;
   uint32_t epoch;
@@ -253,16 +256,6 @@ __device__ __forceinline__ bool group_is_hot(uint32_t last, uint32_t epoch) { re
 #define SMX_STAMP(buf, k) do { } while (0)
 #endif
 
-// Segment of a workgroup in the all-slot kernels: the LAST segments first.  Slots are never reordered, so the segments
-// that do real work in a frame -- recently created or updated surfels -- sit at the end of the slot range, behind
-// thousands of segments whose workgroups return after a test; dispatched in ascending order the heavy workgroups start
-// last and the kernel ends with their latency chains.
-#ifdef SMX_NO_REVERSE
-__device__ __forceinline__ uint32_t segment_of_block() { return blockIdx.x; }
-#else
-__device__ __forceinline__ uint32_t segment_of_block() { return gridDim.x - 1u - blockIdx.x; }
-#endif
-
 // ---- association tiles ------------------------------------------------------------------------------------------
 // The per-pixel association state of a frame (z-buffer minimum, supporting surfel, count, depth sum, conflict key) is
 // built per image TILE in LDS by k_assoc_tiles instead of with device-scope atomics on five dense images: pass A
@@ -270,6 +263,7 @@ __device__ __forceinline__ uint32_t segment_of_block() { return gridDim.x - 1u -
 // workgroup reduces its pairs with LDS atomics (all of the reductions are order-independent and exact: min, integer
 // add) and writes the five images with plain stores.  Nothing is cleared per frame.
 constexpr int kTileW = 32, kTileH = 8, kTilePx = kTileW * kTileH;   // one 256-lane workgroup per tile
+static_assert(kTilePx == kBlock, "the tile kernel runs choose_segment_direction in one of its workgroups");
 // pair code: bits 0-7 pixel inside the tile (row-major, kTileW wide); bit 8: the slot's second ("quadrant") pixel;
 // bit 9: the slot is active for integration (kernels.cu:77-87) -- inactive visible slots still take part in the merge phase
 constexpr uint32_t kPairSecond = 1u << 8, kPairActive = 1u << 9;
@@ -339,6 +333,34 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t mine, uint32_t* wav
   return wave_off + incl - mine;
 }
 
+// Segment of a workgroup in the all-slot kernels (pass A, pass B, the edge kernel): workgroups are dispatched in
+// blockIdx order, and a launch ends with the latency chains of whatever comes last.  Most segments are trivial in a
+// frame (culled, or nothing inside the regulariser's window: the workgroup returns after a test); the work sits in a
+// few hundred segments that are dense with visible / recently updated slots -- at the START of the slot range while
+// the camera revisits old parts of the map, at its END while it explores.  When that dense block is dispatched FIRST
+// it fills the chip, the thousands of trivial workgroups queue behind it and only churn once a heavy round has
+// finished; dispatched LAST, the trivial ones are gone by the time it needs the room (edge kernel alone 50 -> 41 us,
+// frame +9 %; profiles/r09_dispatch_order.md has the variants, including explicit permutations, which were worse).
+// So the launches walk the segments in the direction that ends in the dense block: pass A marks the segments it found
+// active, one workgroup of the tile kernel counts the marks in the lower and the upper half of the used range and
+// leaves the direction in a word of page-locked HOST memory; the host passes whatever it finds there as a kernel argument
+// of the next launches (no synchronisation: the value may be a frame or two old, and any value is correct -- it only
+// decides in which order the same workgroups run).
+__device__ __forceinline__ uint32_t segment_of_block(uint32_t descending) {
+  return descending ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+}
+// (one workgroup of kBlock threads; act[s] != 0: active; n_used = segments that hold slots)
+__device__ __forceinline__ void choose_segment_direction(const uint8_t* __restrict__ act, uint32_t n_used, uint32_t* __restrict__ descending,
+                                                         uint32_t* wave_tot /* LDS [kBlock / 64] */) {
+  int balance = 0;   // active segments in the lower half - in the upper half
+  const uint32_t half = n_used / 2;
+  for (uint32_t k = threadIdx.x; k < n_used; k += kBlock)   // (coalesced, independent loads)
+    if (act[k]) balance += k < half ? 1 : -1;
+  uint32_t total;
+  (void)block_excl_scan((uint32_t)(balance + 4096), wave_tot, total);   // (sum of the biased values: |balance| < 4096 per lane)
+  if (threadIdx.x == 0) *descending = ((int)total - 4096 * kBlock) > 0 ? 1u : 0u;
+}
+
 // "These loads travel together": pins loaded values at this point of the program, so that every load issued above is in
 // flight before the first of them is waited for.  Without it the compiler sinks independent loads below the branches
 // that follow (it cannot know that a dependent round trip costs microseconds on the frame's latency chain and a wasted
@@ -370,7 +392,7 @@ __global__ void k_reset_frame_stats(DevState* st) {   // (value-distribution cou
 // lane).  The z-buffer minimum itself (:1463) is formed by k_assoc_tiles from the pairs appended here.
 __global__ void __launch_bounds__(kBlock)
 k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, const uint8_t* __restrict__ flags_prev, DevState* st) {
-  const uint32_t seg_id = segment_of_block();
+  const uint32_t seg_id = segment_of_block(L.descending);
   __shared__ uint32_t wave_tot[kBlock / 64];
   __shared__ float box_part[kBlock / 64][8];
   __shared__ int skip_segment;
@@ -405,6 +427,7 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, const uint8_t* __res
       const uchar4 of = *reinterpret_cast<const uchar4*>(&flags_prev[i0]);
       *reinterpret_cast<uchar4*>(&L.flags8[i0]) = make_uchar4(of.x & 2u, of.y & 2u, of.z & 2u, of.w & 2u);
     }
+    if (threadIdx.x == 0) L.seg_act[seg_id] = 0;
     return;  // (vis_seg stays 0, the box stays as it is)
   }
   uint32_t vis_bits = 0;
@@ -463,7 +486,8 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, const uint8_t* __res
     if (key[j] != kNoPair && lds_tables) rank[j] = atomicAdd(&tile_lds[key[j] >> 10], 1u);
   }
   // (a slot inside the regulariser window: the group is hot -- same value from every writer, one byte store per wavefront)
-  if (__ballot(lane_recent) && (threadIdx.x & 63) == 0) L.hot_epoch[base >> L.hot_shift] = (uint8_t)L.epoch;
+  const bool wave_recent = __ballot(lane_recent) != 0;
+  if (wave_recent && (threadIdx.x & 63) == 0) L.hot_epoch[base >> L.hot_shift] = (uint8_t)L.epoch;
   // the segment's bounding box and newest stamp (wave shuffles, then one partial per wavefront through LDS)
   int newest_s = have_stamp ? (int)newest : (int)0x80000000;
 #pragma unroll
@@ -480,6 +504,7 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, const uint8_t* __res
     float* bp = box_part[threadIdx.x >> 6];
     bp[0] = bmin[0]; bp[1] = bmin[1]; bp[2] = bmin[2]; bp[3] = bmax[0]; bp[4] = bmax[1]; bp[5] = bmax[2];
     bp[6] = __int_as_float(newest_s);
+    bp[7] = wave_recent ? 1.0f : 0.0f;
   }
   uint32_t total;
   uint32_t off = base + block_excl_scan((uint32_t)__popc(vis_bits), wave_tot, total);  // (synchronises)
@@ -516,6 +541,7 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, const uint8_t* __res
   }
   if (threadIdx.x == 0) {
     L.vis_seg[seg_id] = total;
+    L.seg_act[seg_id] = (total != 0 || box_part[0][7] + box_part[1][7] + box_part[2][7] + box_part[3][7] != 0.0f) ? 1 : 0;
     emit_chunks(L.vis_chunks, seg_id, total, kSeg / kBlock);
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     int ns = (int)0x80000000;
@@ -686,8 +712,15 @@ __device__ __forceinline__ void for_uncached_pairs(const Surfels& S, const Frame
 __global__ void __launch_bounds__(kTilePx)
 k_assoc_tiles(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<const float2> normals, TileBins tb,
               uint32_t* __restrict__ next_ovf_count, uint8_t* __restrict__ merge_flag, DevState* st,
-              unsigned long long* stamps) {
+              const uint8_t* __restrict__ seg_act, uint32_t nseg, uint32_t* __restrict__ direction_out, unsigned long long* stamps) {
   __shared__ TileLds t;
+  __shared__ uint32_t order_wave_tot[kTilePx / 64];
+  // side job of the first workgroup: the direction in which the launches that follow walk the segments (segment_of_block)
+  if (blockIdx.x == 0) {
+    const uint32_t n_used = min(nseg, (st->surfel_count + (uint32_t)kSeg - 1u) / (uint32_t)kSeg);
+    choose_segment_direction(seg_act, n_used, direction_out, order_wave_tot);
+    __syncthreads();
+  }
   SMX_STAMP(stamps, 0);
   const uint32_t tile = blockIdx.x, lane = threadIdx.x;
   const int x = (int)(tile % (uint32_t)tb.tiles_x) * kTileW + (int)(lane % kTileW);
@@ -1549,7 +1582,7 @@ template <bool kDetach, bool kAccumulate>
 __global__ void __launch_bounds__(kBlockB)
 k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict__ inwin8, uint32_t* __restrict__ need_seg,
                 DevState* st) {
-  const uint32_t seg_id = segment_of_block();
+  const uint32_t seg_id = segment_of_block(L.descending);
   extern __shared__ __align__(16) uint8_t lhot[];   // the hot-group table (n_hot_groups bytes, padded to 16)
   // B1: pure streaming.  Per slot: detach (:1430-1433), which of its neighbours lie inside the regulariser
   // window (4-bit mask -> inwin8), membership in the recent list.  No LDS accumulators here, so the
@@ -1659,8 +1692,8 @@ __global__ void __launch_bounds__(kBlockAcc)
 k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ grad_acc,
                  long long* __restrict__ grad_local, float4* __restrict__ inbox,
                  const uint8_t* __restrict__ inwin8, const uint8_t* __restrict__ flags8,
-                 const uint32_t* __restrict__ need_seg, DevState* st, uint32_t epoch) {
-  const uint32_t seg_id = segment_of_block();
+                 const uint32_t* __restrict__ need_seg, DevState* st, uint32_t epoch, uint32_t descending) {
+  const uint32_t seg_id = segment_of_block(descending);
   __shared__ unsigned long long lacc[kSegAcc * 2];  // per target: (gx | gy), (gz | sender classes)
   const uint32_t N = st->surfel_count;
   const uint32_t base = seg_id * kSegAcc;
@@ -2158,6 +2191,8 @@ struct smx_recon_s {
   unsigned long long* stamps;   // -DSMX_STAMPS builds: [2][8192 workgroups][16] shader clocks (tile kernel, blend kernel)
   uint32_t bin_cap_full;    // the bins' allocated capacity (tb.cap is lowered by the A/B switch that forces overflows)
   uint32_t* vis_count_set[2];   // chunk counters of the visible list, alternating by call (k_update_and_create zeroes the next call's)
+  uint32_t* dir_host;           // page-locked word: the direction the tile kernel last chose for the all-slot kernels
+  uint32_t* dir_dev;            // (segment_of_block); its device alias
   int sc_cur;
   int hot_holdoff;          // > 0: pass B does not use the hot-group table (decremented per Integrate call)
   int hot_filter_enabled;   // A/B switch (smx_recon_set_scan_mode bit 2 clears it)
@@ -2279,7 +2314,7 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
     }
     SlotTimer t(r, st, kSlotRegAccumulate);
     hipLaunchKernelGGL(k_reg_accumulate, dim3(div_up((long long)r->nsegB * kSegB, kSegAcc)), dim3(kBlockAcc), 0, st, r->S, rf2, weight, r->grad_acc, r->grad_local,
-                       r->inbox, r->inwin8, r->L.flags8, r->need_seg, r->st, r->reg_epoch);
+                       r->inbox, r->inwin8, r->L.flags8, r->need_seg, r->st, r->reg_epoch, r->L.descending);
   }
   if (copy_only) {
     SlotTimer t(r, st, kSlotRegUpdate);
@@ -2350,6 +2385,11 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->L.recent_list, (size_t)r->nsegB * kSegB, false));
   SMX_TRY(dev_alloc(&r->L.vis_seg, (size_t)r->nseg, true));
   SMX_TRY(dev_alloc(&r->L.seg_box, (size_t)r->nseg * 8, true));
+  SMX_TRY(dev_alloc(&r->L.seg_act, (size_t)r->nseg, true));
+  // (the direction word of segment_of_block: written by the tile kernel, read by the host without synchronisation)
+  SMX_HIP(hipHostMalloc(reinterpret_cast<void**>(&r->dir_host), sizeof(uint32_t), hipHostMallocMapped));
+  *r->dir_host = 0;
+  SMX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&r->dir_dev), r->dir_host, 0));
   SMX_TRY(dev_alloc(&r->L.recent_seg, (size_t)r->nsegB, true));
   // chunk descriptors: every chunk of every segment in the worst case, + room for the index a walk forms first
   SMX_TRY(dev_alloc(&r->L.vis_chunks.desc, (size_t)r->nseg * (kSeg / kBlock) + 65536, true));
@@ -2435,10 +2475,11 @@ int smx_recon_destroy(smx_recon r) {
   SMX_ON_DEVICE(r->device);
   void* ptrs[] = {r->sc.supporting, r->sc.counts, r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth,
                   r->tb.pairs, r->tb.count, r->tb.ovf, r->ovf_count_set[0], r->ovf_count_set[1],
-                  r->vis_count_set[0], r->vis_count_set[1], r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1], r->L.hot_epoch,
+                  r->vis_count_set[0], r->vis_count_set[1], r->L.seg_act, r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1], r->L.hot_epoch,
                   r->merge_flag, r->inwin8, r->need_seg, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->block_offsets, r->st};
   if (r->reg_stream) { (void)hipStreamSynchronize(r->reg_stream); (void)hipStreamDestroy(r->reg_stream); }
+  if (r->dir_host) { (void)hipDeviceSynchronize(); (void)hipHostFree(r->dir_host); }
   if (r->ev_front) (void)hipEventDestroy(r->ev_front);
   if (r->ev_upd) (void)hipEventDestroy(r->ev_upd);
   if (r->ev_reg) (void)hipEventDestroy(r->ev_reg);
@@ -2597,6 +2638,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   if (tm) SMX_HIP(hipEventRecord(r->ev[0], sF));
   // two chunk counters / overflow counters in alternation: the kernels of this call read theirs while they reset the
   // next call's (k_update_and_create / k_assoc_tiles)
+  r->L.descending = *reinterpret_cast<volatile uint32_t*>(r->dir_host);
   r->sc_cur ^= 1;
   r->L.vis_chunks.count = r->vis_count_set[r->sc_cur];
   r->tb.ovf_count = r->ovf_count_set[r->sc_cur];
@@ -2606,9 +2648,11 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     r->table_valid = true; r->table_frame = frame_index; r->table_window = c.reg_window; }
   // (smx_recon_integrate_inputs_ready) from here on the input images are read
   if (hook_ready) SMX_HIP(hipStreamWaitEvent(sF, hook_ready, 0));
+  // (the tile kernel also leaves the direction for later launches' segment_of_block in host memory, see there)
   { SlotTimer t(r, sF, kSlotAssocTiles);
     hipLaunchKernelGGL(k_assoc_tiles, dim3(r->tb.n_tiles), dim3(kTilePx), 0, sF, r->S, c, r->sc, in.depth, in.normals, r->tb,
-                       r->ovf_count_set[r->sc_cur ^ 1], r->merge_flag, r->st, r->stamps ? r->stamps : nullptr); }
+                       r->ovf_count_set[r->sc_cur ^ 1], r->merge_flag, r->st, r->L.seg_act, (uint32_t)r->nseg, r->dir_dev,
+                       r->stamps ? r->stamps : nullptr); }
   // (the stage times of GetTimings: data association = pass A + the tile kernel, which also decides the merges)
   if (tm) { SMX_HIP(hipEventRecord(r->ev[1], sF)); SMX_HIP(hipEventRecord(r->ev[2], sF)); SMX_HIP(hipEventRecord(r->ev[3], sF)); SMX_HIP(hipEventRecord(r->ev[4], sF)); }
   const int halo = p->measurement_blending_radius - 1;
