@@ -662,9 +662,12 @@ int smx_bilateral_filtering_and_depth_cutoff(
   const int radius = (int)(radius_factor * sigma_xy + 0.5f);                       // cu:135
   SMX_CHECK_ARG(radius >= 0 && radius <= kMaxBilateralRadius);
   const int tiles_x = div_up(output_depth->width, kBilTileW), n_tiles = tiles_x * div_up(output_depth->height, kBilTileH);
-  // Two workgroups per CU: the filter is ALU-bound and runs beside the surfel kernels (preprocessing of the next
-  // frame overlaps Integrate); a launch that floods every CU slows those down more than it gains here.
-  const int max_blocks = 2 * device_cu_count();
+  // At most eight workgroups per CU in the grid (one per tile at 640x480, four tiles per workgroup at 1280x960).  Two
+  // of these 256-register workgroups fill a CU's register files, and the filter runs beside the surfel kernels
+  // (preprocessing of the next frames overlaps Integrate): with few long-lived workgroups (2 per CU, rounds 1-2) a CU
+  // stays closed to everything else for the whole filter; short-lived ones hand it back between tiles
+  // (profiles/r09g_bilateral_grid.txt: C2 4557 -> 4755 frames/s).
+  const int max_blocks = 8 * device_cu_count();
   const dim3 grid(n_tiles < max_blocks ? n_tiles : max_blocks);
   const float denom_xy = 2.0f * sigma_xy * sigma_xy, region_r2 = depth_valid_region_radius * depth_valid_region_radius;
   const Img<const uint16_t> src = as_img<const uint16_t>(input_depth);
