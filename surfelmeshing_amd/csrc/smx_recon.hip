@@ -1470,6 +1470,12 @@ __device__ __forceinline__ void new_create_body(const Surfels& S, const FrameCtx
   // own for one workgroup); workgroup 0 publishes the counts (cc:291) and the offsets (debug decode).
   extern __shared__ uint32_t block_offsets[];  // [n_scan_blocks] exclusive
   __shared__ uint32_t wave_tot[kBlock / 64];
+  // (a workgroup whose pixels hold no flagged pixel has nothing to create: most of them, in a map that is not growing.
+  // Its pixels lie in ONE scan block -- the grid has one workgroup per kBlock pixels -- whose total says so.  Workgroup 0
+  // stays: it publishes the counts.)
+  static_assert(kScanPxPerBlock % kBlock == 0, "a creating workgroup's pixels lie inside one scan block");
+  if (block != 0 && n_blocks * (uint32_t)kBlock >= (uint32_t)(c.W * c.H) &&
+      block_sums[(block * (uint32_t)kBlock) / (uint32_t)kScanPxPerBlock] == 0) return;
   const int per = (n_scan_blocks + kBlock - 1) / kBlock;
   uint32_t mine = 0;
   for (int j = 0; j < per; ++j) {
