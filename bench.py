@@ -261,6 +261,8 @@ def main():
                     help="frames of the extra pass whose inputs arrive from page-locked host memory (0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the full-size GPU-vs-oracle check")
     ap.add_argument("--no-overlap", action="store_true", help="A/B: no frame pipelining inside Integrate")
+    ap.add_argument("--caller-stream", choices=["null", "plain", "high", "low"], default="null",
+                    help="A/B: the stream Integrate is called on (null = the legacy default stream)")
     ap.add_argument("--run-ahead", action="store_true", help="A/B: preprocessing two steps ahead, waits routed off the caller's stream")
     ap.add_argument("--scan-mode", type=int, default=0, help="A/B: smx_recon_set_scan_mode bits (1 = all-slot scans, 2 = multi-launch blend, 4 = no hot-group filter in pass B)")
     ap.add_argument("--dry-run", action="store_true", help="rank path only (no GPU, gloo): see the module docstring")
@@ -329,6 +331,9 @@ def run_integrate(args):
     api.StreamSynchronize(None)
 
     rec = wl.pipe.reconstruction
+    if args.caller_stream != "null":
+        api.StreamSynchronize(None)
+        wl.pipe.stream = api.Stream({"plain": None, "high": 1, "low": -1}[args.caller_stream])
     rec.set_stats_enabled(False)   # the distribution counters are single-address atomics: off while timing
     if args.run_ahead:
         wl.pipe.set_run_ahead(True)
