@@ -2723,14 +2723,15 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   SMX_LAUNCH_CHECK();
   int rc = SMX_OK;
   const int iters = p->regularization_iterations_per_integration_iteration;
-  if (pipelined) {
-    // the input images are free from here on, and the map is ready for the next call's pass A: the caller's stream
-    // continues behind this point (a device-side wait; the host does not block)
-    SMX_HIP(hipEventRecord(r->ev_upd, sR));
-    SMX_HIP(hipStreamWaitEvent(sF, r->ev_upd, 0));
+  // The input images are free from here on, and the map is ready for the next call's pass A: the caller's stream
+  // continues behind this point (a device-side wait; the host does not block).  The caller's "inputs consumed" event
+  // (smx_recon_integrate_hooks) marks the same point: one record serves both (every event operation on the internal
+  // stream sits on the frame-to-frame critical chain).
+  {
+    const hipEvent_t mark = hook_consumed ? hook_consumed : r->ev_upd;
+    if (pipelined || hook_consumed) SMX_HIP(hipEventRecord(mark, sR));
+    if (pipelined) SMX_HIP(hipStreamWaitEvent(sF, mark, 0));
   }
-  // (smx_recon_integrate_hooks) marked on the side so that the caller's stream does not carry the record
-  if (hook_consumed) SMX_HIP(hipEventRecord(hook_consumed, sR));
   if (iters == 0) {
     rc = enqueue_regularize(r, sR, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
                             p->regularization_frame_window_size, true, true, false);
