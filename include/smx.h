@@ -311,7 +311,8 @@ int smx_recon_debug_download_scratch(smx_recon r, smx_stream s, int32_t which, v
  * the reference does instead of the compacted lists; bit 1: measurement blending as the reference's
  * start + iteration launches instead of the fused LDS kernel; bit 2: the regulariser's link scan gathers the flag byte
  * of every far link (no hot-group filter); bit 3: association bins of 16 pairs per tile, so that most pairs travel
- * through the overflow list. */
+ * through the overflow list; bit 4: pass A reserves bin space pair by pair instead of per (workgroup, tile) through
+ * an LDS table (the path images of more than 8192 tiles take). */
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode);
 /* Frame pipelining (default on): the regulariser of a frame runs on an internal stream beside the first
  * kernels of the next smx_recon_integrate call (which only read what the regulariser does not write).

@@ -391,13 +391,14 @@ __global__ void k_reset_frame_stats(DevState* st) {   // (value-distribution cou
 // table.  One workgroup per segment of kSeg slots; rows 18,0,1,2 are streamed with 16-byte lane loads (4 slots per
 // lane).  The z-buffer minimum itself (:1463) is formed by k_assoc_tiles from the pairs appended here.
 __global__ void __launch_bounds__(kBlock)
-k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, const uint8_t* __restrict__ flags_prev, DevState* st) {
+k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, const uint8_t* __restrict__ flags_prev, DevState* st,
+               int use_lds_tables) {
   const uint32_t seg_id = segment_of_block(L.descending);
   __shared__ uint32_t wave_tot[kBlock / 64];
   __shared__ float box_part[kBlock / 64][8];
   __shared__ int skip_segment;
   extern __shared__ uint32_t tile_lds[];   // [n_tiles] pairs of this workgroup per tile, [n_tiles] base of its run in the tile's bin
-  const bool lds_tables = tb.n_tiles <= kMaxTilesLds;
+  const bool lds_tables = use_lds_tables != 0;   // (n_tiles <= kMaxTilesLds)
   const uint32_t N = st->surfel_count;
   const uint32_t base = seg_id * kSeg;
   if (base >= N) return;  // uniform per workgroup
@@ -2195,6 +2196,7 @@ struct smx_recon_s {
   TileBins tb;              // pass A's pairs, binned by association tile
   uint32_t* ovf_count_set[2];   // overflow counters, alternating by call (the tile kernel zeroes the next call's)
   unsigned long long* stamps;   // -DSMX_STAMPS builds: [2][8192 workgroups][16] shader clocks (tile kernel, blend kernel)
+  int no_lds_tables;        // A/B switch (scan mode bit 4)
   uint32_t bin_cap_full;    // the bins' allocated capacity (tb.cap is lowered by the A/B switch that forces overflows)
   uint32_t* vis_count_set[2];   // chunk counters of the visible list, alternating by call (k_update_and_create zeroes the next call's)
   uint32_t* dir_host;           // page-locked word: the direction the tile kernel last chose for the all-slot kernels
@@ -2562,12 +2564,13 @@ int smx_recon_set_overlap(smx_recon r, int32_t enabled) {
 }
 
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
-  SMX_CHECK_ARG(r != nullptr && mode >= 0 && mode <= 15);
+  SMX_CHECK_ARG(r != nullptr && mode >= 0 && mode <= 31);
   SMX_ON_DEVICE(r->device);
   r->scan_mode = mode & 1;
   r->blend_multi_launch = (mode >> 1) & 1;
   r->hot_filter_enabled = ((mode >> 2) & 1) ? 0 : 1;
   r->tb.cap = ((mode >> 3) & 1) ? 16u : r->bin_cap_full;   // 16 pairs per bin: most pairs travel through the overflow list
+  r->no_lds_tables = (mode >> 4) & 1;                     // pass A reserves bin space per pair (the path of images with > 8192 tiles)
   return SMX_OK;
 }
 
@@ -2649,8 +2652,9 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   r->L.vis_chunks.count = r->vis_count_set[r->sc_cur];
   r->tb.ovf_count = r->ovf_count_set[r->sc_cur];
   { SlotTimer t(r, sF, kSlotScanVisible);
-    const size_t lds = r->tb.n_tiles <= kMaxTilesLds ? (size_t)r->tb.n_tiles * 8 : 0;
-    hipLaunchKernelGGL(k_scan_visible, gs, b, lds, sF, r->S, c, r->L, r->tb, flags_prev, r->st);
+    const bool lds_tables = r->tb.n_tiles <= kMaxTilesLds && !r->no_lds_tables;
+    hipLaunchKernelGGL(k_scan_visible, gs, b, lds_tables ? (size_t)r->tb.n_tiles * 8 : 0, sF, r->S, c, r->L, r->tb, flags_prev,
+                       r->st, lds_tables ? 1 : 0);
     r->table_valid = true; r->table_frame = frame_index; r->table_window = c.reg_window; }
   // (smx_recon_integrate_inputs_ready) from here on the input images are read
   if (hook_ready) SMX_HIP(hipStreamWaitEvent(sF, hook_ready, 0));

@@ -228,7 +228,7 @@ def test_cuda_buffer_roundtrips(smx):
 
 
 # ---- full pipeline --------------------------------------------------------------------------
-@pytest.mark.parametrize("scan_mode", [0, 1, 2, 3, 4, 8])   # (4: pass B without its hot-group filter; 8: association bins of 16 pairs, the rest through the overflow list)
+@pytest.mark.parametrize("scan_mode", [0, 1, 2, 3, 4, 8, 16, 24])   # (4: pass B without its hot-group filter; 8: association bins of 16 pairs, the rest through the overflow list; 16: bin space reserved pair by pair)
 def test_stream_parity_every_frame(smx, scan_mode):
     s = small_stream(obstacle_until=10)               # vanishing obstacle -> conflicts and replacements
     po, pg = _pipes(smx, s, 60000, scan_mode=scan_mode)
@@ -244,6 +244,16 @@ def test_stream_parity_every_frame(smx, scan_mode):
     run_both(po, pg, s, list(range(4, 26)), check)
     assert seen["replaced"] > 50 and seen["merged"] > 10 and seen["conflict"] > 100, seen
     assert po.recon.surfels_size > 10000
+
+
+@pytest.mark.parametrize("w,h", [(170, 101), (97, 64)])
+def test_stream_parity_image_sizes_that_cut_tiles(smx, w, h):
+    """Image sizes that are no multiple of the association tiles (32 x 8), the blend tiles (32 x 32) or the scan blocks:
+    partial tiles at the right and bottom edges in every per-pixel kernel."""
+    s = small_stream(w, h, obstacle_until=8)
+    po, pg = _pipes(smx, s, 60000)
+    run_both(po, pg, s, list(range(4, 18)), lambda f: _compare_state(po, pg))
+    assert po.recon.surfels_size > 3000
 
 
 @pytest.mark.parametrize("kw", [
