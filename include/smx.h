@@ -312,7 +312,9 @@ int smx_recon_debug_download_scratch(smx_recon r, smx_stream s, int32_t which, v
  * start + iteration launches instead of the fused LDS kernel; bit 2: the regulariser's link scan gathers the flag byte
  * of every far link (no hot-group filter); bit 3: association bins of 16 pairs per tile, so that most pairs travel
  * through the overflow list; bit 4: pass A reserves bin space pair by pair instead of per (workgroup, tile) through
- * an LDS table (the path images of more than 8192 tiles take). */
+ * an LDS table (the path images of more than 8192 tiles take); bit 5: the regulariser's far-term bins hold 4 records
+ * per destination segment, bit 6: a sender workgroup addresses 2 destination segments through the bins -- the other far
+ * terms take the atomic accumulators (the overflow paths of those bins). */
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode);
 /* Frame pipelining (default on): the regulariser of a frame runs on an internal stream beside the first
  * kernels of the next smx_recon_integrate call (which only read what the regulariser does not write).

@@ -16,7 +16,7 @@
 //   pass B  k_neighbor_scan    one streaming pass over the neighbour records
 //                              (16 B/slot): detach, which links point into the
 //                              regulariser window, list of recently updated slots;
-//   k_reg_accumulate           gradient terms of those links (inbox stores / LDS
+//   k_reg_accumulate           gradient terms of those links (far-term bins / LDS
 //                              sums / packed global atomics) and every recent slot's
 //                              own smoothness term, needy segments only;
 //   k_reg_step                 regulariser step over the recent list only, no gathers.
@@ -247,6 +247,24 @@ struct Lists {
 };
 // hot = active in this call or the previous one (or, seen from the pass B that runs beside it, in the next one)
 __device__ __forceinline__ bool group_is_hot(uint32_t last, uint32_t epoch) { return ((epoch - last + 1u) & 255u) <= 2u; }
+
+// Far-term bins of the regulariser (k_reg_accumulate -> k_reg_step): one bin per destination segment of kSegB slots.
+// A gradient term whose target lies outside the sender's segment is APPENDED to the target segment's bin -- record =
+// (target's position in its segment | sender class << 10, gx, gy, gz in 2^-22 fixed point) -- and the segment's
+// workgroup of k_reg_step sums its bin in LDS.  The reference pushes these terms with four float atomics each
+// (kernels.cu:2176-2182); rounds 1-2 used exclusive "inbox" slots for symmetric links and two packed 64-bit atomics for
+// the rest (0.43 M device-scope atomics and 0.39 M random 16-byte stores per frame at C2, and 64 bytes of inbox per
+// recent slot read back by the step).  Appending costs one returning atomic per (sender workgroup, destination segment)
+// -- 55 k per frame -- and the records of such a pair are adjacent.
+struct FarBins {
+  uint4* rec;            // [segments][cap]
+  uint32_t* count;       // [segments * kCountStride]: word 0 = terms appended since the bin was last consumed (may exceed cap),
+                         // word 1 = "some terms for this segment went to grad_acc instead"; both zeroed by the consumer
+  uint32_t cap;
+  uint32_t hash_mask;    // size - 1 of the sender's LDS table of destinations (kFarHash - 1; tests shrink it)
+};
+constexpr uint32_t kFarBinCap = 4096;   // records per bin (64 KB per 1024 slots: what the inbox took)
+constexpr int kFarHash = 1024;          // destinations one sender workgroup can address through the bins
 
 // Phase stamps inside a kernel (builds with -DSMX_STAMPS only; tools/stamps.py): lane 0 of every workgroup stores the
 // shader clock at marked points, the host averages the differences.
@@ -1670,7 +1688,7 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
   const int any = __syncthreads_or(need);
   if (threadIdx.x == 0) {
     L.recent_seg[seg_id] = total;
-    emit_chunks(L.rec_chunks, seg_id, total, kSegB / kBlock);
+    if (total) L.rec_chunks.desc[atomicAdd(L.rec_chunks.count, 1u)] = seg_id | ((total - 1u) << 22);   // (one walk step per segment)
     if (kAccumulate) need_seg[seg_id] = (any || total) ? 1u : 0u;  // k_reg_accumulate also serves recent slots
     if (stats && total) atomicAdd(&st->recent_count, total);
   }
@@ -1682,26 +1700,37 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
 // gathered neighbour positions and parks it in the G record, so that k_reg_step gathers nothing.
 //
 // The reference pushes every edge's gradient term to the neighbour with four float atomicAdds.  Device-scope
-// atomics are the slowest thing this chip does, so the terms travel three ways, all of which end in the same
+// atomics are the slowest thing this chip does, so the terms travel two ways, both of which end in the same
 // exact integer sum (the three gradient components quantised to 2^-22 m, the weights counted per sender class and
 // multiplied out in 2^-32 fixed point by the reader -- integer addition: the split cannot change the result):
 //   1. target inside the workgroup's own segment (3 of 4 edges): summed in LDS, stored once per target, coalesced
 //      (grad_local); the words hold (gx | gy) and (gz | sender class counts) as signed 32-bit halves (pack_pair);
-//   2. otherwise, the target lists the source back at slot k: the term is STORED, without any atomic, into
-//      inbox[target][k] -- a slot only this source writes, stamped with the call's epoch; k_reg_step converts it;
-//   3. otherwise: TWO 64-bit global atomics per term (grad_acc), same packing.
-// (Round 1 preferred the inbox to the LDS sums: 16-byte stores into random lines cost more than LDS atomics --
-// reg_accumulate 67 -> 57 us alone, +2 % frames/s, profiles/r02p_ab.txt.)
+//   2. otherwise: appended to the bin of the target's segment (FarBins).  The term draws a rank from an LDS counter of
+//      its destination (a small open-addressed table keyed by segment number), one lane per destination reserves the
+//      workgroup's run in the bin with ONE returning atomic, and after a barrier every term is stored at base + rank
+//      (the scheme of pass A's tile bins).  k_reg_step sums the bin in LDS.
+//   A term that finds neither room in the table nor in the bin goes to grad_acc with two packed 64-bit atomics (the
+//   path every far term of an asymmetric link took in rounds 1-2) and leaves a mark beside the bin's counter: the
+//   reader looks into grad_acc only then.
+// two packed words per term: (gx | gy) and (gz | one count in the byte of the sender's class)
+__device__ __forceinline__ void far_term_spill(long long* __restrict__ grad_acc, const FarBins& fb, uint32_t target,
+                                               int qx, int qy, int qz, int neighbor_count) {
+  unsigned long long* a = reinterpret_cast<unsigned long long*>(&grad_acc[2 * (size_t)target]);
+  atomicAdd(&a[0], pack_pair(qx, qy));
+  atomicAdd(&a[1], pack_pair(qz, 1 << (8 * (neighbor_count - 1))));
+  fb.count[(size_t)(target / kSegB) * kCountStride + 1] = 1u;   // (the reader of that segment looks into grad_acc)
+}
 constexpr int kSegAcc = 1024;     // slots per accumulation workgroup (16 KB of LDS sums)
 constexpr int kBlockAcc = 512;
 static_assert(kSegAcc % kSegB == 0 && kSegAcc % kBlockAcc == 0, "segment sizes must nest");
 __global__ void __launch_bounds__(kBlockAcc)
 k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ grad_acc,
-                 long long* __restrict__ grad_local, float4* __restrict__ inbox,
+                 long long* __restrict__ grad_local, FarBins fb,
                  const uint8_t* __restrict__ inwin8, const uint8_t* __restrict__ flags8,
-                 const uint32_t* __restrict__ need_seg, DevState* st, uint32_t epoch, uint32_t descending) {
+                 const uint32_t* __restrict__ need_seg, DevState* st, uint32_t descending) {
   const uint32_t seg_id = segment_of_block(descending);
   __shared__ unsigned long long lacc[kSegAcc * 2];  // per target: (gx | gy), (gz | sender classes)
+  __shared__ uint32_t hkey[kFarHash], hcnt[kFarHash];   // far destinations of this workgroup: segment, terms -> base in the bin
   const uint32_t N = st->surfel_count;
   const uint32_t base = seg_id * kSegAcc;
   if (base >= N) return;
@@ -1711,12 +1740,12 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
   if (!need) return;
 #pragma unroll
   for (int k = 0; k < kSegAcc * 2 / kBlockAcc; ++k) lacc[k * kBlockAcc + threadIdx.x] = 0;
+#pragma unroll
+  for (int k = 0; k < kFarHash / kBlockAcc; ++k) { hkey[k * kBlockAcc + threadIdx.x] = kInvalid; hcnt[k * kBlockAcc + threadIdx.x] = 0; }
   __syncthreads();
   // Both slots of a lane travel together through three levels of loads, every load of a level requested before the
-  // first one is used: (1) mask + flag bytes, (2) the slots' own T, S, N records, (3) one 32-byte record per link.
-  // The link records are read whole and compared without branches: a chain of `a == i ? 0 : b == i ? 1 : ...` makes the
-  // compiler fetch the second half of a record lazily, word by word, three dependent round trips per link
-  // (tools/isa_phases.py: 28 waits on this kernel's path before, 4 now).
+  // first one is used: (1) mask + flag bytes, (2) the slots' own T, S, N records, (3) one 16-byte record per link
+  // (tools/isa_phases.py shows the waits).
   constexpr int kSub = kSegAcc / kBlockAcc;
   uint32_t idx[kSub], mask[kSub];
   bool rec[kSub], act[kSub];
@@ -1740,7 +1769,6 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
   }
   uint32_t gmask[kSub];
   float4 ts[kSub][4];
-  uint4 tt[kSub][4];
 #pragma unroll
   for (int sub = 0; sub < kSub; ++sub) {
     const uint32_t nb[4] = {own_t[sub].x, own_t[sub].y, own_t[sub].z, own_t[sub].w};
@@ -1753,16 +1781,16 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
     }
     gmask[sub] = gm;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      // one 32-byte record per link: the neighbour's smooth position and (the copy of) its own links; unused links
-      // read the slot's own record
-      const float4* lr = S.group(kGroupS, (gm & (1u << q)) ? nb[q] : (act[sub] ? idx[sub] : base));
-      ts[sub][q] = lr[0];
-      tt[sub][q] = *reinterpret_cast<const uint4*>(lr + 1);
-    }
+    for (int q = 0; q < 4; ++q)   // the neighbour's smooth position; unused links read the slot's own record
+      ts[sub][q] = *S.group(kGroupS, (gm & (1u << q)) ? nb[q] : (act[sub] ? idx[sub] : base));
   }
+  // far terms wait in registers for their place in the destination's bin: (table entry | rank << 10, target, q22 x 3)
+  uint32_t far_where[kSub][4], far_target[kSub][4];
+  int far_q[kSub][4][3];
 #pragma unroll
   for (int sub = 0; sub < kSub; ++sub) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) far_where[sub][q] = kInvalid;
     if (!act[sub]) continue;
     const uint32_t i = idx[sub];
     const uint32_t nb[4] = {own_t[sub].x, own_t[sub].y, own_t[sub].z, own_t[sub].w};
@@ -1770,53 +1798,45 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
     const Vec3 sp = {own_s[sub].x, own_s[sub].y, own_s[sub].z};
     const Vec3 nrm = {own_n[sub].x, own_n[sub].y, own_n[sub].z};
     const float r2 = own_n[sub].w;
-    Vec3 np[4];
-    int back_slot[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      np[q].x = ts[sub][q].x; np[q].y = ts[sub][q].y; np[q].z = ts[sub][q].z;
-      const uint32_t eq = (tt[sub][q].x == i ? 1u : 0u) | (tt[sub][q].y == i ? 2u : 0u) | (tt[sub][q].z == i ? 4u : 0u) |
-                          (tt[sub][q].w == i ? 8u : 0u);
-      back_slot[q] = eq ? (int)__builtin_ctz(eq) : -1;   // (the first position that lists the source back)
-    }
     const int neighbor_count = msk ? __popc(msk) : 1;
     const float factor = 2 * weight / (float)neighbor_count;  // :2153
-    const float wk = weight / (float)neighbor_count;          // :2182
     int own_count = 0;
     Vec3 rg = {0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (!(gmask[sub] & (1u << q))) continue;
-      const Vec3 t = {np[q].x - sp.x, np[q].y - sp.y, np[q].z - sp.z};
+      const Vec3 t = {ts[sub][q].x - sp.x, ts[sub][q].y - sp.y, ts[sub][q].z - sp.z};
       const float nd = nrm.x * t.x + nrm.y * t.y + nrm.z * t.z;
       bool pruned = false;
       if (msk & (1u << q)) {
         const float f = factor * nd;
-        const float4 term = make_float4(f * nrm.x, f * nrm.y, f * nrm.z, wk);
+        const Vec3 term = {f * nrm.x, f * nrm.y, f * nrm.z};   // (the weight term, :2182, travels as the sender's class)
         // the fixed-point channel carries |component| < 16 m (q22_from_float clamps): a huge regularizer_weight or a
         // corrupt position is reported instead of silently bending the gradient
         if (!(fabsf(term.x) < 16.0f && fabsf(term.y) < 16.0f && fabsf(term.z) < 16.0f)) st->reg_saturated = 1u;
-        // the exclusive inbox slot is only usable if this source has ONE in-window edge to that target
-        bool once = true;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (k != q && (msk & (1u << k)) && nb[k] == nb[q]) once = false;
+        const int qx = q22_from_float(term.x), qy = q22_from_float(term.y), qz = q22_from_float(term.z);
         const uint32_t rel = nb[q] - base;
         if (rel < (uint32_t)kSegAcc) {
           // component-major LDS layout: consecutive lanes (consecutive targets) hit consecutive banks
-          atomicAdd(&lacc[rel], pack_pair(q22_from_float(term.x), q22_from_float(term.y)));
-          atomicAdd(&lacc[kSegAcc + rel], pack_pair(q22_from_float(term.z), 1 << (8 * (neighbor_count - 1))));
-        } else if (back_slot[q] >= 0 && once) {
-          // w carries (call epoch, neighbour count) instead of weight / count: the reader recomputes the quotient
-          // and ignores slots of older calls, so nobody has to clear the inbox
-          inbox[4 * (size_t)nb[q] + back_slot[q]] =
-              make_float4(term.x, term.y, term.z, __uint_as_float((epoch << 3) | (uint32_t)neighbor_count));
+          atomicAdd(&lacc[rel], pack_pair(qx, qy));
+          atomicAdd(&lacc[kSegAcc + rel], pack_pair(qz, 1 << (8 * (neighbor_count - 1))));
         } else {
-          // two packed words per term: (gx | gy) and (gz | one count in the byte of the sender's class)
-          const unsigned long long w0 = pack_pair(q22_from_float(term.x), q22_from_float(term.y));
-          const unsigned long long w1 = pack_pair(q22_from_float(term.z), 1 << (8 * (neighbor_count - 1)));
-          unsigned long long* a = reinterpret_cast<unsigned long long*>(&grad_acc[2 * (size_t)nb[q]]);
-          atomicAdd(&a[0], w0);
-          atomicAdd(&a[1], w1);
+          // find (or claim) the destination's entry in the LDS table, then draw a rank
+          const uint32_t dseg = nb[q] / kSegB;
+          uint32_t h = (dseg * 2654435761u) >> 16;
+          uint32_t where = kInvalid;
+          for (int probe = 0; probe < 16; ++probe) {
+            h &= fb.hash_mask;
+            const uint32_t seen = atomicCAS(&hkey[h], kInvalid, dseg);
+            if (seen == kInvalid || seen == dseg) { where = h | (atomicAdd(&hcnt[h], 1u) << 10); break; }
+            ++h;
+          }
+          if (where == kInvalid) {
+            far_term_spill(grad_acc, fb, nb[q], qx, qy, qz, neighbor_count);
+          } else {
+            far_where[sub][q] = where; far_target[sub][q] = nb[q] | ((uint32_t)(neighbor_count - 1) << 30);
+            far_q[sub][q][0] = qx; far_q[sub][q][1] = qy; far_q[sub][q][2] = qz;
+          }
         }
         const float d2 = t.x * t.x + t.y * t.y + t.z * t.z;
         if (d2 > rf2 * r2) { S.set_neighbor(i, q, kInvalid); pruned = true; }  // :2190-2192
@@ -1831,6 +1851,13 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
     if (rec[sub]) *S.group(kGroupG, i) = make_float4(rg.x, rg.y, rg.z, __int_as_float(own_count));
   }
   __syncthreads();
+  // one lane per destination reserves the workgroup's run in that bin; the table then holds the run's start
+#pragma unroll
+  for (int k = 0; k < kFarHash / kBlockAcc; ++k) {
+    const uint32_t e = k * kBlockAcc + threadIdx.x;
+    const uint32_t dseg = hkey[e];
+    if (dseg != kInvalid) hcnt[e] = atomicAdd(&fb.count[(size_t)dseg * kCountStride], hcnt[e]);
+  }
   // store the in-segment sums (only this workgroup writes the grad_local entries of its segment)
 #pragma unroll
   for (int sub = 0; sub < kSegAcc / kBlockAcc; ++sub) {
@@ -1838,6 +1865,22 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
     const unsigned long long v0 = lacc[rel], v1 = lacc[kSegAcc + rel];
     if (v0 | v1)
       *reinterpret_cast<ulonglong2*>(&grad_local[2 * (size_t)(base + rel)]) = make_ulonglong2(v0, v1);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int sub = 0; sub < kSub; ++sub) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t where = far_where[sub][q];
+      if (where == kInvalid) continue;
+      const uint32_t target = far_target[sub][q] & 0x3FFFFFFFu, cls = far_target[sub][q] >> 30;
+      const uint32_t pos = hcnt[where & 1023u] + (where >> 10);
+      if (pos < fb.cap)
+        fb.rec[(size_t)(target / kSegB) * fb.cap + pos] =
+            make_uint4((target % kSegB) | (cls << 10), (uint32_t)far_q[sub][q][0], (uint32_t)far_q[sub][q][1], (uint32_t)far_q[sub][q][2]);
+      else
+        far_term_spill(grad_acc, fb, target, far_q[sub][q][0], far_q[sub][q][1], far_q[sub][q][2], (int)cls + 1);
+    }
   }
 }
 
@@ -1850,90 +1893,136 @@ k_rebuild_flags(Surfels S, uint32_t frame, int reg_window, uint8_t* __restrict__
     flags8[i] = make_flags(S.u(kLastUpdateStamp, i), S.u(kColor, i), frame, reg_window);
 }
 
-// RegularizeSurfelsCUDAKernel, kernels.cu:2197-2290, over the recent list.
+// RegularizeSurfelsCUDAKernel, kernels.cu:2197-2290, over the recent list: one walk step per segment that holds recent
+// slots (descriptor = segment | (recent slots - 1) << 22), four slots per lane.  The step's workgroup first sums the
+// far terms of the segment's bin in LDS (FarBins; same packed words as k_reg_accumulate's in-segment sums) and empties
+// the bin.
+constexpr int kStepSub = kSegB / kBlock;
 __global__ void __launch_bounds__(kBlock)
 k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long* __restrict__ grad_local,
-           const float4* __restrict__ inbox, Lists L, DevState* st, uint32_t epoch) {
-  uint32_t desc;
-  const uint32_t n_steps = walk_begin<true>(L.rec_chunks, 0u, blockIdx.x, desc);
+           FarBins fb, Lists L, DevState* st) {
+  __shared__ unsigned long long lfar[kSegB * 2];   // per target of the segment: (gx | gy), (gz | sender classes)
+  const uint32_t n_steps = *L.rec_chunks.count;
+  uint32_t desc = L.rec_chunks.desc[blockIdx.x];
+  bool lds_used = false;
   for (uint32_t w = blockIdx.x; w < n_steps; w += gridDim.x) {
-    const uint32_t cur = desc;
-    desc = walk_next<true>(L.rec_chunks, w + gridDim.x, n_steps);   // (the next step's descriptor travels while this one is worked on)
-    uint32_t i;
-    if (!walk_entry<true, kSegB>(L.recent_list, cur, w, 0u, threadIdx.x, i)) continue;
-    const Vec3 mp = {S.f(kX, i), S.f(kY, i), S.f(kZ, i)};
-    const Vec3 sp = {S.f(kSmoothX, i), S.f(kSmoothY, i), S.f(kSmoothZ, i)};
-    // exact fixed-point sums: contributions from other segments (global atomics) + from the own segment
-    // (accumulated in LDS by pass B and stored plainly); integer addition, so the split does not matter
-    ulonglong2* ap = reinterpret_cast<ulonglong2*>(&grad_acc[2 * (size_t)i]);
-    ulonglong2* lp = reinterpret_cast<ulonglong2*>(&grad_local[2 * (size_t)i]);
-    const ulonglong2 a = *ap, l = *lp;
-    const float4* ib = &inbox[4 * (size_t)i];
-    const float4 in0 = ib[0], in1 = ib[1], in2 = ib[2], in3 = ib[3];
-    if (a.x | a.y) *ap = make_ulonglong2(0, 0);  // keep the accumulators zero between calls
-    if (l.x | l.y) *lp = make_ulonglong2(0, 0);
-    long long sum[3];
-    int ylo, cls;
-    unpack_pair((long long)(a.x + l.x), sum[0], ylo);
-    unpack_pair((long long)(a.y + l.y), sum[2], cls);
-    sum[1] = ylo;
-    uint32_t senders[4] = {(uint32_t)cls & 255u, ((uint32_t)cls >> 8) & 255u, ((uint32_t)cls >> 16) & 255u, (uint32_t)cls >> 24};
-    // terms delivered through the exclusive inbox slots: valid if stamped by this call's k_reg_accumulate
-    const float4 ins[4] = {in0, in1, in2, in3};
+    const uint32_t seg = desc & 0x003FFFFFu, total = (desc >> 22) + 1u;
+    desc = (w + gridDim.x < n_steps) ? L.rec_chunks.desc[w + gridDim.x] : 0u;   // (the next step's descriptor travels while this one is worked on)
+    const uint32_t seg_base = seg * kSegB;
+    const uint2 bin_state = *reinterpret_cast<const uint2*>(&fb.count[(size_t)seg * kCountStride]);
+    const uint32_t n_far = min(bin_state.x, fb.cap);
+    const bool spilled = bin_state.y != 0;
+    // the slots' own records: requested before the bin is summed
+    uint32_t idx[kStepSub];
+    bool on[kStepSub];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t code = __float_as_uint(ins[k].w);
-      if ((code >> 3) != epoch) continue;
-      sum[0] += q22_from_float(ins[k].x); sum[1] += q22_from_float(ins[k].y); sum[2] += q22_from_float(ins[k].z);
-      senders[((code & 7u) - 1u) & 3u] += 1u;
+    for (int sub = 0; sub < kStepSub; ++sub) {
+      const uint32_t e = sub * kBlock + threadIdx.x;
+      on[sub] = e < total;
+      idx[sub] = on[sub] ? L.recent_list[seg_base + e] : seg_base;
     }
-    // the packed class counters are bytes (the top one signed): far more senders than any real map produces, but a
-    // count near the limit may already have carried -- reported, never silent
-    if (senders[0] >= 100u || senders[1] >= 100u || senders[2] >= 100u || senders[3] >= 100u) st->reg_saturated = 1u;
-    // sum over the senders of weight / (sender's neighbour count) (:2182), exact: per class, count x 2^-32 quotient
-    long long wsum_q = 0;
+    float4 rp[kStepSub], rs[kStepSub], rn[kStepSub], rgr[kStepSub];
+    ulonglong2 rl[kStepSub];
 #pragma unroll
-    for (int cnt = 1; cnt <= 4; ++cnt)
-      if (senders[cnt - 1]) wsum_q += (long long)senders[cnt - 1] * q_from_float(weight / (float)cnt);
-    const float acc[4] = {q22_to_float(sum[0]), q22_to_float(sum[1]), q22_to_float(sum[2]), q_to_float(wsum_q)};
-    Vec3 grad = {2 * (sp.x - mp.x) + acc[0], 2 * (sp.y - mp.y) + acc[1], 2 * (sp.z - mp.z) + acc[2]};
-    // own term and neighbour count: formed by k_reg_accumulate from the pre-step smooth positions
-    const float4 own_g = *S.group(kGroupG, i);
-    const Vec3 rg = {own_g.x, own_g.y, own_g.z};
-    const int neighbor_count = __float_as_int(own_g.w);
-    if (neighbor_count > 0) {
-      const float factor = 2 * weight / (float)neighbor_count;
-      grad.x = grad.x + factor * rg.x; grad.y = grad.y + factor * rg.y; grad.z = grad.z + factor * rg.z;
+    for (int sub = 0; sub < kStepSub; ++sub) {
+      const uint32_t i = idx[sub];
+      rp[sub] = *S.group(kGroupP, i); rs[sub] = *S.group(kGroupS, i); rn[sub] = *S.group(kGroupN, i); rgr[sub] = *S.group(kGroupG, i);
+      rl[sub] = *reinterpret_cast<const ulonglong2*>(&grad_local[2 * (size_t)i]);
     }
-    const float wsum = 1 + weight + acc[3];  // :2267
-    const float kStep = 0.5f / wsum;
-    const float max_step = 1.0f * sqrtf(S.f(kRadiusSq, i));
-    const float step_len = kStep * sqrtf(grad.x * grad.x + grad.y * grad.y + grad.z * grad.z);
-    float step = kStep;
-    if (step_len > max_step) step = max_step / step_len * kStep;
-    // No kernel reads another slot's smooth position after k_reg_accumulate, so the result goes straight to the
-    // S record: the reference's parking rows and RegularizeSurfelsCUDAUpdateKernel (:2283-2308) are not needed.
-    if (L.dirty8) L.dirty8[i] = 1;
-    S.f(kSmoothX, i) = sp.x - step * grad.x;
-    S.f(kSmoothY, i) = sp.y - step * grad.y;
-    S.f(kSmoothZ, i) = sp.z - step * grad.z;
+    if (n_far) {
+      if (lds_used) __syncthreads();   // (the previous step's readers are done)
+#pragma unroll
+      for (int k = 0; k < kSegB * 2 / kBlock; ++k) lfar[k * kBlock + threadIdx.x] = 0;
+      __syncthreads();
+      const uint4* bin = fb.rec + (size_t)seg * fb.cap;
+      for (uint32_t k0 = 0; k0 < n_far; k0 += 4 * kBlock) {
+        uint4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const uint32_t k = k0 + u * kBlock + threadIdx.x; t[u] = bin[k < n_far ? k : 0]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (k0 + u * kBlock + threadIdx.x >= n_far) continue;
+          const uint32_t rel = t[u].x & 1023u, cls = t[u].x >> 10;
+          atomicAdd(&lfar[rel], pack_pair((int)t[u].y, (int)t[u].z));
+          atomicAdd(&lfar[kSegB + rel], pack_pair((int)t[u].w, 1 << (8 * cls)));
+        }
+      }
+      __syncthreads();
+      lds_used = true;
+    }
+    if ((bin_state.x | bin_state.y) && threadIdx.x == 0)
+      *reinterpret_cast<uint2*>(&fb.count[(size_t)seg * kCountStride]) = make_uint2(0u, 0u);
+#pragma unroll
+    for (int sub = 0; sub < kStepSub; ++sub) {
+      if (!on[sub]) continue;
+      const uint32_t i = idx[sub];
+      const Vec3 mp = {rp[sub].x, rp[sub].y, rp[sub].z};
+      const Vec3 sp = {rs[sub].x, rs[sub].y, rs[sub].z};
+      // exact fixed-point sums: terms from the own segment (summed in LDS by k_reg_accumulate, stored plainly), from
+      // other segments (the bin) and, rarely, from grad_acc; integer addition, so the split does not matter
+      ulonglong2 acc2 = rl[sub];
+      ulonglong2* lp = reinterpret_cast<ulonglong2*>(&grad_local[2 * (size_t)i]);
+      if (acc2.x | acc2.y) *lp = make_ulonglong2(0, 0);   // keep the accumulators zero between calls
+      if (n_far) { acc2.x += lfar[i - seg_base]; acc2.y += lfar[kSegB + (i - seg_base)]; }
+      if (spilled) {
+        ulonglong2* ap = reinterpret_cast<ulonglong2*>(&grad_acc[2 * (size_t)i]);
+        const ulonglong2 a = *ap;
+        if (a.x | a.y) *ap = make_ulonglong2(0, 0);
+        acc2.x += a.x; acc2.y += a.y;
+      }
+      long long sum[3];
+      int ylo, cls;
+      unpack_pair((long long)acc2.x, sum[0], ylo);
+      unpack_pair((long long)acc2.y, sum[2], cls);
+      sum[1] = ylo;
+      const uint32_t senders[4] = {(uint32_t)cls & 255u, ((uint32_t)cls >> 8) & 255u, ((uint32_t)cls >> 16) & 255u, (uint32_t)cls >> 24};
+      // the packed class counters are bytes (the top one signed): far more senders than any real map produces, but a
+      // count near the limit may already have carried -- reported, never silent
+      if (senders[0] >= 100u || senders[1] >= 100u || senders[2] >= 100u || senders[3] >= 100u) st->reg_saturated = 1u;
+      // sum over the senders of weight / (sender's neighbour count) (:2182), exact: per class, count x 2^-32 quotient
+      long long wsum_q = 0;
+#pragma unroll
+      for (int cnt = 1; cnt <= 4; ++cnt)
+        if (senders[cnt - 1]) wsum_q += (long long)senders[cnt - 1] * q_from_float(weight / (float)cnt);
+      const float acc[4] = {q22_to_float(sum[0]), q22_to_float(sum[1]), q22_to_float(sum[2]), q_to_float(wsum_q)};
+      Vec3 grad = {2 * (sp.x - mp.x) + acc[0], 2 * (sp.y - mp.y) + acc[1], 2 * (sp.z - mp.z) + acc[2]};
+      // own term and neighbour count: formed by k_reg_accumulate from the pre-step smooth positions
+      const Vec3 rg = {rgr[sub].x, rgr[sub].y, rgr[sub].z};
+      const int neighbor_count = __float_as_int(rgr[sub].w);
+      if (neighbor_count > 0) {
+        const float factor = 2 * weight / (float)neighbor_count;
+        grad.x = grad.x + factor * rg.x; grad.y = grad.y + factor * rg.y; grad.z = grad.z + factor * rg.z;
+      }
+      const float wsum = 1 + weight + acc[3];  // :2267
+      const float kStep = 0.5f / wsum;
+      const float max_step = 1.0f * sqrtf(rn[sub].w);
+      const float step_len = kStep * sqrtf(grad.x * grad.x + grad.y * grad.y + grad.z * grad.z);
+      float step = kStep;
+      if (step_len > max_step) step = max_step / step_len * kStep;
+      // No kernel reads another slot's smooth position after k_reg_accumulate, so the result goes straight to the
+      // S record: the reference's parking rows and RegularizeSurfelsCUDAUpdateKernel (:2283-2308) are not needed.
+      if (L.dirty8) L.dirty8[i] = 1;
+      S.f(kSmoothX, i) = sp.x - step * grad.x;
+      S.f(kSmoothY, i) = sp.y - step * grad.y;
+      S.f(kSmoothZ, i) = sp.z - step * grad.z;
+    }
   }
 }
 
 // RegularizeSurfelsCUDACopyOnlyKernel (:2310-2327), over the recent list.
 __global__ void __launch_bounds__(kBlock)
 k_reg_copy_raw(Surfels S, Lists L, const DevState* st) {
-  uint32_t desc;
-  const uint32_t n_steps = walk_begin<true>(L.rec_chunks, 0u, blockIdx.x, desc);
+  const uint32_t n_steps = *L.rec_chunks.count;
   for (uint32_t w = blockIdx.x; w < n_steps; w += gridDim.x) {
-    const uint32_t cur = desc;
-    desc = walk_next<true>(L.rec_chunks, w + gridDim.x, n_steps);   // (the next step's descriptor travels while this one is worked on)
-    uint32_t i;
-    if (!walk_entry<true, kSegB>(L.recent_list, cur, w, 0u, threadIdx.x, i)) continue;
-    if (L.dirty8) L.dirty8[i] = 1;
-    S.f(kSmoothX, i) = S.f(kX, i);
-    S.f(kSmoothY, i) = S.f(kY, i);
-    S.f(kSmoothZ, i) = S.f(kZ, i);
+    const uint32_t desc = L.rec_chunks.desc[w];
+    const uint32_t seg = desc & 0x003FFFFFu, total = (desc >> 22) + 1u;
+    for (uint32_t e = threadIdx.x; e < total; e += kBlock) {
+      const uint32_t i = L.recent_list[seg * kSegB + e];
+      if (L.dirty8) L.dirty8[i] = 1;
+      S.f(kSmoothX, i) = S.f(kX, i);
+      S.f(kSmoothY, i) = S.f(kY, i);
+      S.f(kSmoothZ, i) = S.f(kZ, i);
+    }
   }
 }
 
@@ -2178,7 +2267,7 @@ struct smx_recon_s {
   Surfels S;
   long long* grad_acc;      // [slots][2] packed fixed point (see pack_pair), cross-segment contributions (atomics)
   long long* grad_local;    // [slots][2] in-segment contributions (plain stores)
-  float4* inbox;            // [slots][4] terms stored by the neighbour a slot lists at position k (no atomics)
+  FarBins fb;               // far terms of the regulariser, per destination segment (see FarBins)
   Lists L;
   int nseg;                 // number of kSeg-slot segments (= workgroups of pass A)
   int nsegB;                // number of kSegB-slot segments (= workgroups of pass B)
@@ -2233,7 +2322,6 @@ struct smx_recon_s {
   bool staging_busy;      // row downloads in flight, and the next user may come on another stream
   int grid_surfels;  // persistent grid for the grid-stride all-slot kernels
   int grid_list;     // persistent grid of the chunked list kernels
-  uint32_t reg_epoch = 0;  // regulariser calls so far (stamps the inbox slots)
   // Frame pipelining: the regulariser of frame f runs on an internal stream while the caller's stream already
   // executes clear / pass A / associate / merge / blend of frame f+1 (those read only P and N records, which the
   // regulariser does not write, and a second copy of the flag table).  Every entry point first orders the
@@ -2315,21 +2403,16 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
     }
   }
   if (!copy_only) {
-    // inbox slots are stamped with the call's epoch (29 bits); on wrap-around the old stamps are wiped
-    if (++r->reg_epoch >= (1u << 29)) {
-      SMX_HIP(hipMemsetAsync(r->inbox, 0, 4 * ((size_t)r->S.pitch + kSegAcc) * sizeof(float4), st));
-      r->reg_epoch = 1;
-    }
     SlotTimer t(r, st, kSlotRegAccumulate);
     hipLaunchKernelGGL(k_reg_accumulate, dim3(div_up((long long)r->nsegB * kSegB, kSegAcc)), dim3(kBlockAcc), 0, st, r->S, rf2, weight, r->grad_acc, r->grad_local,
-                       r->inbox, r->inwin8, r->L.flags8, r->need_seg, r->st, r->reg_epoch, r->L.descending);
+                       r->fb, r->inwin8, r->L.flags8, r->need_seg, r->st, r->L.descending);
   }
   if (copy_only) {
     SlotTimer t(r, st, kSlotRegUpdate);
     hipLaunchKernelGGL(k_reg_copy_raw, gl, b, 0, st, r->S, r->L, r->st);
   } else {
     SlotTimer t(r, st, kSlotRegStep);
-    hipLaunchKernelGGL(k_reg_step, gl, b, 0, st, r->S, weight, r->grad_acc, r->grad_local, r->inbox, r->L, r->st, r->reg_epoch);
+    hipLaunchKernelGGL(k_reg_step, gl, b, 0, st, r->S, weight, r->grad_acc, r->grad_local, r->fb, r->L, r->st);
   }
   SMX_LAUNCH_CHECK();
   return SMX_OK;
@@ -2386,9 +2469,11 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->S.base, (size_t)kQuadsPerSlot * 4 * r->S.pitch, true));
   SMX_TRY(dev_alloc(&r->grad_acc, 2 * ((size_t)r->S.pitch + kSegAcc), true));
   SMX_TRY(dev_alloc(&r->grad_local, 2 * ((size_t)r->S.pitch + kSegAcc), true));
-  SMX_TRY(dev_alloc(&r->inbox, 4 * ((size_t)r->S.pitch + kSegAcc), true));
   r->nseg = div_up((long long)r->S.pitch, kSeg);
   r->nsegB = div_up((long long)r->S.pitch, kSegB);
+  r->fb.cap = kFarBinCap; r->fb.hash_mask = (uint32_t)kFarHash - 1u;
+  SMX_TRY(dev_alloc(&r->fb.rec, (size_t)r->nsegB * kFarBinCap, false));
+  SMX_TRY(dev_alloc(&r->fb.count, ((size_t)r->nsegB + 1) * kCountStride, true));
   SMX_TRY(dev_alloc(&r->L.vis_list, (size_t)r->nseg * kSeg, false));
   SMX_TRY(dev_alloc(&r->L.recent_list, (size_t)r->nsegB * kSegB, false));
   SMX_TRY(dev_alloc(&r->L.vis_seg, (size_t)r->nseg, true));
@@ -2483,7 +2568,7 @@ int smx_recon_destroy(smx_recon r) {
   SMX_ON_DEVICE(r->device);
   void* ptrs[] = {r->sc.supporting, r->sc.counts, r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth,
                   r->tb.pairs, r->tb.count, r->tb.ovf, r->ovf_count_set[0], r->ovf_count_set[1],
-                  r->vis_count_set[0], r->vis_count_set[1], r->L.seg_act, r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->inbox, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1], r->L.hot_epoch,
+                  r->vis_count_set[0], r->vis_count_set[1], r->L.seg_act, r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->fb.rec, r->fb.count, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1], r->L.hot_epoch,
                   r->merge_flag, r->inwin8, r->need_seg, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->block_offsets, r->st};
   if (r->reg_stream) { (void)hipStreamSynchronize(r->reg_stream); (void)hipStreamDestroy(r->reg_stream); }
@@ -2564,13 +2649,15 @@ int smx_recon_set_overlap(smx_recon r, int32_t enabled) {
 }
 
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
-  SMX_CHECK_ARG(r != nullptr && mode >= 0 && mode <= 31);
+  SMX_CHECK_ARG(r != nullptr && mode >= 0 && mode <= 127);
   SMX_ON_DEVICE(r->device);
   r->scan_mode = mode & 1;
   r->blend_multi_launch = (mode >> 1) & 1;
   r->hot_filter_enabled = ((mode >> 2) & 1) ? 0 : 1;
   r->tb.cap = ((mode >> 3) & 1) ? 16u : r->bin_cap_full;   // 16 pairs per bin: most pairs travel through the overflow list
   r->no_lds_tables = (mode >> 4) & 1;                     // pass A reserves bin space per pair (the path of images with > 8192 tiles)
+  r->fb.cap = ((mode >> 5) & 1) ? 4u : kFarBinCap;        // 4 records per far-term bin: most far terms spill to grad_acc
+  r->fb.hash_mask = ((mode >> 6) & 1) ? 1u : (uint32_t)kFarHash - 1u;   // 2 destinations per sender workgroup: the rest spills
   return SMX_OK;
 }
 
@@ -3084,7 +3171,7 @@ int smx_recon_debug_upload_surfels(smx_recon r, smx_stream s, const float* rows,
   SMX_HIP(hipMemcpyAsync(r->st, &h, sizeof(h), hipMemcpyHostToDevice, st));
   SMX_HIP(hipMemsetAsync(r->grad_acc, 0, 2 * r->S.pitch * sizeof(long long), st));
   SMX_HIP(hipMemsetAsync(r->grad_local, 0, 2 * r->S.pitch * sizeof(long long), st));
-  SMX_HIP(hipMemsetAsync(r->inbox, 0, 4 * r->S.pitch * sizeof(float4), st));
+  SMX_HIP(hipMemsetAsync(r->fb.count, 0, (size_t)r->nsegB * kCountStride * sizeof(uint32_t), st));
   SMX_HIP(hipMemsetAsync(r->merge_flag, 0, r->S.pitch, st));
   if (r->L.dirty8) SMX_HIP(hipMemsetAsync(r->L.dirty8, 1, (size_t)r->nseg * kSeg, st));
   int rc = invalidate_derived(r, st);
