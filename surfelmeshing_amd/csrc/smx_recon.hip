@@ -68,10 +68,8 @@ struct DevState {
 //   T  Neighbor0..3                  -- what pass B streams (16 B/slot)
 //   C  Confidence, CreationStamp, Color, -
 //   G  GradientX, GradientY, GradientZ, -  (parked next smooth position)
-// S is a 32-byte record: the second half is a COPY of the slot's T record.  The regulariser needs, per link, the
-// neighbour's smooth position and the neighbour's own links (does it list me back?): two 16-byte gathers from two arrays
-// cost two cache-line requests, one 32-byte record costs one (profiles/r02a_ubench.txt: 61 us vs 32 us for the 1.6 M
-// links of a frame).  T stays a dense 16-byte array for pass B's all-slot stream; every writer of T writes both.
+// (Rounds 1-2 kept a copy of T in the second half of a 32-byte S record, so that the regulariser could see with one
+// gather whether a neighbour lists the slot back; with the far-term bins nobody asks that question any more.)
 // The reference's row order only matters at the boundary (TransferAllToCPU, ExportVertices, the debug row
 // accessors); pack/unpack kernels convert there.  Rows 14-16 (Accum*, never used) and 23 (GradientCount,
 // replaced by the fixed-point accumulators) have no storage.
@@ -85,32 +83,23 @@ __host__ __device__ constexpr int row_sub(int row) {
   return row <= 2 ? row : row <= 5 ? row - 3 : row == 6 ? 0 : row == 7 ? 3 : row <= 10 ? row - 8
        : row <= 13 ? row - 11 : row == 17 ? 1 : row == 18 ? 3 : row <= 22 ? row - 19 : row == 24 ? 2 : -1;
 }
-// start of each group array and its record size, in 16-byte units (x pitch / per slot)
-__host__ __device__ constexpr int group_start(int g) { return g == kGroupP ? 0 : g == kGroupS ? 1 : g == kGroupN ? 3 : g == kGroupT ? 4 : g == kGroupC ? 5 : 6; }
-__host__ __device__ constexpr int group_stride(int g) { return g == kGroupS ? 2 : 1; }
-constexpr int kQuadsPerSlot = 7;   // 112 bytes per slot
+// start of each group array in units of pitch x 16 bytes
+__host__ __device__ constexpr int group_start(int g) { return g; }
+constexpr int kQuadsPerSlot = 6;   // 96 bytes per slot
 struct Surfels {
   float* base;
   size_t pitch;  // slots per group array (multiple of 64)
   __host__ __device__ __forceinline__ size_t quad(int g, uint32_t i) const {
-    return (size_t)group_start(g) * pitch + (size_t)i * group_stride(g);
+    return (size_t)group_start(g) * pitch + (size_t)i;
   }
   __device__ __forceinline__ float& f(int row, uint32_t i) const { return base[quad(row_group(row), i) * 4 + row_sub(row)]; }
   __device__ __forceinline__ uint32_t& u(int row, uint32_t i) const {
     return reinterpret_cast<uint32_t*>(base)[quad(row_group(row), i) * 4 + row_sub(row)];
   }
-  // whole 16-byte group of slot i (S: the first half of its 32-byte record)
+  // whole 16-byte group of slot i
   __device__ __forceinline__ float4* group(int g, uint32_t i) const { return reinterpret_cast<float4*>(base) + quad(g, i); }
-  // the copy of the T record inside the S record, and the only two ways T is ever written
-  __device__ __forceinline__ uint4* tcopy(uint32_t i) const { return reinterpret_cast<uint4*>(group(kGroupS, i) + 1); }
-  __device__ __forceinline__ void set_neighbors(uint32_t i, const uint4& t) const {
-    *reinterpret_cast<uint4*>(group(kGroupT, i)) = t;
-    *tcopy(i) = t;
-  }
-  __device__ __forceinline__ void set_neighbor(uint32_t i, int q, uint32_t v) const {
-    u(kNeighbor0 + q, i) = v;
-    reinterpret_cast<uint32_t*>(tcopy(i))[q] = v;
-  }
+  __device__ __forceinline__ void set_neighbors(uint32_t i, const uint4& t) const { *reinterpret_cast<uint4*>(group(kGroupT, i)) = t; }
+  __device__ __forceinline__ void set_neighbor(uint32_t i, int q, uint32_t v) const { u(kNeighbor0 + q, i) = v; }
 };
 
 struct FrameCtx {
@@ -2109,7 +2098,6 @@ k_unpack_rows(Surfels S, RowList rl, const float* __restrict__ in, uint32_t coun
     for (int k = 0; k < rl.n; ++k) {
       const int g = row_group(rl.rows[k]), sub = row_sub(rl.rows[k]);
       if (g >= 0) S.base[S.quad(g, i) * 4 + sub] = in[(size_t)k * count + i];
-      if (g == kGroupT) reinterpret_cast<float*>(S.tcopy(i))[sub] = in[(size_t)k * count + i];   // (T lives twice)
     }
 }
 
