@@ -307,6 +307,9 @@ enum {
   SMX_SCRATCH_NEW_INDICES = 6      /* u32 [W*H], exclusive ranks */
 };
 int smx_recon_debug_download_scratch(smx_recon r, smx_stream s, int32_t which, void* dst);
+/* Number of 1024-slot segments the last regulariser link scan did not have to read (every link of theirs stays among
+ * slots nothing happened to; only with the statistics counters off -- the edge counters visit every link).  Tests. */
+int smx_recon_debug_count_skipped_segments(smx_recon r, smx_stream s, uint32_t* out);
 /* A/B switches; results are identical in every mode.  bit 0: every surfel kernel scans all slots like
  * the reference does instead of the compacted lists; bit 1: measurement blending as the reference's
  * start + iteration launches instead of the fused LDS kernel; bit 2: the regulariser's link scan gathers the flag byte

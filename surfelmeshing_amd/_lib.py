@@ -90,7 +90,7 @@ EXPORTS = [
     "smx_recon_set_timing_enabled", "smx_recon_counts", "smx_recon_get_stats", "smx_recon_set_stats_enabled",
     "smx_recon_kernel_slot_count", "smx_recon_kernel_slot_name", "smx_recon_get_kernel_timings",
     "smx_recon_profile_begin", "smx_recon_profile_end",
-    "smx_recon_debug_download_surfels", "smx_recon_debug_upload_surfels", "smx_recon_debug_download_scratch",
+    "smx_recon_debug_download_surfels", "smx_recon_debug_upload_surfels", "smx_recon_debug_download_scratch", "smx_recon_debug_count_skipped_segments",
     "smx_recon_set_scan_mode", "smx_recon_set_overlap", "smx_recon_integrate_hooks", "smx_recon_integrate_inputs_ready",
     "smx_nn_create", "smx_nn_destroy", "smx_nn_build", "smx_nn_query_batch", "smx_nn_query_self", "smx_nn_set_query_mode", "smx_nn_set_stats_enabled", "smx_nn_get_stats",
     "smx_synth_render_room",

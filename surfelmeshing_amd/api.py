@@ -573,6 +573,11 @@ class CUDASurfelReconstruction:
                 "conflicting": (3, np.uint32), "first_depth": (4, np.float32), "new_flags": (5, np.uint8),
                 "new_indices": (6, np.uint32)}
 
+    def debug_count_skipped_segments(self):
+        out = C.c_uint32(0)
+        _lib.check(_lib.load().smx_recon_debug_count_skipped_segments(self._h, _sv(self._last_stream), C.byref(out)))
+        return int(out.value)
+
     def debug_download_scratch(self, name):
         which, dt = self._SCRATCH[name]
         out = np.empty((self.depth_camera.height(), self.depth_camera.width()), dt)

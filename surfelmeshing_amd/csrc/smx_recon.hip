@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "smx_common.hpp"
 
@@ -230,10 +231,12 @@ struct Lists {
   uint8_t* seg_act;       // per pass-A segment: 1 = pass A found visible or recently updated slots in it this frame
   uint32_t descending;    // != 0: this call's all-slot kernels walk the segments downwards (segment_of_block)
   uint8_t* hot_epoch;
+  uint16_t* seg_targets;  // per pass-B segment: bitmap of the groups its links point into (see k_neighbor_scan)
   uint32_t n_hot_groups;
   uint32_t epoch;
   int hot_shift;          // slots per group = 1 << hot_shift: the smallest power of two >= 1024 that keeps the table <= 4 KB
 };
+constexpr int kMaxHotGroups = 4096;
 // hot = active in this call or the previous one (or, seen from the pass B that runs beside it, in the next one)
 __device__ __forceinline__ bool group_is_hot(uint32_t last, uint32_t epoch) { return ((epoch - last + 1u) & 255u) <= 2u; }
 
@@ -1598,6 +1601,7 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
                 DevState* st) {
   const uint32_t seg_id = segment_of_block(L.descending);
   extern __shared__ __align__(16) uint8_t lhot[];   // the hot-group table (n_hot_groups bytes, padded to 16)
+  __shared__ uint32_t ltargets[kMaxHotGroups / 32];  // bit g: a link of this segment points into group g (another segment)
   // B1: pure streaming.  Per slot: detach (:1430-1433), which of its neighbours lie inside the regulariser
   // window (4-bit mask -> inwin8), membership in the recent list.  No LDS accumulators here, so the
   // occupancy stays high; the accumulation itself runs in k_reg_accumulate on the few segments that need it.
@@ -1619,9 +1623,40 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
   // place.  So with BOTH groups cold the byte cannot change anything.  The table (one byte per group: <= 4 KB)
   // is copied to LDS, so the test itself is an LDS read, not another gather.  (use_hot = 0 for two calls whenever
   // flags or links were written outside Integrate.)
-  if (use_hot)
-    for (uint32_t g = threadIdx.x * 16; g < L.n_hot_groups; g += kBlockB * 16)
-      *reinterpret_cast<uint4*>(&lhot[g]) = *reinterpret_cast<const uint4*>(&L.hot_epoch[g]);
+  //
+  // A whole segment is skipped -- its 17 KB of link records and flag bytes not even read -- when its own group is cold
+  // and so is every group one of its links points into: then every flag byte the pass would look at is of no consequence
+  // by the argument above, the segment has no recent slot and no edge into the window.  The set of groups a segment's
+  // links point into is kept as a bitmap per segment (seg_targets: 16 bits per lane, 512 bytes per segment against 17 KB),
+  // rebuilt by every pass that does read the segment.  Links only disappear between such passes (detach, too-far
+  // pruning), except in k_integrate / k_update_and_create, which stamp the group of every slot whose links they write:
+  // the segment is then hot and the next pass rebuilds its bitmap.  (At C2 four segments out of five are skipped:
+  // 93 MB -> ~25 MB per pass.)
+  static_assert(kBlockB * 16 == kMaxHotGroups, "one lane per 16 groups");
+  uint32_t hot16 = 0;   // bit k: group 16 * lane + k is hot
+  if (use_hot) {
+    const uint32_t g = threadIdx.x * 16;
+    if (g < L.n_hot_groups) {
+      const uint4 he = *reinterpret_cast<const uint4*>(&L.hot_epoch[g]);
+      *reinterpret_cast<uint4*>(&lhot[g]) = he;
+      const uint32_t w[4] = {he.x, he.y, he.z, he.w};
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (g + k < L.n_hot_groups && group_is_hot((w[k >> 2] >> (8 * (k & 3))) & 255u, L.epoch)) hot16 |= 1u << k;
+    }
+    if (!stats) {   // (the edge statistics count every link of the map)
+      const uint32_t own_group = base >> L.hot_shift;
+      const uint32_t reached = (uint32_t)L.seg_targets[(size_t)seg_id * kBlockB + threadIdx.x] | (threadIdx.x == own_group / 16 ? 1u << (own_group % 16) : 0u);
+      if (!__syncthreads_or((reached & hot16) != 0)) {
+        if (threadIdx.x == 0) {
+          L.recent_seg[seg_id] = kInvalid;   // (no recent slot; the mark is what smx_recon_debug_count_skipped_segments counts)
+          if (kAccumulate) need_seg[seg_id] = 0u;
+        }
+        return;
+      }
+    }
+  }
+  if (threadIdx.x < kMaxHotGroups / 32) ltargets[threadIdx.x] = 0;
   const uint32_t i0 = base + threadIdx.x * 4;
   uint32_t recent_bits = 0;
   int need = 0;
@@ -1635,6 +1670,35 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
   *reinterpret_cast<uchar4*>(&lflags[threadIdx.x * 4]) = own;
   __syncthreads();
   const bool quiet = use_hot && !group_is_hot(lhot[base >> L.hot_shift], L.epoch);
+  // The far flag bytes of a lane's 16 links are requested TOGETHER (a gather that is not needed reads the lane's own
+  // byte): fetched one after the other inside the loop below, as the compiler would arrange it, the 16 dependent round
+  // trips of a fully active segment's workgroup are what the whole launch lasts (tools/isa_phases.py: 20 waits -> 5).
+  uint32_t far_mask = 0;   // bit 4 j + q: that link leaves the segment and its target's flag byte matters
+  uint32_t far_flag[16];
+  if ((kDetach || kAccumulate) && i0 < N) {   // (the copy-only pass without detaching looks at no flag but the slot's own)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t nb = q == 0 ? trec[j].x : q == 1 ? trec[j].y : q == 2 ? trec[j].z : trec[j].w;
+        if (i0 + j < N && nb != kInvalid && nb - base >= (uint32_t)kSegB &&
+            !(quiet && !group_is_hot(lhot[nb >> L.hot_shift], L.epoch)))   // (both cold: neither bit is of any consequence)
+          far_mask |= 1u << (4 * j + q);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) far_flag[k] = 0;
+  if (__ballot(far_mask != 0) != 0ull) {   // (per wavefront: most wavefronts of the map have nothing to fetch)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const uint4& t = trec[k >> 2];
+      const uint32_t nb = (k & 3) == 0 ? t.x : (k & 3) == 1 ? t.y : (k & 3) == 2 ? t.z : t.w;
+      far_flag[k] = L.flags8[((far_mask >> k) & 1u) ? nb : min(i0, N - 1u)];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) keep(far_flag[k]);
+  }
   if (i0 < N) {
     const uint8_t ownf[4] = {own.x, own.y, own.z, own.w};
     uint8_t inw[4] = {0, 0, 0, 0};
@@ -1652,12 +1716,12 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
         const uint32_t rel = nb - base;
         uint32_t f;
         if (rel < (uint32_t)kSegB) f = lflags[rel];
-        else if (quiet && !group_is_hot(lhot[nb >> L.hot_shift], L.epoch)) f = 0;   // (both bits are of no consequence)
-        else f = L.flags8[nb];
+        else f = ((far_mask >> (4 * j + q)) & 1u) ? far_flag[4 * j + q] : 0u;
         if (kDetach && i < detach_limit && (f & 2u)) {  // :1430-1433
           S.set_neighbor(i, q, kInvalid);
           continue;
         }
+        if (rel >= (uint32_t)kSegB) { const uint32_t g = nb >> L.hot_shift; atomicOr(&ltargets[g >> 5], 1u << (g & 31u)); }
         ++edges;
         if (kAccumulate && (f & 1u)) { inw[j] |= (uint8_t)(1u << q); need = 1; }
       }
@@ -1675,6 +1739,7 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
   for (int j = 0; j < 4; ++j)
     if (recent_bits & (1u << j)) L.recent_list[off++] = i0 + j;
   const int any = __syncthreads_or(need);
+  L.seg_targets[(size_t)seg_id * kBlockB + threadIdx.x] = (uint16_t)(ltargets[threadIdx.x >> 1] >> (16 * (threadIdx.x & 1)));
   if (threadIdx.x == 0) {
     L.recent_seg[seg_id] = total;
     if (total) L.rec_chunks.desc[atomicAdd(L.rec_chunks.count, 1u)] = seg_id | ((total - 1u) << 22);   // (one walk step per segment)
@@ -2480,9 +2545,10 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->flags_buf[1], (size_t)r->nsegB * kSegB, true));
   r->L.flags8 = r->flags_buf[0];
   r->L.hot_shift = 10;
-  while ((((size_t)r->nseg * kSeg) >> r->L.hot_shift) + 1 > 4096) ++r->L.hot_shift;
+  while ((((size_t)r->nseg * kSeg) >> r->L.hot_shift) + 1 > (size_t)kMaxHotGroups) ++r->L.hot_shift;
   r->L.n_hot_groups = (uint32_t)((((size_t)r->nseg * kSeg) >> r->L.hot_shift) + 1);
   SMX_TRY(dev_alloc(&r->L.hot_epoch, (size_t)r->L.n_hot_groups + 64, true));   // (zeros: "last active in call 0")
+  SMX_TRY(dev_alloc(&r->L.seg_targets, (size_t)r->nsegB * kBlockB, true));   // (written by the unfiltered passes of the hold-off calls before anyone reads it)
   r->L.epoch = 128;   // (far from the zeros)
   r->hot_filter_enabled = 1;
   r->hot_holdoff = 3;
@@ -2556,7 +2622,7 @@ int smx_recon_destroy(smx_recon r) {
   SMX_ON_DEVICE(r->device);
   void* ptrs[] = {r->sc.supporting, r->sc.counts, r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth,
                   r->tb.pairs, r->tb.count, r->tb.ovf, r->ovf_count_set[0], r->ovf_count_set[1],
-                  r->vis_count_set[0], r->vis_count_set[1], r->L.seg_act, r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->fb.rec, r->fb.count, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1], r->L.hot_epoch,
+                  r->vis_count_set[0], r->vis_count_set[1], r->L.seg_act, r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->fb.rec, r->fb.count, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1], r->L.hot_epoch, r->L.seg_targets,
                   r->merge_flag, r->inwin8, r->need_seg, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->block_offsets, r->st};
   if (r->reg_stream) { (void)hipStreamSynchronize(r->reg_stream); (void)hipStreamDestroy(r->reg_stream); }
@@ -3227,6 +3293,19 @@ int smx_recon_debug_download_scratch(smx_recon r, smx_stream s, int32_t which, v
   }
   SMX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
   SMX_HIP(hipStreamSynchronize(st));
+  return SMX_OK;
+}
+
+int smx_recon_debug_count_skipped_segments(smx_recon r, smx_stream s, uint32_t* out) {
+  SMX_CHECK_ARG(r != nullptr && out != nullptr);
+  SMX_ON_DEVICE(r->device);
+  { const int rcj = join_regularizer(r, (hipStream_t)s); if (rcj != SMX_OK) return rcj; }
+  std::vector<uint32_t> marks((size_t)r->nsegB);
+  SMX_HIP(hipMemcpyAsync(marks.data(), r->L.recent_seg, marks.size() * 4, hipMemcpyDeviceToHost, (hipStream_t)s));
+  SMX_HIP(hipStreamSynchronize((hipStream_t)s));
+  uint32_t n = 0;
+  for (uint32_t m : marks) n += m == kInvalid ? 1u : 0u;
+  *out = n;
   return SMX_OK;
 }
 

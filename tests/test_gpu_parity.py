@@ -22,7 +22,7 @@ def _pipes(smx, s, max_surfels, pre=None, params_kw=None, scan_mode=0):
     return po, pg
 
 
-def _compare_state(po, pg, check_scratch=True):
+def _compare_state(po, pg, check_scratch=True, check_stats=True):
     n = po.recon.surfels_size
     assert pg.reconstruction.surfels_size() == n
     assert pg.reconstruction.surfel_count() == po.recon.surfel_count
@@ -32,6 +32,8 @@ def _compare_state(po, pg, check_scratch=True):
             got = pg.reconstruction.debug_download_scratch(name)
             assert np.array_equal(got, ref), name
         assert np.array_equal(pg.depth_final.Download(), po.depth_final), "blended depth"
+    if not check_stats:
+        return
     so, sg = po.recon.stats(), pg.reconstruction.stats()
     for k, v in so.items():
         assert sg[k] == v, (k, v, sg[k])
@@ -244,6 +246,33 @@ def test_stream_parity_every_frame(smx, scan_mode):
     run_both(po, pg, s, list(range(4, 26)), check)
     assert seen["replaced"] > 50 and seen["merged"] > 10 and seen["conflict"] > 100, seen
     assert po.recon.surfels_size > 10000
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_stream_parity_with_skipped_segments(smx, overlap):
+    """A camera that turns away from what it mapped, short windows, the statistics counters off: the regulariser's link
+    scan then skips the segments whose links all stay among slots nothing has happened to for two calls (with the
+    counters on it reads every link to count it, which is why no other stream test exercises this).  Every frame is
+    compared; the number of skipped segments must be substantial, and the map the camera comes BACK to at the end -- cold
+    segments turning hot again, new links into them -- must match as well."""
+    s = small_stream(yaw_deg_per_frame=3.0, obstacle_until=8)
+    kw = dict(surfel_integration_active_window_size=4, regularization_frame_window_size=3)
+    po, pg = _pipes(smx, s, 200000, params_kw=kw)
+    pg.reconstruction.set_stats_enabled(False)
+    pg.reconstruction.set_overlap(overlap)
+    skipped = []
+
+    def check(f):
+        _compare_state(po, pg, check_stats=False)
+        skipped.append(pg.reconstruction.debug_count_skipped_segments())
+
+    run_both(po, pg, s, list(range(4, 60)), check)
+    n_segments = (po.recon.surfels_size + 1023) // 1024
+    assert n_segments >= 20 and max(skipped) >= n_segments // 3, (n_segments, skipped)
+    # ... and back again: the yaw runs backwards under increasing frame numbers
+    s2 = small_stream(yaw_deg_per_frame=-3.0, start_yaw_deg=3.0 * 120, obstacle_until=-1)
+    run_both(po, pg, s2, list(range(60, 90)), check)
+    assert min(skipped[-10:]) >= 1, (n_segments, skipped)
 
 
 @pytest.mark.parametrize("w,h", [(170, 101), (97, 64)])

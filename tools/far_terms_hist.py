@@ -64,6 +64,30 @@ def main():
         for g in (4, 16):
             pg = np.unique(s * (1 << 20) + d // g)
             print("  with destinations grouped %d segments: pairs %d" % (g, pg.size))
+    # pass B's segment skipping: a segment has to be read if it holds a recent slot or a link of it reaches a "hot" unit
+    # (a unit of `gran` slots that holds a recent slot)
+    for gran in (2048, 1024, 256, 64, 16, 1):
+        hot_unit = np.zeros(n // gran + 1, bool)
+        hot_unit[np.nonzero(recent)[0] // gran] = True
+        reach = valid & hot_unit[Tc // gran] & ((Tc // SEG) != (src // SEG))
+        seg_reach = np.zeros(n // SEG + 1, bool)
+        seg_reach[src[reach] // SEG] = True
+        own = np.zeros(n // SEG + 1, bool)
+        own[np.nonzero(recent)[0] // SEG] = True
+        own_g = np.zeros(n // SEG + 1, bool)   # own group (max(gran, SEG) slots) hot
+        g2 = max(gran, SEG)
+        own_g[:] = np.repeat(hot_unit if gran >= SEG else own, 1)[(np.arange(n // SEG + 1) * SEG) // g2] if gran >= SEG else own
+        nseg = n // SEG + 1
+        print("units of %5d slots: hot units %6d (%.1f %%); segments to read: own hot %d, + reached %d = %d of %d (%.1f %%)" %
+              (gran, hot_unit.sum(), 100.0 * hot_unit.mean(), own_g.sum(), (seg_reach & ~own_g).sum(), (seg_reach | own_g).sum(), nseg,
+               100.0 * (seg_reach | own_g).mean()))
+    # what the library's pass B actually skips (statistics off: the edge counters read every link)
+    rec = wl.pipe.reconstruction
+    rec.set_stats_enabled(False)
+    for j in range(30, 35):
+        wl.pipe.run_array(*wl.steps([wl.plan(first + j, 4 + j)]))
+        api.StreamSynchronize(None)
+        print("frame +%d: pass B skipped %d of %d segments" % (j, rec.debug_count_skipped_segments(), n // SEG + 1))
     # how far do far links reach?
     m = inwin & ~near
     dist = np.abs(Tc[m] - src[m])
