@@ -42,13 +42,17 @@ ALG_BYTES = {
     # P records + flag bytes of the segments that are read, 2 flag bytes per slot of the culled ones, list + z-buffer
     "scan_visible": lambda st, P: 18.0 * (st["surfels_size"] - 1024.0 * st.get("n_segments_skipped", 0))
                                   + 2.0 * 1024.0 * st.get("n_segments_skipped", 0) + (4.0 + 1.9 * 8.0) * st["n_visible"],
-    "neighbor_scan": lambda st, P: 18.0 * st["surfels_size"] + 1.0 * st["n_edges"] + 4.0 * st["n_recent"],
-    # slots served: contributors and recent slots (mostly the same slots): 50 B own records each; 48 B per link into
-    # the window (target S + T records, 16 B inbox/accumulator store); 16 B own-term record per recent slot
-    "reg_accumulate": lambda st, P: 50.0 * max(st["n_contributors"], st["n_recent"]) + 48.0 * st["n_window_edges"]
-                                    + 16.0 * st["n_recent"],
-    # P, S, r^2, own-term record, three accumulator channels (32 + 32 + 64 B), S store, inbox re-zeroing
-    "reg_step": lambda st, P: 224.0 * st["n_recent"],
+    # T records + flag and mask bytes of the segments that are read (18 B per slot), the hot table + the target-group
+    # bitmap (4.5 KB) of the ones that are skipped, one flag byte per link, the recent list
+    "neighbor_scan": lambda st, P: 18.0 * (st["surfels_size"] - 1024.0 * st.get("n_link_segments_skipped", 0))
+                                   + 4608.0 * st.get("n_link_segments_skipped", 0) + 1.0 * st["n_edges"] + 4.0 * st["n_recent"],
+    # slots served: contributors and recent slots (mostly the same slots): 50 B own records each; per link into the
+    # window the target's S record (16 B) and, for the 29 % of them that leave the segment (tools/far_terms_hist.py), a
+    # 16 B record in the target segment's bin; per recent slot the in-segment sums (16 B) and the own-term record (16 B)
+    "reg_accumulate": lambda st, P: 50.0 * max(st["n_contributors"], st["n_recent"]) + (16.0 + 0.29 * 16.0) * st["n_window_edges"]
+                                    + 32.0 * st["n_recent"],
+    # P, S, N, own-term record, in-segment sums (read + re-zeroed), S store: 112 B per recent slot; the bins' records
+    "reg_step": lambda st, P: 112.0 * st["n_recent"] + 0.29 * 16.0 * st["n_window_edges"],
     "reg_update": lambda st, P: 36.0 * st["n_recent"],
     # association tiles: per pair (~1.9 per visible slot) 8 B + the slot's P and N records (32 B); per pixel the
     # measurement (10 B) and the five images written (24 B); the merge phase's supported-surfel records (32 B per visible slot)
@@ -391,6 +395,9 @@ def run_integrate(args):
     wl.pipe.run_array(*wl.steps(plan[total:total + 1]))
     st = rec.stats()
     rec.set_stats_enabled(False)
+    # (with the counters on the link scan reads every segment; what it skips otherwise: one more frame, counters off)
+    wl.pipe.run_array(*wl.steps(plan[total:total + 1]))
+    st["n_link_segments_skipped"] = rec.debug_count_skipped_segments()
 
     # per-stage and per-kernel device times (separate untimed pass, HIP events on the launch stream)
     rec.set_timing_enabled(3)

@@ -915,13 +915,25 @@ struct BlendMasks {
   int last_ring;                    // the highest non-empty ring (0: nothing to blend in tile + halo)
 };
 __device__ __forceinline__ unsigned long long dilate_row(unsigned long long m) { return m | (m << 1) | (m >> 1); }
-__device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v) {   // lane r gets lane r - 1's value, lane 0 gets 0
-  const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, 1), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1);
-  return (threadIdx.x & 63) == 0 ? 0ull : ((unsigned long long)hi << 32) | lo;
+// lane r gets lane r - 1's / r + 1's value, the first / last lane 0: DPP wave_shr:1 / wave_shl:1, no LDS crossbar trip
+__device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x138, 0xF, 0xF, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, false);
+  return ((unsigned long long)hi << 32) | lo;
 }
-__device__ __forceinline__ unsigned long long shfl_down64(unsigned long long v) {   // lane r gets lane r + 1's value, lane 63 gets 0
-  const uint32_t lo = (uint32_t)__shfl_down((int)(uint32_t)v, 1), hi = (uint32_t)__shfl_down((int)(uint32_t)(v >> 32), 1);
-  return (threadIdx.x & 63) == 63 ? 0ull : ((unsigned long long)hi << 32) | lo;
+__device__ __forceinline__ unsigned long long shfl_down64(unsigned long long v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x130, 0xF, 0xF, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x130, 0xF, 0xF, false);
+  return ((unsigned long long)hi << 32) | lo;
+}
+// The 64-bit mask of the region row a lane belongs to (16 lanes per row: lane = 16 * row-in-wavefront + cg, the lane's
+// bit b standing for column cg + 16 b) from four wavefront ballots: no LDS atomics, no cleared words.
+__device__ __forceinline__ unsigned long long row_mask_from_bits(uint32_t bits) {
+  const int sh = (int)(threadIdx.x & 48u);   // 16 * row-in-wavefront
+  unsigned long long m = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) m |= ((__ballot((bits >> b) & 1u) >> sh) & 0xFFFFull) << (16 * b);
+  return m;
 }
 
 __global__ void __launch_bounds__(kBlendThreads)
@@ -939,14 +951,13 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
   const int tile_x = (int)(blockIdx.x % (uint32_t)tiles_x), tile_y = (int)(blockIdx.x / (uint32_t)tiles_x);
   const int x0 = tile_x * kBlendTile - halo, y0 = tile_y * kBlendTile - halo;
   // ---- load.  This lane's row and its four columns cg, cg + 16, cg + 32, cg + 48 (16 lanes read 16 consecutive cells):
-  // depth and "has a supporting surfel", all requested before the first use
+  // depth and "has a supporting surfel"; and the association sums of the four cells the lane owns in the ring phase
+  // (needed where such a cell turns out to be a border cell: fetched now, the start ring then waits for nothing) -- all
+  // requested before the first use
   const int r = (int)(threadIdx.x >> 4), cg = (int)(threadIdx.x & 15);
-  auto row_bits = [cg](uint32_t bits) -> unsigned long long {   // the lane's four bits at their columns of the row mask
-    return ((unsigned long long)((bits & 1u) | ((bits & 2u) << 15)) << cg) |
-           ((unsigned long long)(((bits >> 2) & 1u) | ((bits & 8u) << 13)) << (cg + 32));
-  };
   uint32_t dv[4], sv[4];
   bool inside[4];
+  long long bs[4]; uint32_t bc[4];
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     const int cx = cg + 16 * b, x = x0 + cx, y = y0 + r;
@@ -956,9 +967,13 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
     sv[b] = sc.supporting[(size_t)yc * W + xc];
   }
 #pragma unroll
-  for (int b = 0; b < 4; ++b) { keep(dv[b]); keep(sv[b]); }
-  if (threadIdx.x < 3 * 64) M.zero[threadIdx.x] = 0;   // (zero, supp, elig are adjacent)
-  __syncthreads();
+  for (int j = 0; j < 4; ++j) {
+    const int R = (r + 16 * j) & 63, C = 4 * cg + j;
+    const size_t g = (size_t)min(max(y0 + R, 0), H - 1) * W + min(max(x0 + C, 0), W - 1);
+    bs[j] = sc.depth_sums[g]; bc[j] = sc.counts[g];
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) { keep(dv[b]); keep(sv[b]); keep((uint32_t)bs[b]); keep((uint32_t)(bs[b] >> 32)); keep(bc[b]); }
   SMX_STAMP(stamps, 1);
   uint32_t zb = 0, sb0 = 0, eb = 0;
 #pragma unroll
@@ -974,9 +989,10 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
     // cells on the region rim cannot be evaluated (their 3x3 window leaves the region) and are not needed
     if (inside[b] && x >= 1 && y >= 1 && x < W - 1 && y < H - 1 && cx >= 1 && r >= 1 && cx < rw - 1 && r < rw - 1) eb |= 1u << b;
   }
-  atomicOr(&M.zero[r], row_bits(zb));
-  if (sb0) atomicOr(&M.supp[r], row_bits(sb0));
-  if (eb) atomicOr(&M.elig[r], row_bits(eb));
+  {
+    const unsigned long long mz = row_mask_from_bits(zb), ms = row_mask_from_bits(sb0), me = row_mask_from_bits(eb);
+    if (cg == 0) { M.zero[r] = mz; M.supp[r] = ms; M.elig[r] = me; }
+  }
   __syncthreads();
   SMX_STAMP(stamps, 2);
   // ---- the fronts of both maps, by the first wavefront: lane = region row
@@ -1028,16 +1044,6 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
         hit_n |= (uint32_t)((M.ring_n[1][R] >> C) & 1ull) << j;
       }
       if (hit_m | hit_n) {
-        long long bs[4]; uint32_t bc[4];   // depth sum and count of the lane's border cells, requested together
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int R = (r0 + 16 * j) & 63, C = 4 * cq + j;
-          const bool need = ((hit_m | hit_n) & (1u << j)) != 0;
-          const size_t g = need ? (size_t)(y0 + R) * W + (x0 + C) : (size_t)0;
-          bs[j] = sc.depth_sums[g]; bc[j] = sc.counts[g];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { keep((uint32_t)bs[j]); keep((uint32_t)(bs[j] >> 32)); keep(bc[j]); }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (!((hit_m | hit_n) & (1u << j))) continue;
@@ -1053,15 +1059,15 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
       }
     }
     for (int it = 2; it <= last_ring; ++it) {
-      __syncthreads();   // the deltas of ring it - 1 are complete
       const float f = (float)(it - 1) * term;
-      uint32_t hit_m = 0, hit_n = 0;
+      uint32_t hit_m = 0, hit_n = 0;   // (the masks are final: read in front of the barrier, not behind it)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int R = (r0 + 16 * j) & 63, C = 4 * cq + j;
         hit_m |= (uint32_t)((M.ring_m[it][R] >> C) & 1ull) << j;
         hit_n |= (uint32_t)((M.ring_n[it][R] >> C) & 1ull) << j;
       }
+      __syncthreads();   // the deltas of ring it - 1 are complete
       // (a cell belongs to one map only -- supported cells to the measurement-border map, unsupported ones to the
       // surfel-border map -- so one code path serves both)
       for (uint32_t todo = hit_m | hit_n; todo; todo &= todo - 1) {
@@ -1488,19 +1494,35 @@ __device__ __forceinline__ void new_create_body(const Surfels& S, const FrameCtx
   if (block != 0 && n_blocks * (uint32_t)kBlock >= (uint32_t)(c.W * c.H) &&
       block_sums[(block * (uint32_t)kBlock) / (uint32_t)kScanPxPerBlock] == 0) return;
   const int per = (n_scan_blocks + kBlock - 1) / kBlock;
-  uint32_t mine = 0;
-  for (int j = 0; j < per; ++j) {
-    const int bidx = threadIdx.x * per + j;
-    if (bidx < n_scan_blocks) mine += block_sums[bidx];
-  }
-  uint32_t total;
-  uint32_t run = block_excl_scan(mine, wave_tot, total);
-  for (int j = 0; j < per; ++j) {
-    const int bidx = threadIdx.x * per + j;
-    if (bidx < n_scan_blocks) { block_offsets[bidx] = run; run += block_sums[bidx]; }
+  const uint32_t base = st->create_base_next;   // (requested with the totals)
+  uint32_t mine = 0, total;
+  if (per <= 8) {   // (images up to 2 M pixels) the lane's totals in one round trip, kept for the second loop
+    uint32_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int bidx = threadIdx.x * per + j;
+      v[j] = (j < per && bidx < n_scan_blocks) ? block_sums[bidx] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mine += v[j];
+    uint32_t run = block_excl_scan(mine, wave_tot, total);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int bidx = threadIdx.x * per + j;
+      if (j < per && bidx < n_scan_blocks) { block_offsets[bidx] = run; run += v[j]; }
+    }
+  } else {
+    for (int j = 0; j < per; ++j) {
+      const int bidx = threadIdx.x * per + j;
+      if (bidx < n_scan_blocks) mine += block_sums[bidx];
+    }
+    uint32_t run = block_excl_scan(mine, wave_tot, total);
+    for (int j = 0; j < per; ++j) {
+      const int bidx = threadIdx.x * per + j;
+      if (bidx < n_scan_blocks) { block_offsets[bidx] = run; run += block_sums[bidx]; }
+    }
   }
   __syncthreads();
-  const uint32_t base = st->create_base_next;
   const uint32_t room = max_surfels - base;
   const uint32_t created = total < room ? total : room;  // cap rule (reference: unchecked, cc:291)
   if (block == 0) {
@@ -1514,55 +1536,82 @@ __device__ __forceinline__ void new_create_body(const Surfels& S, const FrameCtx
   }
   const int kDX[4] = {-1, 1, 0, 0}, kDY[4] = {0, 0, -1, 1};
   const int W = c.W, H = c.H, P = W * H;
+  // This launch sits on the frame-to-frame cycle and lasts as long as its slowest lane, and a creating lane used to be
+  // that lane: four neighbour directions one after the other, each a chain of dependent gathers (supporting surfel ->
+  // its position -> its smooth position), between stores the compiler must not move loads across.  So: every pixel-side
+  // value of the pixel and its four neighbours first, all requested together; then the neighbour surfels' P and S
+  // records together; then the arithmetic (in the reference's order) and the stores.
   for (int k = block * kBlock + threadIdx.x; k < P; k += n_blocks * kBlock) {
     const uint32_t rank = block_offsets[k / kScanPxPerBlock] + ranks[k];
     // ranks[] keeps the block-local values; global rank = block offset + local rank
     if (flags[k] != 1 || rank >= created) continue;
     const int y = k / W, x = k - y * W;
     const uint32_t i = base + rank;
-    const float depth = c.inv_depth_scaling * (float)in.depth(y, x);
+    const uint32_t depth_u = in.depth(y, x);
+    const float2 nxy = in.normals(y, x);
+    const uchar3 col = in.color(y, x);
+    const float r2 = in.radius(y, x);
+    uint32_t nsup[4], nflag[4], nrank_local[4], ndepth_u[4];
+    int kks[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      // (a flagged pixel has four neighbours inside the image: the flag pass leaves the border out, kernels.cu:90-111)
+      const int yy = min(max(y + kDY[d], 0), H - 1), xx = min(max(x + kDX[d], 0), W - 1);
+      kks[d] = yy * W + xx;
+      nsup[d] = sc.supporting[kks[d]];
+      nflag[d] = flags[kks[d]];
+      nrank_local[d] = ranks[kks[d]];
+      ndepth_u[d] = in.depth(yy, xx);
+    }
+    keep(depth_u); keep(nxy); keep(r2); keep((uint32_t)col.x | ((uint32_t)col.y << 8) | ((uint32_t)col.z << 16));
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { keep(nsup[d]); keep(nflag[d]); keep(nrank_local[d]); keep(ndepth_u[d]); }
+    float4 np4[4], ns4[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t gidx = nsup[d] != kInvalid ? nsup[d] : base;   // (unused: any valid slot)
+      np4[d] = *S.group(kGroupP, gidx);
+      ns4[d] = *S.group(kGroupS, gidx);
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { keep(np4[d]); keep(ns4[d]); }
+    const float depth = c.inv_depth_scaling * (float)depth_u;
     const Vec3 lp = {depth * (c.up.fx_inv * (float)x + c.up.cx_inv), depth * (c.up.fy_inv * (float)y + c.up.cy_inv), depth};
     const Vec3 gp = mul(c.G, lp);
-    S.f(kX, i) = gp.x; S.f(kY, i) = gp.y; S.f(kZ, i) = gp.z;
-    const float2 nxy = in.normals(y, x);
     const Vec3 mn = {nxy.x, nxy.y, meas_normal_z(nxy.x, nxy.y)};
     const Vec3 gn = rotate(c.G, mn);
-    S.f(kNormalX, i) = gn.x; S.f(kNormalY, i) = gn.y; S.f(kNormalZ, i) = gn.z;
-    const uchar3 col = in.color(y, x);
-    S.u(kColor, i) = (uint32_t)col.x | ((uint32_t)col.y << 8) | ((uint32_t)col.z << 16);
-    S.f(kConfidence, i) = 1;
-    S.u(kCreationStamp, i) = c.frame;
-    S.u(kLastUpdateStamp, i) = c.frame;
-    flags8[i] = make_flags(c.frame, 0u, c.frame, c.reg_window);
-    a.hot_epoch[i >> a.hot_shift] = (uint8_t)a.epoch;
-    if (a.dirty8) a.dirty8[i] = 1;
-    const float r2 = in.radius(y, x);
-    S.f(kRadiusSq, i) = r2;
     Vec3 sum = {0, 0, 0};
     int count_plus_1 = 1;
     uint32_t nbs[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      const int kk = (y + kDY[d]) * W + (x + kDX[d]);
-      uint32_t nb = sc.supporting[kk];
+      uint32_t nb = nsup[d];
       if (nb != kInvalid) {
-        const float dx = S.f(kX, nb) - gp.x, dy = S.f(kY, nb) - gp.y, dz = S.f(kZ, nb) - gp.z;
+        const float dx = np4[d].x - gp.x, dy = np4[d].y - gp.y, dz = np4[d].z - gp.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
         if (d2 > c.rf2 * r2) nb = kInvalid;
         else {
-          sum.x = sum.x + S.f(kSmoothX, nb); sum.y = sum.y + S.f(kSmoothY, nb); sum.z = sum.z + S.f(kSmoothZ, nb);
+          sum.x = sum.x + ns4[d].x; sum.y = sum.y + ns4[d].y; sum.z = sum.z + ns4[d].z;
           ++count_plus_1;
         }
-      } else if (flags[kk] == 1) {
-        const uint32_t nrank = block_offsets[kk / kScanPxPerBlock] + ranks[kk];
+      } else if (nflag[d] == 1) {
+        const uint32_t nrank = block_offsets[kks[d] / kScanPxPerBlock] + nrank_local[d];
         if (nrank < created) {
-          const float od = c.inv_depth_scaling * (float)in.depth(y + kDY[d], x + kDX[d]);
+          const float od = c.inv_depth_scaling * (float)ndepth_u[d];
           const float ad2 = (depth - od) * (depth - od);
           if (ad2 <= c.rf2 * r2) nb = base + nrank;
         }
       }
       nbs[d] = nb;
     }
+    *S.group(kGroupP, i) = make_float4(gp.x, gp.y, gp.z, __uint_as_float(c.frame));                       // X, Y, Z, LastUpdateStamp
+    *S.group(kGroupN, i) = make_float4(gn.x, gn.y, gn.z, r2);                                              // normal, RadiusSquared
+    S.f(kConfidence, i) = 1;
+    S.u(kCreationStamp, i) = c.frame;
+    S.u(kColor, i) = (uint32_t)col.x | ((uint32_t)col.y << 8) | ((uint32_t)col.z << 16);
+    flags8[i] = make_flags(c.frame, 0u, c.frame, c.reg_window);
+    a.hot_epoch[i >> a.hot_shift] = (uint8_t)a.epoch;
+    if (a.dirty8) a.dirty8[i] = 1;
     S.set_neighbors(i, make_uint4(nbs[0], nbs[1], nbs[2], nbs[3]));
     S.f(kSmoothX, i) = (gp.x + sum.x) / (float)count_plus_1;  // :227-229
     S.f(kSmoothY, i) = (gp.y + sum.y) / (float)count_plus_1;
