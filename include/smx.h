@@ -317,7 +317,8 @@ int smx_recon_debug_count_skipped_segments(smx_recon r, smx_stream s, uint32_t* 
  * through the overflow list; bit 4: pass A reserves bin space pair by pair instead of per (workgroup, tile) through
  * an LDS table (the path images of more than 8192 tiles take); bit 5: the regulariser's far-term bins hold 4 records
  * per destination segment, bit 6: a sender workgroup addresses 2 destination segments through the bins -- the other far
- * terms take the atomic accumulators (the overflow paths of those bins). */
+ * terms take the atomic accumulators (the overflow paths of those bins); bit 7: the blend's other tile size (the
+ * library picks 32 x 32 or 40 x 40 pixels by the number of tiles per compute unit; this bit swaps the choice). */
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode);
 /* Frame pipelining (default on): the regulariser of a frame runs on an internal stream beside the first
  * kernels of the next smx_recon_integrate call (which only read what the regulariser does not write).

@@ -900,7 +900,10 @@ k_blend_iter(int it, float term, float ds, Img<uint16_t> depth, Scratch sc, Blen
 // their neighbours' deltas, in the reference's window order.  A ring costs what it changes, not nine LDS reads for
 // every cell of the region (profiles/r04g: that ring loop was 47 of the old kernel's 66 us), and the loop ends with the
 // last non-empty ring.
-constexpr int kBlendTile = 32;
+// Tile edge: 32 or 40 pixels (template parameter), chosen per launch so that the slowest CU has the least to do: the
+// kernel is bound by what ONE CU can load and ring through for its tiles, and 300 tiles of 32 x 32 (640 x 480) leave 44
+// CUs with two tiles while the others idle after one; 192 tiles of 40 x 40 -- 32 % more cells each, 15 % fewer in total
+// -- give every CU at most one (34.5 -> 27.2 us alone, profiles/r13_ab_notes.md).  The region (tile + 2 halos) must stay <= 64 cells wide.
 constexpr int kBlendThreads = 1024;
 constexpr int kBlendMaxHalo = 16;    // radius <= 17 uses this kernel (region <= 64 x 64), larger radii the multi-launch path
 constexpr int kBlendMaxRings = kBlendMaxHalo + 2;
@@ -936,6 +939,7 @@ __device__ __forceinline__ unsigned long long row_mask_from_bits(uint32_t bits) 
   return m;
 }
 
+template <int kBlendTile>
 __global__ void __launch_bounds__(kBlendThreads)
 k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<uint16_t> out, Scratch sc, int W, int H,
               int tiles_x, unsigned long long* stamps) {
@@ -1679,8 +1683,8 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
   // links point into is kept as a bitmap per segment (seg_targets: 16 bits per lane, 512 bytes per segment against 17 KB),
   // rebuilt by every pass that does read the segment.  Links only disappear between such passes (detach, too-far
   // pruning), except in k_integrate / k_update_and_create, which stamp the group of every slot whose links they write:
-  // the segment is then hot and the next pass rebuilds its bitmap.  (At C2 four segments out of five are skipped:
-  // 93 MB -> ~25 MB per pass.)
+  // the segment is then hot and the next pass rebuilds its bitmap.  (At C2 two segments out of five are skipped;
+  // with groups of 2048 slots a cold segment's thousand far links seldom miss every hot group -- tools/far_terms_hist.py.)
   static_assert(kBlockB * 16 == kMaxHotGroups, "one lane per 16 groups");
   uint32_t hot16 = 0;   // bit k: group 16 * lane + k is hot
   if (use_hot) {
@@ -2388,6 +2392,8 @@ struct smx_recon_s {
   uint32_t* ovf_count_set[2];   // overflow counters, alternating by call (the tile kernel zeroes the next call's)
   unsigned long long* stamps;   // -DSMX_STAMPS builds: [2][8192 workgroups][16] shader clocks (tile kernel, blend kernel)
   int no_lds_tables;        // A/B switch (scan mode bit 4)
+  int blend_other_tile;     // A/B switch (scan mode bit 7)
+  int cu_count;             // compute units of the object's device
   uint32_t bin_cap_full;    // the bins' allocated capacity (tb.cap is lowered by the A/B switch that forces overflows)
   uint32_t* vis_count_set[2];   // chunk counters of the visible list, alternating by call (k_update_and_create zeroes the next call's)
   uint32_t* dir_host;           // page-locked word: the direction the tile kernel last chose for the all-slot kernels
@@ -2660,6 +2666,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_HIP(hipGetDeviceProperties(&prop, device));
   const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   r->grid_surfels = cus * 8;  // 8 x 256-thread workgroups per CU: full occupancy, >> 256 workgroups
+  r->cu_count = cus;
   r->grid_list = cus * 32;  // the lists are sparse: most chunks are empty, so more, shorter walks
   r->stats_enabled = 1;
   *out = r;
@@ -2752,7 +2759,7 @@ int smx_recon_set_overlap(smx_recon r, int32_t enabled) {
 }
 
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
-  SMX_CHECK_ARG(r != nullptr && mode >= 0 && mode <= 127);
+  SMX_CHECK_ARG(r != nullptr && mode >= 0 && mode <= 255);
   SMX_ON_DEVICE(r->device);
   r->scan_mode = mode & 1;
   r->blend_multi_launch = (mode >> 1) & 1;
@@ -2761,6 +2768,7 @@ int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
   r->no_lds_tables = (mode >> 4) & 1;                     // pass A reserves bin space per pair (the path of images with > 8192 tiles)
   r->fb.cap = ((mode >> 5) & 1) ? 4u : kFarBinCap;        // 4 records per far-term bin: most far terms spill to grad_acc
   r->fb.hash_mask = ((mode >> 6) & 1) ? 1u : (uint32_t)kFarHash - 1u;   // 2 destinations per sender workgroup: the rest spills
+  r->blend_other_tile = (mode >> 7) & 1;                  // the blend's other tile size (40 x 40 where it would take 32 x 32 and vice versa)
   return SMX_OK;
 }
 
@@ -2862,12 +2870,24 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   const Img<uint16_t> blended = {r->blended_depth, r->H, r->W, (size_t)r->W * sizeof(uint16_t)};
   if (fused_blend) {
     SlotTimer t(r, sF, kSlotBlend);
-    const int rw = kBlendTile + 2 * halo;
+    // tile edge: the one that leaves the busiest CU the fewest cells (see k_blend_tiles)
+    const int cus = r->cu_count;
+    int tile = 32;
+    if (40 + 2 * halo <= 64) {
+      auto cost = [&](int t) { const long long n = (long long)div_up(r->W, t) * div_up(r->H, t); return ((n + cus - 1) / cus) * (long long)(t + 2 * halo) * (t + 2 * halo); };
+      if ((cost(40) < cost(32)) != (r->blend_other_tile != 0)) tile = 40;
+    }
+    const int rw = tile + 2 * halo;
     const size_t lds = sizeof(BlendMasks) + (size_t)rw * rw * 10;
-    const int tiles_x = div_up(r->W, kBlendTile);
-    const uint32_t n_blend = (uint32_t)(tiles_x * div_up(r->H, kBlendTile));
-    hipLaunchKernelGGL(k_blend_tiles, dim3(n_blend), dim3(kBlendThreads), lds, sF, p->measurement_blending_radius, term, ds,
-                       in.depth, blended, r->sc, r->W, r->H, tiles_x, r->stamps ? r->stamps + 16 * 8192 : nullptr);
+    const int tiles_x = div_up(r->W, tile);
+    const uint32_t n_blend = (uint32_t)(tiles_x * div_up(r->H, tile));
+    unsigned long long* stamps = r->stamps ? r->stamps + 16 * 8192 : nullptr;
+    if (tile == 40)
+      hipLaunchKernelGGL(k_blend_tiles<40>, dim3(n_blend), dim3(kBlendThreads), lds, sF, p->measurement_blending_radius, term, ds,
+                         in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps);
+    else
+      hipLaunchKernelGGL(k_blend_tiles<32>, dim3(n_blend), dim3(kBlendThreads), lds, sF, p->measurement_blending_radius, term, ds,
+                         in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps);
   } else if (p->do_blending) {
     // the reference's own sequence (2 clears + start + iterations, kernels.cc:165-205), in place on the caller's depth
     SlotTimer t(r, sF, kSlotBlend);

@@ -25,7 +25,13 @@ def main():
     for j in range(-4, 40):
         wl.render(first + j, 4 + j)
     plan = [wl.plan(first + j, 4 + j) for j in range(30)]
-    wl.pipe.run_array(*wl.steps(plan))
+    if os.environ.get("SMX_STAMP_ALONE"):   # every kernel alone on the chip: no frame pipelining, one frame at a time
+        wl.pipe.reconstruction.set_overlap(False)
+        for step in plan:
+            wl.pipe.run_array(*wl.steps([step]))
+            api.StreamSynchronize(None)
+    else:
+        wl.pipe.run_array(*wl.steps(plan))
     api.StreamSynchronize(None)
     out = np.zeros((2, 8192, 16), np.uint64)
     _lib.check(L.smx_recon_debug_download_stamps(wl.pipe.reconstruction._h, out.ctypes.data_as(C.c_void_p)))
