@@ -324,7 +324,7 @@ def run_integrate(args):
     # window still hold the end of the growth phase when it begins, and a short warm-up would time a different regime
     # (round 2: 4144 frames/s at --steps 20 --warmup 5 against 3873 at --steps 300 --warmup 20).
     first = g_end + 10
-    cal, reps = 10, 20
+    cal, reps = 37, 20
     SETTLE = 64
     W_user, W = W, W + SETTLE
     total = W + cal + K
@@ -344,16 +344,22 @@ def run_integrate(args):
     if args.scan_mode:
         rec.set_scan_mode(args.scan_mode)
     wl.pipe.run_array(*wl.steps(plan[:W]))
-    # short calibration pass with HIP events around every kernel: which Integrate kernel dominates the frame?
-    # (frame pipelining off here and in the per-kernel pass below, so that kernels are timed one at a time)
-    rec.set_overlap(False)
-    rec.set_timing_enabled(2)
+    # short calibration pass: which Integrate kernel dominates the frame?  Judged IN the frame -- pipelining on, HIP events
+    # around one kernel at a time for a few frames each (alone on the chip the candidates lie within 10 % of each other
+    # and the choice flipped from run to run; beside the other chains of the frame they do not)
     names = rec.kernel_time_names()
     cal_ms = np.zeros(len(names))
-    for j in range(W, W + cal - 1):
-        wl.pipe.run_array(*wl.steps(plan[j:j + 1]))
-        cal_ms += np.array(rec.kernel_times_ms())
-    rec.set_timing_enabled(0)
+    per = (cal - 1) // len(names)
+    rec.set_overlap(not args.no_overlap)
+    for idx, name in enumerate(names):
+        rec.profile_begin(name, per)
+        wl.pipe.run_array(*wl.steps(plan[W + idx * per:W + (idx + 1) * per]))
+        api.StreamSynchronize(None)
+        ms, n = rec.profile_end()
+        cal_ms[idx] = ms if n > 0 else 0.0
+    if (cal - 1) - per * len(names) > 0:
+        wl.pipe.run_array(*wl.steps(plan[W + per * len(names):W + cal - 1]))
+    rec.set_overlap(False)
     # value distributions of the frame in front of the timed window (counters on for this frame only)
     rec.set_stats_enabled(True)
     wl.pipe.run_array(*wl.steps(plan[W + cal - 1:W + cal]))

@@ -315,7 +315,7 @@ int smx_recon_debug_count_skipped_segments(smx_recon r, smx_stream s, uint32_t* 
  * start + iteration launches instead of the fused LDS kernel; bit 2: the regulariser's link scan gathers the flag byte
  * of every far link (no hot-group filter); bit 3: association bins of 16 pairs per tile, so that most pairs travel
  * through the overflow list; bit 4: pass A reserves bin space pair by pair instead of per (workgroup, tile) through
- * an LDS table (the path images of more than 8192 tiles take); bit 5: the regulariser's far-term bins hold 4 records
+ * an LDS table (the path a pair takes that finds no room in that table); bit 5: the regulariser's far-term bins hold 4 records
  * per destination segment, bit 6: a sender workgroup addresses 2 destination segments through the bins -- the other far
  * terms take the atomic accumulators (the overflow paths of those bins); bit 7: the blend's other tile size (the
  * library picks 32 x 32 or 40 x 40 pixels by the number of tiles per compute unit; this bit swaps the choice). */

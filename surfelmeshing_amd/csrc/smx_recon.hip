@@ -291,12 +291,12 @@ struct TileBins {
 
 // Pass A appends its pairs (<= 8 per lane: 4 slots x 2 pixels; key = tile << 10 | code, kNoPair = none) with ONE
 // returning device-scope atomic per (workgroup, tile): every pair takes a rank from an LDS counter of its tile (the
-// table is direct-mapped: n_tiles words), the pair that drew rank 0 reserves the workgroup's run in the tile's bin, and
+// table is open-addressed, keyed by tile number: kPairHash entries), the pair that drew rank 0 reserves the workgroup's run in the tile's bin, and
 // after a barrier every pair is stored at base + rank.  The cost does not depend on how many tiles a workgroup touches
 // (a first version agreed on one tile after the other by wave ballots: fine on average, 100 us for the wavefronts whose
 // 512 pairs fell into a hundred tiles -- profiles/r08_pass_a_append.md).
 constexpr uint32_t kNoPair = 0xFFFFFFFFu;
-constexpr uint32_t kMaxTilesLds = 8192;   // 64 KB for the two tables; larger images fall back to one atomic per pair
+constexpr int kPairHash = 2048;   // entries of pass A's per-workgroup table of tiles (a workgroup has at most 2048 pairs)
 __device__ __forceinline__ void pair_store(const TileBins& tb, uint32_t key, uint32_t slot, uint32_t pos) {
   const uint32_t tile = key >> 10, code = key & 1023u;
   if (pos < tb.cap) tb.pairs[(size_t)tile * tb.cap + pos] = make_uint2(slot, code);
@@ -407,13 +407,17 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, const uint8_t* __res
   __shared__ uint32_t wave_tot[kBlock / 64];
   __shared__ float box_part[kBlock / 64][8];
   __shared__ int skip_segment;
-  extern __shared__ uint32_t tile_lds[];   // [n_tiles] pairs of this workgroup per tile, [n_tiles] base of its run in the tile's bin
-  const bool lds_tables = use_lds_tables != 0;   // (n_tiles <= kMaxTilesLds)
+  // the tiles this workgroup's pairs fall into: open-addressed table keyed by tile number (fixed size: a direct-mapped
+  // one -- a word per tile, 38 KB at 1280 x 960 -- capped the chip at four workgroups per CU, and 18 000 of the 21 600
+  // workgroups of a C3 launch only look at their segment's box); pair_key = tile, later the base of the workgroup's run
+  __shared__ uint32_t pair_key[kPairHash], pair_cnt[kPairHash];
+  const bool lds_tables = use_lds_tables != 0;
   const uint32_t N = st->surfel_count;
   const uint32_t base = seg_id * kSeg;
   if (base >= N) return;  // uniform per workgroup
   if (lds_tables)
-    for (uint32_t k = threadIdx.x; k < tb.n_tiles; k += kBlock) tile_lds[k] = 0;   // (visible before the ranks are drawn: the barrier below)
+#pragma unroll
+    for (int k = 0; k < kPairHash / kBlock; ++k) { pair_key[k * kBlock + threadIdx.x] = kInvalid; pair_cnt[k * kBlock + threadIdx.x] = 0; }   // (visible before the ranks are drawn: the barrier below)
   const uint32_t i0 = base + threadIdx.x * 4;
   const uint32_t in_seg = (N - base < (uint32_t)kSeg) ? N - base : (uint32_t)kSeg;
   // Segment culling.  The box below was formed from every slot of the segment the last time it was read; it is still
@@ -490,11 +494,22 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, const uint8_t* __res
     lane_recent = ((new_flags[0] | new_flags[1] | new_flags[2] | new_flags[3]) & 1u) != 0;
   }
   // ranks inside the workgroup's run of each tile (LDS atomics; the barrier inside the scan below completes them)
+  // (rank = table entry << 16 | rank in the entry; kInvalid: no entry found within 16 probes -- that pair reserves its
+  // place in the bin on its own)
   uint32_t rank[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    rank[j] = 0;
-    if (key[j] != kNoPair && lds_tables) rank[j] = atomicAdd(&tile_lds[key[j] >> 10], 1u);
+    rank[j] = kInvalid;
+    if (key[j] != kNoPair && lds_tables) {
+      const uint32_t tile = key[j] >> 10;
+      uint32_t h = (tile * 2654435761u) >> 16;
+      for (int probe = 0; probe < 16; ++probe) {
+        h &= (uint32_t)kPairHash - 1u;
+        const uint32_t seen = atomicCAS(&pair_key[h], kInvalid, tile);
+        if (seen == kInvalid || seen == tile) { rank[j] = (h << 16) | atomicAdd(&pair_cnt[h], 1u); break; }
+        ++h;
+      }
+    }
   }
   // (a slot inside the regulariser window: the group is hot -- same value from every writer, one byte store per wavefront)
   const bool wave_recent = __ballot(lane_recent) != 0;
@@ -527,15 +542,15 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, const uint8_t* __res
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       got[j] = 0;
-      if (key[j] != kNoPair && rank[j] == 0) {
+      if (key[j] != kNoPair && (rank[j] & 0xFFFFu) == 0 && rank[j] != kInvalid) {
         uint32_t tv = key[j] >> 10;
         asm volatile("" : "+v"(tv));
-        got[j] = atomicAdd(&tb.count[tv * kCountStride], tile_lds[tv]);
+        got[j] = atomicAdd(&tb.count[tv * kCountStride], pair_cnt[rank[j] >> 16]);
       }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      if (key[j] != kNoPair && rank[j] == 0) tile_lds[tb.n_tiles + (key[j] >> 10)] = got[j];
+      if (key[j] != kNoPair && (rank[j] & 0xFFFFu) == 0 && rank[j] != kInvalid) pair_key[rank[j] >> 16] = got[j];   // (every probe is done: the barrier above)
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -544,7 +559,9 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, const uint8_t* __res
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      if (key[j] != kNoPair) pair_store(tb, key[j], i0 + (uint32_t)(j >> 1), tile_lds[tb.n_tiles + (key[j] >> 10)] + rank[j]);
+      if (key[j] != kNoPair)
+        pair_store(tb, key[j], i0 + (uint32_t)(j >> 1),
+                   rank[j] != kInvalid ? pair_key[rank[j] >> 16] + (rank[j] & 0xFFFFu) : atomicAdd(&tb.count[(key[j] >> 10) * kCountStride], 1u));
   } else {
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -2765,7 +2782,7 @@ int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
   r->blend_multi_launch = (mode >> 1) & 1;
   r->hot_filter_enabled = ((mode >> 2) & 1) ? 0 : 1;
   r->tb.cap = ((mode >> 3) & 1) ? 16u : r->bin_cap_full;   // 16 pairs per bin: most pairs travel through the overflow list
-  r->no_lds_tables = (mode >> 4) & 1;                     // pass A reserves bin space per pair (the path of images with > 8192 tiles)
+  r->no_lds_tables = (mode >> 4) & 1;                     // pass A reserves bin space per pair (the path of a pair that finds no entry in the workgroup's table)
   r->fb.cap = ((mode >> 5) & 1) ? 4u : kFarBinCap;        // 4 records per far-term bin: most far terms spill to grad_acc
   r->fb.hash_mask = ((mode >> 6) & 1) ? 1u : (uint32_t)kFarHash - 1u;   // 2 destinations per sender workgroup: the rest spills
   r->blend_other_tile = (mode >> 7) & 1;                  // the blend's other tile size (40 x 40 where it would take 32 x 32 and vice versa)
@@ -2850,8 +2867,8 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   r->L.vis_chunks.count = r->vis_count_set[r->sc_cur];
   r->tb.ovf_count = r->ovf_count_set[r->sc_cur];
   { SlotTimer t(r, sF, kSlotScanVisible);
-    const bool lds_tables = r->tb.n_tiles <= kMaxTilesLds && !r->no_lds_tables;
-    hipLaunchKernelGGL(k_scan_visible, gs, b, lds_tables ? (size_t)r->tb.n_tiles * 8 : 0, sF, r->S, c, r->L, r->tb, flags_prev,
+    const bool lds_tables = !r->no_lds_tables;
+    hipLaunchKernelGGL(k_scan_visible, gs, b, 0, sF, r->S, c, r->L, r->tb, flags_prev,
                        r->st, lds_tables ? 1 : 0);
     r->table_valid = true; r->table_frame = frame_index; r->table_window = c.reg_window; }
   // (smx_recon_integrate_inputs_ready) from here on the input images are read
