@@ -789,87 +789,90 @@ k_query_lanes(QueryArgs a) {
       }
       if (!ball) r2 = -1.0f;
       int rlo[3], rhi[3];
+      // ... and the box of the tile's balls in coordinates (same conservative radius): what the stage keeps
+      float blo[3], bhi[3];
+      {
+        const float qp[3] = {px, py, pz};
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        int mn = ball ? lo[k] : 0x7FFFFFFF, mx = ball ? hi[k] : -1;
+        for (int k = 0; k < 3; ++k) {
+          int mn = ball ? lo[k] : 0x7FFFFFFF, mx = ball ? hi[k] : -1;
+          const float rad = ball ? cover_radius(r2, qp[k]) : 0.0f;
+          float fmn = ball ? qp[k] - rad : __builtin_inff(), fmx = ball ? qp[k] + rad : -__builtin_inff();
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { mn = min(mn, __shfl_xor(mn, off)); mx = max(mx, __shfl_xor(mx, off)); }
-        rlo[k] = mn; rhi[k] = mx;
+          for (int off = 32; off > 0; off >>= 1) {
+            mn = min(mn, __shfl_xor(mn, off)); mx = max(mx, __shfl_xor(mx, off));
+            fmn = fminf(fmn, __shfl_xor(fmn, off)); fmx = fmaxf(fmx, __shfl_xor(fmx, off));
+          }
+          rlo[k] = mn; rhi[k] = mx; blo[k] = fmn; bhi[k] = fmx;
+        }
       }
       bool redo = false;      // the lane's query goes to k_query_tiles
       uint32_t cnt = 0;       // matches of the lane's query (the first kLaneCap of them are in its list)
       unsigned long long n_tests = 0, n_staged = 0;
       if (rhi[0] >= rlo[0]) {   // (uniform) at least one lane has a ball
-        const int blo[3] = {rlo[0] >> kBrickShift, rlo[1] >> kBrickShift, rlo[2] >> kBrickShift};
-        const int bn[3] = {(rhi[0] >> kBrickShift) - blo[0] + 1, (rhi[1] >> kBrickShift) - blo[1] + 1, (rhi[2] >> kBrickShift) - blo[2] + 1};
+        const int kb[3] = {rlo[0] >> kBrickShift, rlo[1] >> kBrickShift, rlo[2] >> kBrickShift};
+        const int bn[3] = {(rhi[0] >> kBrickShift) - kb[0] + 1, (rhi[1] >> kBrickShift) - kb[1] + 1, (rhi[2] >> kBrickShift) - kb[2] + 1};
         const unsigned long long nbricks = (unsigned long long)bn[0] * bn[1] * bn[2];
         if (nbricks > 64ull) {
           redo = ball;
         } else {
           uint32_t s = 0, e = 0;
-          int clo[3] = {0, 0, 0}, chi[3] = {-1, -1, -1};
           if ((unsigned long long)lane < nbricks) {
-            const int bx = blo[0] + (int)(lane % (uint32_t)bn[0]);
-            const int by = blo[1] + (int)((lane / (uint32_t)bn[0]) % (uint32_t)bn[1]);
-            const int bz = blo[2] + (int)(lane / ((uint32_t)bn[0] * (uint32_t)bn[1]));
+            const int bx = kb[0] + (int)(lane % (uint32_t)bn[0]);
+            const int by = kb[1] + (int)((lane / (uint32_t)bn[0]) % (uint32_t)bn[1]);
+            const int bz = kb[2] + (int)(lane / ((uint32_t)bn[0] * (uint32_t)bn[1]));
             if (!find_brick(a.table, a.mask, brick_index(g, bx, by, bz), s, e)) { s = 0; e = 0; }
-            clo[0] = bx << kBrickShift; clo[1] = by << kBrickShift; clo[2] = bz << kBrickShift;
-            chi[0] = clo[0] + kBrickCells - 1; chi[1] = clo[1] + kBrickCells - 1; chi[2] = clo[2] + kBrickCells - 1;
           }
           const uint32_t len = e - s;
           uint32_t incl = len;
 #pragma unroll
           for (int off = 1; off < 64; off <<= 1) { const uint32_t tv = __shfl_up(incl, off); if (lane >= (uint32_t)off) incl += tv; }
           const uint32_t total = lane_u(incl, 63);
-          if (total > (uint32_t)kStageL) {
-            redo = ball;
-          } else if (total > 0) {
+          if (total > 0) {
             __syncthreads();   // (the previous tile's readers are done)
             seg_end[lane] = incl;               // the range of lane L fills flat positions [seg_end[L] - len, seg_end[L])
             seg_src[lane] = s - (incl - len);   // source index = seg_src[L] + flat position (mod 2^32)
             __syncthreads();
-            uint32_t cur = 0;
+            // The stage keeps the records inside the box of the tile's balls, compacted (ballot + popcount): the bricks
+            // around a tile hold 316 points on a surfel surface at cell = 1.5 x spacing, the box 80-100, and every
+            // candidate in the stage costs the whole wavefront a dozen instructions in the walk below, whichever lanes
+            // still care -- the walk was three quarters of this kernel's instructions.  (A record outside the box fails
+            // d2 <= r2 for every query of the tile: cover_radius bounds |dx| of an accepted pair.)
+            uint32_t cur = 0, kept = 0;
             for (uint32_t k0 = 0; k0 < total; k0 += 64) {
               const uint32_t k = min(k0 + lane, total - 1u);
               while (k >= seg_end[cur]) ++cur;
               const float4 v = a.sorted[seg_src[cur] + k];
-              if (k0 + lane < total) stage[k0 + lane] = v;
+              const bool in = k0 + lane < total && v.x >= blo[0] && v.x <= bhi[0] && v.y >= blo[1] && v.y <= bhi[1] &&
+                              v.z >= blo[2] && v.z <= bhi[2];
+              const unsigned long long m = __ballot(in);
+              const uint32_t pos = kept + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+              if (in && pos < (uint32_t)kStageL) stage[pos] = v;
+              kept += (uint32_t)__popcll(m);
             }
             __syncthreads();
-            n_staged = total;
-            unsigned long long segs = __ballot(len > 0);
-            while (segs) {
-              const int sg = __ffsll((long long)segs) - 1;
-              segs &= segs - 1;
-              const uint32_t seg_len = lane_u(len, sg), seg_flat = lane_u(incl - len, sg);
-              const int s0 = __builtin_amdgcn_readlane(clo[0], sg), e0 = __builtin_amdgcn_readlane(chi[0], sg);
-              const int s1 = __builtin_amdgcn_readlane(clo[1], sg), e1 = __builtin_amdgcn_readlane(chi[1], sg);
-              const int s2 = __builtin_amdgcn_readlane(clo[2], sg), e2 = __builtin_amdgcn_readlane(chi[2], sg);
-              // only the bricks the lane's own cell range overlaps (most queries need one or two of the staged ones)
-              const bool ov = ball && s0 <= hi[0] && e0 >= lo[0] && s1 <= hi[1] && e1 >= lo[1] && s2 <= hi[2] && e2 >= lo[2];
-              const unsigned long long ovm = __ballot(ov);
-              if (!ovm) continue;   // (uniform)
-              n_tests += (unsigned long long)__popcll(ovm) * seg_len;
-              // Four candidates per step, all four LDS reads (one address for the whole wavefront: broadcasts) issued
-              // before the first test; a match is appended without a branch (a list that is full keeps overwriting its
-              // spare last entry; cnt keeps counting and marks the query for the other kernel afterwards).
-              const uint32_t lbase = lane * kLaneStride;
-              for (uint32_t k0 = 0; k0 < seg_len; k0 += 4) {
-                float4 rec[4];
+            if (kept > (uint32_t)kStageL) { redo = ball; kept = 0; }   // (more than the stage holds: the other kernel)
+            n_staged = kept;
+            n_tests += (unsigned long long)__popcll(__ballot(ball)) * kept;
+            // Four candidates per step, all four LDS reads (one address for the whole wavefront: broadcasts) issued
+            // before the first test; a match is appended without a branch (a list that is full keeps overwriting its
+            // spare last entry; cnt keeps counting and marks the query for the other kernel afterwards).
+            const uint32_t lbase = lane * kLaneStride;
+            for (uint32_t k0 = 0; k0 < kept; k0 += 4) {
+              float4 rec[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) rec[u] = stage[seg_flat + min(k0 + u, seg_len - 1u)];
+              for (int u = 0; u < 4; ++u) rec[u] = stage[min(k0 + u, kept - 1u)];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                  const float dx = rec[u].x - px, dy = rec[u].y - py, dz = rec[u].z - pz;
-                  const float d2 = dx * dx + dy * dy + dz * dz;
-                  bool ok = ov && (k0 + u < seg_len) && d2 <= r2;
-                  if (a.state != nullptr) {   // (uniform; the filter is the rare case)
-                    if (ok && (a.state[__float_as_uint(rec[u].w)] & a.skip_mask)) ok = false;
-                  }
-                  if (ok) {
-                    l_pos[lbase + min(cnt, (uint32_t)kLaneCap)] = (uint16_t)(seg_flat + k0 + u);
-                    ++cnt;
-                  }
+              for (int u = 0; u < 4; ++u) {
+                const float dx = rec[u].x - px, dy = rec[u].y - py, dz = rec[u].z - pz;
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                bool ok = ball && (k0 + u < kept) && d2 <= r2;
+                if (a.state != nullptr) {   // (uniform; the filter is the rare case)
+                  if (ok && (a.state[__float_as_uint(rec[u].w)] & a.skip_mask)) ok = false;
+                }
+                if (ok) {
+                  l_pos[lbase + min(cnt, (uint32_t)kLaneCap)] = (uint16_t)(k0 + u);
+                  ++cnt;
                 }
               }
             }
