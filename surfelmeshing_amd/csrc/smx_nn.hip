@@ -701,7 +701,12 @@ k_query_tiles(QueryArgs a) {
 // arithmetic, same total order: the rows are identical to k_query_tiles'.  What does not fit the simple shape --
 // more than kLaneCap matches, a region of more than 64 bricks or more than kStageL points -- is marked and answered
 // by k_query_tiles afterwards (same launch sequence, no host round trip).
-constexpr int kStageL = 768;     // staged points per tile (12 KB); a surfel surface holds ~300 around a brick at cell = 1.5 x spacing
+#ifndef SMX_STAGE_L
+#define SMX_STAGE_L 288
+#endif
+constexpr int kStageL = SMX_STAGE_L;     // staged points per tile, after the box filter (a surfel surface at cell = 1.5 x spacing: 60 - 100).
+// LDS decides how many of these one-wavefront workgroups a CU holds, and the kernel lives on that: 768 entries (17 KB with the
+// lists) 2.86 G queries/s at C5, 512: 3.32, 384: 3.87, 288 (9 KB: what the sorted keys need anyway): 4.26 -- profiles/r14_c5_stage.txt
 constexpr int kLaneCap = 32;     // entries of a lane's private list (positions in the stage: 2 bytes each)
 constexpr int kLaneStride = kLaneCap + 2;   // (in 16-bit units: an odd number of 32-bit words per lane)
 
@@ -742,8 +747,11 @@ __device__ __forceinline__ void sort_lane_matches(const float4* __restrict__ sta
 template <bool kSelf>
 __global__ void __launch_bounds__(64)
 k_query_lanes(QueryArgs a) {
-  __shared__ float4 stage[kStageL];
-  __shared__ uint16_t l_pos[64 * kLaneStride];
+  // one block: the stage, then the lanes' lists; the sorted keys later lie over both (neither is needed any more once
+  // every lane holds its keys in registers).  LDS is what limits the wavefronts per CU here.
+  __shared__ __align__(16) unsigned char lds_block[sizeof(float4) * kStageL + sizeof(uint16_t) * 64 * kLaneStride];
+  float4* stage = reinterpret_cast<float4*>(lds_block);
+  uint16_t* l_pos = reinterpret_cast<uint16_t*>(lds_block + sizeof(float4) * kStageL);
   __shared__ uint32_t seg_end[64], seg_src[64];
   const uint32_t lane = threadIdx.x;
   const Grid& g = a.g;
@@ -852,7 +860,7 @@ k_query_lanes(QueryArgs a) {
             }
             __syncthreads();
             if (kept > (uint32_t)kStageL) { redo = ball; kept = 0; }   // (more than the stage holds: the other kernel)
-            n_staged = kept;
+            n_staged = total;   // (statistics: records read from the index; n_tests below counts the tests on the kept ones)
             n_tests += (unsigned long long)__popcll(__ballot(ball)) * kept;
             // Four candidates per step, all four LDS reads (one address for the whole wavefront: broadcasts) issued
             // before the first test; a match is appended without a branch (a list that is full keeps overwriting its
@@ -888,8 +896,8 @@ k_query_lanes(QueryArgs a) {
       __syncthreads();
       if (n_max <= 16u) {   // (uniform) the usual case: every lane sorts its own matches in registers
         constexpr int kOutStride = 17;
-        unsigned long long* o_key = reinterpret_cast<unsigned long long*>(stage);   // (the stage is free once the keys are formed)
-        static_assert(sizeof(unsigned long long) * 64 * kOutStride <= sizeof(float4) * kStageL, "the output rows fit the stage");
+        unsigned long long* o_key = reinterpret_cast<unsigned long long*>(lds_block);   // (stage and lists are free once the keys are formed)
+        static_assert(sizeof(unsigned long long) * 64 * kOutStride <= sizeof(lds_block), "the output rows fit the block");
         if (n_max <= 8u) {
           unsigned long long key[8];
           sort_lane_matches<8>(stage, l_pos, lane * kLaneStride, n, px, py, pz, key);
