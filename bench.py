@@ -326,12 +326,20 @@ def run_integrate(args):
     first = g_end + 10
     cal, reps = 37, 20
     SETTLE = 64
-    W_user, W = W, W + SETTLE
-    total = W + cal + K
+    # Order of the frames: SETTLE untimed frames, the calibration passes (cal frames, counters / events on), the W warm-up
+    # frames and directly behind them the K timed ones -- every step array prepared on the host BEFORE the first of
+    # them runs, so that the device does not idle (and clock down: the first ~15 frames after a pause of a few
+    # milliseconds run 10 % slower) anywhere between the settle frames and the end of the timed region.  The passes that
+    # need the host (statistics, per-kernel times, PCIe-inclusive pass, the snapshot for the CPU baseline) follow.
+    W_user, W = W, SETTLE
+    total = W + cal + W_user + K
     do_host = args.host_frames if (rank == 0 and world == 1) else 0   # PCIe-inclusive pass: rank 0 at N = 1 only
-    for j in range(-4, total + 1 + reps + do_host + 4):
+    do_cpu = rank == 0 and world == 1 and cpu_frames > 0   # CPU baseline: rank 0 at N = 1 only
+    cpu_start = total + 1 + reps + do_host                 # its frames: behind everything else
+    n_plan = cpu_start + (cpu_frames if do_cpu else 0)
+    for j in range(-4, n_plan + 4):
         wl.render(first + j, 4 + j)
-    plan = [wl.plan(first + j, 4 + j) for j in range(total + 1 + reps + do_host)]
+    plan = [wl.plan(first + j, 4 + j) for j in range(n_plan)]
     api.StreamSynchronize(None)
 
     rec = wl.pipe.reconstruction
@@ -343,35 +351,36 @@ def run_integrate(args):
         wl.pipe.set_run_ahead(True)
     if args.scan_mode:
         rec.set_scan_mode(args.scan_mode)
-    wl.pipe.run_array(*wl.steps(plan[:W]))
+    names = rec.kernel_time_names()
+    per = (cal - 1) // len(names)
+    settle_steps = wl.steps(plan[:W])
+    cal_steps = [wl.steps(plan[W + idx * per:W + (idx + 1) * per]) for idx in range(len(names))]
+    cal_rest = wl.steps(plan[W + per * len(names):W + cal - 1]) if (cal - 1) - per * len(names) > 0 else None
+    stats_step = wl.steps(plan[W + cal - 1:W + cal])
+    warm_steps = wl.steps(plan[W + cal:W + cal + W_user]) if W_user > 0 else None
+    timed_steps = wl.steps(plan[W + cal + W_user:W + cal + W_user + K])
+    wl.pipe.run_array(*settle_steps)
     # short calibration pass: which Integrate kernel dominates the frame?  Judged IN the frame -- pipelining on, HIP events
     # around one kernel at a time for a few frames each (alone on the chip the candidates lie within 10 % of each other
     # and the choice flipped from run to run; beside the other chains of the frame they do not)
-    names = rec.kernel_time_names()
     cal_ms = np.zeros(len(names))
-    per = (cal - 1) // len(names)
     rec.set_overlap(not args.no_overlap)
     for idx, name in enumerate(names):
         rec.profile_begin(name, per)
-        wl.pipe.run_array(*wl.steps(plan[W + idx * per:W + (idx + 1) * per]))
+        wl.pipe.run_array(*cal_steps[idx])
         api.StreamSynchronize(None)
         ms, n = rec.profile_end()
         cal_ms[idx] = ms if n > 0 else 0.0
-    if (cal - 1) - per * len(names) > 0:
-        wl.pipe.run_array(*wl.steps(plan[W + per * len(names):W + cal - 1]))
+    if cal_rest is not None:
+        wl.pipe.run_array(*cal_rest)
     rec.set_overlap(False)
-    # value distributions of the frame in front of the timed window (counters on for this frame only)
+    # value distributions of the frame in front of the warm-up frames (counters on for this frame only)
     rec.set_stats_enabled(True)
-    wl.pipe.run_array(*wl.steps(plan[W + cal - 1:W + cal]))
+    wl.pipe.run_array(*stats_step)
     st_before = rec.stats()
     rec.set_stats_enabled(False)
     rec.set_overlap(not args.no_overlap)
     dominant = names[int(np.argmax(cal_ms))]
-    api.StreamSynchronize(None)
-    do_cpu = rank == 0 and world == 1 and cpu_frames > 0   # CPU baseline: rank 0 at N = 1 only
-    state0 = rec.debug_download_surfels() if do_cpu else None
-    merge0 = (rec.surfels_size() - rec.surfel_count()) if state0 is not None else 0
-    timed_steps = wl.steps(plan[W + cal:W + cal + K])
 
     def sync_all():
         torch.cuda.synchronize()
@@ -381,6 +390,8 @@ def run_integrate(args):
 
     # HIP events around the dominant kernel only (2 records per frame on the launch stream) stay on during
     # the timed region; everything else is measured in separate passes.
+    if warm_steps is not None:
+        wl.pipe.run_array(*warm_steps)       # the W warm-up frames: directly in front of the timed region
     rec.profile_begin(dominant, K)
     _lib.check(_lib.load().smx_debug_marker(None, 1))   # delimits the timed region in rocprofv3 kernel traces
     sync_all()
@@ -437,7 +448,7 @@ def run_integrate(args):
                                (args.config, width, height, live, st["surfels_size"]),
                    "max_surfel_count": cap, "streams": world, "parallelism": "1 independent stream per GPU"},
         "distributions": st,
-        "steady_state": {"settle_frames": SETTLE, "note": "untimed frames of the re-traversal in front of --warmup",
+        "steady_state": {"settle_frames": SETTLE, "note": "untimed frames of the re-traversal in front of the calibration passes, the --warmup frames and the timed window",
                          "frame_before_timed_window": {k: st_before[k] for k in ("surfels_size", "n_visible", "n_recent", "n_new")},
                          "frame_after_timed_window": {k: st[k] for k in ("surfels_size", "n_visible", "n_recent", "n_new")}},
         "stage_ms": dict(zip(["data_association", "surfel_merging", "measurement_blending", "integration",
@@ -454,7 +465,10 @@ def run_integrate(args):
         if host_pass is not None:
             result["host_frames"] = host_pass
         if do_cpu:
-            result["cpu_baseline"] = cpu_baseline(wl, plan, W + cal, cpu_frames, state0, merge0, cap,
+            api.StreamSynchronize(None)
+            state0 = rec.debug_download_surfels()
+            merge0 = rec.surfels_size() - rec.surfel_count()
+            result["cpu_baseline"] = cpu_baseline(wl, plan, cpu_start, cpu_frames, state0, merge0, cap,
                                                   not args.no_check, log)
         print(json.dumps(result))
     finish_ranks(world, dist)
@@ -576,7 +590,7 @@ def bilateral_valu_roofline(wl, api, torch, frame):
 
 
 def cpu_baseline(wl, plan, W, frames, state0, merge0, cap, check, log):
-    """The oracle (plain C loops) on the first `frames` frames of the timed window, starting from the same surfel
+    """The oracle (plain C loops) on the `frames` frames behind the snapshot (taken after all GPU passes: the trajectory goes on behind the timed window), starting from the same surfel
     state: once with the per-pixel stages row-parallel on all host cores (the headline CPU number; Integrate itself is
     a sequential scan over the surfels and stays on one core) and once on a single core; the run also serves as a
     full-size parity check of the HIP path.  Plus config C1 (single frame, bilateral + erosion + normals)."""
@@ -617,7 +631,7 @@ def cpu_baseline(wl, plan, W, frames, state0, merge0, cap, check, log):
     nf, t_pre, t_int = timings[cores]
     nf1, t_pre1, t_int1 = timings[1]
     out = {"value": nf / (t_pre + t_int), "unit": "frames/s", "cores": cores, "kind": "port",
-           "sample": "%d frames of the timed window from the same %d-surfel state (oracle, gcc -O2): per-pixel stages "
+           "sample": "%d frames behind the snapshot (the trajectory continued behind the timed window) from the same %d-surfel state (oracle, gcc -O2): per-pixel stages "
                      "row-parallel on %d threads (%.1f ms/frame), Integrate on 1 thread (%.1f ms/frame)" %
                      (nf, n0, cores, 1e3 * t_pre / nf, 1e3 * t_int / nf),
            "one_core": {"value": nf1 / (t_pre1 + t_int1), "unit": "frames/s", "cores": 1, "frames": nf1,
