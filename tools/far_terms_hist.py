@@ -72,11 +72,11 @@ def main():
         reach = valid & hot_unit[Tc // gran] & ((Tc // SEG) != (src // SEG))
         seg_reach = np.zeros(n // SEG + 1, bool)
         seg_reach[src[reach] // SEG] = True
-        own = np.zeros(n // SEG + 1, bool)
+        nseg_all = n // SEG + 1
+        own = np.zeros(nseg_all, bool)            # the segment itself holds a recent slot
         own[np.nonzero(recent)[0] // SEG] = True
-        own_g = np.zeros(n // SEG + 1, bool)   # own group (max(gran, SEG) slots) hot
-        g2 = max(gran, SEG)
-        own_g[:] = np.repeat(hot_unit if gran >= SEG else own, 1)[(np.arange(n // SEG + 1) * SEG) // g2] if gran >= SEG else own
+        # "own group hot": the unit that contains the segment, if units are larger than segments
+        own_g = hot_unit[(np.arange(nseg_all) * SEG) // gran] if gran >= SEG else own
         nseg = n // SEG + 1
         print("units of %5d slots: hot units %6d (%.1f %%); segments to read: own hot %d, + reached %d = %d of %d (%.1f %%)" %
               (gran, hot_unit.sum(), 100.0 * hot_unit.mean(), own_g.sum(), (seg_reach & ~own_g).sum(), (seg_reach | own_g).sum(), nseg,
