@@ -275,12 +275,12 @@ def test_stream_parity_with_skipped_segments(smx, overlap):
     assert min(skipped[-10:]) >= 1, (n_segments, skipped)
 
 
-@pytest.mark.parametrize("w,h", [(170, 101), (97, 64)])
-def test_stream_parity_image_sizes_that_cut_tiles(smx, w, h):
-    """Image sizes that are no multiple of the association tiles (32 x 8), the blend tiles (32 x 32) or the scan blocks:
-    partial tiles at the right and bottom edges in every per-pixel kernel."""
+@pytest.mark.parametrize("w,h,scan_mode", [(170, 101, 0), (97, 64, 0), (170, 101, 128), (97, 64, 128)])
+def test_stream_parity_image_sizes_that_cut_tiles(smx, w, h, scan_mode):
+    """Image sizes that are no multiple of the association tiles (32 x 8), the blend tiles (32 x 32, or 40 x 40 with
+    scan mode 128) or the scan blocks: partial tiles at the right and bottom edges in every per-pixel kernel."""
     s = small_stream(w, h, obstacle_until=8)
-    po, pg = _pipes(smx, s, 60000)
+    po, pg = _pipes(smx, s, 60000, scan_mode=scan_mode)
     run_both(po, pg, s, list(range(4, 18)), lambda f: _compare_state(po, pg))
     assert po.recon.surfels_size > 3000
 
