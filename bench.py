@@ -63,6 +63,15 @@ ALG_BYTES = {
     "blend": lambda st, P: 6.0 * (54.0 * 54.0 / 1024.0) * P + 2.0 * P,
 }
 
+# the driver's preprocessing stages (smx_driver_profile_begin): u16 in + u16 out; + 8 neighbour frames' depths gathered;
+# u16 in -> u16 + float2 normals + float radius out
+PRE_STAGES = ["bilateral", "outlier_fusion", "erode_normals_radii"]
+ALG_BYTES.update({
+    "bilateral": lambda st, P: 4.0 * P,
+    "outlier_fusion": lambda st, P: 4.0 * P + 2.0 * 8 * P,
+    "erode_normals_radii": lambda st, P: 16.0 * P,
+})
+
 CONFIGS = {
     "C2": dict(width=640, height=480, surfels=5_000_000),
     "C3": dict(width=1280, height=960, surfels=20_000_000),
@@ -211,13 +220,11 @@ def host_frames_pass(wl, plan, base, count, api, torch):
                     "(smx_driver_run_streamed); not the headline value"}
 
 
-def algorithmic_bytes(st, P):
-    """SURVEY.md 8(d) byte model of the REFERENCE's per-frame traffic (for comparison only) and this
-    design's own compulsory traffic (DESIGN.md 'Bytes')."""
+def reference_model_bytes(st, P):
+    """SURVEY.md 8(d) byte model of the REFERENCE's per-frame traffic (for comparison only: this design does not move
+    those bytes; its own compulsory traffic is the sum of ALG_BYTES, `roofline.frame.algorithmic_bytes_per_frame`)."""
     N, E = st["surfels_size"], st["n_edges"]
-    ref = 140 * N + 8 * E + 460 * st["n_visible"] + 360 * st["n_recent"] + 122 * st["n_new"] + 193 * P
-    ours = 32 * N + 8 * E + 460 * st["n_visible"] + 360 * st["n_recent"] + 122 * st["n_new"] + 193 * P
-    return ref, ours
+    return 140 * N + 8 * E + 460 * st["n_visible"] + 360 * st["n_recent"] + 122 * st["n_new"] + 193 * P
 
 
 def init_ranks(args):
@@ -231,7 +238,7 @@ def init_ranks(args):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dry_run:
+        if args.dry_run or args.backend == "gloo":
             dist.init_process_group("gloo")
         else:
             torch.cuda.set_device(local_rank)
@@ -239,8 +246,18 @@ def init_ranks(args):
     if not args.dry_run:
         from surfelmeshing_amd import _lib
         _lib.require_gpu()
-        _lib.check(_lib.load().smx_set_device(local_rank if world > 1 else 0))
+        dev = 0
+        if world > 1:
+            # RCCL wants one rank per device; over gloo the ranks may share one (the streams are independent either way)
+            dev = local_rank % _lib.device_count() if args.backend == "gloo" else local_rank
+            if args.backend == "gloo":
+                torch.cuda.set_device(dev)
+        _lib.check(_lib.load().smx_set_device(dev))
     return rank, local_rank, world, dist, torch
+
+
+def reduce_device(args):
+    return "cpu" if (args.dry_run or args.backend == "gloo") else "cuda"
 
 
 def finish_ranks(world, dist):
@@ -269,6 +286,13 @@ def main():
                     help="A/B: the stream Integrate is called on (null = the legacy default stream)")
     ap.add_argument("--run-ahead", action="store_true", help="A/B: preprocessing two steps ahead, waits routed off the caller's stream")
     ap.add_argument("--scan-mode", type=int, default=0, help="A/B: smx_recon_set_scan_mode bits (1 = all-slot scans, 2 = multi-launch blend, 4 = no hot-group filter in pass B)")
+    ap.add_argument("--ub", default="", help="TIMING-ONLY upper bounds, comma list of: hoist-pre (every timed frame preprocessed "
+                    "before the timed region: same results), no-reg (regulariser left out: WRONG map), front-only (pass A + "
+                    "association tiles + blend only: WRONG map).  No parity check, no CPU leg; the line carries 'upper_bound'")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process group of --gpus N > 1: nccl (= RCCL, one rank per GPU) or gloo (CPU reductions; ranks may "
+                         "share a GPU: rank r uses device r mod device_count -- the C4 path on a 1-GPU box)")
+    ap.add_argument("--check-all-ranks", action="store_true", help="N > 1: every rank runs the in-run parity check (oracle) on its own stream")
     ap.add_argument("--dry-run", action="store_true", help="rank path only (no GPU, gloo): see the module docstring")
     ap.add_argument("--quiet", action="store_true")
     args = ap.parse_args()
@@ -324,7 +348,15 @@ def run_integrate(args):
     # window still hold the end of the growth phase when it begins, and a short warm-up would time a different regime
     # (round 2: 4144 frames/s at --steps 20 --warmup 5 against 3873 at --steps 300 --warmup 20).
     first = g_end + 10
-    cal, reps = 37, 20
+    ub = set(x for x in args.ub.split(",") if x)
+    assert ub <= {"hoist-pre", "no-reg", "front-only"}, "unknown --ub item"
+    rec0 = wl.pipe.reconstruction
+    names = rec0.kernel_time_names()
+    # kernels judged in the frame: the Integrate slots (not the empty slot that measures the time stamps themselves, not the
+    # copy-only update that only runs with 0 regulariser iterations) and the driver's three preprocessing stages
+    cal_names = [n for n in names if n in ALG_BYTES] + PRE_STAGES
+    per, reps = 4, 21
+    cal = per * len(cal_names) + 1
     SETTLE = 64
     # Order of the frames: SETTLE untimed frames, the calibration passes (cal frames, counters / events on), the W warm-up
     # frames and directly behind them the K timed ones -- every step array prepared on the host BEFORE the first of
@@ -333,10 +365,11 @@ def run_integrate(args):
     # need the host (statistics, per-kernel times, PCIe-inclusive pass, the snapshot for the CPU baseline) follow.
     W_user, W = W, SETTLE
     total = W + cal + W_user + K
-    do_host = args.host_frames if (rank == 0 and world == 1) else 0   # PCIe-inclusive pass: rank 0 at N = 1 only
-    do_cpu = rank == 0 and world == 1 and cpu_frames > 0   # CPU baseline: rank 0 at N = 1 only
+    do_host = args.host_frames if (rank == 0 and world == 1 and not ub) else 0   # PCIe-inclusive pass: rank 0 at N = 1 only
+    do_cpu = rank == 0 and world == 1 and cpu_frames > 0 and not ub   # CPU baseline: rank 0 at N = 1 only
+    chk_frames = max(1, cpu_frames) if (world > 1 and args.check_all_ranks) else 0
     cpu_start = total + 1 + reps + do_host                 # its frames: behind everything else
-    n_plan = cpu_start + (cpu_frames if do_cpu else 0)
+    n_plan = cpu_start + (cpu_frames if do_cpu else 0) + chk_frames
     for j in range(-4, n_plan + 4):
         wl.render(first + j, 4 + j)
     plan = [wl.plan(first + j, 4 + j) for j in range(n_plan)]
@@ -351,28 +384,27 @@ def run_integrate(args):
         wl.pipe.set_run_ahead(True)
     if args.scan_mode:
         rec.set_scan_mode(args.scan_mode)
-    names = rec.kernel_time_names()
-    per = (cal - 1) // len(names)
     settle_steps = wl.steps(plan[:W])
-    cal_steps = [wl.steps(plan[W + idx * per:W + (idx + 1) * per]) for idx in range(len(names))]
-    cal_rest = wl.steps(plan[W + per * len(names):W + cal - 1]) if (cal - 1) - per * len(names) > 0 else None
+    cal_steps = [wl.steps(plan[W + idx * per:W + (idx + 1) * per]) for idx in range(len(cal_names))]
     stats_step = wl.steps(plan[W + cal - 1:W + cal])
     warm_steps = wl.steps(plan[W + cal:W + cal + W_user]) if W_user > 0 else None
     timed_steps = wl.steps(plan[W + cal + W_user:W + cal + W_user + K])
     wl.pipe.run_array(*settle_steps)
-    # short calibration pass: which Integrate kernel dominates the frame?  Judged IN the frame -- pipelining on, HIP events
+    # short calibration pass: which kernel of the frame lasts longest?  Judged IN the frame -- pipelining on, time stamps
     # around one kernel at a time for a few frames each (alone on the chip the candidates lie within 10 % of each other
-    # and the choice flipped from run to run; beside the other chains of the frame they do not)
-    cal_ms = np.zeros(len(names))
+    # and the choice flipped from run to run; beside the other chains of the frame they do not).  Every kernel of the
+    # frame takes part: the Integrate slots on their streams and the three preprocessing stages on the driver's.
+    cal_ms = {}
     rec.set_overlap(not args.no_overlap)
-    for idx, name in enumerate(names):
-        rec.profile_begin(name, per)
+    for idx, name in enumerate(cal_names):
+        if name in PRE_STAGES:
+            wl.pipe.profile_begin(PRE_STAGES.index(name), per)
+        else:
+            rec.profile_begin(name, per)
         wl.pipe.run_array(*cal_steps[idx])
         api.StreamSynchronize(None)
-        ms, n = rec.profile_end()
-        cal_ms[idx] = ms if n > 0 else 0.0
-    if cal_rest is not None:
-        wl.pipe.run_array(*cal_rest)
+        ms, n = wl.pipe.profile_end() if name in PRE_STAGES else rec.profile_end()
+        cal_ms[name] = ms if n > 0 else 0.0
     rec.set_overlap(False)
     # value distributions of the frame in front of the warm-up frames (counters on for this frame only)
     rec.set_stats_enabled(True)
@@ -380,7 +412,9 @@ def run_integrate(args):
     st_before = rec.stats()
     rec.set_stats_enabled(False)
     rec.set_overlap(not args.no_overlap)
-    dominant = names[int(np.argmax(cal_ms))]
+    in_timed = [n for n in cal_names if not ("hoist-pre" in ub and n in PRE_STAGES)]
+    dominant = max(in_timed, key=lambda n: cal_ms[n])
+    dominant_hbm = max((n for n in in_timed if n not in PRE_STAGES), key=lambda n: cal_ms[n])
 
     def sync_all():
         torch.cuda.synchronize()
@@ -388,11 +422,19 @@ def run_integrate(args):
             dist.barrier()
             torch.cuda.synchronize()
 
-    # HIP events around the dominant kernel only (2 records per frame on the launch stream) stay on during
+    if "hoist-pre" in ub:   # (upper bound: the timed frames find their images preprocessed; same results)
+        if warm_steps is not None:
+            wl.pipe.prepare_array(*warm_steps)
+        wl.pipe.prepare_array(*timed_steps)
+    rec.debug_set_skip((1 if "no-reg" in ub else 0) | (2 if "front-only" in ub else 0))
+    # Time stamps around the dominant kernel only (2 records per frame on the stream it is launched on) stay on during
     # the timed region; everything else is measured in separate passes.
     if warm_steps is not None:
         wl.pipe.run_array(*warm_steps)       # the W warm-up frames: directly in front of the timed region
-    rec.profile_begin(dominant, K)
+    if dominant in PRE_STAGES:
+        wl.pipe.profile_begin(PRE_STAGES.index(dominant), K)
+    else:
+        rec.profile_begin(dominant, K)
     _lib.check(_lib.load().smx_debug_marker(None, 1))   # delimits the timed region in rocprofv3 kernel traces
     sync_all()
     t_start = time.perf_counter()
@@ -400,11 +442,28 @@ def run_integrate(args):
     enqueue_local = time.perf_counter() - t_start   # host side done (returns without synchronising)
     torch.cuda.synchronize()
     elapsed_local = time.perf_counter() - t_start
-    fps, elapsed, _ = multistream.aggregate_throughput(K, elapsed_local, world, dist if world > 1 else None, "cuda")
+    fps, elapsed, _ = multistream.aggregate_throughput(K, elapsed_local, world, dist if world > 1 else None, reduce_device(args))
     if world > 1:
         dist.barrier()
-    dom_ms, dom_n = rec.profile_end()
+    dom_ms, dom_n = wl.pipe.profile_end() if dominant in PRE_STAGES else rec.profile_end()
     _lib.check(_lib.load().smx_debug_marker(None, 2))
+    rec.debug_set_skip(0)
+    P = width * height
+
+    if ub:
+        # timing-only run: no statistics of a map that may be wrong, no roofline, no CPU leg
+        if rank == 0:
+            print(json.dumps({
+                "metric": "UPPER BOUND (timing only), frames/s", "upper_bound": sorted(ub),
+                "note": "hoist-pre: the timed frames were preprocessed before the timed region (results unchanged); no-reg: "
+                        "pass B / edges / step left out (map WRONG); front-only: pass A + tiles + blend only (map WRONG)",
+                "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W_user, "ms_per_step": 1e3 * elapsed / K,
+                "config": {"workload": "%s %dx%d" % (args.config, width, height)},
+                "in_frame_ms_before_the_bound_was_applied": cal_ms,
+                "dominant_in_timed_region": {"kernel": dominant, "avg_launch_ms": dom_ms, "launches": dom_n},
+                "frame_before_timed_window": {k: st_before[k] for k in ("surfels_size", "n_visible", "n_recent", "n_new")}}))
+        finish_ranks(world, dist)
+        return 0
 
     # value distributions of one more frame (counters on)
     rec.set_overlap(False)
@@ -416,17 +475,24 @@ def run_integrate(args):
     wl.pipe.run_array(*wl.steps(plan[total:total + 1]))
     st["n_link_segments_skipped"] = rec.debug_count_skipped_segments()
 
-    # per-stage and per-kernel device times (separate untimed pass, HIP events on the launch stream)
+    # per-stage and per-kernel device times (separate untimed pass, time stamps on the launch stream; the preprocessing
+    # stages one at a time, in turn)
     rec.set_timing_enabled(3)
     stage_ms = np.zeros(7)
     kernel_ms = np.zeros(len(names))
+    pre_alone = {n: [] for n in PRE_STAGES}
     for j in range(total + 1, total + 1 + reps):
+        which = (j - total - 1) % len(PRE_STAGES)
+        wl.pipe.profile_begin(which, 1)
         wl.pipe.run_array(*wl.steps(plan[j:j + 1]))
         stage_ms += np.array(rec.GetTimings())
         kernel_ms += np.array(rec.kernel_times_ms())
+        pre_alone[PRE_STAGES[which]].append(wl.pipe.profile_end()[0])
     stage_ms /= reps
     kernel_ms /= reps
     rec.set_timing_enabled(0)
+    alone_ms = dict(zip(names, [float(x) for x in kernel_ms]))
+    alone_ms.update({n: float(np.mean(v)) for n, v in pre_alone.items() if v})
 
     host_pass = None
     if do_host > 0:
@@ -434,8 +500,7 @@ def run_integrate(args):
         host_pass = host_frames_pass(wl, plan, total + 1 + reps, do_host, api, torch)
         rec.set_overlap(False)
 
-    P = width * height
-    ref_bytes, own_bytes = algorithmic_bytes(st, P)
+    ref_bytes = reference_model_bytes(st, P)
     live = st["surfels_size"] - st["merge_count"]
     result = {
         "metric": "RGB-D frames/s integrated @640x480, 5M live surfels; achieved HBM GB/s" if args.config == "C2" else
@@ -446,7 +511,8 @@ def run_integrate(args):
         "config": {"workload": "%s: synthetic room stream %dx%d, full preprocessing + Integrate per frame, "
                                "%d live surfels (%d slots), steady-state re-traversal" %
                                (args.config, width, height, live, st["surfels_size"]),
-                   "max_surfel_count": cap, "streams": world, "parallelism": "1 independent stream per GPU"},
+                   "max_surfel_count": cap, "streams": world, "parallelism": "1 independent stream per GPU",
+                   "backend": args.backend if world > 1 else None},
         "distributions": st,
         "steady_state": {"settle_frames": SETTLE, "note": "untimed frames of the re-traversal in front of the calibration passes, the --warmup frames and the timed window",
                          "frame_before_timed_window": {k: st_before[k] for k in ("surfels_size", "n_visible", "n_recent", "n_new")},
@@ -454,14 +520,26 @@ def run_integrate(args):
         "stage_ms": dict(zip(["data_association", "surfel_merging", "measurement_blending", "integration",
                               "neighbor_update", "new_surfel_creation", "regularization"], [float(x) for x in stage_ms])),
         "reference_model_bytes_per_frame": ref_bytes,
-        "design_bytes_per_frame": own_bytes,
         "reference_model_GBs": ref_bytes * (K / elapsed) / 1e9,
     }
 
+    parity_all = None
+    if world > 1 and args.check_all_ranks:
+        # C4 readiness: every rank checks its own stream against the oracle (a few frames from its own map)
+        api.StreamSynchronize(None)
+        state0 = rec.debug_download_surfels()
+        merge0 = rec.surfels_size() - rec.surfel_count()
+        nchk = max(1, cpu_frames)
+        mine = cpu_baseline(wl, plan, total + 1 + reps, nchk, state0, merge0, cap, True, False, time_one_core=False).get("parity_check")
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        parity_all = gathered
     if rank == 0:
-        result["roofline"] = roofline_block(st, P, dominant, dom_ms, dom_n, dict(zip(names, [float(x) for x in kernel_ms])),
+        result["roofline"] = roofline_block(st, P, dominant, dominant_hbm, dom_ms, dom_n, alone_ms, cal_ms,
                                             1e3 * elapsed / K, args.config)
-        result["roofline_valu"] = bilateral_valu_roofline(wl, api, torch, plan[0][0])
+        result["roofline_valu"] = bilateral_valu_roofline(wl, api, torch, plan[0][0], cal_ms.get("bilateral"))
+        if parity_all is not None:
+            result["parity_check_per_rank"] = parity_all
         if host_pass is not None:
             result["host_frames"] = host_pass
         if do_cpu:
@@ -500,6 +578,10 @@ def pmc_file(config="C2"):
     return d, None
 
 
+PMC_NOTE = ("HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB): the x2 is the guide's correction for wide coalesced reads on gfx950; "
+            "profiles/r17_counter_calibration.md has the factors measured for this design's own access patterns")
+
+
 def pmc_bytes(k):
     """HBM bytes per launch from FETCH_SIZE / WRITE_SIZE (KB; separate passes).  Correction per
     /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half of the bytes read, so it is
@@ -509,20 +591,32 @@ def pmc_bytes(k):
     return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
 
 
-def roofline_block(st, P, dominant, dom_ms, dom_n, kernel_ms, ms_per_step, config="C2"):
-    """Roofline of the dominant Integrate kernel: algorithmic bytes per launch (ALG_BYTES) / average launch
-    duration measured with HIP events on the launch stream over the timed region; `frame` = all kernels of one frame
-    (PMC bytes of the committed profile of the same build) / the measured frame time."""
+def roofline_block(st, P, dominant, dominant_hbm, dom_ms, dom_n, alone_ms, in_frame_ms, ms_per_step, config="C2"):
+    """Roofline of the kernel that lasts longest IN THE FRAME (every kernel of the frame is a candidate, the preprocessing
+    stages included): algorithmic bytes per launch (ALG_BYTES) / average launch duration measured with time
+    stamps on its launch stream over the timed region.  `frame` = all kernels of one frame / the measured frame time, by
+    the algorithmic bytes of this run and by the PMC bytes of the committed profile of the same build.  `kernels` = every
+    kernel alone (unpipelined pass, the measured cost of an empty pair of time stamps subtracted) and in the frame (the
+    short calibration passes in front of the timed region)."""
     alg = ALG_BYTES[dominant](st, P)
     achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    overhead = alone_ms.get("empty_slot", 0.0)
     per_kernel = {}
-    for k, ms in kernel_ms.items():
+    alg_frame = 0.0
+    for k, ms in alone_ms.items():
         if k in ALG_BYTES and ms > 0:
             b = ALG_BYTES[k](st, P)
-            # the per-kernel pass brackets every launch with two event records (~6 us of overhead per kernel)
-            per_kernel[k] = {"ms_with_event_overhead": ms, "algorithmic_MB": b / 1e6}
+            alg_frame += b
+            net = max(ms - overhead, 1e-6)
+            per_kernel[k] = {"ms_with_event_overhead": ms, "alone_ms": net, "algorithmic_MB": b / 1e6,
+                             "alone_frac_of_hbm_peak": b / (net * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "in_frame_ms": in_frame_ms.get(k),
+                             "in_frame_frac_of_hbm_peak": (b / (in_frame_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS) if in_frame_ms.get(k) else None}
     pmc, why = pmc_file(config)
-    traffic = raw = frame = None
+    traffic = raw = None
+    frame = {"algorithmic_bytes_per_frame": alg_frame, "algorithmic_GBs": alg_frame / (ms_per_step * 1e-3) / 1e9,
+             "algorithmic_frac": alg_frame / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             "note": "sum of the kernels' algorithmic bytes (ALG_BYTES, preprocessing included) / the measured frame time"}
     if pmc is not None:
         at = pmc.get("_meta", {}).get("surfel_slots")
         if not at or abs(at - st["surfels_size"]) > 0.1 * st["surfels_size"]:
@@ -536,19 +630,25 @@ def roofline_block(st, P, dominant, dom_ms, dom_n, kernel_ms, ms_per_step, confi
         raw = {"FETCH_SIZE_KB": k.get("FETCH_SIZE"), "WRITE_SIZE_KB": k.get("WRITE_SIZE"),
                "collected_at_surfel_slots": pmc.get("_meta", {}).get("surfel_slots"),
                "algorithmic_bytes_of_the_pmc_run": alg_own,
-               "traffic_over_algorithmic": (traffic / alg_own) if (traffic and alg_own) else None}
+               "traffic_over_algorithmic": (traffic / alg_own) if (traffic and alg_own) else None,
+               "counter_note": PMC_NOTE}
         total = sum(b for b in (pmc_bytes(v) for n, v in pmc.items() if n != "_meta") if b)
-        frame = {"pmc_bytes_per_frame": total, "GBs": total / (ms_per_step * 1e-3) / 1e9,
-                 "frac": total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "note": "sum over the kernels of one frame of 2 x FETCH_SIZE + WRITE_SIZE / the measured frame time"}
+        frame.update({"pmc_bytes_per_frame": total, "GBs": total / (ms_per_step * 1e-3) / 1e9,
+                      "frac": total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "pmc_note": "sum over the kernels of one frame of 2 x FETCH_SIZE + WRITE_SIZE / the measured frame time"})
     return {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_pmc_raw": raw, "traffic_refused": why,
             "frame": frame, "algorithmic_bytes_per_launch": alg,
             "avg_launch_ms": dom_ms, "launches_timed": dom_n, "surfel_slots": st["surfels_size"],
-            "kernels_untimed_pass": per_kernel}
+            "longest_surfel_kernel_in_frame": dominant_hbm,
+            "note": ("the longest kernel in the frame is a preprocessing stage bound by VALU issue, not by HBM (4 bytes per pixel): "
+                     "its VALU roofline is `roofline_valu`; `longest_surfel_kernel_in_frame` names the longest HBM-side kernel, "
+                     "whose fractions are in `kernels`") if dominant in PRE_STAGES else None,
+            "event_overhead_ms": overhead,
+            "kernels": per_kernel}
 
 
-def bilateral_valu_roofline(wl, api, torch, frame):
+def bilateral_valu_roofline(wl, api, torch, frame, in_frame_ms=None):
     """The longest single dispatch of a frame is the bilateral filter, and it is VALU-bound (113 taps x exp at radius 6):
     its roofline is the FP32 vector peak.  Flops per in-region pixel and tap: range term 5 (sub, mul, mul, add + the
     spatial table value), det_expf 19 (2 mul/rint, 2 fma range reduction, 6 fma polynomial, 2 mul + add, scale),
@@ -584,12 +684,14 @@ def bilateral_valu_roofline(wl, api, torch, frame):
     return {"bound": "valu_fp32", "kernel": "k_bilateral_p<%d>" % radius, "achieved": tf, "peak": VALU_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS, "flop_per_launch": flops, "taps": taps,
             "avg_launch_ms_alone": ms,
+            "avg_launch_ms_in_frame": in_frame_ms,
+            "frac_in_frame": (flops / (in_frame_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS) if in_frame_ms else None,
             "note": "timed alone, back to back; inside the frame it shares the chip with two other chains.  28 flop per "
                     "tap is the algorithm's count; the kernel issues 13.5 VALU instructions per tap (two taps per packed "
                     "fp32 instruction wherever the ISA has one), peak = packed FMA rate"}
 
 
-def cpu_baseline(wl, plan, W, frames, state0, merge0, cap, check, log):
+def cpu_baseline(wl, plan, W, frames, state0, merge0, cap, check, log, time_one_core=True):
     """The oracle (plain C loops) on the `frames` frames behind the snapshot (taken after all GPU passes: the trajectory goes on behind the timed window), starting from the same surfel
     state: once with the per-pixel stages row-parallel on all host cores (the headline CPU number; Integrate itself is
     a sequential scan over the surfels and stays on one core) and once on a single core; the run also serves as a
@@ -608,7 +710,7 @@ def cpu_baseline(wl, plan, W, frames, state0, merge0, cap, check, log):
     cores = min(os.cpu_count() or 1, 32)   # threads actually used (one row band each; more bands than this only add dispatch overhead)
     po = None
     timings = {}
-    for threads in (cores, 1):
+    for threads in ((cores, 1) if time_one_core else (cores,)):
         binding.set_row_threads(threads)
         po = OraclePipeline(wl.w, wl.h, wl.fx, wl.fy, wl.cx, wl.cy, cap, wl.pre)
         po.recon.surfels()[:, :n0] = state0
@@ -629,14 +731,18 @@ def cpu_baseline(wl, plan, W, frames, state0, merge0, cap, check, log):
             po_full = po
     binding.set_row_threads(1)
     nf, t_pre, t_int = timings[cores]
-    nf1, t_pre1, t_int1 = timings[1]
-    out = {"value": nf / (t_pre + t_int), "unit": "frames/s", "cores": cores, "kind": "port",
+    nf1, t_pre1, t_int1 = timings.get(1, (1, 0.0, 0.0))
+    out = {"value": nf / (t_pre + t_int), "unit": "frames/s", "cores": cores, "integrate_cores": 1, "kind": "port",
+           "cores_note": "%d threads serve the per-pixel stages only (%.0f %% of the CPU time per frame is Integrate on ONE core: "
+                         "a sequential scan over the surfels)" % (cores, 100.0 * t_int / (t_pre + t_int)),
            "sample": "%d frames behind the snapshot (the trajectory continued behind the timed window) from the same %d-surfel state (oracle, gcc -O2): per-pixel stages "
                      "row-parallel on %d threads (%.1f ms/frame), Integrate on 1 thread (%.1f ms/frame)" %
                      (nf, n0, cores, 1e3 * t_pre / nf, 1e3 * t_int / nf),
-           "one_core": {"value": nf1 / (t_pre1 + t_int1), "unit": "frames/s", "cores": 1, "frames": nf1,
-                        "per_pixel_stages_ms": 1e3 * t_pre1 / nf1, "integrate_ms": 1e3 * t_int1 / nf1},
-           "c1_single_frame": c1_timing(wl.w, wl.h)}
+           }
+    if time_one_core:
+        out["one_core"] = {"value": nf1 / (t_pre1 + t_int1), "unit": "frames/s", "cores": 1, "frames": nf1,
+                           "per_pixel_stages_ms": 1e3 * t_pre1 / nf1, "integrate_ms": 1e3 * t_int1 / nf1}
+        out["c1_single_frame"] = c1_timing(wl.w, wl.h)
     if check:
         from surfelmeshing_amd.pipeline import FramePipeline
         po = po_full
@@ -786,7 +892,7 @@ def run_c5(args):
         query_self(1.0)
     torch.cuda.synchronize()
     elapsed_local = time.perf_counter() - t_start
-    qps, elapsed, _ = multistream.aggregate_throughput(float(n) * steps, elapsed_local, world, dist if world > 1 else None, "cuda")
+    qps, elapsed, _ = multistream.aggregate_throughput(float(n) * steps, elapsed_local, world, dist if world > 1 else None, reduce_device(args))
     _lib.check(L.smx_debug_marker(None, 2))
     # counters of one more pass -> algorithmic bytes per query (16 (position + r^2) + 12 x the candidates
     # staged per tile, amortised over the queries of the tile + 8 per result + 4 (count))

@@ -84,6 +84,10 @@ int smx_event_create(smx_event* out);
 int smx_event_destroy(smx_event e);
 int smx_event_record(smx_event e, smx_stream s);
 int smx_stream_wait_event(smx_stream s, smx_event e);
+/* Events that carry a time stamp (measurement only: the driver's per-stage profile of the preprocessing stream);
+ * smx_event_elapsed_ms blocks until `stop` has completed. */
+int smx_event_create_timed(smx_event* out);
+int smx_event_elapsed_ms(smx_event start, smx_event stop, float* ms);
 /* Launches an empty kernel (k_smx_marker) that delimits regions in kernel traces. */
 int smx_debug_marker(smx_stream s, int32_t id);
 
@@ -318,8 +322,14 @@ int smx_recon_debug_count_skipped_segments(smx_recon r, smx_stream s, uint32_t* 
  * an LDS table (the path a pair takes that finds no room in that table); bit 5: the regulariser's far-term bins hold 4 records
  * per destination segment, bit 6: a sender workgroup addresses 2 destination segments through the bins -- the other far
  * terms take the atomic accumulators (the overflow paths of those bins); bit 7: the blend's other tile size (the
- * library picks 32 x 32 or 40 x 40 pixels by the number of tiles per compute unit; this bit swaps the choice). */
+ * library picks 32 x 32 or 40 x 40 pixels by the number of tiles per compute unit; this bit swaps the choice);
+ * bit 8: the list kernels run on a grid of four workgroups, so that every workgroup walks many steps. */
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode);
+/* TIMING ONLY -- the map is WRONG afterwards: leaves launches of smx_recon_integrate out, for the upper-bound runs of
+ * bench.py --ub (what would the frame rate be without this chain?).  bit 0: no regulariser (pass B, edges, step);
+ * bit 1: the front of the frame only (pass A, association tiles, blend): no integration, neighbour update, creation
+ * or regulariser either.  The stream hand-offs stay as they are.  0 = off. */
+int smx_recon_debug_set_skip(smx_recon r, int32_t mask);
 /* Frame pipelining (default on): the regulariser of a frame runs on an internal stream beside the first
  * kernels of the next smx_recon_integrate call (which only read what the regulariser does not write).
  * Every entry point that takes a stream first orders that stream after the pending regulariser, so the

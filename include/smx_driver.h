@@ -81,6 +81,14 @@ int smx_driver_set_fused_tail(smx_driver d, int32_t enabled);
  * (three sets of work images) and its dependencies are routed through smx_recon_integrate_hooks, so that from the third
  * step of a call on the caller's stream carries one event record and one wait per frame instead of two and two. */
 int smx_driver_set_run_ahead(smx_driver d, int32_t enabled);
+/* Measurement hooks (bench.py).  smx_driver_debug_prepare: preprocess the n steps now, each into work images of its
+ * own, and wait; the following smx_driver_run calls integrate those images in order instead of preprocessing (same
+ * results; the preprocessing queue stays empty while the frames run).  smx_driver_profile_begin / _end: time stamps
+ * around one preprocessing stage (0 = bilateral filter, 1 = outlier cull, 2 = erosion + normals + radii) of the next
+ * max_frames frames, on the stream the stage runs on; _end returns the average duration. */
+int smx_driver_debug_prepare(smx_driver d, smx_stream s, const smx_driver_step* steps, int32_t n);
+int smx_driver_profile_begin(smx_driver d, int32_t stage, int32_t max_frames);
+int smx_driver_profile_end(smx_driver d, float* avg_ms, int32_t* frames);
 /* Working buffers after the last frame: final (blended) depth, normals, radius. */
 int smx_driver_work_descs(smx_driver d, smx_buffer_desc* depth, smx_buffer_desc* normals, smx_buffer_desc* radius);
 

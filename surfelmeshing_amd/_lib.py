@@ -78,7 +78,7 @@ class NNStats(C.Structure):
 EXPORTS = [
     "smx_last_error", "smx_device_count", "smx_set_device", "smx_device_name",
     "smx_stream_create", "smx_stream_create_with_priority", "smx_host_alloc", "smx_host_free", "smx_stream_destroy", "smx_stream_synchronize", "smx_debug_marker",
-    "smx_event_create", "smx_event_destroy", "smx_event_record", "smx_stream_wait_event",
+    "smx_event_create", "smx_event_create_timed", "smx_event_elapsed_ms", "smx_event_destroy", "smx_event_record", "smx_stream_wait_event",
     "smx_buffer_create", "smx_buffer_destroy", "smx_buffer_get_desc", "smx_buffer_upload", "smx_buffer_download",
     "smx_buffer_upload_part", "smx_buffer_download_part", "smx_buffer_clear", "smx_buffer_set_to",
     "smx_bilateral_filtering_and_depth_cutoff", "smx_outlier_depth_map_fusion", "smx_erode_depth_map",
@@ -91,7 +91,7 @@ EXPORTS = [
     "smx_recon_kernel_slot_count", "smx_recon_kernel_slot_name", "smx_recon_get_kernel_timings",
     "smx_recon_profile_begin", "smx_recon_profile_end",
     "smx_recon_debug_download_surfels", "smx_recon_debug_upload_surfels", "smx_recon_debug_download_scratch", "smx_recon_debug_count_skipped_segments",
-    "smx_recon_set_scan_mode", "smx_recon_set_overlap", "smx_recon_integrate_hooks", "smx_recon_integrate_inputs_ready",
+    "smx_recon_set_scan_mode", "smx_recon_debug_set_skip", "smx_recon_set_overlap", "smx_recon_integrate_hooks", "smx_recon_integrate_inputs_ready",
     "smx_nn_create", "smx_nn_destroy", "smx_nn_build", "smx_nn_query_batch", "smx_nn_query_self", "smx_nn_set_query_mode", "smx_nn_set_stats_enabled", "smx_nn_get_stats",
     "smx_synth_render_room",
 ]

@@ -551,6 +551,10 @@ class CUDASurfelReconstruction:
     def set_scan_mode(self, mode):
         _lib.check(_lib.load().smx_recon_set_scan_mode(self._h, C.c_int32(mode)))
 
+    def debug_set_skip(self, mask):
+        """TIMING ONLY (smx_recon_debug_set_skip): bit 0 = no regulariser, bit 1 = front of the frame only."""
+        _lib.check(_lib.load().smx_recon_debug_set_skip(self._h, C.c_int32(mask)))
+
     def set_overlap(self, enabled):
         """Frame pipelining on/off (regulariser of frame f beside the first kernels of frame f+1)."""
         _lib.check(_lib.load().smx_recon_set_overlap(self._h, C.c_int32(1 if enabled else 0)))

@@ -126,6 +126,21 @@ int smx_event_create(smx_event* out) {
   return SMX_OK;
 }
 
+int smx_event_create_timed(smx_event* out) {
+  SMX_CHECK_ARG(out != nullptr);
+  hipEvent_t e;
+  SMX_HIP(hipEventCreate(&e));
+  *out = (smx_event)e;
+  return SMX_OK;
+}
+
+int smx_event_elapsed_ms(smx_event start, smx_event stop, float* ms) {
+  SMX_CHECK_ARG(start != nullptr && stop != nullptr && ms != nullptr);
+  SMX_HIP(hipEventSynchronize((hipEvent_t)stop));
+  SMX_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return SMX_OK;
+}
+
 int smx_event_destroy(smx_event e) {
   if (e) SMX_HIP(hipEventDestroy((hipEvent_t)e));
   return SMX_OK;

@@ -50,6 +50,13 @@ struct smx_driver_s {
   bool run_ahead = false;  // smx_driver_run: preprocessing two steps ahead, dependencies routed off the caller's stream (A/B: -1 %)
   bool fuse_tail = true;   // erosion + normals + radii as one launch (A/B: smx_driver_set_fused_tail)
   unsigned long long frame_counter = 0;
+  // smx_driver_debug_prepare: work sets preprocessed ahead of time, consumed in order by the next runs (measurement)
+  std::vector<std::unique_ptr<WorkSet>> prepared;
+  size_t prepared_next = 0;
+  // smx_driver_profile_begin: timed events around one preprocessing stage, one pair per frame
+  int prof_stage = -1;
+  std::vector<smx_event> prof_ev;
+  size_t prof_n = 0;
 
   explicit smx_driver_s(const smx_driver_config& c, const float* intr)
       : cfg(c), camera(c.width, c.height, intr), reconstruction(c.max_surfel_count, camera),
@@ -59,7 +66,21 @@ struct smx_driver_s {
     SMX_SHIM_CHECK(smx_event_create(&run_start));
     SMX_SHIM_CHECK(smx_stream_synchronize(nullptr));
   }
-  ~smx_driver_s() { smx_stream_synchronize(pre_stream); smx_stream_destroy(pre_stream); smx_event_destroy(run_start); }
+  ~smx_driver_s() {
+    smx_stream_synchronize(pre_stream); smx_stream_synchronize(nullptr);
+    smx_stream_destroy(pre_stream); smx_event_destroy(run_start);
+    for (smx_event e : prof_ev) smx_event_destroy(e);
+  }
+};
+
+// (measurement) brackets one preprocessing stage with timed events while a profile is running
+struct StageTimer {
+  smx_driver_s* d; cudaStream_t st; bool on;
+  StageTimer(smx_driver_s* d_, cudaStream_t st_, int stage) : d(d_), st(st_) {
+    on = d->prof_stage == stage && 2 * d->prof_n + 1 < d->prof_ev.size();
+    if (on) (void)smx_event_record(d->prof_ev[2 * d->prof_n], st);
+  }
+  ~StageTimer() { if (on) { (void)smx_event_record(d->prof_ev[2 * d->prof_n + 1], st); ++d->prof_n; } }
 };
 
 namespace smx { void set_error(const char* fmt, ...); }  // libsmx's thread-local error text (smx_last_error)
@@ -80,11 +101,12 @@ static int preprocess_frame(smx_driver d, cudaStream_t stream, const smx_driver_
   const float* cam = d->camera.parameters();
 
   // Bilateral filtering and depth cutoff (:1015-1024)
+  { StageTimer t_(d, stream, 0);
   BilateralFilteringAndDepthCutoffCUDA(stream, c.bilateral_filter_sigma_xy, c.bilateral_filter_sigma_depth_factor,
                                        /*value_to_ignore*/ 0, c.bilateral_filter_radius_factor,
                                        (u16)(c.depth_scaling * c.max_depth > 65535.f ? 65535.f : c.depth_scaling * c.max_depth),
                                        c.depth_valid_region_radius, depth_buffer.ToCUDA(),
-                                       &ws->filtered_depth_buffer_A.ToCUDA());
+                                       &ws->filtered_depth_buffer_A.ToCUDA()); }
   CUDABuffer<u16>* src = &ws->filtered_depth_buffer_A;
   CUDABuffer<u16>* dst = &ws->filtered_depth_buffer_B;
 
@@ -110,6 +132,7 @@ static int preprocess_frame(smx_driver d, cudaStream_t stream, const smx_driver_
                                                cam[0], cam[1], cam[2], cam[3], other_depths, others_TR_reference,      \
                                                &dst->ToCUDA());                                                        \
   } while (0)
+    StageTimer t_(d, stream, 1);
     switch (st.other_count) {
       case 2: SMX_CALL_OUTLIER_FUSION(2); break;
       case 4: SMX_CALL_OUTLIER_FUSION(4); break;
@@ -122,6 +145,7 @@ static int preprocess_frame(smx_driver d, cudaStream_t stream, const smx_driver_
   }
   // Depth map erosion (:1128-1140), normals (:1154-1164), radii (:1180-1191): one fused launch (same images)
   if (d->fuse_tail) {
+    StageTimer t_(d, stream, 2);
     ErodeNormalsRadiiCUDA(stream, c.depth_erosion_radius, c.observation_angle_threshold_deg, c.point_radius_extension_factor,
                           c.point_radius_clamp_factor, c.depth_scaling, cam[0], cam[1], cam[2], cam[3], src->ToCUDA(),
                           &dst->ToCUDA(), &ws->normals_buffer.ToCUDA(), &ws->radius_buffer.ToCUDA());
@@ -326,8 +350,62 @@ static int run_ahead(smx_driver d, smx_stream s, const smx_driver_step* steps, i
   return SMX_OK;
 }
 
+// (measurement: bench.py --ub hoist-pre) Preprocesses the n steps NOW, each into a work set of its own, and waits for
+// them; the next smx_driver_run calls integrate those sets in order instead of preprocessing -- the same images, the same
+// results, with the preprocessing queue empty while the frames are timed.
+int smx_driver_debug_prepare(smx_driver d, smx_stream s, const smx_driver_step* steps, int32_t n) {
+  if (!d || (!steps && n > 0)) return fail("null argument");
+  SMX_SHIM_CHECK(smx_stream_synchronize(s));
+  if (d->prepared_next >= d->prepared.size()) { d->prepared.clear(); d->prepared_next = 0; }
+  for (int i = 0; i < n; ++i) {
+    std::unique_ptr<WorkSet> ws(new WorkSet(d->cfg.height, d->cfg.width));
+    ++d->frame_counter;
+    const int rc = preprocess_frame(d, d->pre_stream, steps[i], ws.get());
+    if (rc != SMX_OK) return rc;
+    d->prepared.push_back(std::move(ws));
+  }
+  SMX_SHIM_CHECK(smx_stream_synchronize(d->pre_stream));
+  return SMX_OK;
+}
+
+int smx_driver_profile_begin(smx_driver d, int32_t stage, int32_t max_frames) {
+  if (!d || stage < 0 || stage > 2 || max_frames <= 0) return fail("invalid argument");
+  while (d->prof_ev.size() < 2 * (size_t)max_frames) {
+    smx_event e = nullptr;
+    SMX_SHIM_CHECK(smx_event_create_timed(&e));
+    d->prof_ev.push_back(e);
+  }
+  d->prof_stage = stage; d->prof_n = 0;
+  return SMX_OK;
+}
+
+int smx_driver_profile_end(smx_driver d, float* avg_ms, int32_t* frames) {
+  if (!d || !avg_ms || !frames) return fail("null argument");
+  double sum = 0;
+  for (size_t i = 0; i < d->prof_n; ++i) {
+    float ms = 0;
+    SMX_SHIM_CHECK(smx_event_elapsed_ms(d->prof_ev[2 * i], d->prof_ev[2 * i + 1], &ms));
+    sum += ms;
+  }
+  *frames = (int32_t)d->prof_n;
+  *avg_ms = d->prof_n ? (float)(sum / (double)d->prof_n) : 0.0f;
+  d->prof_stage = -1; d->prof_n = 0;
+  return SMX_OK;
+}
+
 int smx_driver_run(smx_driver d, smx_stream s, const smx_driver_step* steps, int32_t n) {
   if (!d || (!steps && n > 0)) return fail("null argument");
+  if (d->prepared_next < d->prepared.size()) {
+    for (int i = 0; i < n; ++i) {
+      if (d->prepared_next >= d->prepared.size()) return fail("fewer prepared work sets than steps");
+      WorkSet* ws = d->prepared[d->prepared_next++].get();
+      const int rc = integrate_frame(d, s, steps[i], ws);
+      if (rc != SMX_OK) return rc;
+      d->prev = d->last;
+      d->last = ws;
+    }
+    return SMX_OK;
+  }
   // Everything already enqueued on s (frame uploads / renders, earlier runs) precedes the first preprocessing.
   if (d->overlap) {
     SMX_SHIM_CHECK(smx_event_record(d->run_start, s));

@@ -936,6 +936,10 @@ struct BlendMasks {
 };
 __device__ __forceinline__ unsigned long long dilate_row(unsigned long long m) { return m | (m << 1) | (m >> 1); }
 // lane r gets lane r - 1's / r + 1's value, the first / last lane 0: DPP wave_shr:1 / wave_shl:1, no LDS crossbar trip
+// (GFX9-family encodings; the whole file is written for wave64 on gfx950 -- DESIGN.md -- and the build says so)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libsmx device code is written for gfx950 (wave64, GFX9 DPP controls, packed fp32): build with --offload-arch=gfx950"
+#endif
 __device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x138, 0xF, 0xF, false);
   const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, false);
@@ -2074,6 +2078,10 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long*
       __syncthreads();
       lds_used = true;
     }
+    // (n_far is uniform: word 0 only changes behind the barriers above.  With an empty bin nothing has ordered the other
+    // wavefronts' loads of bin_state before the reset below -- they drift freely across barrier-free steps -- and a
+    // wavefront that read the spill mark late would find it gone and drop its slots' grad_acc terms.)
+    if (!n_far) __syncthreads();
     if ((bin_state.x | bin_state.y) && threadIdx.x == 0)
       *reinterpret_cast<uint2*>(&fb.count[(size_t)seg * kCountStride]) = make_uint2(0u, 0u);
 #pragma unroll
@@ -2447,6 +2455,8 @@ struct smx_recon_s {
   bool staging_busy;      // row downloads in flight, and the next user may come on another stream
   int grid_surfels;  // persistent grid for the grid-stride all-slot kernels
   int grid_list;     // persistent grid of the chunked list kernels
+  int grid_list_full; // (grid_list is lowered by the A/B switch that forces long walks)
+  int debug_skip;    // smx_recon_debug_set_skip (timing only)
   // Frame pipelining: the regulariser of frame f runs on an internal stream while the caller's stream already
   // executes clear / pass A / associate / merge / blend of frame f+1 (those read only P and N records, which the
   // regulariser does not write, and a second copy of the flag table).  Every entry point first orders the
@@ -2468,11 +2478,13 @@ enum : int {
   kSlotScanVisible = 0, kSlotAssocTiles, kSlotBlend, kSlotIntegrate,
   kSlotUpdateNeighbors, kSlotNeighborScan,
   kSlotRegAccumulate, kSlotRegStep,
-  kSlotRegUpdate, kSlotCount
+  kSlotRegUpdate,
+  kSlotEmpty,   // nothing between its two time stamps: what a pair of stamps costs (subtracted by bench.py)
+  kSlotCount
 };
 static const char* const kSlotNames[kSlotCount] = {
   "scan_visible", "assoc_tiles", "blend", "integrate+new_flags", "update_neighbors+create",
-  "neighbor_scan", "reg_accumulate", "reg_step", "reg_update"};
+  "neighbor_scan", "reg_accumulate", "reg_step", "reg_update", "empty_slot"};
 
 struct SlotTimer {
   smx_recon r; hipStream_t st; int slot; bool kev, prof;
@@ -2562,6 +2574,13 @@ int release_staging(smx_recon r, hipStream_t st) {
   return SMX_OK;
 }
 
+// (for the create functions, whose failure paths have to release what exists so far instead of returning on the spot)
+int hip_rc(hipError_t e, const char* what) {
+  if (e == hipSuccess) return SMX_OK;
+  set_error("%s failed: %s", what, hipGetErrorString(e));
+  return SMX_ERR_HIP;
+}
+
 template <typename T>
 int dev_alloc(T** p, size_t count, bool zero) {
   SMX_HIP(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
@@ -2575,7 +2594,8 @@ extern "C" {
 
 int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
                      float fx, float fy, float cx, float cy, int32_t device_id, smx_recon* out) {
-  SMX_CHECK_ARG(out != nullptr && max_surfel_count > 0 && max_surfel_count < 0x7FFFFFFFu);
+  // (slot indices travel with two class bits on top in k_reg_accumulate's pending far terms: far_target)
+  SMX_CHECK_ARG(out != nullptr && max_surfel_count > 0 && max_surfel_count <= (1u << 30));
   SMX_CHECK_ARG(width >= 3 && height >= 3);
   int device = 0;
   { const int rcd = resolve_device(device_id, &device); if (rcd != SMX_OK) return rcd; }
@@ -2605,9 +2625,9 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->L.seg_box, (size_t)r->nseg * 8, true));
   SMX_TRY(dev_alloc(&r->L.seg_act, (size_t)r->nseg, true));
   // (the direction word of segment_of_block: written by the tile kernel, read by the host without synchronisation)
-  SMX_HIP(hipHostMalloc(reinterpret_cast<void**>(&r->dir_host), sizeof(uint32_t), hipHostMallocMapped));
+  SMX_TRY(hip_rc(hipHostMalloc(reinterpret_cast<void**>(&r->dir_host), sizeof(uint32_t), hipHostMallocMapped), "hipHostMalloc"));
   *r->dir_host = 0;
-  SMX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&r->dir_dev), r->dir_host, 0));
+  SMX_TRY(hip_rc(hipHostGetDevicePointer(reinterpret_cast<void**>(&r->dir_dev), r->dir_host, 0), "hipHostGetDevicePointer"));
   SMX_TRY(dev_alloc(&r->L.recent_seg, (size_t)r->nsegB, true));
   // chunk descriptors: every chunk of every segment in the worst case, + room for the index a walk forms first
   SMX_TRY(dev_alloc(&r->L.vis_chunks.desc, (size_t)r->nseg * (kSeg / kBlock) + 65536, true));
@@ -2661,30 +2681,30 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->block_sums, (size_t)r->n_scan_blocks, true));
   SMX_TRY(dev_alloc(&r->block_offsets, (size_t)r->n_scan_blocks, true));
   SMX_TRY(dev_alloc(&r->st, 1, true));
-#undef SMX_TRY
-  for (int i = 0; i < 14; ++i) SMX_HIP(hipEventCreate(&r->ev[i]));
-  for (int i = 0; i < 2 * 16; ++i) SMX_HIP(hipEventCreate(&r->kev[i]));
+  for (int i = 0; i < 14; ++i) SMX_TRY(hip_rc(hipEventCreate(&r->ev[i]), "hipEventCreate"));
+  for (int i = 0; i < 2 * 16; ++i) SMX_TRY(hip_rc(hipEventCreate(&r->kev[i]), "hipEventCreate"));
   {
     // the regulariser is on the frame-to-frame critical path, the work it overlaps with is not
     int lo = 0, hi = 0;
-    SMX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    SMX_HIP(hipStreamCreateWithPriority(&r->reg_stream, hipStreamNonBlocking, hi));
+    SMX_TRY(hip_rc(hipDeviceGetStreamPriorityRange(&lo, &hi), "hipDeviceGetStreamPriorityRange"));
+    SMX_TRY(hip_rc(hipStreamCreateWithPriority(&r->reg_stream, hipStreamNonBlocking, hi), "hipStreamCreateWithPriority"));
   }
   // (device-scope release: these events order GPU streams, the host never reads data behind them)
   const unsigned evf = hipEventDisableTiming | hipEventReleaseToDevice;
-  SMX_HIP(hipEventCreateWithFlags(&r->ev_front, evf));
-  SMX_HIP(hipEventCreateWithFlags(&r->ev_upd, evf));
-  SMX_HIP(hipEventCreateWithFlags(&r->ev_reg, evf));
-  SMX_HIP(hipEventCreateWithFlags(&r->ev_staging, hipEventDisableTiming));
+  SMX_TRY(hip_rc(hipEventCreateWithFlags(&r->ev_front, evf), "hipEventCreateWithFlags"));
+  SMX_TRY(hip_rc(hipEventCreateWithFlags(&r->ev_upd, evf), "hipEventCreateWithFlags"));
+  SMX_TRY(hip_rc(hipEventCreateWithFlags(&r->ev_reg, evf), "hipEventCreateWithFlags"));
+  SMX_TRY(hip_rc(hipEventCreateWithFlags(&r->ev_staging, hipEventDisableTiming), "hipEventCreateWithFlags"));
   r->overlap_enabled = 1;
   r->prof_slot = -1;
   r->timing_enabled = 1;
   hipDeviceProp_t prop;
-  SMX_HIP(hipGetDeviceProperties(&prop, device));
+  SMX_TRY(hip_rc(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties"));
+#undef SMX_TRY
   const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   r->grid_surfels = cus * 8;  // 8 x 256-thread workgroups per CU: full occupancy, >> 256 workgroups
   r->cu_count = cus;
-  r->grid_list = cus * 32;  // the lists are sparse: most chunks are empty, so more, shorter walks
+  r->grid_list = r->grid_list_full = cus * 32;  // the lists are sparse: most chunks are empty, so more, shorter walks
   r->stats_enabled = 1;
   *out = r;
   return SMX_OK;
@@ -2776,8 +2796,9 @@ int smx_recon_set_overlap(smx_recon r, int32_t enabled) {
 }
 
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
-  SMX_CHECK_ARG(r != nullptr && mode >= 0 && mode <= 255);
+  SMX_CHECK_ARG(r != nullptr && mode >= 0 && mode <= 511);
   SMX_ON_DEVICE(r->device);
+  r->grid_list = ((mode >> 8) & 1) ? 4 : r->grid_list_full;   // four workgroups walk every list: many steps each
   r->scan_mode = mode & 1;
   r->blend_multi_launch = (mode >> 1) & 1;
   r->hot_filter_enabled = ((mode >> 2) & 1) ? 0 : 1;
@@ -2789,14 +2810,21 @@ int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
   return SMX_OK;
 }
 
+int smx_recon_debug_set_skip(smx_recon r, int32_t mask) {
+  SMX_CHECK_ARG(r != nullptr && mask >= 0 && mask <= 3);
+  r->debug_skip = mask;
+  return SMX_OK;
+}
+
 int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float depth_scaling,
                         const smx_buffer_desc* depth, const smx_buffer_desc* normals,
                         const smx_buffer_desc* radius, const smx_buffer_desc* color,
                         const float global_T_local[12], const smx_integrate_params* p) {
-  SMX_CHECK_ARG(r && depth && normals && radius && color && global_T_local && p);
-  SMX_ON_DEVICE(r->device);
+  SMX_CHECK_ARG(r != nullptr);
   const hipEvent_t hook_consumed = r->hook_consumed, hook_chain = r->hook_chain, hook_ready = r->hook_ready;   // one-shot, also when the call fails
   r->hook_consumed = nullptr; r->hook_chain = nullptr; r->hook_ready = nullptr;
+  SMX_CHECK_ARG(depth && normals && radius && color && global_T_local && p);
+  SMX_ON_DEVICE(r->device);
   SMX_CHECK_ARG(depth->width == r->W && depth->height == r->H && normals->width == r->W && normals->height == r->H);
   SMX_CHECK_ARG(radius->width == r->W && radius->height == r->H && color->width == r->W && color->height == r->H);
   // (the radius is only read when blending is on: do_blending is an independent flag, APP/main.cc:348-354)
@@ -2927,17 +2955,21 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   // Everything up to here only read P and N records; from here on they (and T, S) are written, so the previous
   // call's regulariser has to be done: it is, by stream order -- the rest of the call follows it on the internal stream.
   if (pipelined) {
+    // (work on the internal stream from here on: whatever happens below, later entry points order themselves behind it)
+    r->reg_pending = true;
     SMX_HIP(hipEventRecord(r->ev_front, sF));
     SMX_HIP(hipStreamWaitEvent(sR, r->ev_front, 0));
   }
   if (tm) SMX_HIP(hipEventRecord(r->ev[6], sR));
-  { SlotTimer t(r, sR, kSlotIntegrate);
+  const bool front_only = (r->debug_skip & 2) != 0, skip_reg = (r->debug_skip & 3) != 0;   // (timing only)
+  if (front_only) SMX_HIP(hipMemsetAsync(r->vis_count_set[r->sc_cur ^ 1], 0, sizeof(uint32_t), sR));   // (k_update_and_create's side job)
+  if (!front_only) { SlotTimer t(r, sR, kSlotIntegrate);
     const uint32_t nfb = (uint32_t)r->n_scan_blocks;
     const dim3 gi(nfb + (uint32_t)r->grid_list);
     if (r->scan_mode) hipLaunchKernelGGL((k_integrate<false>), gi, b, 0, sR, r->S, c, r->sc, in_integrate, r->L, r->merge_flag, r->st, nf, nfb);
     else hipLaunchKernelGGL((k_integrate<true>), gi, b, 0, sR, r->S, c, r->sc, in_integrate, r->L, r->merge_flag, r->st, nf, nfb); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[7], sR)); SMX_HIP(hipEventRecord(r->ev[8], sR)); }
-  { SlotTimer t(r, sR, kSlotUpdateNeighbors);
+  if (!front_only) { SlotTimer t(r, sR, kSlotUpdateNeighbors);
     CreateArgs ca;
     ca.flags = r->new_flags; ca.ranks = r->new_ranks; ca.block_sums = r->block_sums; ca.block_offsets_out = r->block_offsets;
     ca.n_scan_blocks = r->n_scan_blocks; ca.max_surfels = r->max_surfels; ca.flags8 = r->L.flags8; ca.dirty8 = r->L.dirty8;
@@ -2951,6 +2983,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   // (the detach half of UpdateNeighborsCUDA runs fused into pass B below)
   if (tm) { SMX_HIP(hipEventRecord(r->ev[9], sR)); SMX_HIP(hipEventRecord(r->ev[10], sR)); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[11], sR)); SMX_HIP(hipEventRecord(r->ev[12], sR)); }
+  if (r->timing_enabled & 2) { SlotTimer t(r, sR, kSlotEmpty); }
   SMX_LAUNCH_CHECK();
   int rc = SMX_OK;
   const int iters = p->regularization_iterations_per_integration_iteration;
@@ -2963,7 +2996,8 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     if (pipelined || hook_consumed) SMX_HIP(hipEventRecord(mark, sR));
     if (pipelined) SMX_HIP(hipStreamWaitEvent(sF, mark, 0));
   }
-  if (iters == 0) {
+  if (skip_reg) {
+  } else if (iters == 0) {
     rc = enqueue_regularize(r, sR, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
                             p->regularization_frame_window_size, true, true, false);
   } else {
@@ -2976,7 +3010,6 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   // (smx_recon_integrate_hooks) whatever this event covers is complete before the regulariser counts as complete,
   // i.e. before the second half of the next call and all of the call after it
   if (hook_chain) SMX_HIP(hipStreamWaitEvent(sR, hook_chain, 0));
-  if (pipelined) r->reg_pending = true;
   return SMX_OK;
 }
 

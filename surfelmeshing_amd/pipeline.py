@@ -184,7 +184,7 @@ class DriverStep(_C.Structure):
 DRIVER_EXPORTS = ["smx_driver_create", "smx_driver_destroy", "smx_driver_recon", "smx_driver_upload_frame",
                   "smx_driver_render_frame", "smx_driver_release_frame", "smx_driver_frame_descs", "smx_driver_run",
                   "smx_driver_work_descs", "smx_driver_download_frame", "smx_driver_download_work", "smx_driver_set_overlap", "smx_driver_set_fused_tail", "smx_driver_set_run_ahead",
-                  "smx_driver_run_streamed"]
+                  "smx_driver_run_streamed", "smx_driver_debug_prepare", "smx_driver_profile_begin", "smx_driver_profile_end"]
 
 
 class DriverHostFrame(_C.Structure):
@@ -284,6 +284,19 @@ class NativeFramePipeline:
 
     def run_array(self, arr, n):
         _smxlib.check(_smxlib.load().smx_driver_run(self._d, self._s(), arr, _C.c_int32(n)))
+
+    def prepare_array(self, arr, n):
+        """(measurement) smx_driver_debug_prepare: the next run_array calls find these steps preprocessed."""
+        _smxlib.check(_smxlib.load().smx_driver_debug_prepare(self._d, self._s(), arr, _C.c_int32(n)))
+
+    def profile_begin(self, stage, max_frames):
+        """(measurement) time stamps around preprocessing stage 0 / 1 / 2 (bilateral, outlier cull, erode + normals + radii)."""
+        _smxlib.check(_smxlib.load().smx_driver_profile_begin(self._d, _C.c_int32(stage), _C.c_int32(max_frames)))
+
+    def profile_end(self):
+        ms, n = _C.c_float(), _C.c_int32()
+        _smxlib.check(_smxlib.load().smx_driver_profile_end(self._d, _C.byref(ms), _C.byref(n)))
+        return ms.value, n.value
 
     def run_streamed(self, steps, uploads):
         """smx_driver_run_streamed: steps (list of DriverStep), uploads = per step None or (frame_index, depth, color)

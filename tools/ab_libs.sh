@@ -9,7 +9,7 @@ for rep in $(seq $REPS); do
     timeout 300 python bench.py --steps 300 --warmup 20 --cpu-frames 0 --host-frames 0 --quiet $SMX_BENCH_FLAGS 2>/dev/null | python -c "import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); r=d['roofline']; k=r.get('kernels_untimed_pass',{})
-        print('%-8s %7.1f  %s in-frame %.1f | alone:' % ('$v', d['value'], r['kernel'], r['avg_launch_ms']*1e3), ' '.join('%s %.1f' % (n[:9], v['ms_with_event_overhead']*1e3) for n,v in k.items()))" | tee -a gpurun_out/${TAG}_libs.txt
+        d=json.loads(l); r=d['roofline']; k=r.get('kernels',{})
+        print('%-8s %7.1f  %s in-frame %.1f | alone:' % ('$v', d['value'], r['kernel'], r['avg_launch_ms']*1e3), ' '.join('%s %.1f' % (n[:9], v['alone_ms']*1e3) for n,v in k.items()))" | tee -a gpurun_out/${TAG}_libs.txt
   done
 done

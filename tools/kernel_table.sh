@@ -5,6 +5,6 @@ for v in "$@"; do
   env $envs timeout 300 python bench.py $flags --steps 200 --warmup 20 --cpu-frames 0 --host-frames 0 --quiet 2>/dev/null | python -c "import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); k=d['roofline']['kernels_untimed_pass']
-        print('$v', round(d['value'],1), ' '.join('%s=%.1f' % (n, v['ms_with_event_overhead']*1e3) for n, v in k.items()))"
+        d=json.loads(l); k=d['roofline']['kernels']
+        print('$v', round(d['value'],1), ' '.join('%s=%.1f' % (n, v['alone_ms']*1e3) for n, v in k.items()))"
 done
