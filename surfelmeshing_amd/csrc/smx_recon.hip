@@ -220,6 +220,7 @@ struct Lists {
   uint32_t* vis_list;     // slots that project into the image this frame
   float* seg_box;         // per pass-A segment: min xyz, max xyz, covered slot count (u32), newest stamp (u32)
   uint32_t* vis_seg;
+  uint8_t* seg_streak;      // per pass-A segment: in how many calls in a row pass A has culled it (k_scan_visible, step 2)
   uint32_t* recent_list;  // slots whose last update stamp lies inside the regulariser window
   uint32_t* recent_seg;
   uint8_t* flags8;        // per slot: bit 0 = stamp inside the regulariser window, bit 1 = detach request
@@ -398,189 +399,270 @@ __global__ void k_reset_frame_stats(DevState* st) {   // (value-distribution cou
 // ---------------------------------------------------------------------------------------------
 // Pass A.  The all-slot half of RenderMinDepthCUDAKernel (kernels.cu:1466-1557): which slots project into the image and
 // onto which pixels -- fused with the construction of the visible list and the refresh of the "recent" bit of the flag
-// table.  One workgroup per segment of kSeg slots; rows 18,0,1,2 are streamed with 16-byte lane loads (4 slots per
-// lane).  The z-buffer minimum itself (:1463) is formed by k_assoc_tiles from the pairs appended here.
-__global__ void __launch_bounds__(kBlock)
+// table.  Rows 18,0,1,2 are streamed with 16-byte lane loads (4 slots per lane).  The z-buffer minimum itself (:1463) is
+// formed by k_assoc_tiles from the pairs appended here.
+//
+// The launch has a CHIP-SIZED grid (G workgroups, as many as the chip holds at once), not one workgroup per segment:
+// workgroup w owns the segments w, w + G, w + 2 G, ... -- strided, because the segments with work in them form one
+// contiguous block of the slot range, which this way spreads evenly over the workgroups.  Rounds 1-3 launched a workgroup
+// per segment: 5 400 at C2 and 21 600 at C3, three quarters of which looked at one box, copied 1 KB of flag bytes and
+// left -- each of them a dependent chain (count -> box -> decision -> barrier -> copy) in a dispatch slot the segments
+// with work in them were waiting for (profiles/r14a: the C3 launch was dispatch-shaped).  Now:
+//   1. cull: lane t of the workgroup tests the box of the workgroup's t-th segment, every lane at once -- ONE round trip
+//      for all of a workgroup's boxes, requested before the slot count is known;
+//   2. the culled segments' flag bytes (recent bit off, detach bit carried over) are copied by the whole workgroup, the
+//      loads of up to four segments in flight together -- and not at all for a segment that was already culled in the
+//      two previous calls: the two copies of the flag table alternate by call, nothing but pass A writes flag bytes of
+//      slots that are not visible, so the table written two calls ago already holds this call's bytes (seg_streak);
+//   3. the surviving segments, one after the other, as before.
+constexpr int kCullLanes = kBlock;   // segments per workgroup the cull step can test (the host sizes the grid accordingly)
+__global__ void __launch_bounds__(kBlock, 8)
 k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, const uint8_t* __restrict__ flags_prev, DevState* st,
-               int use_lds_tables) {
-  const uint32_t seg_id = segment_of_block(L.descending);
+               int use_lds_tables, uint32_t nseg_alloc) {
   __shared__ uint32_t wave_tot[kBlock / 64];
   __shared__ float box_part[kBlock / 64][8];
-  __shared__ int skip_segment;
+  __shared__ unsigned long long survive_mask[kBlock / 64], copy_mask[kBlock / 64];
   // the tiles this workgroup's pairs fall into: open-addressed table keyed by tile number (fixed size: a direct-mapped
-  // one -- a word per tile, 38 KB at 1280 x 960 -- capped the chip at four workgroups per CU, and 18 000 of the 21 600
-  // workgroups of a C3 launch only look at their segment's box); pair_key = tile, later the base of the workgroup's run
+  // one -- a word per tile, 38 KB at 1280 x 960 -- capped the chip at four workgroups per CU); pair_key = tile, later the
+  // base of the workgroup's run
   __shared__ uint32_t pair_key[kPairHash], pair_cnt[kPairHash];
   const bool lds_tables = use_lds_tables != 0;
+  const uint32_t G = gridDim.x, wg = blockIdx.x;
+  // ---- 1. cull.  Segment culling: the box was formed from every slot of the segment the last time it was read; it is
+  // still valid if the segment has not grown since and had no visible slot in the previous frame (only visible slots are
+  // moved, restamped, merged or replaced).  If it is out of view and its newest stamp has left the regulariser window,
+  // this frame's result for the segment is known without reading its 16 KB of P records: nothing visible, no recent bit.
+  const uint32_t my_seg = wg + threadIdx.x * G;
+  const bool have_seg = my_seg < nseg_alloc;
+  const uint32_t sidx = have_seg ? my_seg : 0u;   // (segment 0 stands in: no branch around the loads)
+  const float4 b0 = *reinterpret_cast<const float4*>(&L.seg_box[8 * (size_t)sidx]);       // lo.xyz, hi.x
+  const float4 b1 = *reinterpret_cast<const float4*>(&L.seg_box[8 * (size_t)sidx + 4]);   // hi.yz, covered slots, newest stamp
+  const uint32_t vis_prev = L.vis_seg[sidx];
+  const uint32_t streak = L.seg_streak[sidx];
   const uint32_t N = st->surfel_count;
-  const uint32_t base = seg_id * kSeg;
-  if (base >= N) return;  // uniform per workgroup
-  if (lds_tables)
-#pragma unroll
-    for (int k = 0; k < kPairHash / kBlock; ++k) { pair_key[k * kBlock + threadIdx.x] = kInvalid; pair_cnt[k * kBlock + threadIdx.x] = 0; }   // (visible before the ranks are drawn: the barrier below)
-  const uint32_t i0 = base + threadIdx.x * 4;
-  const uint32_t in_seg = (N - base < (uint32_t)kSeg) ? N - base : (uint32_t)kSeg;
-  // Segment culling.  The box below was formed from every slot of the segment the last time it was read; it is still
-  // valid if the segment has not grown since and had no visible slot in the previous frame (only visible slots are
-  // moved, restamped, merged or replaced).  If it is out of view and its newest stamp has left the regulariser
-  // window, this frame's result for the segment is known without reading its 16 KB of P records: nothing visible,
-  // no recent bit.
-  float* box = &L.seg_box[8 * (size_t)seg_id];
-  if (threadIdx.x == 0) {
-    int skip = 0;
-    if (__float_as_uint(box[6]) == in_seg && L.vis_seg[seg_id] == 0 &&
-        stamp_outside_window(__float_as_uint(box[7]), c.frame, c.reg_window)) {
-      const Vec3 lo = {box[0], box[1], box[2]}, hi = {box[3], box[4], box[5]};
-      skip = box_out_of_view(lo, hi, c) ? 1 : 0;
+  const uint32_t n_used = (N + (uint32_t)kSeg - 1u) / (uint32_t)kSeg;
+  if (wg >= n_used) return;  // uniform per workgroup: not even its first segment holds slots
+  const bool mine = have_seg && my_seg < n_used;
+  bool skip = false;
+  if (mine) {
+    const uint32_t seg_base = my_seg * (uint32_t)kSeg;
+    const uint32_t in_seg = (N - seg_base < (uint32_t)kSeg) ? N - seg_base : (uint32_t)kSeg;
+    if (__float_as_uint(b1.z) == in_seg && vis_prev == 0 && stamp_outside_window(__float_as_uint(b1.w), c.frame, c.reg_window)) {
+      const Vec3 lo = {b0.x, b0.y, b0.z}, hi = {b0.w, b1.x, b1.y};
+      skip = box_out_of_view(lo, hi, c);
     }
-    skip_segment = skip;
-    if (skip && c.stats) atomicAdd(&st->n_segments_skipped, 1u);
+    if (skip) {
+      L.seg_act[my_seg] = 0;   // (vis_seg stays 0, the box stays as it is)
+      if (streak < 255u) L.seg_streak[my_seg] = (uint8_t)(streak + 1u);
+      if (c.stats) atomicAdd(&st->n_segments_skipped, 1u);
+    } else if (streak) {
+      L.seg_streak[my_seg] = 0;
+    }
+  }
+  {
+    const unsigned long long sm = __ballot(mine && !skip), cm = __ballot(skip && streak < 2u);
+    if ((threadIdx.x & 63) == 0) { survive_mask[threadIdx.x >> 6] = sm; copy_mask[threadIdx.x >> 6] = cm; }
   }
   __syncthreads();
-  if (skip_segment) {
-    if (i0 < N) {
-      const uchar4 of = *reinterpret_cast<const uchar4*>(&flags_prev[i0]);
-      *reinterpret_cast<uchar4*>(&L.flags8[i0]) = make_uchar4(of.x & 2u, of.y & 2u, of.z & 2u, of.w & 2u);
-    }
-    if (threadIdx.x == 0) L.seg_act[seg_id] = 0;
-    return;  // (vis_seg stays 0, the box stays as it is)
-  }
-  uint32_t vis_bits = 0;
-  bool lane_recent = false;
-  float bmin[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bmax[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-  uint32_t newest = 0;   // in the wrap-around order of stamp_outside_window: compared as signed
-  bool have_stamp = false;
-  // the pairs of the lane's four slots: entry 2 j = slot j's own pixel, 2 j + 1 = its quadrant pixel
-  uint32_t key[8];
+  // ---- 2. flag bytes of the culled segments
+#pragma unroll 1
+  for (int q = 0; q < kBlock / 64; ++q) {
+    const unsigned long long mq = copy_mask[q];
+    uint32_t mlo = __builtin_amdgcn_readfirstlane((uint32_t)mq), mhi = __builtin_amdgcn_readfirstlane((uint32_t)(mq >> 32));
+    unsigned long long m = ((unsigned long long)mhi << 32) | mlo;   // (uniform: the loop runs on the scalar unit)
+    while (m) {
+      uint32_t at[4];
+      uchar4 v[4];
+      int cnt = 0;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) key[j] = kNoPair;
-  if (i0 < N) {
-    // four consecutive P records (X, Y, Z, stamp) = 64 contiguous bytes per lane; the group arrays are
-    // padded to a multiple of 64 slots, so the loads stay inside the array
-    const float4* P = S.group(kGroupP, i0);
-    const float4 p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3];
-    const uchar4 of = *reinterpret_cast<const uchar4*>(&flags_prev[i0]);  // (detach bits carry over)
-    const uint32_t stamps[4] = {__float_as_uint(p0.w), __float_as_uint(p1.w), __float_as_uint(p2.w), __float_as_uint(p3.w)};
-    const float xs[4] = {p0.x, p1.x, p2.x, p3.x};
-    const float ys[4] = {p0.y, p1.y, p2.y, p3.y};
-    const float zs[4] = {p0.z, p1.z, p2.z, p3.z};
-    const uint8_t old_flags[4] = {of.x, of.y, of.z, of.w};
-    uint8_t new_flags[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t i = i0 + j;
-      new_flags[j] = (uint8_t)((old_flags[j] & 2u) | (stamp_outside_window(stamps[j], c.frame, c.reg_window) ? 0u : 1u));
-      Proj p;
-      const Vec3 g = {xs[j], ys[j], zs[j]};
-      if (i < N) {
-        bmin[0] = fminf(bmin[0], g.x); bmin[1] = fminf(bmin[1], g.y); bmin[2] = fminf(bmin[2], g.z);
-        bmax[0] = fmaxf(bmax[0], g.x); bmax[1] = fmaxf(bmax[1], g.y); bmax[2] = fmaxf(bmax[2], g.z);
-        if (!have_stamp || (int)stamps[j] > (int)newest) { newest = stamps[j]; have_stamp = true; }
+      for (int j = 0; j < 4; ++j) {
+        at[j] = kInvalid;
+        if (m) {
+          const uint32_t k = (uint32_t)__builtin_ctzll(m);
+          m &= m - 1;
+          const uint32_t i0 = (wg + ((uint32_t)q * 64u + k) * G) * (uint32_t)kSeg + threadIdx.x * 4;
+          if (i0 < N) at[j] = i0;
+          ++cnt;
+        }
       }
-      if (i < N && maybe_in_image(g, c) && project_pos(g, c, p)) {
-        vis_bits |= 1u << j;
-        const bool active = is_active(stamps[j], c.frame, c.window);
-        if (active && c.stats) atomicAdd(&st->n_visible, 1u);
-        const uint32_t act = active ? kPairActive : 0u;
-        key[2 * j] = (((uint32_t)(p.py / kTileH) * (uint32_t)tb.tiles_x + (uint32_t)(p.px / kTileW)) << 10) |
-                     (uint32_t)((p.py % kTileH) * kTileW + (p.px % kTileW)) | act;
-        int ox, oy;
-        if (active && quadrant(p, c, ox, oy))   // (:1506-1549: the second z-buffer pixel, active slots only)
-          key[2 * j + 1] = (((uint32_t)(oy / kTileH) * (uint32_t)tb.tiles_x + (uint32_t)(ox / kTileW)) << 10) |
-                           (uint32_t)((oy % kTileH) * kTileW + (ox % kTileW)) | act | kPairSecond;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const uchar4*>(&flags_prev[at[j] != kInvalid ? at[j] : 0u]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (at[j] != kInvalid) *reinterpret_cast<uchar4*>(&L.flags8[at[j]]) = make_uchar4(v[j].x & 2u, v[j].y & 2u, v[j].z & 2u, v[j].w & 2u);
+      (void)cnt;
+    }
+  }
+  // ---- 3. the surviving segments
+  bool first_segment = true;
+#pragma unroll 1
+  for (int q = 0; q < kBlock / 64; ++q) {
+    const unsigned long long mq = survive_mask[q];
+    uint32_t mlo = __builtin_amdgcn_readfirstlane((uint32_t)mq), mhi = __builtin_amdgcn_readfirstlane((uint32_t)(mq >> 32));
+    unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+#pragma unroll 1
+    while (m) {
+      const uint32_t kbit = (uint32_t)__builtin_ctzll(m);
+      m &= m - 1;
+      const uint32_t seg_id = wg + ((uint32_t)q * 64u + kbit) * G;
+      // (everything below is per segment: a lane number the optimiser cannot see through keeps it from hoisting the
+      // per-lane addresses of a dozen arrays out of the loop and holding them in registers across it -- 96 VGPRs instead
+      // of 51, five workgroups per CU instead of eight)
+      uint32_t tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));
+      const uint32_t base = seg_id * (uint32_t)kSeg;
+      const uint32_t i0 = base + tid * 4;
+      const uint32_t in_seg = (N - base < (uint32_t)kSeg) ? N - base : (uint32_t)kSeg;
+      float* box = &L.seg_box[8 * (size_t)seg_id];
+      // four consecutive P records (X, Y, Z, stamp) = 64 contiguous bytes per lane, requested first; the group arrays are
+      // padded to a multiple of 64 slots, so the loads stay inside the array
+      float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0;
+      uchar4 of = make_uchar4(0, 0, 0, 0);
+      if (i0 < N) {
+        const float4* P = S.group(kGroupP, i0);
+        p0 = P[0]; p1 = P[1]; p2 = P[2]; p3 = P[3];
+        of = *reinterpret_cast<const uchar4*>(&flags_prev[i0]);  // (detach bits carry over)
+      }
+      if (!first_segment) __syncthreads();   // (the previous segment's readers of the tables and partials are done)
+      first_segment = false;
+      if (lds_tables) {
+#pragma unroll
+        for (int k = 0; k < kPairHash / kBlock; ++k) { pair_key[k * kBlock + tid] = kInvalid; pair_cnt[k * kBlock + tid] = 0; }
+        __syncthreads();   // (visible before the ranks are drawn)
+      }
+      uint32_t vis_bits = 0;
+      bool lane_recent = false;
+      float bmin[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bmax[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+      uint32_t newest = 0;   // in the wrap-around order of stamp_outside_window: compared as signed
+      bool have_stamp = false;
+      // the pairs of the lane's four slots: entry 2 j = slot j's own pixel, 2 j + 1 = its quadrant pixel
+      uint32_t key[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) key[j] = kNoPair;
+      if (i0 < N) {
+        const uint32_t stamps[4] = {__float_as_uint(p0.w), __float_as_uint(p1.w), __float_as_uint(p2.w), __float_as_uint(p3.w)};
+        const float xs[4] = {p0.x, p1.x, p2.x, p3.x};
+        const float ys[4] = {p0.y, p1.y, p2.y, p3.y};
+        const float zs[4] = {p0.z, p1.z, p2.z, p3.z};
+        const uint8_t old_flags[4] = {of.x, of.y, of.z, of.w};
+        uint8_t new_flags[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t i = i0 + j;
+          new_flags[j] = (uint8_t)((old_flags[j] & 2u) | (stamp_outside_window(stamps[j], c.frame, c.reg_window) ? 0u : 1u));
+          Proj p;
+          const Vec3 g = {xs[j], ys[j], zs[j]};
+          if (i < N) {
+            bmin[0] = fminf(bmin[0], g.x); bmin[1] = fminf(bmin[1], g.y); bmin[2] = fminf(bmin[2], g.z);
+            bmax[0] = fmaxf(bmax[0], g.x); bmax[1] = fmaxf(bmax[1], g.y); bmax[2] = fmaxf(bmax[2], g.z);
+            if (!have_stamp || (int)stamps[j] > (int)newest) { newest = stamps[j]; have_stamp = true; }
+          }
+          if (i < N && maybe_in_image(g, c) && project_pos(g, c, p)) {
+            vis_bits |= 1u << j;
+            const bool active = is_active(stamps[j], c.frame, c.window);
+            if (active && c.stats) atomicAdd(&st->n_visible, 1u);
+            const uint32_t act = active ? kPairActive : 0u;
+            key[2 * j] = (((uint32_t)(p.py / kTileH) * (uint32_t)tb.tiles_x + (uint32_t)(p.px / kTileW)) << 10) |
+                         (uint32_t)((p.py % kTileH) * kTileW + (p.px % kTileW)) | act;
+            int ox, oy;
+            if (active && quadrant(p, c, ox, oy))   // (:1506-1549: the second z-buffer pixel, active slots only)
+              key[2 * j + 1] = (((uint32_t)(oy / kTileH) * (uint32_t)tb.tiles_x + (uint32_t)(ox / kTileW)) << 10) |
+                               (uint32_t)((oy % kTileH) * kTileW + (ox % kTileW)) | act | kPairSecond;
+          }
+        }
+        *reinterpret_cast<uchar4*>(&L.flags8[i0]) = make_uchar4(new_flags[0], new_flags[1], new_flags[2], new_flags[3]);
+        lane_recent = ((new_flags[0] | new_flags[1] | new_flags[2] | new_flags[3]) & 1u) != 0;
+      }
+      // ranks inside the workgroup's run of each tile (LDS atomics; the barrier inside the scan below completes them)
+      // (rank = table entry << 16 | rank in the entry; kInvalid: no entry found within 16 probes -- that pair reserves its
+      // place in the bin on its own)
+      uint32_t rank[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        rank[j] = kInvalid;
+        if (key[j] != kNoPair && lds_tables) {
+          const uint32_t tile = key[j] >> 10;
+          uint32_t h = (tile * 2654435761u) >> 16;
+          for (int probe = 0; probe < 16; ++probe) {
+            h &= (uint32_t)kPairHash - 1u;
+            const uint32_t seen = atomicCAS(&pair_key[h], kInvalid, tile);
+            if (seen == kInvalid || seen == tile) { rank[j] = (h << 16) | atomicAdd(&pair_cnt[h], 1u); break; }
+            ++h;
+          }
+        }
+      }
+      // (a slot inside the regulariser window: the group is hot -- same value from every writer, one byte store per wavefront)
+      const bool wave_recent = __ballot(lane_recent) != 0;
+      if (wave_recent && (tid & 63) == 0) L.hot_epoch[base >> L.hot_shift] = (uint8_t)L.epoch;
+      // the segment's bounding box and newest stamp (wave shuffles, then one partial per wavefront through LDS)
+      int newest_s = have_stamp ? (int)newest : (int)0x80000000;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          bmin[k] = fminf(bmin[k], __shfl_xor(bmin[k], off));
+          bmax[k] = fmaxf(bmax[k], __shfl_xor(bmax[k], off));
+        }
+        const int o = __shfl_xor(newest_s, off);
+        newest_s = o > newest_s ? o : newest_s;
+      }
+      if ((tid & 63) == 0) {
+        float* bp = box_part[tid >> 6];
+        bp[0] = bmin[0]; bp[1] = bmin[1]; bp[2] = bmin[2]; bp[3] = bmax[0]; bp[4] = bmax[1]; bp[5] = bmax[2];
+        bp[6] = __int_as_float(newest_s);
+        bp[7] = wave_recent ? 1.0f : 0.0f;
+      }
+      uint32_t total;
+      uint32_t off = base + block_excl_scan((uint32_t)__popc(vis_bits), wave_tot, total);  // (synchronises)
+      // the pair that drew rank 0 reserves the run of its (workgroup, tile); all reservations of the workgroup are in
+      // flight together (the tile number goes through an opaque VGPR: with a visibly uniform address the compiler's atomic
+      // optimizer wraps the operation in a wave reduction + readfirstlane, i.e. a wait for each result in turn)
+      if (lds_tables) {
+        uint32_t got[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          got[j] = 0;
+          if (key[j] != kNoPair && (rank[j] & 0xFFFFu) == 0 && rank[j] != kInvalid) {
+            uint32_t tv = key[j] >> 10;
+            asm volatile("" : "+v"(tv));
+            got[j] = atomicAdd(&tb.count[tv * kCountStride], pair_cnt[rank[j] >> 16]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (key[j] != kNoPair && (rank[j] & 0xFFFFu) == 0 && rank[j] != kInvalid) pair_key[rank[j] >> 16] = got[j];   // (every probe is done: the barrier above)
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (vis_bits & (1u << j)) L.vis_list[off++] = i0 + j;
+      if (lds_tables) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (key[j] != kNoPair)
+            pair_store(tb, key[j], i0 + (uint32_t)(j >> 1),
+                       rank[j] != kInvalid ? pair_key[rank[j] >> 16] + (rank[j] & 0xFFFFu) : atomicAdd(&tb.count[(key[j] >> 10) * kCountStride], 1u));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (key[j] != kNoPair) pair_store(tb, key[j], i0 + (uint32_t)(j >> 1), atomicAdd(&tb.count[(key[j] >> 10) * kCountStride], 1u));
+      }
+      if (tid == 0) {
+        L.vis_seg[seg_id] = total;
+        L.seg_act[seg_id] = (total != 0 || box_part[0][7] + box_part[1][7] + box_part[2][7] + box_part[3][7] != 0.0f) ? 1 : 0;
+        emit_chunks(L.vis_chunks, seg_id, total, kSeg / kBlock);
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        int ns = (int)0x80000000;
+        for (int w = 0; w < kBlock / 64; ++w) {
+          for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], box_part[w][k]); hi[k] = fmaxf(hi[k], box_part[w][3 + k]); }
+          const int o = __float_as_int(box_part[w][6]);
+          ns = o > ns ? o : ns;
+        }
+        box[0] = lo[0]; box[1] = lo[1]; box[2] = lo[2]; box[3] = hi[0]; box[4] = hi[1]; box[5] = hi[2];
+        box[6] = __uint_as_float(in_seg);
+        box[7] = __int_as_float(ns);
       }
     }
-    *reinterpret_cast<uchar4*>(&L.flags8[i0]) = make_uchar4(new_flags[0], new_flags[1], new_flags[2], new_flags[3]);
-    lane_recent = ((new_flags[0] | new_flags[1] | new_flags[2] | new_flags[3]) & 1u) != 0;
-  }
-  // ranks inside the workgroup's run of each tile (LDS atomics; the barrier inside the scan below completes them)
-  // (rank = table entry << 16 | rank in the entry; kInvalid: no entry found within 16 probes -- that pair reserves its
-  // place in the bin on its own)
-  uint32_t rank[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    rank[j] = kInvalid;
-    if (key[j] != kNoPair && lds_tables) {
-      const uint32_t tile = key[j] >> 10;
-      uint32_t h = (tile * 2654435761u) >> 16;
-      for (int probe = 0; probe < 16; ++probe) {
-        h &= (uint32_t)kPairHash - 1u;
-        const uint32_t seen = atomicCAS(&pair_key[h], kInvalid, tile);
-        if (seen == kInvalid || seen == tile) { rank[j] = (h << 16) | atomicAdd(&pair_cnt[h], 1u); break; }
-        ++h;
-      }
-    }
-  }
-  // (a slot inside the regulariser window: the group is hot -- same value from every writer, one byte store per wavefront)
-  const bool wave_recent = __ballot(lane_recent) != 0;
-  if (wave_recent && (threadIdx.x & 63) == 0) L.hot_epoch[base >> L.hot_shift] = (uint8_t)L.epoch;
-  // the segment's bounding box and newest stamp (wave shuffles, then one partial per wavefront through LDS)
-  int newest_s = have_stamp ? (int)newest : (int)0x80000000;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      bmin[k] = fminf(bmin[k], __shfl_xor(bmin[k], off));
-      bmax[k] = fmaxf(bmax[k], __shfl_xor(bmax[k], off));
-    }
-    const int o = __shfl_xor(newest_s, off);
-    newest_s = o > newest_s ? o : newest_s;
-  }
-  if ((threadIdx.x & 63) == 0) {
-    float* bp = box_part[threadIdx.x >> 6];
-    bp[0] = bmin[0]; bp[1] = bmin[1]; bp[2] = bmin[2]; bp[3] = bmax[0]; bp[4] = bmax[1]; bp[5] = bmax[2];
-    bp[6] = __int_as_float(newest_s);
-    bp[7] = wave_recent ? 1.0f : 0.0f;
-  }
-  uint32_t total;
-  uint32_t off = base + block_excl_scan((uint32_t)__popc(vis_bits), wave_tot, total);  // (synchronises)
-  // the pair that drew rank 0 reserves the run of its (workgroup, tile); all reservations of the workgroup are in
-  // flight together (the tile number goes through an opaque VGPR: with a visibly uniform address the compiler's atomic
-  // optimizer wraps the operation in a wave reduction + readfirstlane, i.e. a wait for each result in turn)
-  if (lds_tables) {
-    uint32_t got[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      got[j] = 0;
-      if (key[j] != kNoPair && (rank[j] & 0xFFFFu) == 0 && rank[j] != kInvalid) {
-        uint32_t tv = key[j] >> 10;
-        asm volatile("" : "+v"(tv));
-        got[j] = atomicAdd(&tb.count[tv * kCountStride], pair_cnt[rank[j] >> 16]);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (key[j] != kNoPair && (rank[j] & 0xFFFFu) == 0 && rank[j] != kInvalid) pair_key[rank[j] >> 16] = got[j];   // (every probe is done: the barrier above)
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if (vis_bits & (1u << j)) L.vis_list[off++] = i0 + j;
-  if (lds_tables) {
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (key[j] != kNoPair)
-        pair_store(tb, key[j], i0 + (uint32_t)(j >> 1),
-                   rank[j] != kInvalid ? pair_key[rank[j] >> 16] + (rank[j] & 0xFFFFu) : atomicAdd(&tb.count[(key[j] >> 10) * kCountStride], 1u));
-  } else {
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (key[j] != kNoPair) pair_store(tb, key[j], i0 + (uint32_t)(j >> 1), atomicAdd(&tb.count[(key[j] >> 10) * kCountStride], 1u));
-  }
-  if (threadIdx.x == 0) {
-    L.vis_seg[seg_id] = total;
-    L.seg_act[seg_id] = (total != 0 || box_part[0][7] + box_part[1][7] + box_part[2][7] + box_part[3][7] != 0.0f) ? 1 : 0;
-    emit_chunks(L.vis_chunks, seg_id, total, kSeg / kBlock);
-    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    int ns = (int)0x80000000;
-    for (int w = 0; w < kBlock / 64; ++w) {
-      for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], box_part[w][k]); hi[k] = fmaxf(hi[k], box_part[w][3 + k]); }
-      const int o = __float_as_int(box_part[w][6]);
-      ns = o > ns ? o : ns;
-    }
-    box[0] = lo[0]; box[1] = lo[1]; box[2] = lo[2]; box[3] = hi[0]; box[4] = hi[1]; box[5] = hi[2];
-    box[6] = __uint_as_float(in_seg);
-    box[7] = __int_as_float(ns);
   }
 }
 
@@ -1669,11 +1751,11 @@ k_update_and_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, Crea
 // neighbour's colour word (:1430) and stamp (:2132) are replaced by ONE byte gather from the flag table
 // (L2-resident: 1 B/slot).  The gradient clear (kernels.cu:2099-2113) is gone: the fixed-point
 // accumulators are zero between calls (k_reg_step zeroes what it consumes).
+constexpr int kScanSegsPerBlock = 64;   // segments per workgroup pass B can decide about at once (the host sizes the grid accordingly)
 template <bool kDetach, bool kAccumulate>
 __global__ void __launch_bounds__(kBlockB)
 k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict__ inwin8, uint32_t* __restrict__ need_seg,
                 DevState* st) {
-  const uint32_t seg_id = segment_of_block(L.descending);
   extern __shared__ __align__(16) uint8_t lhot[];   // the hot-group table (n_hot_groups bytes, padded to 16)
   __shared__ uint32_t ltargets[kMaxHotGroups / 32];  // bit g: a link of this segment points into group g (another segment)
   // B1: pure streaming.  Per slot: detach (:1430-1433), which of its neighbours lie inside the regulariser
@@ -1681,9 +1763,16 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
   // occupancy stays high; the accumulation itself runs in k_reg_accumulate on the few segments that need it.
   __shared__ uint32_t wave_tot[kBlockB / 64];
   __shared__ __attribute__((aligned(4))) uint8_t lflags[kSegB];  // the segment's own flag bytes
+  __shared__ uint32_t read_lo, read_hi;   // bit k: the workgroup's k-th segment has to be read
+  // Chip-sized grid like pass A's: workgroup w owns the segments w, w + G, w + 2 G, ...; it copies the hot-group table to
+  // LDS ONCE, decides for all of its segments together which have to be read (their 512-byte bitmaps requested in one
+  // go), and streams those one after the other.  (Rounds 1-3: one workgroup per segment, 5 400 table copies and as many
+  // dependent decide-then-load chains per launch at C2.)
+  const uint32_t G = gridDim.x, wg = blockIdx.x;
   const uint32_t N = st->surfel_count;
-  const uint32_t base = seg_id * kSegB;
-  if (base >= N) return;
+  const uint32_t n_used = (N + (uint32_t)kSegB - 1u) / (uint32_t)kSegB;
+  if (wg >= n_used) return;   // uniform: not even the workgroup's first segment holds slots
+  const uint32_t n_mine = (n_used - 1u - wg) / G + 1u;   // <= kScanSegsPerBlock
   // The reference detaches BEFORE it creates new surfels (kernels.cc:333-339 precedes cc:264-286), so
   // slots created in this frame keep links to flagged surfels until the next frame.
   const uint32_t detach_limit = st->create_base;
@@ -1707,7 +1796,9 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
   // the segment is then hot and the next pass rebuilds its bitmap.  (At C2 two segments out of five are skipped;
   // with groups of 2048 slots a cold segment's thousand far links seldom miss every hot group -- tools/far_terms_hist.py.)
   static_assert(kBlockB * 16 == kMaxHotGroups, "one lane per 16 groups");
+  if (threadIdx.x == 0) { read_lo = 0u; read_hi = 0u; }
   uint32_t hot16 = 0;   // bit k: group 16 * lane + k is hot
+  const bool filter = use_hot && !stats;   // (the edge statistics count every link of the map)
   if (use_hot) {
     const uint32_t g = threadIdx.x * 16;
     if (g < L.n_hot_groups) {
@@ -1718,107 +1809,142 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
       for (int k = 0; k < 16; ++k)
         if (g + k < L.n_hot_groups && group_is_hot((w[k >> 2] >> (8 * (k & 3))) & 255u, L.epoch)) hot16 |= 1u << k;
     }
-    if (!stats) {   // (the edge statistics count every link of the map)
-      const uint32_t own_group = base >> L.hot_shift;
-      const uint32_t reached = (uint32_t)L.seg_targets[(size_t)seg_id * kBlockB + threadIdx.x] | (threadIdx.x == own_group / 16 ? 1u << (own_group % 16) : 0u);
-      if (!__syncthreads_or((reached & hot16) != 0)) {
-        if (threadIdx.x == 0) {
-          L.recent_seg[seg_id] = kInvalid;   // (no recent slot; the mark is what smx_recon_debug_count_skipped_segments counts)
-          if (kAccumulate) need_seg[seg_id] = 0u;
+  }
+  __syncthreads();   // (the mask words are zero, the table is in LDS)
+  if (filter) {
+    // the lane's 16 bits of every segment's bitmap: up to 8 segments' rows in flight together
+#pragma unroll 1
+    for (uint32_t k0 = 0; k0 < n_mine; k0 += 8) {
+      uint32_t row[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t k = k0 + j < n_mine ? k0 + j : k0;
+        row[j] = (uint32_t)L.seg_targets[(size_t)(wg + k * G) * kBlockB + threadIdx.x];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t k = k0 + j;
+        if (k >= n_mine) break;   // uniform
+        const uint32_t own_group = ((wg + k * G) * (uint32_t)kSegB) >> L.hot_shift;
+        const uint32_t reached = row[j] | (threadIdx.x == own_group / 16 ? 1u << (own_group % 16) : 0u);
+        if (__ballot((reached & hot16) != 0) != 0ull && (threadIdx.x & 63) == 0) atomicOr(k < 32 ? &read_lo : &read_hi, 1u << (k & 31u));
+      }
+    }
+    __syncthreads();
+  }
+  unsigned long long todo;
+  {
+    const unsigned long long all = n_mine >= 64u ? ~0ull : ((1ull << n_mine) - 1ull);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(read_lo), hi = __builtin_amdgcn_readfirstlane(read_hi);
+    todo = filter ? ((((unsigned long long)hi << 32) | lo) & all) : all;
+    // the segments that are not read: no recent slot (the mark is what smx_recon_debug_count_skipped_segments counts)
+    if (threadIdx.x < n_mine && !((todo >> threadIdx.x) & 1ull)) {
+      const uint32_t seg = wg + threadIdx.x * G;
+      L.recent_seg[seg] = kInvalid;
+      if (kAccumulate) need_seg[seg] = 0u;
+    }
+  }
+  bool first_segment = true;
+#pragma unroll 1
+  while (todo) {
+    const uint32_t kbit = (uint32_t)__builtin_ctzll(todo);
+    todo &= todo - 1;
+    const uint32_t seg_id = wg + kbit * G;
+    uint32_t tid = threadIdx.x;   // (opaque to the optimiser: per-lane addresses are not hoisted out of the loop, see pass A)
+    asm volatile("" : "+v"(tid));
+    const uint32_t base = seg_id * (uint32_t)kSegB;
+    const uint32_t i0 = base + tid * 4;
+    uchar4 own = make_uchar4(0, 0, 0, 0);
+    uint4 trec[4];  // the T records (4 neighbour ids) of the lane's 4 slots: 64 contiguous bytes
+    if (i0 < N) {
+      own = *reinterpret_cast<const uchar4*>(&L.flags8[i0]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) trec[j] = *reinterpret_cast<const uint4*>(S.group(kGroupT, i0 + j));
+    }
+    if (!first_segment) __syncthreads();   // (the previous segment's readers of lflags / ltargets / wave_tot are done)
+    first_segment = false;
+    if (tid < kMaxHotGroups / 32) ltargets[tid] = 0;
+    uint32_t recent_bits = 0;
+    int need = 0;
+    *reinterpret_cast<uchar4*>(&lflags[tid * 4]) = own;
+    __syncthreads();
+    const bool quiet = use_hot && !group_is_hot(lhot[base >> L.hot_shift], L.epoch);
+    // The far flag bytes of a lane's 16 links are requested TOGETHER (a gather that is not needed reads the lane's own
+    // byte): fetched one after the other inside the loop below, as the compiler would arrange it, the 16 dependent round
+    // trips of a fully active segment's workgroup are what the whole launch lasts (tools/isa_phases.py: 20 waits -> 5).
+    uint32_t far_mask = 0;   // bit 4 j + q: that link leaves the segment and its target's flag byte matters
+    uint32_t far_flag[16];
+    if ((kDetach || kAccumulate) && i0 < N) {   // (the copy-only pass without detaching looks at no flag but the slot's own)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t nb = q == 0 ? trec[j].x : q == 1 ? trec[j].y : q == 2 ? trec[j].z : trec[j].w;
+          if (i0 + j < N && nb != kInvalid && nb - base >= (uint32_t)kSegB &&
+              !(quiet && !group_is_hot(lhot[nb >> L.hot_shift], L.epoch)))   // (both cold: neither bit is of any consequence)
+            far_mask |= 1u << (4 * j + q);
         }
-        return;
       }
     }
-  }
-  if (threadIdx.x < kMaxHotGroups / 32) ltargets[threadIdx.x] = 0;
-  const uint32_t i0 = base + threadIdx.x * 4;
-  uint32_t recent_bits = 0;
-  int need = 0;
-  uchar4 own = make_uchar4(0, 0, 0, 0);
-  uint4 trec[4];  // the T records (4 neighbour ids) of the lane's 4 slots: 64 contiguous bytes
-  if (i0 < N) {
-    own = *reinterpret_cast<const uchar4*>(&L.flags8[i0]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) trec[j] = *reinterpret_cast<const uint4*>(S.group(kGroupT, i0 + j));
-  }
-  *reinterpret_cast<uchar4*>(&lflags[threadIdx.x * 4]) = own;
-  __syncthreads();
-  const bool quiet = use_hot && !group_is_hot(lhot[base >> L.hot_shift], L.epoch);
-  // The far flag bytes of a lane's 16 links are requested TOGETHER (a gather that is not needed reads the lane's own
-  // byte): fetched one after the other inside the loop below, as the compiler would arrange it, the 16 dependent round
-  // trips of a fully active segment's workgroup are what the whole launch lasts (tools/isa_phases.py: 20 waits -> 5).
-  uint32_t far_mask = 0;   // bit 4 j + q: that link leaves the segment and its target's flag byte matters
-  uint32_t far_flag[16];
-  if ((kDetach || kAccumulate) && i0 < N) {   // (the copy-only pass without detaching looks at no flag but the slot's own)
+    for (int k = 0; k < 16; ++k) far_flag[k] = 0;
+    if (__ballot(far_mask != 0) != 0ull) {   // (per wavefront: most wavefronts of the map have nothing to fetch)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t nb = q == 0 ? trec[j].x : q == 1 ? trec[j].y : q == 2 ? trec[j].z : trec[j].w;
-        if (i0 + j < N && nb != kInvalid && nb - base >= (uint32_t)kSegB &&
-            !(quiet && !group_is_hot(lhot[nb >> L.hot_shift], L.epoch)))   // (both cold: neither bit is of any consequence)
-          far_mask |= 1u << (4 * j + q);
+      for (int k = 0; k < 16; ++k) {
+        const uint4& t = trec[k >> 2];
+        const uint32_t nb = (k & 3) == 0 ? t.x : (k & 3) == 1 ? t.y : (k & 3) == 2 ? t.z : t.w;
+        far_flag[k] = L.flags8[((far_mask >> k) & 1u) ? nb : min(i0, N - 1u)];
       }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) keep(far_flag[k]);
     }
-  }
+    if (i0 < N) {
+      const uint8_t ownf[4] = {own.x, own.y, own.z, own.w};
+      uint8_t inw[4] = {0, 0, 0, 0};
+      uint32_t edges = 0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) far_flag[k] = 0;
-  if (__ballot(far_mask != 0) != 0ull) {   // (per wavefront: most wavefronts of the map have nothing to fetch)
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t i = i0 + j;
+        if (i >= N) continue;
+        if (ownf[j] & 1u) recent_bits |= 1u << j;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const uint4& t = trec[k >> 2];
-      const uint32_t nb = (k & 3) == 0 ? t.x : (k & 3) == 1 ? t.y : (k & 3) == 2 ? t.z : t.w;
-      far_flag[k] = L.flags8[((far_mask >> k) & 1u) ? nb : min(i0, N - 1u)];
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) keep(far_flag[k]);
-  }
-  if (i0 < N) {
-    const uint8_t ownf[4] = {own.x, own.y, own.z, own.w};
-    uint8_t inw[4] = {0, 0, 0, 0};
-    uint32_t edges = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t i = i0 + j;
-      if (i >= N) continue;
-      if (ownf[j] & 1u) recent_bits |= 1u << j;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t nb = q == 0 ? trec[j].x : q == 1 ? trec[j].y : q == 2 ? trec[j].z : trec[j].w;
-        if (nb == kInvalid) continue;
-        // three of four links stay inside the segment: those flags come from the LDS copy
-        const uint32_t rel = nb - base;
-        uint32_t f;
-        if (rel < (uint32_t)kSegB) f = lflags[rel];
-        else f = ((far_mask >> (4 * j + q)) & 1u) ? far_flag[4 * j + q] : 0u;
-        if (kDetach && i < detach_limit && (f & 2u)) {  // :1430-1433
-          S.set_neighbor(i, q, kInvalid);
-          continue;
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t nb = q == 0 ? trec[j].x : q == 1 ? trec[j].y : q == 2 ? trec[j].z : trec[j].w;
+          if (nb == kInvalid) continue;
+          // three of four links stay inside the segment: those flags come from the LDS copy
+          const uint32_t rel = nb - base;
+          uint32_t f;
+          if (rel < (uint32_t)kSegB) f = lflags[rel];
+          else f = ((far_mask >> (4 * j + q)) & 1u) ? far_flag[4 * j + q] : 0u;
+          if (kDetach && i < detach_limit && (f & 2u)) {  // :1430-1433
+            S.set_neighbor(i, q, kInvalid);
+            continue;
+          }
+          if (rel >= (uint32_t)kSegB) { const uint32_t g = nb >> L.hot_shift; atomicOr(&ltargets[g >> 5], 1u << (g & 31u)); }
+          ++edges;
+          if (kAccumulate && (f & 1u)) { inw[j] |= (uint8_t)(1u << q); need = 1; }
         }
-        if (rel >= (uint32_t)kSegB) { const uint32_t g = nb >> L.hot_shift; atomicOr(&ltargets[g >> 5], 1u << (g & 31u)); }
-        ++edges;
-        if (kAccumulate && (f & 1u)) { inw[j] |= (uint8_t)(1u << q); need = 1; }
+      }
+      if (kAccumulate) *reinterpret_cast<uchar4*>(&inwin8[i0]) = make_uchar4(inw[0], inw[1], inw[2], inw[3]);
+      if (stats && kAccumulate && edges) {
+        atomicAdd(&st->n_edges, edges);
+        const uint32_t we = __popc(inw[0]) + __popc(inw[1]) + __popc(inw[2]) + __popc(inw[3]);
+        if (we) { atomicAdd(&st->n_window_edges, we); atomicAdd(&st->n_contributors, (uint32_t)((inw[0] != 0) + (inw[1] != 0) + (inw[2] != 0) + (inw[3] != 0))); }
       }
     }
-    if (kAccumulate) *reinterpret_cast<uchar4*>(&inwin8[i0]) = make_uchar4(inw[0], inw[1], inw[2], inw[3]);
-    if (stats && kAccumulate && edges) {
-      atomicAdd(&st->n_edges, edges);
-      const uint32_t we = __popc(inw[0]) + __popc(inw[1]) + __popc(inw[2]) + __popc(inw[3]);
-      if (we) { atomicAdd(&st->n_window_edges, we); atomicAdd(&st->n_contributors, (uint32_t)((inw[0] != 0) + (inw[1] != 0) + (inw[2] != 0) + (inw[3] != 0))); }
-    }
-  }
-  uint32_t total;
-  uint32_t off = base + block_excl_scan<kBlockB / 64>((uint32_t)__popc(recent_bits), wave_tot, total);
+    uint32_t total;
+    uint32_t off = base + block_excl_scan<kBlockB / 64>((uint32_t)__popc(recent_bits), wave_tot, total);
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if (recent_bits & (1u << j)) L.recent_list[off++] = i0 + j;
-  const int any = __syncthreads_or(need);
-  L.seg_targets[(size_t)seg_id * kBlockB + threadIdx.x] = (uint16_t)(ltargets[threadIdx.x >> 1] >> (16 * (threadIdx.x & 1)));
-  if (threadIdx.x == 0) {
-    L.recent_seg[seg_id] = total;
-    if (total) L.rec_chunks.desc[atomicAdd(L.rec_chunks.count, 1u)] = seg_id | ((total - 1u) << 22);   // (one walk step per segment)
-    if (kAccumulate) need_seg[seg_id] = (any || total) ? 1u : 0u;  // k_reg_accumulate also serves recent slots
-    if (stats && total) atomicAdd(&st->recent_count, total);
+    for (int j = 0; j < 4; ++j)
+      if (recent_bits & (1u << j)) L.recent_list[off++] = i0 + j;
+    const int any = __syncthreads_or(need);
+    L.seg_targets[(size_t)seg_id * kBlockB + tid] = (uint16_t)(ltargets[tid >> 1] >> (16 * (tid & 1)));
+    if (tid == 0) {
+      L.recent_seg[seg_id] = total;
+      if (total) L.rec_chunks.desc[atomicAdd(L.rec_chunks.count, 1u)] = seg_id | ((total - 1u) << 22);   // (one walk step per segment)
+      if (kAccumulate) need_seg[seg_id] = (any || total) ? 1u : 0u;  // k_reg_accumulate also serves recent slots
+      if (stats && total) atomicAdd(&st->recent_count, total);
+    }
   }
 }
 
@@ -2518,12 +2644,15 @@ int join_regularizer(smx_recon r, hipStream_t st) {
 // (k_update_and_create) has reset their counter, everywhere else it is done here.
 int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, float weight, int window,
                        bool detach, bool copy_only, bool zero_chunks) {
-  const dim3 g(r->nsegB), bB(kBlockB), gl(r->grid_list), b(kBlock);
+  // pass B: chip-sized grid (k_neighbor_scan), more workgroups only if one would own more segments than it can decide about
+  const dim3 g((unsigned)std::max(r->cu_count * 8, div_up(r->nsegB, kScanSegsPerBlock))), bB(kBlockB), gl(r->grid_list), b(kBlock);
   const float rf2 = rf * rf;
   if (!r->table_valid || r->table_frame != frame || r->table_window != window) {
     hipLaunchKernelGGL(k_rebuild_flags, dim3(r->grid_surfels), b, 0, st, r->S, frame, window, r->L.flags8, r->st);
     r->table_valid = true; r->table_frame = frame; r->table_window = window;
     r->hot_holdoff = 3;   // (the flags were rewritten outside pass A: this pass and those of the next two calls gather everything)
+    // (... and pass A copies the flag bytes of every segment it culls again: the table it would otherwise rely on is this one)
+    SMX_HIP(hipMemsetAsync(r->L.seg_streak, 0, (size_t)r->nseg, st));
   }
   const int stats = r->stats_enabled;
   const int use_hot = (r->hot_holdoff == 0 && !r->scan_mode && r->hot_filter_enabled) ? 1 : 0;
@@ -2624,6 +2753,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->L.vis_seg, (size_t)r->nseg, true));
   SMX_TRY(dev_alloc(&r->L.seg_box, (size_t)r->nseg * 8, true));
   SMX_TRY(dev_alloc(&r->L.seg_act, (size_t)r->nseg, true));
+  SMX_TRY(dev_alloc(&r->L.seg_streak, (size_t)r->nseg, true));
   // (the direction word of segment_of_block: written by the tile kernel, read by the host without synchronisation)
   SMX_TRY(hip_rc(hipHostMalloc(reinterpret_cast<void**>(&r->dir_host), sizeof(uint32_t), hipHostMallocMapped), "hipHostMalloc"));
   *r->dir_host = 0;
@@ -2715,7 +2845,7 @@ int smx_recon_destroy(smx_recon r) {
   SMX_ON_DEVICE(r->device);
   void* ptrs[] = {r->sc.supporting, r->sc.counts, r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth,
                   r->tb.pairs, r->tb.count, r->tb.ovf, r->ovf_count_set[0], r->ovf_count_set[1],
-                  r->vis_count_set[0], r->vis_count_set[1], r->L.seg_act, r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->fb.rec, r->fb.count, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1], r->L.hot_epoch, r->L.seg_targets,
+                  r->vis_count_set[0], r->vis_count_set[1], r->L.seg_act, r->L.seg_streak, r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->fb.rec, r->fb.count, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1], r->L.hot_epoch, r->L.seg_targets,
                   r->merge_flag, r->inwin8, r->need_seg, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->block_offsets, r->st};
   if (r->reg_stream) { (void)hipStreamSynchronize(r->reg_stream); (void)hipStreamDestroy(r->reg_stream); }
@@ -2896,8 +3026,11 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   r->tb.ovf_count = r->ovf_count_set[r->sc_cur];
   { SlotTimer t(r, sF, kSlotScanVisible);
     const bool lds_tables = !r->no_lds_tables;
-    hipLaunchKernelGGL(k_scan_visible, gs, b, 0, sF, r->S, c, r->L, r->tb, flags_prev,
-                       r->st, lds_tables ? 1 : 0);
+    // chip-sized grid: as many workgroups as the chip holds at once (8 per CU), more only if a workgroup would own more
+    // segments than its cull step has lanes
+    const dim3 ga((unsigned)std::max(r->cu_count * 8, div_up(r->nseg, kCullLanes)));
+    hipLaunchKernelGGL(k_scan_visible, ga, b, 0, sF, r->S, c, r->L, r->tb, flags_prev,
+                       r->st, lds_tables ? 1 : 0, (uint32_t)r->nseg);
     r->table_valid = true; r->table_frame = frame_index; r->table_window = c.reg_window; }
   // (smx_recon_integrate_inputs_ready) from here on the input images are read
   if (hook_ready) SMX_HIP(hipStreamWaitEvent(sF, hook_ready, 0));
