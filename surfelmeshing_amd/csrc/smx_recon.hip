@@ -402,114 +402,111 @@ __global__ void k_reset_frame_stats(DevState* st) {   // (value-distribution cou
 // table.  Rows 18,0,1,2 are streamed with 16-byte lane loads (4 slots per lane).  The z-buffer minimum itself (:1463) is
 // formed by k_assoc_tiles from the pairs appended here.
 //
-// The launch has a CHIP-SIZED grid (G workgroups, as many as the chip holds at once), not one workgroup per segment:
-// workgroup w owns the segments w, w + G, w + 2 G, ... -- strided, because the segments with work in them form one
-// contiguous block of the slot range, which this way spreads evenly over the workgroups.  Rounds 1-3 launched a workgroup
-// per segment: 5 400 at C2 and 21 600 at C3, three quarters of which looked at one box, copied 1 KB of flag bytes and
-// left -- each of them a dependent chain (count -> box -> decision -> barrier -> copy) in a dispatch slot the segments
-// with work in them were waiting for (profiles/r14a: the C3 launch was dispatch-shaped).  Now:
-//   1. cull: lane t of the workgroup tests the box of the workgroup's t-th segment, every lane at once -- ONE round trip
-//      for all of a workgroup's boxes, requested before the slot count is known;
-//   2. the culled segments' flag bytes (recent bit off, detach bit carried over) are copied by the whole workgroup, the
-//      loads of up to four segments in flight together -- and not at all for a segment that was already culled in the
-//      two previous calls: the two copies of the flag table alternate by call, nothing but pass A writes flag bytes of
-//      slots that are not visible, so the table written two calls ago already holds this call's bytes (seg_streak);
-//   3. the surviving segments, one after the other, as before.
-constexpr int kCullLanes = kBlock;   // segments per workgroup the cull step can test (the host sizes the grid accordingly)
-__global__ void __launch_bounds__(kBlock, 8)
-k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, const uint8_t* __restrict__ flags_prev, DevState* st,
-               int use_lds_tables, uint32_t nseg_alloc) {
+// Two launches.  k_cull_segments (a lane per segment, a few dozen workgroups) decides which segments have to be read
+// at all and compacts them into a SURVIVOR LIST; k_scan_visible, on a chip-sized grid, walks that list, so that the
+// three quarters of the segments that are out of view cost neither a workgroup nor a dispatch slot.  (Rounds 1-3: one
+// workgroup per segment -- 5 400 at C2, 21 600 at C3, most of which tested a box, copied 1 KB of flag bytes and left,
+// each a dependent chain in a slot the segments with work were waiting for.  A first version of this round gave every
+// workgroup of a chip-sized grid a strided share of ALL segments and let it cull its own: one launch, but the segments
+// with work then queue up behind each other inside the workgroups that happen to own several -- 25 -> 31 us alone at C2,
+// profiles/r17_ab_notes.md.)
+//
+// Segment culling: a segment's box was formed from every slot of it the last time it was read; it is still valid if
+// the segment cannot have grown (it was full) and had no visible slot in the previous frame (only visible slots are
+// moved, restamped, merged or replaced).  If it is out of view and its newest stamp has left the regulariser window,
+// this frame's result for the segment is known without reading its 16 KB of P records: nothing visible, no recent bit.
+// The decision needs the new pose and what the PREVIOUS pass A left -- not the slot count (a partial segment is simply
+// never culled) and nothing integrate / update / create of the previous call write -- so the launch can run beside those:
+// smx_recon_integrate enqueues it in front of the caller's stream's wait for the previous call's map wherever it may.
+// The culled segments' flag bytes (recent bit off, detach bit carried over) are copied by k_scan_visible (the copy of the
+// table it writes may still be read by the previous call's regulariser when the cull runs) -- and not at all for a segment
+// that was already culled in the two previous calls: the two copies of the flag table alternate by call, nothing but
+// pass A writes flag bytes of slots that are not visible, so the table written two calls ago already holds this call's
+// bytes (seg_streak).
+struct SegWork {
+  uint32_t* surv_list;   // segments pass A has to read in this call (any order)
+  uint32_t* copy_list;   // culled segments whose flag bytes have to be copied
+  uint32_t* count;       // [0] survivors, [1] copies; zeroed for the next call by k_assoc_tiles
+};
+__global__ void __launch_bounds__(kBlock)
+k_cull_segments(FrameCtx c, Lists L, SegWork sw, DevState* st, uint32_t nseg_alloc, uint32_t max_new_slots) {
+  const uint32_t seg = blockIdx.x * kBlock + threadIdx.x;
+  const bool have_seg = seg < nseg_alloc;
+  const uint32_t sidx = have_seg ? seg : 0u;   // (segment 0 stands in: no branch around the loads)
+  const float4 b0 = *reinterpret_cast<const float4*>(&L.seg_box[8 * (size_t)sidx]);       // lo.xyz, hi.x
+  const float4 b1 = *reinterpret_cast<const float4*>(&L.seg_box[8 * (size_t)sidx + 4]);   // hi.yz, covered slots, newest stamp
+  const uint32_t vis_prev = L.vis_seg[sidx];
+  const uint32_t streak = L.seg_streak[sidx];
+  // (the previous call's creation kernel may be advancing the count while this runs: whichever value is read, the count
+  // pass A will see is at most max_new_slots -- one per pixel -- above it; k_scan_visible drops entries beyond the end)
+  const uint32_t n_bound = st->surfel_count + max_new_slots;
+  const bool mine = have_seg && (unsigned long long)seg * kSeg < (unsigned long long)n_bound;
+  bool skip = false;
+  if (mine && __float_as_uint(b1.z) == (uint32_t)kSeg && vis_prev == 0 &&
+      stamp_outside_window(__float_as_uint(b1.w), c.frame, c.reg_window)) {
+    const Vec3 lo = {b0.x, b0.y, b0.z}, hi = {b0.w, b1.x, b1.y};
+    skip = box_out_of_view(lo, hi, c);
+  }
+  const bool survive = mine && !skip, copy = skip && streak < 2u;
+  if (skip) {
+    L.seg_act[seg] = 0;   // (vis_seg stays 0, the box stays as it is)
+    if (streak < 255u) L.seg_streak[seg] = (uint8_t)(streak + 1u);
+  } else if (mine && streak) {
+    L.seg_streak[seg] = 0;
+  }
+  // compaction: ballot + popcount ranks inside the wavefront, one returning atomic per wavefront and list
+  const unsigned long long sm = __ballot(survive), cm = __ballot(copy);
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t sbase = 0, cbase = 0;
+  if (lane == 0) {
+    if (sm) sbase = atomicAdd(&sw.count[0], (uint32_t)__popcll(sm));
+    if (cm) cbase = atomicAdd(&sw.count[1], (uint32_t)__popcll(cm));
+  }
+  sbase = __shfl(sbase, 0); cbase = __shfl(cbase, 0);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  if (survive) sw.surv_list[sbase + (uint32_t)__popcll(sm & below)] = seg;
+  if (copy) sw.copy_list[cbase + (uint32_t)__popcll(cm & below)] = seg;
+  if (c.stats) {
+    const unsigned long long km = __ballot(skip);
+    if (lane == 0 && km) atomicAdd(&st->n_segments_skipped, (uint32_t)__popcll(km));
+  }
+}
+
+__global__ void __launch_bounds__(kBlock, 8)   // (eight workgroups per CU: <= 64 VGPRs)
+k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, SegWork sw, const uint8_t* __restrict__ flags_prev, DevState* st,
+               int use_lds_tables) {
   __shared__ uint32_t wave_tot[kBlock / 64];
   __shared__ float box_part[kBlock / 64][8];
-  __shared__ unsigned long long survive_mask[kBlock / 64], copy_mask[kBlock / 64];
   // the tiles this workgroup's pairs fall into: open-addressed table keyed by tile number (fixed size: a direct-mapped
   // one -- a word per tile, 38 KB at 1280 x 960 -- capped the chip at four workgroups per CU); pair_key = tile, later the
   // base of the workgroup's run
   __shared__ uint32_t pair_key[kPairHash], pair_cnt[kPairHash];
   const bool lds_tables = use_lds_tables != 0;
   const uint32_t G = gridDim.x, wg = blockIdx.x;
-  // ---- 1. cull.  Segment culling: the box was formed from every slot of the segment the last time it was read; it is
-  // still valid if the segment has not grown since and had no visible slot in the previous frame (only visible slots are
-  // moved, restamped, merged or replaced).  If it is out of view and its newest stamp has left the regulariser window,
-  // this frame's result for the segment is known without reading its 16 KB of P records: nothing visible, no recent bit.
-  const uint32_t my_seg = wg + threadIdx.x * G;
-  const bool have_seg = my_seg < nseg_alloc;
-  const uint32_t sidx = have_seg ? my_seg : 0u;   // (segment 0 stands in: no branch around the loads)
-  const float4 b0 = *reinterpret_cast<const float4*>(&L.seg_box[8 * (size_t)sidx]);       // lo.xyz, hi.x
-  const float4 b1 = *reinterpret_cast<const float4*>(&L.seg_box[8 * (size_t)sidx + 4]);   // hi.yz, covered slots, newest stamp
-  const uint32_t vis_prev = L.vis_seg[sidx];
-  const uint32_t streak = L.seg_streak[sidx];
+  const uint32_t n_surv = sw.count[0], n_copy = sw.count[1];
+  uint32_t next_seg = sw.surv_list[wg];   // (the list has room for any index formed here; requested with the counts)
   const uint32_t N = st->surfel_count;
-  const uint32_t n_used = (N + (uint32_t)kSeg - 1u) / (uint32_t)kSeg;
-  if (wg >= n_used) return;  // uniform per workgroup: not even its first segment holds slots
-  const bool mine = have_seg && my_seg < n_used;
-  bool skip = false;
-  if (mine) {
-    const uint32_t seg_base = my_seg * (uint32_t)kSeg;
-    const uint32_t in_seg = (N - seg_base < (uint32_t)kSeg) ? N - seg_base : (uint32_t)kSeg;
-    if (__float_as_uint(b1.z) == in_seg && vis_prev == 0 && stamp_outside_window(__float_as_uint(b1.w), c.frame, c.reg_window)) {
-      const Vec3 lo = {b0.x, b0.y, b0.z}, hi = {b0.w, b1.x, b1.y};
-      skip = box_out_of_view(lo, hi, c);
-    }
-    if (skip) {
-      L.seg_act[my_seg] = 0;   // (vis_seg stays 0, the box stays as it is)
-      if (streak < 255u) L.seg_streak[my_seg] = (uint8_t)(streak + 1u);
-      if (c.stats) atomicAdd(&st->n_segments_skipped, 1u);
-    } else if (streak) {
-      L.seg_streak[my_seg] = 0;
+  // ---- the culled segments' flag bytes (one list entry per walk step, all 256 lanes: 1 KB)
+  for (uint32_t e = wg; e < n_copy; e += G) {
+    const uint32_t i0 = sw.copy_list[e] * (uint32_t)kSeg + threadIdx.x * 4;
+    if (i0 < N) {
+      const uchar4 of = *reinterpret_cast<const uchar4*>(&flags_prev[i0]);
+      *reinterpret_cast<uchar4*>(&L.flags8[i0]) = make_uchar4(of.x & 2u, of.y & 2u, of.z & 2u, of.w & 2u);
     }
   }
-  {
-    const unsigned long long sm = __ballot(mine && !skip), cm = __ballot(skip && streak < 2u);
-    if ((threadIdx.x & 63) == 0) { survive_mask[threadIdx.x >> 6] = sm; copy_mask[threadIdx.x >> 6] = cm; }
-  }
-  __syncthreads();
-  // ---- 2. flag bytes of the culled segments
-#pragma unroll 1
-  for (int q = 0; q < kBlock / 64; ++q) {
-    const unsigned long long mq = copy_mask[q];
-    uint32_t mlo = __builtin_amdgcn_readfirstlane((uint32_t)mq), mhi = __builtin_amdgcn_readfirstlane((uint32_t)(mq >> 32));
-    unsigned long long m = ((unsigned long long)mhi << 32) | mlo;   // (uniform: the loop runs on the scalar unit)
-    while (m) {
-      uint32_t at[4];
-      uchar4 v[4];
-      int cnt = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        at[j] = kInvalid;
-        if (m) {
-          const uint32_t k = (uint32_t)__builtin_ctzll(m);
-          m &= m - 1;
-          const uint32_t i0 = (wg + ((uint32_t)q * 64u + k) * G) * (uint32_t)kSeg + threadIdx.x * 4;
-          if (i0 < N) at[j] = i0;
-          ++cnt;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const uchar4*>(&flags_prev[at[j] != kInvalid ? at[j] : 0u]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (at[j] != kInvalid) *reinterpret_cast<uchar4*>(&L.flags8[at[j]]) = make_uchar4(v[j].x & 2u, v[j].y & 2u, v[j].z & 2u, v[j].w & 2u);
-      (void)cnt;
-    }
-  }
-  // ---- 3. the surviving segments
+  // ---- the surviving segments: a walk over the list, the next entry requested while this one is worked on
   bool first_segment = true;
 #pragma unroll 1
-  for (int q = 0; q < kBlock / 64; ++q) {
-    const unsigned long long mq = survive_mask[q];
-    uint32_t mlo = __builtin_amdgcn_readfirstlane((uint32_t)mq), mhi = __builtin_amdgcn_readfirstlane((uint32_t)(mq >> 32));
-    unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
-#pragma unroll 1
-    while (m) {
-      const uint32_t kbit = (uint32_t)__builtin_ctzll(m);
-      m &= m - 1;
-      const uint32_t seg_id = wg + ((uint32_t)q * 64u + kbit) * G;
+  for (uint32_t e = wg; e < n_surv; e += G) {
+    {
+      const uint32_t seg_id = next_seg;
+      next_seg = (e + G < n_surv) ? sw.surv_list[e + G] : 0u;
       // (everything below is per segment: a lane number the optimiser cannot see through keeps it from hoisting the
       // per-lane addresses of a dozen arrays out of the loop and holding them in registers across it -- 96 VGPRs instead
       // of 51, five workgroups per CU instead of eight)
       uint32_t tid = threadIdx.x;
       asm volatile("" : "+v"(tid));
+      if (seg_id * (uint32_t)kSeg >= N) continue;   // (the cull step's bound on the slot count was generous)
       const uint32_t base = seg_id * (uint32_t)kSeg;
       const uint32_t i0 = base + tid * 4;
       const uint32_t in_seg = (N - base < (uint32_t)kSeg) ? N - base : (uint32_t)kSeg;
@@ -822,7 +819,8 @@ __device__ __forceinline__ void for_uncached_pairs(const Surfels& S, const Frame
 __global__ void __launch_bounds__(kTilePx)
 k_assoc_tiles(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<const float2> normals, TileBins tb,
               uint32_t* __restrict__ next_ovf_count, uint8_t* __restrict__ merge_flag, DevState* st,
-              const uint8_t* __restrict__ seg_act, uint32_t nseg, uint32_t* __restrict__ direction_out, unsigned long long* stamps) {
+              const uint8_t* __restrict__ seg_act, uint32_t nseg, uint32_t* __restrict__ direction_out, uint32_t* __restrict__ seg_work_count,
+              unsigned long long* stamps) {
   __shared__ TileLds t;
   __shared__ uint32_t order_wave_tot[kTilePx / 64];
   // side job of the first workgroup: the direction in which the launches that follow walk the segments (segment_of_block)
@@ -871,7 +869,7 @@ k_assoc_tiles(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<
   // (every lane has read the counters: ready for the next call's pass A)
   if (lane == 0) {
     tb.count[tile * kCountStride] = 0;
-    if (tile == 0) *next_ovf_count = 0;
+    if (tile == 0) { *next_ovf_count = 0; seg_work_count[0] = 0; seg_work_count[1] = 0; }   // (pass A of this call has read them: ready for the next call's cull step)
     if (c.stats) {
       atomicAdd(&st->n_pairs, n_total);
       atomicMax(&st->max_tile_pairs, n_total);
@@ -1751,11 +1749,11 @@ k_update_and_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, Crea
 // neighbour's colour word (:1430) and stamp (:2132) are replaced by ONE byte gather from the flag table
 // (L2-resident: 1 B/slot).  The gradient clear (kernels.cu:2099-2113) is gone: the fixed-point
 // accumulators are zero between calls (k_reg_step zeroes what it consumes).
-constexpr int kScanSegsPerBlock = 64;   // segments per workgroup pass B can decide about at once (the host sizes the grid accordingly)
 template <bool kDetach, bool kAccumulate>
 __global__ void __launch_bounds__(kBlockB)
 k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict__ inwin8, uint32_t* __restrict__ need_seg,
                 DevState* st) {
+  const uint32_t seg_id = segment_of_block(L.descending);
   extern __shared__ __align__(16) uint8_t lhot[];   // the hot-group table (n_hot_groups bytes, padded to 16)
   __shared__ uint32_t ltargets[kMaxHotGroups / 32];  // bit g: a link of this segment points into group g (another segment)
   // B1: pure streaming.  Per slot: detach (:1430-1433), which of its neighbours lie inside the regulariser
@@ -1763,16 +1761,9 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
   // occupancy stays high; the accumulation itself runs in k_reg_accumulate on the few segments that need it.
   __shared__ uint32_t wave_tot[kBlockB / 64];
   __shared__ __attribute__((aligned(4))) uint8_t lflags[kSegB];  // the segment's own flag bytes
-  __shared__ uint32_t read_lo, read_hi;   // bit k: the workgroup's k-th segment has to be read
-  // Chip-sized grid like pass A's: workgroup w owns the segments w, w + G, w + 2 G, ...; it copies the hot-group table to
-  // LDS ONCE, decides for all of its segments together which have to be read (their 512-byte bitmaps requested in one
-  // go), and streams those one after the other.  (Rounds 1-3: one workgroup per segment, 5 400 table copies and as many
-  // dependent decide-then-load chains per launch at C2.)
-  const uint32_t G = gridDim.x, wg = blockIdx.x;
   const uint32_t N = st->surfel_count;
-  const uint32_t n_used = (N + (uint32_t)kSegB - 1u) / (uint32_t)kSegB;
-  if (wg >= n_used) return;   // uniform: not even the workgroup's first segment holds slots
-  const uint32_t n_mine = (n_used - 1u - wg) / G + 1u;   // <= kScanSegsPerBlock
+  const uint32_t base = seg_id * kSegB;
+  if (base >= N) return;
   // The reference detaches BEFORE it creates new surfels (kernels.cc:333-339 precedes cc:264-286), so
   // slots created in this frame keep links to flagged surfels until the next frame.
   const uint32_t detach_limit = st->create_base;
@@ -1796,9 +1787,7 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
   // the segment is then hot and the next pass rebuilds its bitmap.  (At C2 two segments out of five are skipped;
   // with groups of 2048 slots a cold segment's thousand far links seldom miss every hot group -- tools/far_terms_hist.py.)
   static_assert(kBlockB * 16 == kMaxHotGroups, "one lane per 16 groups");
-  if (threadIdx.x == 0) { read_lo = 0u; read_hi = 0u; }
   uint32_t hot16 = 0;   // bit k: group 16 * lane + k is hot
-  const bool filter = use_hot && !stats;   // (the edge statistics count every link of the map)
   if (use_hot) {
     const uint32_t g = threadIdx.x * 16;
     if (g < L.n_hot_groups) {
@@ -1809,86 +1798,46 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
       for (int k = 0; k < 16; ++k)
         if (g + k < L.n_hot_groups && group_is_hot((w[k >> 2] >> (8 * (k & 3))) & 255u, L.epoch)) hot16 |= 1u << k;
     }
-  }
-  __syncthreads();   // (the mask words are zero, the table is in LDS)
-  if (filter) {
-    // the lane's 16 bits of every segment's bitmap: up to 8 segments' rows in flight together
-#pragma unroll 1
-    for (uint32_t k0 = 0; k0 < n_mine; k0 += 8) {
-      uint32_t row[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const uint32_t k = k0 + j < n_mine ? k0 + j : k0;
-        row[j] = (uint32_t)L.seg_targets[(size_t)(wg + k * G) * kBlockB + threadIdx.x];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const uint32_t k = k0 + j;
-        if (k >= n_mine) break;   // uniform
-        const uint32_t own_group = ((wg + k * G) * (uint32_t)kSegB) >> L.hot_shift;
-        const uint32_t reached = row[j] | (threadIdx.x == own_group / 16 ? 1u << (own_group % 16) : 0u);
-        if (__ballot((reached & hot16) != 0) != 0ull && (threadIdx.x & 63) == 0) atomicOr(k < 32 ? &read_lo : &read_hi, 1u << (k & 31u));
+    if (!stats) {   // (the edge statistics count every link of the map)
+      const uint32_t own_group = base >> L.hot_shift;
+      const uint32_t reached = (uint32_t)L.seg_targets[(size_t)seg_id * kBlockB + threadIdx.x] | (threadIdx.x == own_group / 16 ? 1u << (own_group % 16) : 0u);
+      if (!__syncthreads_or((reached & hot16) != 0)) {
+        if (threadIdx.x == 0) {
+          L.recent_seg[seg_id] = kInvalid;   // (no recent slot; the mark is what smx_recon_debug_count_skipped_segments counts)
+          if (kAccumulate) need_seg[seg_id] = 0u;
+        }
+        return;
       }
     }
-    __syncthreads();
   }
-  unsigned long long todo;
-  {
-    const unsigned long long all = n_mine >= 64u ? ~0ull : ((1ull << n_mine) - 1ull);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane(read_lo), hi = __builtin_amdgcn_readfirstlane(read_hi);
-    todo = filter ? ((((unsigned long long)hi << 32) | lo) & all) : all;
-    // the segments that are not read: no recent slot (the mark is what smx_recon_debug_count_skipped_segments counts)
-    if (threadIdx.x < n_mine && !((todo >> threadIdx.x) & 1ull)) {
-      const uint32_t seg = wg + threadIdx.x * G;
-      L.recent_seg[seg] = kInvalid;
-      if (kAccumulate) need_seg[seg] = 0u;
-    }
-  }
-  bool first_segment = true;
-#pragma unroll 1
-  while (todo) {
-    const uint32_t kbit = (uint32_t)__builtin_ctzll(todo);
-    todo &= todo - 1;
-    const uint32_t seg_id = wg + kbit * G;
-    uint32_t tid = threadIdx.x;   // (opaque to the optimiser: per-lane addresses are not hoisted out of the loop, see pass A)
-    asm volatile("" : "+v"(tid));
-    const uint32_t base = seg_id * (uint32_t)kSegB;
-    const uint32_t i0 = base + tid * 4;
-    uchar4 own = make_uchar4(0, 0, 0, 0);
-    uint4 trec[4];  // the T records (4 neighbour ids) of the lane's 4 slots: 64 contiguous bytes
+  const uint32_t i0 = base + threadIdx.x * 4;
+  // A QUIET segment -- its own group is cold, it is read because its bitmap reaches a hot group -- has no recent slot
+  // (pass A found none in the group) and none of its in-segment links can matter (source and target share the cold
+  // group: the argument above), so all there is to do is to look at the far links that end in a hot group.  No own flag
+  // bytes, no LDS copy of them, no barrier in front of the link loop, a dozen instructions per link instead of fifty:
+  // the kernel's wave-time was the largest of the frame (SQ_WAVE_CYCLES, profiles/r17a_SQ_WAIT_ANY.md) and two fifths of
+  // it VALU issue.  The bitmap is not rebuilt either: links only disappear while the own group is cold, so the old
+  // bitmap remains a superset of the groups the segment reaches, which is all the skip test above needs.
+  if (use_hot && !stats && (kDetach || kAccumulate) && !group_is_hot(lhot[base >> L.hot_shift], L.epoch)) {
+    uint4 trec[4];
+    uint32_t far_mask = 0;
     if (i0 < N) {
-      own = *reinterpret_cast<const uchar4*>(&L.flags8[i0]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) trec[j] = *reinterpret_cast<const uint4*>(S.group(kGroupT, i0 + j));
-    }
-    if (!first_segment) __syncthreads();   // (the previous segment's readers of lflags / ltargets / wave_tot are done)
-    first_segment = false;
-    if (tid < kMaxHotGroups / 32) ltargets[tid] = 0;
-    uint32_t recent_bits = 0;
-    int need = 0;
-    *reinterpret_cast<uchar4*>(&lflags[tid * 4]) = own;
-    __syncthreads();
-    const bool quiet = use_hot && !group_is_hot(lhot[base >> L.hot_shift], L.epoch);
-    // The far flag bytes of a lane's 16 links are requested TOGETHER (a gather that is not needed reads the lane's own
-    // byte): fetched one after the other inside the loop below, as the compiler would arrange it, the 16 dependent round
-    // trips of a fully active segment's workgroup are what the whole launch lasts (tools/isa_phases.py: 20 waits -> 5).
-    uint32_t far_mask = 0;   // bit 4 j + q: that link leaves the segment and its target's flag byte matters
-    uint32_t far_flag[16];
-    if ((kDetach || kAccumulate) && i0 < N) {   // (the copy-only pass without detaching looks at no flag but the slot's own)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const uint32_t nb = q == 0 ? trec[j].x : q == 1 ? trec[j].y : q == 2 ? trec[j].z : trec[j].w;
-          if (i0 + j < N && nb != kInvalid && nb - base >= (uint32_t)kSegB &&
-              !(quiet && !group_is_hot(lhot[nb >> L.hot_shift], L.epoch)))   // (both cold: neither bit is of any consequence)
+          if (nb - base >= (uint32_t)kSegB && nb != kInvalid && i0 + j < N && group_is_hot(lhot[nb >> L.hot_shift], L.epoch))
             far_mask |= 1u << (4 * j + q);
         }
       }
     }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) far_flag[k] = 0;
-    if (__ballot(far_mask != 0) != 0ull) {   // (per wavefront: most wavefronts of the map have nothing to fetch)
+    uint8_t inw[4] = {0, 0, 0, 0};
+    int need = 0;
+    if (__ballot(far_mask != 0) != 0ull) {   // (per wavefront)
+      uint32_t far_flag[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         const uint4& t = trec[k >> 2];
@@ -1897,54 +1846,110 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
       }
 #pragma unroll
       for (int k = 0; k < 16; ++k) keep(far_flag[k]);
-    }
-    if (i0 < N) {
-      const uint8_t ownf[4] = {own.x, own.y, own.z, own.w};
-      uint8_t inw[4] = {0, 0, 0, 0};
-      uint32_t edges = 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t i = i0 + j;
-        if (i >= N) continue;
-        if (ownf[j] & 1u) recent_bits |= 1u << j;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const uint32_t nb = q == 0 ? trec[j].x : q == 1 ? trec[j].y : q == 2 ? trec[j].z : trec[j].w;
-          if (nb == kInvalid) continue;
-          // three of four links stay inside the segment: those flags come from the LDS copy
-          const uint32_t rel = nb - base;
-          uint32_t f;
-          if (rel < (uint32_t)kSegB) f = lflags[rel];
-          else f = ((far_mask >> (4 * j + q)) & 1u) ? far_flag[4 * j + q] : 0u;
-          if (kDetach && i < detach_limit && (f & 2u)) {  // :1430-1433
-            S.set_neighbor(i, q, kInvalid);
-            continue;
-          }
-          if (rel >= (uint32_t)kSegB) { const uint32_t g = nb >> L.hot_shift; atomicOr(&ltargets[g >> 5], 1u << (g & 31u)); }
-          ++edges;
-          if (kAccumulate && (f & 1u)) { inw[j] |= (uint8_t)(1u << q); need = 1; }
-        }
-      }
-      if (kAccumulate) *reinterpret_cast<uchar4*>(&inwin8[i0]) = make_uchar4(inw[0], inw[1], inw[2], inw[3]);
-      if (stats && kAccumulate && edges) {
-        atomicAdd(&st->n_edges, edges);
-        const uint32_t we = __popc(inw[0]) + __popc(inw[1]) + __popc(inw[2]) + __popc(inw[3]);
-        if (we) { atomicAdd(&st->n_window_edges, we); atomicAdd(&st->n_contributors, (uint32_t)((inw[0] != 0) + (inw[1] != 0) + (inw[2] != 0) + (inw[3] != 0))); }
+      for (int k = 0; k < 16; ++k) {
+        if (!((far_mask >> k) & 1u)) continue;
+        const uint32_t f = far_flag[k];
+        if (kDetach && i0 + (uint32_t)(k >> 2) < detach_limit && (f & 2u)) { S.set_neighbor(i0 + (uint32_t)(k >> 2), k & 3, kInvalid); continue; }  // :1430-1433
+        if (kAccumulate && (f & 1u)) { inw[k >> 2] |= (uint8_t)(1u << (k & 3)); need = 1; }
       }
     }
-    uint32_t total;
-    uint32_t off = base + block_excl_scan<kBlockB / 64>((uint32_t)__popc(recent_bits), wave_tot, total);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (recent_bits & (1u << j)) L.recent_list[off++] = i0 + j;
+    if (kAccumulate && i0 < N) *reinterpret_cast<uchar4*>(&inwin8[i0]) = make_uchar4(inw[0], inw[1], inw[2], inw[3]);
     const int any = __syncthreads_or(need);
-    L.seg_targets[(size_t)seg_id * kBlockB + tid] = (uint16_t)(ltargets[tid >> 1] >> (16 * (tid & 1)));
-    if (tid == 0) {
-      L.recent_seg[seg_id] = total;
-      if (total) L.rec_chunks.desc[atomicAdd(L.rec_chunks.count, 1u)] = seg_id | ((total - 1u) << 22);   // (one walk step per segment)
-      if (kAccumulate) need_seg[seg_id] = (any || total) ? 1u : 0u;  // k_reg_accumulate also serves recent slots
-      if (stats && total) atomicAdd(&st->recent_count, total);
+    if (threadIdx.x == 0) {
+      L.recent_seg[seg_id] = 0;
+      if (kAccumulate) need_seg[seg_id] = any ? 1u : 0u;
     }
+    return;
+  }
+  if (threadIdx.x < kMaxHotGroups / 32) ltargets[threadIdx.x] = 0;
+  uint32_t recent_bits = 0;
+  int need = 0;
+  uchar4 own = make_uchar4(0, 0, 0, 0);
+  uint4 trec[4];  // the T records (4 neighbour ids) of the lane's 4 slots: 64 contiguous bytes
+  if (i0 < N) {
+    own = *reinterpret_cast<const uchar4*>(&L.flags8[i0]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) trec[j] = *reinterpret_cast<const uint4*>(S.group(kGroupT, i0 + j));
+  }
+  *reinterpret_cast<uchar4*>(&lflags[threadIdx.x * 4]) = own;
+  __syncthreads();
+  const bool quiet = use_hot && !group_is_hot(lhot[base >> L.hot_shift], L.epoch);
+  // The far flag bytes of a lane's 16 links are requested TOGETHER (a gather that is not needed reads the lane's own
+  // byte): fetched one after the other inside the loop below, as the compiler would arrange it, the 16 dependent round
+  // trips of a fully active segment's workgroup are what the whole launch lasts (tools/isa_phases.py: 20 waits -> 5).
+  uint32_t far_mask = 0;   // bit 4 j + q: that link leaves the segment and its target's flag byte matters
+  uint32_t far_flag[16];
+  if ((kDetach || kAccumulate) && i0 < N) {   // (the copy-only pass without detaching looks at no flag but the slot's own)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t nb = q == 0 ? trec[j].x : q == 1 ? trec[j].y : q == 2 ? trec[j].z : trec[j].w;
+        if (i0 + j < N && nb != kInvalid && nb - base >= (uint32_t)kSegB &&
+            !(quiet && !group_is_hot(lhot[nb >> L.hot_shift], L.epoch)))   // (both cold: neither bit is of any consequence)
+          far_mask |= 1u << (4 * j + q);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) far_flag[k] = 0;
+  if (__ballot(far_mask != 0) != 0ull) {   // (per wavefront: most wavefronts of the map have nothing to fetch)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const uint4& t = trec[k >> 2];
+      const uint32_t nb = (k & 3) == 0 ? t.x : (k & 3) == 1 ? t.y : (k & 3) == 2 ? t.z : t.w;
+      far_flag[k] = L.flags8[((far_mask >> k) & 1u) ? nb : min(i0, N - 1u)];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) keep(far_flag[k]);
+  }
+  if (i0 < N) {
+    const uint8_t ownf[4] = {own.x, own.y, own.z, own.w};
+    uint8_t inw[4] = {0, 0, 0, 0};
+    uint32_t edges = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t i = i0 + j;
+      if (i >= N) continue;
+      if (ownf[j] & 1u) recent_bits |= 1u << j;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t nb = q == 0 ? trec[j].x : q == 1 ? trec[j].y : q == 2 ? trec[j].z : trec[j].w;
+        if (nb == kInvalid) continue;
+        // three of four links stay inside the segment: those flags come from the LDS copy
+        const uint32_t rel = nb - base;
+        uint32_t f;
+        if (rel < (uint32_t)kSegB) f = lflags[rel];
+        else f = ((far_mask >> (4 * j + q)) & 1u) ? far_flag[4 * j + q] : 0u;
+        if (kDetach && i < detach_limit && (f & 2u)) {  // :1430-1433
+          S.set_neighbor(i, q, kInvalid);
+          continue;
+        }
+        if (rel >= (uint32_t)kSegB) { const uint32_t g = nb >> L.hot_shift; atomicOr(&ltargets[g >> 5], 1u << (g & 31u)); }
+        ++edges;
+        if (kAccumulate && (f & 1u)) { inw[j] |= (uint8_t)(1u << q); need = 1; }
+      }
+    }
+    if (kAccumulate) *reinterpret_cast<uchar4*>(&inwin8[i0]) = make_uchar4(inw[0], inw[1], inw[2], inw[3]);
+    if (stats && kAccumulate && edges) {
+      atomicAdd(&st->n_edges, edges);
+      const uint32_t we = __popc(inw[0]) + __popc(inw[1]) + __popc(inw[2]) + __popc(inw[3]);
+      if (we) { atomicAdd(&st->n_window_edges, we); atomicAdd(&st->n_contributors, (uint32_t)((inw[0] != 0) + (inw[1] != 0) + (inw[2] != 0) + (inw[3] != 0))); }
+    }
+  }
+  uint32_t total;
+  uint32_t off = base + block_excl_scan<kBlockB / 64>((uint32_t)__popc(recent_bits), wave_tot, total);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (recent_bits & (1u << j)) L.recent_list[off++] = i0 + j;
+  const int any = __syncthreads_or(need);
+  L.seg_targets[(size_t)seg_id * kBlockB + threadIdx.x] = (uint16_t)(ltargets[threadIdx.x >> 1] >> (16 * (threadIdx.x & 1)));
+  if (threadIdx.x == 0) {
+    L.recent_seg[seg_id] = total;
+    if (total) L.rec_chunks.desc[atomicAdd(L.rec_chunks.count, 1u)] = seg_id | ((total - 1u) << 22);   // (one walk step per segment)
+    if (kAccumulate) need_seg[seg_id] = (any || total) ? 1u : 0u;  // k_reg_accumulate also serves recent slots
+    if (stats && total) atomicAdd(&st->recent_count, total);
   }
 }
 
@@ -2540,6 +2545,9 @@ struct smx_recon_s {
   int blend_multi_launch;   // A/B switch: 1 = the reference's start + iteration launches instead of the fused kernel
   Scratch sc;               // the association images (every pixel is rewritten by k_assoc_tiles in every call)
   TileBins tb;              // pass A's pairs, binned by association tile
+  SegWork sw;               // pass A's work lists (k_cull_segments -> k_scan_visible)
+  bool sw_dirty;            // a call failed between the cull step and the tile kernel: the lists' counters are not zero
+  hipEvent_t pending_mark;  // != null: the caller's stream has not waited for the previous call's update + create yet (smx_recon_integrate)
   uint32_t* ovf_count_set[2];   // overflow counters, alternating by call (the tile kernel zeroes the next call's)
   unsigned long long* stamps;   // -DSMX_STAMPS builds: [2][8192 workgroups][16] shader clocks (tile kernel, blend kernel)
   int no_lds_tables;        // A/B switch (scan mode bit 4)
@@ -2636,6 +2644,7 @@ int join_regularizer(smx_recon r, hipStream_t st) {
   if (r->reg_pending) {
     SMX_HIP(hipEventRecord(r->ev_reg, r->reg_stream));
     SMX_HIP(hipStreamWaitEvent(st, r->ev_reg, 0));
+    if (st == r->last_stream) r->pending_mark = nullptr;   // (that stream now waits for more than the deferred mark covers)
   }
   return SMX_OK;
 }
@@ -2644,8 +2653,7 @@ int join_regularizer(smx_recon r, hipStream_t st) {
 // (k_update_and_create) has reset their counter, everywhere else it is done here.
 int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, float weight, int window,
                        bool detach, bool copy_only, bool zero_chunks) {
-  // pass B: chip-sized grid (k_neighbor_scan), more workgroups only if one would own more segments than it can decide about
-  const dim3 g((unsigned)std::max(r->cu_count * 8, div_up(r->nsegB, kScanSegsPerBlock))), bB(kBlockB), gl(r->grid_list), b(kBlock);
+  const dim3 g(r->nsegB), bB(kBlockB), gl(r->grid_list), b(kBlock);
   const float rf2 = rf * rf;
   if (!r->table_valid || r->table_frame != frame || r->table_window != window) {
     hipLaunchKernelGGL(k_rebuild_flags, dim3(r->grid_surfels), b, 0, st, r->S, frame, window, r->L.flags8, r->st);
@@ -2754,6 +2762,9 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->L.seg_box, (size_t)r->nseg * 8, true));
   SMX_TRY(dev_alloc(&r->L.seg_act, (size_t)r->nseg, true));
   SMX_TRY(dev_alloc(&r->L.seg_streak, (size_t)r->nseg, true));
+  SMX_TRY(dev_alloc(&r->sw.surv_list, (size_t)r->nseg + 65536, true));   // (+ room for the index a walk forms first)
+  SMX_TRY(dev_alloc(&r->sw.copy_list, (size_t)r->nseg + 65536, true));
+  SMX_TRY(dev_alloc(&r->sw.count, 2, true));
   // (the direction word of segment_of_block: written by the tile kernel, read by the host without synchronisation)
   SMX_TRY(hip_rc(hipHostMalloc(reinterpret_cast<void**>(&r->dir_host), sizeof(uint32_t), hipHostMallocMapped), "hipHostMalloc"));
   *r->dir_host = 0;
@@ -2845,7 +2856,7 @@ int smx_recon_destroy(smx_recon r) {
   SMX_ON_DEVICE(r->device);
   void* ptrs[] = {r->sc.supporting, r->sc.counts, r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth,
                   r->tb.pairs, r->tb.count, r->tb.ovf, r->ovf_count_set[0], r->ovf_count_set[1],
-                  r->vis_count_set[0], r->vis_count_set[1], r->L.seg_act, r->L.seg_streak, r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->fb.rec, r->fb.count, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1], r->L.hot_epoch, r->L.seg_targets,
+                  r->vis_count_set[0], r->vis_count_set[1], r->L.seg_act, r->L.seg_streak, r->sw.surv_list, r->sw.copy_list, r->sw.count, r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->fb.rec, r->fb.count, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1], r->L.hot_epoch, r->L.seg_targets,
                   r->merge_flag, r->inwin8, r->need_seg, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->block_offsets, r->st};
   if (r->reg_stream) { (void)hipStreamSynchronize(r->reg_stream); (void)hipStreamDestroy(r->reg_stream); }
@@ -3026,19 +3037,24 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   r->tb.ovf_count = r->ovf_count_set[r->sc_cur];
   { SlotTimer t(r, sF, kSlotScanVisible);
     const bool lds_tables = !r->no_lds_tables;
-    // chip-sized grid: as many workgroups as the chip holds at once (8 per CU), more only if a workgroup would own more
-    // segments than its cull step has lanes
-    const dim3 ga((unsigned)std::max(r->cu_count * 8, div_up(r->nseg, kCullLanes)));
-    hipLaunchKernelGGL(k_scan_visible, ga, b, 0, sF, r->S, c, r->L, r->tb, flags_prev,
-                       r->st, lds_tables ? 1 : 0, (uint32_t)r->nseg);
+    // the cull step: needs the pose and what the previous pass A left, nothing the previous call's second half writes --
+    // so it goes in FRONT of this stream's wait for that half wherever the wait could be deferred (below)
+    if (r->sw_dirty) SMX_HIP(hipMemsetAsync(r->sw.count, 0, 2 * sizeof(uint32_t), sF));
+    r->sw_dirty = true;
+    hipLaunchKernelGGL(k_cull_segments, dim3((unsigned)div_up(r->nseg, kBlock)), b, 0, sF, c, r->L, r->sw, r->st, (uint32_t)r->nseg, (uint32_t)P);
+    if (r->pending_mark) { SMX_HIP(hipStreamWaitEvent(sF, r->pending_mark, 0)); r->pending_mark = nullptr; }
+    // chip-sized grid: as many workgroups as the chip holds at once (8 per CU) walk the survivor list
+    const dim3 ga((unsigned)(r->cu_count * 8));
+    hipLaunchKernelGGL(k_scan_visible, ga, b, 0, sF, r->S, c, r->L, r->tb, r->sw, flags_prev, r->st, lds_tables ? 1 : 0);
     r->table_valid = true; r->table_frame = frame_index; r->table_window = c.reg_window; }
   // (smx_recon_integrate_inputs_ready) from here on the input images are read
   if (hook_ready) SMX_HIP(hipStreamWaitEvent(sF, hook_ready, 0));
   // (the tile kernel also leaves the direction for later launches' segment_of_block in host memory, see there)
   { SlotTimer t(r, sF, kSlotAssocTiles);
     hipLaunchKernelGGL(k_assoc_tiles, dim3(r->tb.n_tiles), dim3(kTilePx), 0, sF, r->S, c, r->sc, in.depth, in.normals, r->tb,
-                       r->ovf_count_set[r->sc_cur ^ 1], r->merge_flag, r->st, r->L.seg_act, (uint32_t)r->nseg, r->dir_dev,
-                       r->stamps ? r->stamps : nullptr); }
+                       r->ovf_count_set[r->sc_cur ^ 1], r->merge_flag, r->st, r->L.seg_act, (uint32_t)r->nseg, r->dir_dev, r->sw.count,
+                       r->stamps ? r->stamps : nullptr);
+    r->sw_dirty = false; }
   // (the stage times of GetTimings: data association = pass A + the tile kernel, which also decides the merges)
   if (tm) { SMX_HIP(hipEventRecord(r->ev[1], sF)); SMX_HIP(hipEventRecord(r->ev[2], sF)); SMX_HIP(hipEventRecord(r->ev[3], sF)); SMX_HIP(hipEventRecord(r->ev[4], sF)); }
   const int halo = p->measurement_blending_radius - 1;
@@ -3127,7 +3143,11 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   {
     const hipEvent_t mark = hook_consumed ? hook_consumed : r->ev_upd;
     if (pipelined || hook_consumed) SMX_HIP(hipEventRecord(mark, sR));
-    if (pipelined) SMX_HIP(hipStreamWaitEvent(sF, mark, 0));
+    // A caller that asked for the "inputs consumed" event orders the reuse of its images itself; its stream then only has
+    // to wait before the next call's pass A reads the map -- and that call's cull step, which does not, may go first.
+    // (Every other entry point orders its stream after the whole internal stream: join_regularizer.)
+    if (pipelined && hook_consumed) r->pending_mark = mark;
+    else if (pipelined) SMX_HIP(hipStreamWaitEvent(sF, mark, 0));
   }
   if (skip_reg) {
   } else if (iters == 0) {
