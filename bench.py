@@ -39,9 +39,12 @@ VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 (vector)
 # or write counted once, cache effects and line granularity excluded.  N = slots, V = visible slots, R = slots
 # inside the regulariser window, C = slots with a link into the window, Ew = such links, E = all links, P = pixels.
 ALG_BYTES = {
-    # P records + flag bytes of the segments that are read, 2 flag bytes per slot of the culled ones, list + z-buffer
-    "scan_visible": lambda st, P: 18.0 * (st["surfels_size"] - 1024.0 * st.get("n_segments_skipped", 0))
-                                  + 2.0 * 1024.0 * st.get("n_segments_skipped", 0) + (4.0 + 1.9 * 8.0) * st["n_visible"],
+    # pass A's cull step: box (32 B), previous count, streak byte per segment; one list entry per surviving segment
+    "cull_segments": lambda st, P: 37.0 * (st["surfels_size"] / 1024.0) + 4.0 * (st["surfels_size"] / 1024.0 - st.get("n_segments_skipped", 0)),
+    # P records + flag bytes of the segments that are read (the culled ones' flag bytes are copied only in the first two
+    # calls after a segment drops out of view: not counted), 16 B of chunk descriptors per segment read, list + pairs
+    "scan_visible": lambda st, P: (18.0 + 16.0 / 1024.0) * (st["surfels_size"] - 1024.0 * st.get("n_segments_skipped", 0))
+                                  + (4.0 + 1.9 * 8.0) * st["n_visible"],
     # T records + flag and mask bytes of the segments that are read (18 B per slot), the hot table + the target-group
     # bitmap (4.5 KB) of the ones that are skipped, one flag byte per link, the recent list
     "neighbor_scan": lambda st, P: 18.0 * (st["surfels_size"] - 1024.0 * st.get("n_link_segments_skipped", 0))
@@ -554,7 +557,7 @@ def run_integrate(args):
 
 
 # kernel-slot name -> kernel name in rocprofv3 output
-SLOT_KERNEL = {"reg_accumulate": "k_reg_accumulate", "reg_step": "k_reg_step", "neighbor_scan": "k_neighbor_scan<true, true>",
+SLOT_KERNEL = {"cull_segments": "k_cull_segments", "reg_accumulate": "k_reg_accumulate", "reg_step": "k_reg_step", "neighbor_scan": "k_neighbor_scan<true, true>",
                "scan_visible": "k_scan_visible", "assoc_tiles": "k_assoc_tiles", "blend": "k_blend_tiles",
                "integrate+new_flags": "k_integrate<true>", "update_neighbors+create": "k_update_and_create<true>",}
 

@@ -210,10 +210,12 @@ constexpr int kSeg = 1024;
 // hundred slots apart), i.e. the fewer 64-bit global atomics remain.
 constexpr int kSegB = 1024;
 constexpr int kBlockB = kSegB / 4;
-// The non-empty 256-entry chunks of a segmented list, appended by the pass that builds the list (one atomic per
-// non-empty segment): descriptor = chunk id (segment * chunks-per-segment + sub-chunk) | (entries - 1) << 24.  The list
-// kernels walk these instead of probing every chunk of every segment: on the frame's binding cycle each dependent
-// memory round trip costs microseconds, and a probe that finds an empty chunk is one (profiles/r04_critical_cycle_notes.md).
+// The 256-entry chunks of a segmented list, written by the pass that builds the list into descriptor slots of their own
+// (store_chunks; pass B: one slot per segment): descriptor = chunk id (segment * chunks-per-segment + sub-chunk) |
+// (entries - 1) << 24, kInvalid = empty.  The list kernels walk the slots -- the next one requested while the current one
+// is worked on -- instead of probing every chunk of every segment through the segment's count: on the frame's binding
+// cycle each dependent memory round trip costs microseconds (profiles/r04_critical_cycle_notes.md).  `count` = walk steps
+// of the visible list (four per segment pass A read).
 struct Chunks { uint32_t* desc; uint32_t* count; };
 struct Lists {
   Chunks vis_chunks, rec_chunks;
@@ -304,15 +306,20 @@ __device__ __forceinline__ void pair_store(const TileBins& tb, uint32_t key, uin
   else tb.ovf[atomicAdd(tb.ovf_count, 1u)] = make_uint4(tile, slot, code, 0u);
 }
 
-// (thread 0 of the workgroup that built a segment's list)
-__device__ __forceinline__ void emit_chunks(const Chunks& ch, uint32_t segment, uint32_t total, uint32_t chunks_per_segment) {
-  if (total == 0) return;
-  const uint32_t nc = (total + kBlock - 1) / kBlock;
-  const uint32_t pos = atomicAdd(ch.count, nc);
-  for (uint32_t k = 0; k < nc; ++k) {
-    const uint32_t in_chunk = min((uint32_t)kBlock, total - k * kBlock);
-    ch.desc[pos + k] = (segment * chunks_per_segment + k) | ((in_chunk - 1u) << 24);
+// (thread 0 of the workgroup that built a segment's list) The descriptors of the segment that is entry `entry` of pass A's
+// survivor list go to the four slots 4 * entry .. 4 * entry + 3, kInvalid = no such chunk: plain stores.  (Rounds 1-3
+// appended them behind ONE counter: a returning atomic per non-empty segment -- 1 300 per launch at C2, 5 400 at C3, all
+// arriving within the same few microseconds at the end of their workgroups' chains, and atomics on one address retire at
+// ~12 ns each: the tail of the launch was that queue, 16 of pass A's 25 us alone at C2 and 59 of 59 at C3.)
+static_assert(kSeg / kBlock == 4, "four chunk descriptors per segment travel as one uint4");
+__device__ __forceinline__ void store_chunks(const Chunks& ch, uint32_t entry, uint32_t segment, uint32_t total) {
+  uint32_t d[4];
+#pragma unroll
+  for (uint32_t k = 0; k < 4; ++k) {
+    const uint32_t in_chunk = total > k * kBlock ? min((uint32_t)kBlock, total - k * kBlock) : 0u;
+    d[k] = in_chunk ? ((segment * 4u + k) | ((in_chunk - 1u) << 24)) : kInvalid;
   }
+  *reinterpret_cast<uint4*>(&ch.desc[4 * (size_t)entry]) = make_uint4(d[0], d[1], d[2], d[3]);
 }
 
 __device__ __forceinline__ bool stamp_outside_window(uint32_t stamp, uint32_t frame, int window) {
@@ -454,15 +461,24 @@ k_cull_segments(FrameCtx c, Lists L, SegWork sw, DevState* st, uint32_t nseg_all
   } else if (mine && streak) {
     L.seg_streak[seg] = 0;
   }
-  // compaction: ballot + popcount ranks inside the wavefront, one returning atomic per wavefront and list
+  // compaction: ballot + popcount ranks inside the wavefront, wavefront offsets through LDS, ONE returning atomic per
+  // workgroup and list (two dozen per launch at C2)
+  __shared__ uint32_t wave_n[2][kBlock / 64], list_base[2];
   const unsigned long long sm = __ballot(survive), cm = __ballot(copy);
-  const uint32_t lane = threadIdx.x & 63u;
-  uint32_t sbase = 0, cbase = 0;
-  if (lane == 0) {
-    if (sm) sbase = atomicAdd(&sw.count[0], (uint32_t)__popcll(sm));
-    if (cm) cbase = atomicAdd(&sw.count[1], (uint32_t)__popcll(cm));
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (lane == 0) { wave_n[0][wave] = (uint32_t)__popcll(sm); wave_n[1][wave] = (uint32_t)__popcll(cm); }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    uint32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) total += wave_n[threadIdx.x][w];
+    list_base[threadIdx.x] = total ? atomicAdd(&sw.count[threadIdx.x], total) : 0u;
   }
-  sbase = __shfl(sbase, 0); cbase = __shfl(cbase, 0);
+  __syncthreads();
+  uint32_t sbase = list_base[0], cbase = list_base[1];
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w)
+    if ((uint32_t)w < wave) { sbase += wave_n[0][w]; cbase += wave_n[1][w]; }
   const unsigned long long below = (1ull << lane) - 1ull;
   if (survive) sw.surv_list[sbase + (uint32_t)__popcll(sm & below)] = seg;
   if (copy) sw.copy_list[cbase + (uint32_t)__popcll(cm & below)] = seg;
@@ -486,6 +502,9 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, SegWork sw, const ui
   const uint32_t n_surv = sw.count[0], n_copy = sw.count[1];
   uint32_t next_seg = sw.surv_list[wg];   // (the list has room for any index formed here; requested with the counts)
   const uint32_t N = st->surfel_count;
+  // (the list kernels' number of walk steps: four descriptor slots per survivor; the survivor count itself is zeroed for
+  // the next call's cull step long before integrate / update + create of this call ask)
+  if (wg == 0 && threadIdx.x == 0) *L.vis_chunks.count = 4u * n_surv;
   // ---- the culled segments' flag bytes (one list entry per walk step, all 256 lanes: 1 KB)
   for (uint32_t e = wg; e < n_copy; e += G) {
     const uint32_t i0 = sw.copy_list[e] * (uint32_t)kSeg + threadIdx.x * 4;
@@ -506,7 +525,10 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, SegWork sw, const ui
       // of 51, five workgroups per CU instead of eight)
       uint32_t tid = threadIdx.x;
       asm volatile("" : "+v"(tid));
-      if (seg_id * (uint32_t)kSeg >= N) continue;   // (the cull step's bound on the slot count was generous)
+      if (seg_id * (uint32_t)kSeg >= N) {   // (the cull step's bound on the slot count was generous)
+        if (threadIdx.x == 0) store_chunks(L.vis_chunks, e, seg_id, 0u);
+        continue;
+      }
       const uint32_t base = seg_id * (uint32_t)kSeg;
       const uint32_t i0 = base + tid * 4;
       const uint32_t in_seg = (N - base < (uint32_t)kSeg) ? N - base : (uint32_t)kSeg;
@@ -647,7 +669,7 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, SegWork sw, const ui
       if (tid == 0) {
         L.vis_seg[seg_id] = total;
         L.seg_act[seg_id] = (total != 0 || box_part[0][7] + box_part[1][7] + box_part[2][7] + box_part[3][7] != 0.0f) ? 1 : 0;
-        emit_chunks(L.vis_chunks, seg_id, total, kSeg / kBlock);
+        store_chunks(L.vis_chunks, e, seg_id, total);
         float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
         int ns = (int)0x80000000;
         for (int w = 0; w < kBlock / 64; ++w) {
@@ -684,7 +706,7 @@ __device__ __forceinline__ bool walk_entry(const uint32_t* __restrict__ list, ui
   if (kUseList) {
     constexpr uint32_t kChunksPerSeg = kSegSize / kBlock;
     const uint32_t chunk = desc & 0x00FFFFFFu;
-    if (lane > (desc >> 24)) return false;
+    if (desc == kInvalid || lane > (desc >> 24)) return false;   // (kInvalid: an empty descriptor slot)
     i = list[(chunk / kChunksPerSeg) * kSegSize + (chunk % kChunksPerSeg) * kBlock + lane];
     return true;
   }
@@ -1804,6 +1826,7 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
       if (!__syncthreads_or((reached & hot16) != 0)) {
         if (threadIdx.x == 0) {
           L.recent_seg[seg_id] = kInvalid;   // (no recent slot; the mark is what smx_recon_debug_count_skipped_segments counts)
+          L.rec_chunks.desc[seg_id] = kInvalid;
           if (kAccumulate) need_seg[seg_id] = 0u;
         }
         return;
@@ -1858,6 +1881,7 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
     const int any = __syncthreads_or(need);
     if (threadIdx.x == 0) {
       L.recent_seg[seg_id] = 0;
+      L.rec_chunks.desc[seg_id] = kInvalid;
       if (kAccumulate) need_seg[seg_id] = any ? 1u : 0u;
     }
     return;
@@ -1947,7 +1971,7 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
   L.seg_targets[(size_t)seg_id * kBlockB + threadIdx.x] = (uint16_t)(ltargets[threadIdx.x >> 1] >> (16 * (threadIdx.x & 1)));
   if (threadIdx.x == 0) {
     L.recent_seg[seg_id] = total;
-    if (total) L.rec_chunks.desc[atomicAdd(L.rec_chunks.count, 1u)] = seg_id | ((total - 1u) << 22);   // (one walk step per segment)
+    L.rec_chunks.desc[seg_id] = total ? (seg_id | ((total - 1u) << 22)) : kInvalid;   // (one walk step per segment, its own slot: no counter)
     if (kAccumulate) need_seg[seg_id] = (any || total) ? 1u : 0u;  // k_reg_accumulate also serves recent slots
     if (stats && total) atomicAdd(&st->recent_count, total);
   }
@@ -2161,12 +2185,15 @@ __global__ void __launch_bounds__(kBlock)
 k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long* __restrict__ grad_local,
            FarBins fb, Lists L, DevState* st) {
   __shared__ unsigned long long lfar[kSegB * 2];   // per target of the segment: (gx | gy), (gz | sender classes)
-  const uint32_t n_steps = *L.rec_chunks.count;
+  // one descriptor slot per segment in use (pass B wrote every one of them: kInvalid = no recent slot there)
+  const uint32_t n_steps = (st->surfel_count + (uint32_t)kSegB - 1u) / (uint32_t)kSegB;
   uint32_t desc = L.rec_chunks.desc[blockIdx.x];
   bool lds_used = false;
   for (uint32_t w = blockIdx.x; w < n_steps; w += gridDim.x) {
-    const uint32_t seg = desc & 0x003FFFFFu, total = (desc >> 22) + 1u;
+    const uint32_t cur = desc;
     desc = (w + gridDim.x < n_steps) ? L.rec_chunks.desc[w + gridDim.x] : 0u;   // (the next step's descriptor travels while this one is worked on)
+    if (cur == kInvalid) continue;
+    const uint32_t seg = cur & 0x003FFFFFu, total = (cur >> 22) + 1u;
     const uint32_t seg_base = seg * kSegB;
     const uint2 bin_state = *reinterpret_cast<const uint2*>(&fb.count[(size_t)seg * kCountStride]);
     const uint32_t n_far = min(bin_state.x, fb.cap);
@@ -2275,9 +2302,10 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long*
 // RegularizeSurfelsCUDACopyOnlyKernel (:2310-2327), over the recent list.
 __global__ void __launch_bounds__(kBlock)
 k_reg_copy_raw(Surfels S, Lists L, const DevState* st) {
-  const uint32_t n_steps = *L.rec_chunks.count;
+  const uint32_t n_steps = (st->surfel_count + (uint32_t)kSegB - 1u) / (uint32_t)kSegB;
   for (uint32_t w = blockIdx.x; w < n_steps; w += gridDim.x) {
     const uint32_t desc = L.rec_chunks.desc[w];
+    if (desc == kInvalid) continue;
     const uint32_t seg = desc & 0x003FFFFFu, total = (desc >> 22) + 1u;
     for (uint32_t e = threadIdx.x; e < total; e += kBlock) {
       const uint32_t i = L.recent_list[seg * kSegB + e];
@@ -2613,12 +2641,13 @@ enum : int {
   kSlotUpdateNeighbors, kSlotNeighborScan,
   kSlotRegAccumulate, kSlotRegStep,
   kSlotRegUpdate,
+  kSlotCull,    // pass A's cull step (enqueued in front of the stream wait for the previous call's map)
   kSlotEmpty,   // nothing between its two time stamps: what a pair of stamps costs (subtracted by bench.py)
   kSlotCount
 };
 static const char* const kSlotNames[kSlotCount] = {
   "scan_visible", "assoc_tiles", "blend", "integrate+new_flags", "update_neighbors+create",
-  "neighbor_scan", "reg_accumulate", "reg_step", "reg_update", "empty_slot"};
+  "neighbor_scan", "reg_accumulate", "reg_step", "reg_update", "cull_segments", "empty_slot"};
 
 struct SlotTimer {
   smx_recon r; hipStream_t st; int slot; bool kev, prof;
@@ -3035,14 +3064,15 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   r->sc_cur ^= 1;
   r->L.vis_chunks.count = r->vis_count_set[r->sc_cur];
   r->tb.ovf_count = r->ovf_count_set[r->sc_cur];
-  { SlotTimer t(r, sF, kSlotScanVisible);
-    const bool lds_tables = !r->no_lds_tables;
-    // the cull step: needs the pose and what the previous pass A left, nothing the previous call's second half writes --
+  { // the cull step: needs the pose and what the previous pass A left, nothing the previous call's second half writes --
     // so it goes in FRONT of this stream's wait for that half wherever the wait could be deferred (below)
+    SlotTimer t(r, sF, kSlotCull);
     if (r->sw_dirty) SMX_HIP(hipMemsetAsync(r->sw.count, 0, 2 * sizeof(uint32_t), sF));
     r->sw_dirty = true;
-    hipLaunchKernelGGL(k_cull_segments, dim3((unsigned)div_up(r->nseg, kBlock)), b, 0, sF, c, r->L, r->sw, r->st, (uint32_t)r->nseg, (uint32_t)P);
-    if (r->pending_mark) { SMX_HIP(hipStreamWaitEvent(sF, r->pending_mark, 0)); r->pending_mark = nullptr; }
+    hipLaunchKernelGGL(k_cull_segments, dim3((unsigned)div_up(r->nseg, kBlock)), b, 0, sF, c, r->L, r->sw, r->st, (uint32_t)r->nseg, (uint32_t)P); }
+  if (r->pending_mark) { SMX_HIP(hipStreamWaitEvent(sF, r->pending_mark, 0)); r->pending_mark = nullptr; }
+  { SlotTimer t(r, sF, kSlotScanVisible);
+    const bool lds_tables = !r->no_lds_tables;
     // chip-sized grid: as many workgroups as the chip holds at once (8 per CU) walk the survivor list
     const dim3 ga((unsigned)(r->cu_count * 8));
     hipLaunchKernelGGL(k_scan_visible, ga, b, 0, sF, r->S, c, r->L, r->tb, r->sw, flags_prev, r->st, lds_tables ? 1 : 0);
