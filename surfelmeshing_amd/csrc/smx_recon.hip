@@ -210,13 +210,21 @@ constexpr int kSeg = 1024;
 // hundred slots apart), i.e. the fewer 64-bit global atomics remain.
 constexpr int kSegB = 1024;
 constexpr int kBlockB = kSegB / 4;
-// The 256-entry chunks of a segmented list, written by the pass that builds the list into descriptor slots of their own
-// (store_chunks; pass B: one slot per segment): descriptor = chunk id (segment * chunks-per-segment + sub-chunk) |
-// (entries - 1) << 24, kInvalid = empty.  The list kernels walk the slots -- the next one requested while the current one
-// is worked on -- instead of probing every chunk of every segment through the segment's count: on the frame's binding
-// cycle each dependent memory round trip costs microseconds (profiles/r04_critical_cycle_notes.md).  `count` = walk steps
-// of the visible list (four per segment pass A read).
-struct Chunks { uint32_t* desc; uint32_t* count; };
+// The non-empty 256-entry chunks of a segmented list, appended by the pass that builds the list: descriptor = chunk id
+// (segment * chunks-per-segment + sub-chunk) | (entries - 1) << 24.  The list kernels walk these instead of probing every
+// chunk of every segment: on the frame's binding cycle each dependent memory round trip costs microseconds, and a probe
+// that finds an empty chunk is one (profiles/r04_critical_cycle_notes.md).
+// The descriptors go to kSubLists INTERLEAVED sub-lists, each with a counter in a cache line of its own: walk step w is
+// entry w / kSubLists of sub-list w % kSubLists.  Rounds 1-3 had ONE list behind ONE counter: a returning atomic per
+// non-empty segment, 1 300 per launch of pass A at C2 and 5 400 at C3, all arriving within the same few microseconds at
+// the end of their workgroups' chains -- and atomics on one address retire at ~12 ns each, so the tail of the launch was
+// that queue.  Sixteen counters take a sixteenth each; the producers deal their segments round-robin, so the sub-lists
+// stay equally long up to the spread of the descriptors per segment, and a walk that covers kSubLists x the longest one
+// meets few empty steps.  A consumer still finds its first descriptor without waiting for any counter (its place does
+// not depend on them), which is what a prefix over the sub-lists would have cost.
+constexpr uint32_t kCountStride = 32;     // one counter per 128-byte line: atomics on one line serialise, whatever word they hit
+constexpr uint32_t kSubLists = 16;
+struct Chunks { uint32_t* desc; uint32_t* count; uint32_t stride; };   // desc[k * stride + j], count[k * kCountStride]
 struct Lists {
   Chunks vis_chunks, rec_chunks;
   uint32_t* vis_list;     // slots that project into the image this frame
@@ -280,7 +288,6 @@ static_assert(kTilePx == kBlock, "the tile kernel runs choose_segment_direction 
 // pair code: bits 0-7 pixel inside the tile (row-major, kTileW wide); bit 8: the slot's second ("quadrant") pixel;
 // bit 9: the slot is active for integration (kernels.cu:77-87) -- inactive visible slots still take part in the merge phase
 constexpr uint32_t kPairSecond = 1u << 8, kPairActive = 1u << 9;
-constexpr uint32_t kCountStride = 32;     // one pair counter per 128-byte line: atomics on one line serialise, whatever word they hit
 constexpr uint32_t kTileBinCap = 8192;   // pairs per bin (64 KB): 32 per pixel before a tile spills to the overflow list
 struct TileBins {
   uint2* pairs;          // [n_tiles][cap]: (slot, code)
@@ -306,20 +313,16 @@ __device__ __forceinline__ void pair_store(const TileBins& tb, uint32_t key, uin
   else tb.ovf[atomicAdd(tb.ovf_count, 1u)] = make_uint4(tile, slot, code, 0u);
 }
 
-// (thread 0 of the workgroup that built a segment's list) The descriptors of the segment that is entry `entry` of pass A's
-// survivor list go to the four slots 4 * entry .. 4 * entry + 3, kInvalid = no such chunk: plain stores.  (Rounds 1-3
-// appended them behind ONE counter: a returning atomic per non-empty segment -- 1 300 per launch at C2, 5 400 at C3, all
-// arriving within the same few microseconds at the end of their workgroups' chains, and atomics on one address retire at
-// ~12 ns each: the tail of the launch was that queue, 16 of pass A's 25 us alone at C2 and 59 of 59 at C3.)
-static_assert(kSeg / kBlock == 4, "four chunk descriptors per segment travel as one uint4");
-__device__ __forceinline__ void store_chunks(const Chunks& ch, uint32_t entry, uint32_t segment, uint32_t total) {
-  uint32_t d[4];
-#pragma unroll
-  for (uint32_t k = 0; k < 4; ++k) {
-    const uint32_t in_chunk = total > k * kBlock ? min((uint32_t)kBlock, total - k * kBlock) : 0u;
-    d[k] = in_chunk ? ((segment * 4u + k) | ((in_chunk - 1u) << 24)) : kInvalid;
+// (thread 0 of the workgroup that built a segment's list; `deal` picks the sub-list: consecutive values for consecutive segments)
+__device__ __forceinline__ void emit_chunks(const Chunks& ch, uint32_t deal, uint32_t segment, uint32_t total, uint32_t chunks_per_segment) {
+  if (total == 0) return;
+  const uint32_t k = deal % kSubLists;
+  const uint32_t nc = (total + kBlock - 1) / kBlock;
+  const uint32_t pos = atomicAdd(&ch.count[k * kCountStride], nc);
+  for (uint32_t q = 0; q < nc; ++q) {
+    const uint32_t in_chunk = min((uint32_t)kBlock, total - q * kBlock);
+    ch.desc[(size_t)k * ch.stride + pos + q] = (segment * chunks_per_segment + q) | ((in_chunk - 1u) << 24);
   }
-  *reinterpret_cast<uint4*>(&ch.desc[4 * (size_t)entry]) = make_uint4(d[0], d[1], d[2], d[3]);
 }
 
 __device__ __forceinline__ bool stamp_outside_window(uint32_t stamp, uint32_t frame, int window) {
@@ -502,9 +505,6 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, SegWork sw, const ui
   const uint32_t n_surv = sw.count[0], n_copy = sw.count[1];
   uint32_t next_seg = sw.surv_list[wg];   // (the list has room for any index formed here; requested with the counts)
   const uint32_t N = st->surfel_count;
-  // (the list kernels' number of walk steps: four descriptor slots per survivor; the survivor count itself is zeroed for
-  // the next call's cull step long before integrate / update + create of this call ask)
-  if (wg == 0 && threadIdx.x == 0) *L.vis_chunks.count = 4u * n_surv;
   // ---- the culled segments' flag bytes (one list entry per walk step, all 256 lanes: 1 KB)
   for (uint32_t e = wg; e < n_copy; e += G) {
     const uint32_t i0 = sw.copy_list[e] * (uint32_t)kSeg + threadIdx.x * 4;
@@ -525,10 +525,7 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, SegWork sw, const ui
       // of 51, five workgroups per CU instead of eight)
       uint32_t tid = threadIdx.x;
       asm volatile("" : "+v"(tid));
-      if (seg_id * (uint32_t)kSeg >= N) {   // (the cull step's bound on the slot count was generous)
-        if (threadIdx.x == 0) store_chunks(L.vis_chunks, e, seg_id, 0u);
-        continue;
-      }
+      if (seg_id * (uint32_t)kSeg >= N) continue;   // (the cull step's bound on the slot count was generous)
       const uint32_t base = seg_id * (uint32_t)kSeg;
       const uint32_t i0 = base + tid * 4;
       const uint32_t in_seg = (N - base < (uint32_t)kSeg) ? N - base : (uint32_t)kSeg;
@@ -669,7 +666,7 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, SegWork sw, const ui
       if (tid == 0) {
         L.vis_seg[seg_id] = total;
         L.seg_act[seg_id] = (total != 0 || box_part[0][7] + box_part[1][7] + box_part[2][7] + box_part[3][7] != 0.0f) ? 1 : 0;
-        store_chunks(L.vis_chunks, e, seg_id, total);
+        emit_chunks(L.vis_chunks, e, seg_id, total, kSeg / kBlock);
         float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
         int ns = (int)0x80000000;
         for (int w = 0; w < kBlock / 64; ++w) {
@@ -688,17 +685,29 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, SegWork sw, const ui
 // List kernels walk the list's chunk descriptors (one entry per lane), grid-striding so that the visible slots --
 // which cluster in a few segments -- still spread over the whole chip.  In the A/B "scan mode" every slot is visited
 // instead, in chunks of kBlock slots.
-// number of walk steps; the first descriptor is requested together with the count (the array is long enough for any
-// index a walk can form)
+// number of walk steps; the first descriptor is requested together with the counters (the sub-lists are long enough for
+// any index a walk can form).  cntv: lane l holds the length of sub-list l % kSubLists.
 template <bool kUseList>
-__device__ __forceinline__ uint32_t walk_begin(const Chunks& ch, uint32_t n_slots_scan, uint32_t first, uint32_t& desc) {
-  if (kUseList) { desc = ch.desc[first]; return *ch.count; }
-  desc = 0;
+__device__ __forceinline__ uint32_t walk_begin(const Chunks& ch, uint32_t n_slots_scan, uint32_t first, uint32_t& desc, uint32_t& cntv) {
+  if (kUseList) {
+    desc = ch.desc[(size_t)(first % kSubLists) * ch.stride + first / kSubLists];
+    cntv = ch.count[(threadIdx.x % kSubLists) * kCountStride];
+    uint32_t longest = cntv;
+#pragma unroll
+    for (uint32_t off = kSubLists / 2; off > 0; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, (int)off));
+    return __builtin_amdgcn_readfirstlane(longest) * kSubLists;
+  }
+  desc = 0; cntv = 0;
   return (n_slots_scan + kBlock - 1) / kBlock;
 }
 template <bool kUseList>
 __device__ __forceinline__ uint32_t walk_next(const Chunks& ch, uint32_t c, uint32_t n_steps) {
-  return (kUseList && c < n_steps) ? ch.desc[c] : 0u;
+  return (kUseList && c < n_steps) ? ch.desc[(size_t)(c % kSubLists) * ch.stride + c / kSubLists] : 0u;
+}
+// (is walk step c an entry of its sub-list, or beyond that sub-list's end?)
+__device__ __forceinline__ bool walk_step_valid(uint32_t c, uint32_t cntv) {
+  const uint32_t k = __builtin_amdgcn_readfirstlane(c % kSubLists);
+  return c / kSubLists < (uint32_t)__builtin_amdgcn_readlane((int)cntv, (int)k);
 }
 template <bool kUseList, int kSegSize = kSeg>
 __device__ __forceinline__ bool walk_entry(const uint32_t* __restrict__ list, uint32_t desc, uint32_t c, uint32_t n_slots_scan,
@@ -706,7 +715,7 @@ __device__ __forceinline__ bool walk_entry(const uint32_t* __restrict__ list, ui
   if (kUseList) {
     constexpr uint32_t kChunksPerSeg = kSegSize / kBlock;
     const uint32_t chunk = desc & 0x00FFFFFFu;
-    if (desc == kInvalid || lane > (desc >> 24)) return false;   // (kInvalid: an empty descriptor slot)
+    if (lane > (desc >> 24)) return false;
     i = list[(chunk / kChunksPerSeg) * kSegSize + (chunk % kChunksPerSeg) * kBlock + lane];
     return true;
   }
@@ -1442,12 +1451,13 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
   const uint32_t block = blockIdx.x - n_flag_blocks, n_blocks = gridDim.x - n_flag_blocks;
   const uint32_t n_scan = kUseList ? 0u : st->surfel_count;
   uint32_t merged_here = 0;
-  uint32_t desc;
-  const uint32_t n_steps = walk_begin<kUseList>(L.vis_chunks, n_scan, block, desc);
+  uint32_t desc, cntv;
+  const uint32_t n_steps = walk_begin<kUseList>(L.vis_chunks, n_scan, block, desc, cntv);
   for (uint32_t w = block; w < n_steps; w += n_blocks) {
     const uint32_t cur = desc;
     desc = walk_next<kUseList>(L.vis_chunks, w + n_blocks, n_steps);   // (the next step's descriptor travels while this one is worked on)
     uint32_t i;
+    if (kUseList && !walk_step_valid(w, cntv)) continue;
     if (!walk_entry<kUseList>(L.vis_list, cur, w, n_scan, threadIdx.x, i)) continue;
     if (merge_flag[i]) {
       // apply the merge marks, kernels.cu:1987-1989 (decided in k_merge_decide)
@@ -1508,13 +1518,14 @@ __device__ __forceinline__ void update_neighbors_body(const Surfels& S, const Fr
   // (the slot count BEFORE this frame's creation: the creating workgroups of the same launch advance surfel_count)
   const uint32_t n_scan = kUseList ? 0u : st->create_base_next;
   // (this launch precedes the regulariser's pass B on every path through Integrate: its chunk counter starts at zero)
-  if (block == 0 && threadIdx.x == 0) *L.rec_chunks.count = 0;
-  uint32_t desc;
-  const uint32_t n_steps = walk_begin<kUseList>(L.vis_chunks, n_scan, block, desc);
+  if (block == 0 && threadIdx.x < kSubLists) L.rec_chunks.count[threadIdx.x * kCountStride] = 0;
+  uint32_t desc, cntv;
+  const uint32_t n_steps = walk_begin<kUseList>(L.vis_chunks, n_scan, block, desc, cntv);
   for (uint32_t w = block; w < n_steps; w += n_blocks) {
     const uint32_t cur = desc;
     desc = walk_next<kUseList>(L.vis_chunks, w + n_blocks, n_steps);   // (the next step's descriptor travels while this one is worked on)
     uint32_t i;
+    if (kUseList && !walk_step_valid(w, cntv)) continue;
     if (!walk_entry<kUseList>(L.vis_list, cur, w, n_scan, threadIdx.x, i)) continue;
     // the slot's three records in flight together (P: position + stamp, N: normal + r^2, T: neighbour ids)
     const float4 p4 = *S.group(kGroupP, i), n4 = *S.group(kGroupN, i);
@@ -1758,7 +1769,7 @@ k_update_and_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, Crea
   } else {
     const uint32_t block = blockIdx.x - n_create_blocks, n_blocks = gridDim.x - n_create_blocks;
     // (pass A of the next call, which follows this launch, appends to the other chunk counter)
-    if (block == 0 && threadIdx.x == 0) *a.next_vis_chunk_count = 0;
+    if (block == 0 && threadIdx.x < kSubLists) a.next_vis_chunk_count[threadIdx.x * kCountStride] = 0;
     update_neighbors_body<kUseList>(S, c, sc, in, L, st, block, n_blocks);
   }
 }
@@ -1826,7 +1837,6 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
       if (!__syncthreads_or((reached & hot16) != 0)) {
         if (threadIdx.x == 0) {
           L.recent_seg[seg_id] = kInvalid;   // (no recent slot; the mark is what smx_recon_debug_count_skipped_segments counts)
-          L.rec_chunks.desc[seg_id] = kInvalid;
           if (kAccumulate) need_seg[seg_id] = 0u;
         }
         return;
@@ -1881,7 +1891,6 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
     const int any = __syncthreads_or(need);
     if (threadIdx.x == 0) {
       L.recent_seg[seg_id] = 0;
-      L.rec_chunks.desc[seg_id] = kInvalid;
       if (kAccumulate) need_seg[seg_id] = any ? 1u : 0u;
     }
     return;
@@ -1971,7 +1980,10 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
   L.seg_targets[(size_t)seg_id * kBlockB + threadIdx.x] = (uint16_t)(ltargets[threadIdx.x >> 1] >> (16 * (threadIdx.x & 1)));
   if (threadIdx.x == 0) {
     L.recent_seg[seg_id] = total;
-    L.rec_chunks.desc[seg_id] = total ? (seg_id | ((total - 1u) << 22)) : kInvalid;   // (one walk step per segment, its own slot: no counter)
+    if (total) {   // (one walk step per segment)
+      const uint32_t k = seg_id % kSubLists;
+      L.rec_chunks.desc[(size_t)k * L.rec_chunks.stride + atomicAdd(&L.rec_chunks.count[k * kCountStride], 1u)] = seg_id | ((total - 1u) << 22);
+    }
     if (kAccumulate) need_seg[seg_id] = (any || total) ? 1u : 0u;  // k_reg_accumulate also serves recent slots
     if (stats && total) atomicAdd(&st->recent_count, total);
   }
@@ -2185,14 +2197,13 @@ __global__ void __launch_bounds__(kBlock)
 k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long* __restrict__ grad_local,
            FarBins fb, Lists L, DevState* st) {
   __shared__ unsigned long long lfar[kSegB * 2];   // per target of the segment: (gx | gy), (gz | sender classes)
-  // one descriptor slot per segment in use (pass B wrote every one of them: kInvalid = no recent slot there)
-  const uint32_t n_steps = (st->surfel_count + (uint32_t)kSegB - 1u) / (uint32_t)kSegB;
-  uint32_t desc = L.rec_chunks.desc[blockIdx.x];
+  uint32_t desc, cntv;
+  const uint32_t n_steps = walk_begin<true>(L.rec_chunks, 0u, blockIdx.x, desc, cntv);
   bool lds_used = false;
   for (uint32_t w = blockIdx.x; w < n_steps; w += gridDim.x) {
     const uint32_t cur = desc;
-    desc = (w + gridDim.x < n_steps) ? L.rec_chunks.desc[w + gridDim.x] : 0u;   // (the next step's descriptor travels while this one is worked on)
-    if (cur == kInvalid) continue;
+    desc = walk_next<true>(L.rec_chunks, w + gridDim.x, n_steps);   // (the next step's descriptor travels while this one is worked on)
+    if (!walk_step_valid(w, cntv)) continue;
     const uint32_t seg = cur & 0x003FFFFFu, total = (cur >> 22) + 1u;
     const uint32_t seg_base = seg * kSegB;
     const uint2 bin_state = *reinterpret_cast<const uint2*>(&fb.count[(size_t)seg * kCountStride]);
@@ -2302,10 +2313,11 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long*
 // RegularizeSurfelsCUDACopyOnlyKernel (:2310-2327), over the recent list.
 __global__ void __launch_bounds__(kBlock)
 k_reg_copy_raw(Surfels S, Lists L, const DevState* st) {
-  const uint32_t n_steps = (st->surfel_count + (uint32_t)kSegB - 1u) / (uint32_t)kSegB;
+  uint32_t desc, cntv;
+  const uint32_t n_steps = walk_begin<true>(L.rec_chunks, 0u, blockIdx.x, desc, cntv);
   for (uint32_t w = blockIdx.x; w < n_steps; w += gridDim.x) {
-    const uint32_t desc = L.rec_chunks.desc[w];
-    if (desc == kInvalid) continue;
+    desc = walk_next<true>(L.rec_chunks, w, n_steps);
+    if (!walk_step_valid(w, cntv)) continue;
     const uint32_t seg = desc & 0x003FFFFFu, total = (desc >> 22) + 1u;
     for (uint32_t e = threadIdx.x; e < total; e += kBlock) {
       const uint32_t i = L.recent_list[seg * kSegB + e];
@@ -2317,9 +2329,9 @@ k_reg_copy_raw(Surfels S, Lists L, const DevState* st) {
   }
 }
 
-__global__ void k_reset_recent(DevState* st, int stats, uint32_t* rec_chunk_count) {
-  if (stats) { st->recent_count = 0; st->n_edges = 0; st->n_window_edges = 0; st->n_contributors = 0; }
-  if (rec_chunk_count) *rec_chunk_count = 0;
+__global__ void k_reset_recent(DevState* st, int stats, uint32_t* rec_chunk_count) {   // (one workgroup of kSubLists threads)
+  if (stats && threadIdx.x == 0) { st->recent_count = 0; st->n_edges = 0; st->n_window_edges = 0; st->n_contributors = 0; }
+  if (rec_chunk_count) rec_chunk_count[threadIdx.x * kCountStride] = 0;
 }
 
 // ---- changed-surfel delta for the mesher ---------------------------------------------------------
@@ -2696,7 +2708,7 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
   const size_t hot_lds = ((size_t)r->L.n_hot_groups + 15) & ~(size_t)15;
   {
     SlotTimer t(r, st, kSlotNeighborScan);
-    if (stats || zero_chunks) hipLaunchKernelGGL(k_reset_recent, dim3(1), dim3(1), 0, st, r->st, stats, zero_chunks ? r->L.rec_chunks.count : nullptr);
+    if (stats || zero_chunks) hipLaunchKernelGGL(k_reset_recent, dim3(1), dim3(kSubLists), 0, st, r->st, stats, zero_chunks ? r->L.rec_chunks.count : nullptr);
     if (copy_only) {
       if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, false>), g, bB, hot_lds, st, r->S, stats, use_hot, r->L, r->inwin8, r->need_seg, r->st);
       else hipLaunchKernelGGL((k_neighbor_scan<false, false>), g, bB, hot_lds, st, r->S, stats, use_hot, r->L, r->inwin8, r->need_seg, r->st);
@@ -2800,9 +2812,13 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(hip_rc(hipHostGetDevicePointer(reinterpret_cast<void**>(&r->dir_dev), r->dir_host, 0), "hipHostGetDevicePointer"));
   SMX_TRY(dev_alloc(&r->L.recent_seg, (size_t)r->nsegB, true));
   // chunk descriptors: every chunk of every segment in the worst case, + room for the index a walk forms first
-  SMX_TRY(dev_alloc(&r->L.vis_chunks.desc, (size_t)r->nseg * (kSeg / kBlock) + 65536, true));
-  SMX_TRY(dev_alloc(&r->L.rec_chunks.desc, (size_t)r->nsegB * (kSegB / kBlock) + 65536, true));
-  SMX_TRY(dev_alloc(&r->L.rec_chunks.count, 1, true));
+  // chunk descriptors: kSubLists interleaved sub-lists; one holds at most every kSubLists-th segment's chunks, + room for
+  // the index a walk forms before it knows the lengths
+  r->L.vis_chunks.stride = (uint32_t)(div_up(r->nseg, kSubLists) * (kSeg / kBlock) + 8192);
+  r->L.rec_chunks.stride = (uint32_t)(div_up(r->nsegB, kSubLists) + 8192);
+  SMX_TRY(dev_alloc(&r->L.vis_chunks.desc, (size_t)kSubLists * r->L.vis_chunks.stride, true));
+  SMX_TRY(dev_alloc(&r->L.rec_chunks.desc, (size_t)kSubLists * r->L.rec_chunks.stride, true));
+  SMX_TRY(dev_alloc(&r->L.rec_chunks.count, (size_t)kSubLists * kCountStride, true));
   SMX_TRY(dev_alloc(&r->flags_buf[0], (size_t)r->nsegB * kSegB, true));
   SMX_TRY(dev_alloc(&r->flags_buf[1], (size_t)r->nsegB * kSegB, true));
   r->L.flags8 = r->flags_buf[0];
@@ -2823,7 +2839,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->sc.confl_key, P, true));
   SMX_TRY(dev_alloc(&r->sc.first_depth, P, true));
   for (int k = 0; k < 2; ++k) {
-    SMX_TRY(dev_alloc(&r->vis_count_set[k], 1, true));
+    SMX_TRY(dev_alloc(&r->vis_count_set[k], (size_t)kSubLists * kCountStride, true));
     SMX_TRY(dev_alloc(&r->ovf_count_set[k], 1, true));
   }
   r->L.vis_chunks.count = r->vis_count_set[0];
@@ -3141,7 +3157,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   }
   if (tm) SMX_HIP(hipEventRecord(r->ev[6], sR));
   const bool front_only = (r->debug_skip & 2) != 0, skip_reg = (r->debug_skip & 3) != 0;   // (timing only)
-  if (front_only) SMX_HIP(hipMemsetAsync(r->vis_count_set[r->sc_cur ^ 1], 0, sizeof(uint32_t), sR));   // (k_update_and_create's side job)
+  if (front_only) SMX_HIP(hipMemsetAsync(r->vis_count_set[r->sc_cur ^ 1], 0, sizeof(uint32_t) * kSubLists * kCountStride, sR));   // (k_update_and_create's side job)
   if (!front_only) { SlotTimer t(r, sR, kSlotIntegrate);
     const uint32_t nfb = (uint32_t)r->n_scan_blocks;
     const dim3 gi(nfb + (uint32_t)r->grid_list);
@@ -3496,9 +3512,9 @@ static int invalidate_derived(smx_recon r, hipStream_t st) {
   SMX_HIP(hipMemsetAsync(r->L.vis_seg, 0, (size_t)r->nseg * 4, st));
   SMX_HIP(hipMemsetAsync(r->L.seg_box, 0, (size_t)r->nseg * 8 * sizeof(float), st));
   SMX_HIP(hipMemsetAsync(r->L.recent_seg, 0, (size_t)r->nsegB * 4, st));
-  SMX_HIP(hipMemsetAsync(r->vis_count_set[0], 0, 4, st));
-  SMX_HIP(hipMemsetAsync(r->vis_count_set[1], 0, 4, st));
-  SMX_HIP(hipMemsetAsync(r->L.rec_chunks.count, 0, 4, st));
+  SMX_HIP(hipMemsetAsync(r->vis_count_set[0], 0, sizeof(uint32_t) * kSubLists * kCountStride, st));
+  SMX_HIP(hipMemsetAsync(r->vis_count_set[1], 0, sizeof(uint32_t) * kSubLists * kCountStride, st));
+  SMX_HIP(hipMemsetAsync(r->L.rec_chunks.count, 0, sizeof(uint32_t) * kSubLists * kCountStride, st));
   hipLaunchKernelGGL(k_rebuild_flags, dim3(r->grid_surfels), dim3(kBlock), 0, st, r->S, 0u, 0x7FFFFFFF, r->L.flags8, r->st);
   SMX_LAUNCH_CHECK();
   r->table_valid = false;
