@@ -581,8 +581,10 @@ def pmc_file(config="C2"):
     return d, None
 
 
-PMC_NOTE = ("HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB): the x2 is the guide's correction for wide coalesced reads on gfx950; "
-            "profiles/r17_counter_calibration.md has the factors measured for this design's own access patterns")
+PMC_NOTE = ("HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB).  Calibrated on known byte counts in this design's own access patterns "
+            "(profiles/r17_counter_calibration.md): every read request to memory is 128 bytes and FETCH_SIZE books it as 64, for "
+            "streams and 16-byte gathers alike (a gather moves the whole 128-byte line); WRITE_SIZE is exact (32-byte requests for "
+            "sparse 16-byte stores)")
 
 
 def pmc_bytes(k):
@@ -930,15 +932,18 @@ def run_c5(args):
         k = next((v for name, v in pmc.items() if name.startswith("k_query_lanes")), {})
         c5_traffic = pmc_bytes(k)
         if "SQ_INSTS_VALU" in k:
-            # one wave64 VALU instruction occupies a SIMD for 4 cycles: a CU issues at most one per cycle
-            peak = 256 * 2.4e9
+            # a wave64 VALU instruction issues over 2 cycles on a SIMD-32, four SIMDs per CU: two per CU per cycle
+            # (measured: 1.79 with v_add_f32 at 8 wavefronts per SIMD, profiles/r17_counter_calibration.md)
+            peak = 256 * 2 * 2.4e9
             rate = k["SQ_INSTS_VALU"] / (ms_step * 1e-3)
             c5_valu = {"bound": "valu-issue", "kernel": "k_query_lanes", "valu_wave_instructions_per_launch": k["SQ_INSTS_VALU"],
                        "salu_wave_instructions_per_launch": k.get("SQ_INSTS_SALU"), "waves_per_launch": k.get("SQ_WAVES"),
                        "valu_wave_instructions_per_query": k["SQ_INSTS_VALU"] / n,
                        "achieved": rate / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s", "frac": rate / peak,
-                       "note": "SQ_INSTS_VALU of the committed PMC pass / this run's step time; peak = 256 CUs x 1 VALU "
-                               "wave-instruction per cycle x 2.4 GHz"}
+                       "frac_of_measured_ceiling": rate / (256 * 1.79 * 2.4e9),
+                       "note": "SQ_INSTS_VALU of the committed PMC pass / this run's step time; peak = 256 CUs x 2 VALU "
+                               "wave-instructions per cycle x 2.4 GHz (4 SIMD-32 per CU, 2 cycles per wave64 instruction); the "
+                               "measured ceiling is 1.79 per CU per cycle (profiles/r17_counter_calibration.md)"}
     result = {
         "metric": "radius-neighbor queries/s, every one of 50M surfels queries its own neighbourhood, K=64 (BASELINE.json configs[4])",
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": ms_step,
