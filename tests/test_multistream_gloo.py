@@ -94,3 +94,32 @@ def test_bench_dry_run_single_rank():
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["dry_run"] and d["n_gpus"] == 1 and d["units_all_ranks"] == 4
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """C4 readiness without the 8-GPU node: bench.py's REAL timed path with two ranks under torch.distributed.run, process
+    group gloo (RCCL refuses two ranks on one device; the streams are independent, the only collectives are the barrier and
+    the MAX / SUM reductions of the timing).  Both ranks grow their own map on the one GPU, run the timed window
+    concurrently, and check their own stream against the oracle; rank 0 prints one line with n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    from common import ROOT
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--backend", "gloo", "--surfels", "300000", "--steps", "20", "--warmup", "5",
+                        "--cpu-frames", "2", "--host-frames", "0", "--check-all-ranks", "--quiet"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["backend"] == "gloo" and d["config"]["streams"] == 2
+    checks = d["parity_check_per_rank"]
+    assert len(checks) == 2
+    for c in checks:
+        assert c["counts_equal"] and c["rows_not_bit_equal"] == [] and c["frames"] == 2, checks
