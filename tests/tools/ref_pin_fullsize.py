@@ -37,12 +37,20 @@ need = set()
 for p in plan:
     need.add(p[0]); need.update(p[1])
 colors = {}
+# Conflicts at full size (the plain re-traversal integrates into a consistent map and sees none): a disc of
+# the image is pushed 25 % farther away in every frame of the pin -- a hole opens behind mapped surface, the surfels in
+# front of it are seen through (free-space carving: conflict, confidence decrement, replacement).
+yy, xx = np.mgrid[0:480, 0:640]
+hole = (xx - 400) ** 2 + (yy - 200) ** 2 <= 70 ** 2
 for f in sorted(need):
     d, c = wl.pipe.download_frame(f)
+    d = d.copy()
+    d[hole & (d > 0)] = np.minimum(65535, d[hole & (d > 0)].astype(np.float64) * 1.25).astype(np.uint16)
     pf.upload(f, d, c); colors[f] = c
 params = orc.IntegrateParams.defaults()
 report = {"what": "reference kernels (oracle/_ref, compiled from /root/reference) vs the CPU oracle at the bench's size, "
                   "same state and preprocessed frame per frame, the reference run's race outcomes imposed on the oracle",
+          "conflict_stream": "a disc of 70 px radius pushed 25 % farther away in every frame (a hole behind mapped surface)",
           "width": 640, "height": 480, "slots_at_start": int(S.shape[1]), "merged_at_start": int(merge0), "frames": []}
 for f, others, T, pose in plan:
     pf.preprocess(f, others, T)
@@ -81,6 +89,7 @@ for f, others, T, pose in plan:
     report["frames"].append({
         "frame": int(f), "slots": [int(n), int(cr['surfels_size'])], "merges": [int(po.merge_count), int(cr['merge_count'])],
         "new": [int(po.stats()['n_new']), int(cr['n_new'])], "race_outcomes": {k: int(v) for k, v in ovr.items()},
+        "conflict_hits": int(po.stats()['n_conflict_hits']), "replaced": int(po.stats()['n_replaced']),
         "association_images_differing_pixels": {
             "supporting": int((so['supporting'] != sr['supporting']).sum()), "counts": int((so['support_counts'] != sr['support_counts']).sum()),
             "conflicting": int((so['conflicting'] != sr['conflicting']).sum()),
