@@ -37,20 +37,29 @@ need = set()
 for p in plan:
     need.add(p[0]); need.update(p[1])
 colors = {}
-# Conflicts at full size (the plain re-traversal integrates into a consistent map and sees none): a disc of
-# the image is pushed 25 % farther away in every frame of the pin -- a hole opens behind mapped surface, the surfels in
+# Conflicts at full size (the plain re-traversal integrates into a consistent map and sees none): a patch of
+# the surface is pushed 25 % farther away in every frame of the pin -- a hole opens behind mapped surface, the surfels in
 # front of it are seen through (free-space carving: conflict, confidence decrement, replacement).
+# The hole is fixed in the WORLD (a sphere around the point the first pin frame sees at pixel (400, 200)): a disc fixed in
+# the image moves over the surface with the camera, and the 9-frame outlier cull removes it.
 yy, xx = np.mgrid[0:480, 0:640]
-hole = (xx - 400) ** 2 + (yy - 200) ** 2 <= 70 ** 2
+def world_points(f, d):
+    R, t = bench.pose64(f - first + 4, 0.0)
+    z = d.astype(np.float64) / wl.pre.depth_scaling
+    pc = np.stack([(xx + 0.5 - wl.cx) / wl.fx * z, (yy + 0.5 - wl.cy) / wl.fy * z, z], -1)
+    return pc @ R.T + t
+d0, _ = wl.pipe.download_frame(plan[0][0])
+centre = world_points(plan[0][0], d0)[200, 400]
 for f in sorted(need):
     d, c = wl.pipe.download_frame(f)
     d = d.copy()
-    d[hole & (d > 0)] = np.minimum(65535, d[hole & (d > 0)].astype(np.float64) * 1.25).astype(np.uint16)
+    hole = (np.linalg.norm(world_points(f, d) - centre, axis=-1) < 0.35) & (d > 0)
+    d[hole] = np.minimum(65535, d[hole].astype(np.float64) * 1.25).astype(np.uint16)
     pf.upload(f, d, c); colors[f] = c
 params = orc.IntegrateParams.defaults()
 report = {"what": "reference kernels (oracle/_ref, compiled from /root/reference) vs the CPU oracle at the bench's size, "
                   "same state and preprocessed frame per frame, the reference run's race outcomes imposed on the oracle",
-          "conflict_stream": "a disc of 70 px radius pushed 25 % farther away in every frame (a hole behind mapped surface)",
+          "conflict_stream": "the surface inside a world-fixed sphere of 0.35 m pushed 25 % farther away in every frame (a hole behind mapped surface)",
           "width": 640, "height": 480, "slots_at_start": int(S.shape[1]), "merged_at_start": int(merge0), "frames": []}
 for f, others, T, pose in plan:
     pf.preprocess(f, others, T)
