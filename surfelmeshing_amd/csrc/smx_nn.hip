@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "smx_common.hpp"
 
@@ -206,6 +207,9 @@ void exclusive_scan_inplace(uint32_t* data, size_t n, uint32_t* ws, hipStream_t 
 }
 
 // ---- LSD radix sort of (u64 key, u32 value), 8 bits per pass ----------------------------------------------------------
+// (Round 4 measured 11-bit digits -- 3 passes instead of 5 for the 33-bit keys of C5, 4096-key tiles: index build 4.1 ->
+// 5.4 ms.  A pass scatters a tile's keys in runs of tile / radix: 8 keys = 64 bytes with 256 digits, 2 keys = 16 bytes with
+// 2048 -- half of every 32-byte sector and the 4-byte values worse; fewer passes do not make up for it.)
 // A tile of 2048 keys per workgroup.  Histogram: LDS atomics, one store per (digit, tile).  Ranks: wave w owns the
 // 512 consecutive keys [w*512, (w+1)*512) of the tile and walks them 64 at a time; lanes with equal digits find each
 // other with 8 ballots, so the rank of a key among the equal digits before it is a popcount -- stable, no atomics.
@@ -702,13 +706,16 @@ k_query_tiles(QueryArgs a) {
 // more than kLaneCap matches, a region of more than 64 bricks or more than kStageL points -- is marked and answered
 // by k_query_tiles afterwards (same launch sequence, no host round trip).
 #ifndef SMX_STAGE_L
-#define SMX_STAGE_L 288
+#define SMX_STAGE_L 256
 #endif
 constexpr int kStageL = SMX_STAGE_L;     // staged points per tile, after the box filter (a surfel surface at cell = 1.5 x spacing: 60 - 100).
+static_assert(kStageL <= 256, "a lane's list holds stage positions as bytes");
 // LDS decides how many of these one-wavefront workgroups a CU holds, and the kernel lives on that: 768 entries (17 KB with the
-// lists) 2.86 G queries/s at C5, 512: 3.32, 384: 3.87, 288 (9 KB: what the sorted keys need anyway): 4.26 -- profiles/r14_c5_stage.txt
-constexpr int kLaneCap = 32;     // entries of a lane's private list (positions in the stage: 2 bytes each)
-constexpr int kLaneStride = kLaneCap + 2;   // (in 16-bit units: an odd number of 32-bit words per lane)
+// lists) 2.86 G queries/s at C5, 512: 3.32, 384: 3.87, 288 (9 KB: what the sorted keys needed to park in) 4.26 --
+// profiles/r14_c5_stage.txt.  Round 4: the sorted rows leave the registers directly (no parking), the lists hold bytes,
+// the staging loop's two small tables lie over the lists: 6.25 KB, 25 workgroups per CU.
+constexpr int kLaneCap = 32;     // entries of a lane's private list (positions in the stage: 1 byte each)
+constexpr int kLaneStride = kLaneCap + 4;   // bytes: 33 entries (the last one is the spare a full list keeps overwriting), an odd number of 32-bit words per lane
 
 // The lane's matches, sorted in registers by Batcher's odd-even merge network over 64-bit keys (dist^2 bits << 32 |
 // index: a non-negative float orders like its bit pattern, so one unsigned 64-bit compare is the (dist^2, index) order),
@@ -716,7 +723,7 @@ constexpr int kLaneStride = kLaneCap + 2;   // (in 16-bit units: an odd number o
 // the wavefront sorts its own list at the same time: N = 16 costs 63 compare-exchanges for all 64 queries together,
 // where ranking the matches of one query after the other costs about as much per QUERY.
 template <int N>
-__device__ __forceinline__ void sort_lane_matches(const float4* __restrict__ stage, const uint16_t* __restrict__ l_pos, uint32_t lbase,
+__device__ __forceinline__ void sort_lane_matches(const float4* __restrict__ stage, const uint8_t* __restrict__ l_pos, uint32_t lbase,
                                                   uint32_t n, float px, float py, float pz, unsigned long long (&key)[N]) {
 #pragma unroll
   for (int e = 0; e < N; ++e) {
@@ -727,6 +734,7 @@ __device__ __forceinline__ void sort_lane_matches(const float4* __restrict__ sta
       const float d2 = dx * dx + dy * dy + dz * dz;   // (the same subtraction and sum as in the test that accepted it)
       key[e] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)__float_as_uint(rec.w);
     }
+    if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (four records in flight at a time: all N of them cost 4 N registers)
   }
 #pragma unroll
   for (int p = 1; p < N; p <<= 1)
@@ -749,10 +757,13 @@ __global__ void __launch_bounds__(64)
 k_query_lanes(QueryArgs a) {
   // one block: the stage, then the lanes' lists; the sorted keys later lie over both (neither is needed any more once
   // every lane holds its keys in registers).  LDS is what limits the wavefronts per CU here.
-  __shared__ __align__(16) unsigned char lds_block[sizeof(float4) * kStageL + sizeof(uint16_t) * 64 * kLaneStride];
+  __shared__ __align__(16) unsigned char lds_block[sizeof(float4) * kStageL + 64 * kLaneStride];
   float4* stage = reinterpret_cast<float4*>(lds_block);
-  uint16_t* l_pos = reinterpret_cast<uint16_t*>(lds_block + sizeof(float4) * kStageL);
-  __shared__ uint32_t seg_end[64], seg_src[64];
+  uint8_t* l_pos = lds_block + sizeof(float4) * kStageL;
+  // (the staging loop's tables lie over the lists: the lists are written by the walk, which follows the staging)
+  static_assert(2 * 64 * sizeof(uint32_t) <= 64 * kLaneStride, "seg_end / seg_src fit the list area");
+  uint32_t* seg_end = reinterpret_cast<uint32_t*>(l_pos);
+  uint32_t* seg_src = seg_end + 64;
   const uint32_t lane = threadIdx.x;
   const Grid& g = a.g;
   const uint32_t n_tiles = kSelf ? a.mask + 1u : *a.n_tiles;
@@ -879,7 +890,7 @@ k_query_lanes(QueryArgs a) {
                   if (ok && (a.state[__float_as_uint(rec[u].w)] & a.skip_mask)) ok = false;
                 }
                 if (ok) {
-                  l_pos[lbase + min(cnt, (uint32_t)kLaneCap)] = (uint16_t)(k0 + u);
+                  l_pos[lbase + min(cnt, (uint32_t)kLaneCap)] = (uint8_t)(k0 + u);
                   ++cnt;
                 }
               }
@@ -895,33 +906,39 @@ k_query_lanes(QueryArgs a) {
       for (int off = 32; off > 0; off >>= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, off));
       __syncthreads();
       if (n_max <= 16u) {   // (uniform) the usual case: every lane sorts its own matches in registers
-        constexpr int kOutStride = 17;
-        unsigned long long* o_key = reinterpret_cast<unsigned long long*>(lds_block);   // (stage and lists are free once the keys are formed)
-        static_assert(sizeof(unsigned long long) * 64 * kOutStride <= sizeof(lds_block), "the output rows fit the block");
+        // ... and writes its own row from them: 16-byte stores while whole groups of four entries lie inside the row (the
+        // rows are 16-byte aligned when K is a multiple of 4), single entries for the rest.  (Rounds 2-3 parked the keys
+        // lane-major in LDS and wrote the rows one query at a time, entry e from lane e: 8.7 KB of LDS -- what capped the
+        // workgroups per CU -- and a loop of 34 broadcasts + stores per tile.)
+        auto rows_out = [&](auto& key, auto n_const) {
+          constexpr int N = decltype(n_const)::value;
+          if (have && n_out) {
+            uint32_t* oi = a.out_idx + (size_t)q * K;
+            float* od = a.out_d2 + (size_t)q * K;
+            const bool wide = (K & 3) == 0;
+#pragma unroll
+            for (int e = 0; e < N; e += 4) {
+              if ((uint32_t)e >= n_out) break;
+              if (wide && (uint32_t)(e + 4) <= n_out) {
+                *reinterpret_cast<uint4*>(oi + e) = make_uint4((uint32_t)key[e], (uint32_t)key[e + 1], (uint32_t)key[e + 2], (uint32_t)key[e + 3]);
+                *reinterpret_cast<float4*>(od + e) = make_float4(__uint_as_float((uint32_t)(key[e] >> 32)), __uint_as_float((uint32_t)(key[e + 1] >> 32)),
+                                                                 __uint_as_float((uint32_t)(key[e + 2] >> 32)), __uint_as_float((uint32_t)(key[e + 3] >> 32)));
+              } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                  if ((uint32_t)(e + u) < n_out) { oi[e + u] = (uint32_t)key[e + u]; od[e + u] = __uint_as_float((uint32_t)(key[e + u] >> 32)); }
+              }
+            }
+          }
+        };
         if (n_max <= 8u) {
           unsigned long long key[8];
           sort_lane_matches<8>(stage, l_pos, lane * kLaneStride, n, px, py, pz, key);
-          __syncthreads();
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o_key[lane * kOutStride + e] = key[e];
+          rows_out(key, std::integral_constant<int, 8>());
         } else {
           unsigned long long key[16];
           sort_lane_matches<16>(stage, l_pos, lane * kLaneStride, n, px, py, pz, key);
-          __syncthreads();
-#pragma unroll
-          for (int e = 0; e < 16; ++e) o_key[lane * kOutStride + e] = key[e];
-        }
-        __syncthreads();
-        // rows out, one query at a time: lane e writes entry e (one contiguous piece of each output row)
-        for (uint32_t ql = 0; ql < nt; ++ql) {
-          const uint32_t nq = lane_u(n_out, (int)ql);
-          if (nq == 0) continue;   // (uniform)
-          const uint32_t qq = lane_u(q, (int)ql);
-          if (lane < nq) {
-            const unsigned long long kv = o_key[ql * kOutStride + lane];
-            a.out_idx[(size_t)qq * K + lane] = (uint32_t)kv;
-            a.out_d2[(size_t)qq * K + lane] = __uint_as_float((uint32_t)(kv >> 32));
-          }
+          rows_out(key, std::integral_constant<int, 16>());
         }
       } else {
       // Rows out, one query at a time: lane e takes the query's e-th match (recomputed from the stage: the same
