@@ -275,6 +275,32 @@ def test_stream_parity_with_skipped_segments(smx, overlap):
     assert min(skipped[-10:]) >= 1, (n_segments, skipped)
 
 
+def test_culled_segments_and_standalone_regularize(smx):
+    """Pass A's cull step and the flag bytes of culled segments (round 4): a camera that turns away leaves segments culled
+    for many calls in a row -- from the third call on their flag bytes are no longer copied between the two copies of the
+    flag table.  A standalone Regularize with ANOTHER window in the middle rewrites the current copy for every slot (recent
+    bits appear in culled segments), so the copies have to be made again afterwards; the frames that follow -- more culled
+    calls, then the camera coming back -- must match the oracle frame by frame, regulariser included."""
+    s = small_stream(yaw_deg_per_frame=3.0, obstacle_until=8)
+    kw = dict(surfel_integration_active_window_size=4, regularization_frame_window_size=3)
+    po, pg = _pipes(smx, s, 200000, params_kw=kw)
+    pg.reconstruction.set_stats_enabled(False)
+
+    def check(f):
+        _compare_state(po, pg, check_stats=False)
+
+    run_both(po, pg, s, list(range(4, 40)), check)
+    skipped_before = pg.reconstruction.debug_count_skipped_segments()
+    assert skipped_before >= 5, skipped_before
+    for window in (40, 3):   # a window that makes old slots recent again, then the stream's own
+        po.recon.regularize(39, 10.0, 2.0, window)
+        pg.reconstruction.Regularize(None, 39, 10.0, 2.0, window)
+        _compare_state(po, pg, check_scratch=False, check_stats=False)
+    run_both(po, pg, s, list(range(40, 60)), check)
+    s2 = small_stream(yaw_deg_per_frame=-3.0, start_yaw_deg=3.0 * 120, obstacle_until=-1)
+    run_both(po, pg, s2, list(range(60, 85)), check)
+
+
 @pytest.mark.parametrize("w,h,scan_mode", [(170, 101, 0), (97, 64, 0), (170, 101, 128), (97, 64, 128)])
 def test_stream_parity_image_sizes_that_cut_tiles(smx, w, h, scan_mode):
     """Image sizes that are no multiple of the association tiles (32 x 8), the blend tiles (32 x 32, or 40 x 40 with
