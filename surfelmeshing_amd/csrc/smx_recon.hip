@@ -1493,7 +1493,7 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
       if (L.dirty8) L.dirty8[i] = 1;
       *S.group(kGroupP, i) = R.P; *S.group(kGroupN, i) = R.N; *S.group(kGroupC, i) = R.C;
       if (R.replaced) {
-        S.f(kSmoothX, i) = R.new_smooth.x; S.f(kSmoothY, i) = R.new_smooth.y; S.f(kSmoothZ, i) = R.new_smooth.z;
+        *S.group(kGroupS, i) = make_float4(R.new_smooth.x, R.new_smooth.y, R.new_smooth.z, 0.0f);   // (whole records: see k_reg_step)
         S.set_neighbors(i, make_uint4(kInvalid, kInvalid, kInvalid, kInvalid));
       }
     }
@@ -1744,16 +1744,15 @@ __device__ __forceinline__ void new_create_body(const Surfels& S, const FrameCtx
     }
     *S.group(kGroupP, i) = make_float4(gp.x, gp.y, gp.z, __uint_as_float(c.frame));                       // X, Y, Z, LastUpdateStamp
     *S.group(kGroupN, i) = make_float4(gn.x, gn.y, gn.z, r2);                                              // normal, RadiusSquared
-    S.f(kConfidence, i) = 1;
-    S.u(kCreationStamp, i) = c.frame;
-    S.u(kColor, i) = (uint32_t)col.x | ((uint32_t)col.y << 8) | ((uint32_t)col.z << 16);
+    // (whole 16-byte records, the unused fourth words included: a sector that is not fully dirty is written back as a slow partial write)
+    *S.group(kGroupC, i) = make_float4(1.0f, __uint_as_float(c.frame),
+                                       __uint_as_float((uint32_t)col.x | ((uint32_t)col.y << 8) | ((uint32_t)col.z << 16)), 0.0f);
     flags8[i] = make_flags(c.frame, 0u, c.frame, c.reg_window);
     a.hot_epoch[i >> a.hot_shift] = (uint8_t)a.epoch;
     if (a.dirty8) a.dirty8[i] = 1;
     S.set_neighbors(i, make_uint4(nbs[0], nbs[1], nbs[2], nbs[3]));
-    S.f(kSmoothX, i) = (gp.x + sum.x) / (float)count_plus_1;  // :227-229
-    S.f(kSmoothY, i) = (gp.y + sum.y) / (float)count_plus_1;
-    S.f(kSmoothZ, i) = (gp.z + sum.z) / (float)count_plus_1;
+    *S.group(kGroupS, i) = make_float4((gp.x + sum.x) / (float)count_plus_1, (gp.y + sum.y) / (float)count_plus_1,
+                                       (gp.z + sum.z) / (float)count_plus_1, 0.0f);  // :227-229
   }
 }
 
@@ -2157,9 +2156,12 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
 #pragma unroll
   for (int sub = 0; sub < kSegAcc / kBlockAcc; ++sub) {
     const uint32_t rel = sub * kBlockAcc + threadIdx.x;
+    // (every slot of the segment, zeros included: 16 KB of full lines per workgroup.  Storing only the non-zero sums left
+    // holes -- partial sectors, which this chip writes back at a seventh of the rate of full ones -- and obliged the step
+    // kernel to zero what it had read; the step only ever reads the entries of recent slots, whose segment is rewritten
+    // here in every pass that precedes it.)
     const unsigned long long v0 = lacc[rel], v1 = lacc[kSegAcc + rel];
-    if (v0 | v1)
-      *reinterpret_cast<ulonglong2*>(&grad_local[2 * (size_t)(base + rel)]) = make_ulonglong2(v0, v1);
+    *reinterpret_cast<ulonglong2*>(&grad_local[2 * (size_t)(base + rel)]) = make_ulonglong2(v0, v1);
   }
   __syncthreads();
 #pragma unroll
@@ -2262,8 +2264,6 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long*
       // exact fixed-point sums: terms from the own segment (summed in LDS by k_reg_accumulate, stored plainly), from
       // other segments (the bin) and, rarely, from grad_acc; integer addition, so the split does not matter
       ulonglong2 acc2 = rl[sub];
-      ulonglong2* lp = reinterpret_cast<ulonglong2*>(&grad_local[2 * (size_t)i]);
-      if (acc2.x | acc2.y) *lp = make_ulonglong2(0, 0);   // keep the accumulators zero between calls
       if (n_far) { acc2.x += lfar[i - seg_base]; acc2.y += lfar[kSegB + (i - seg_base)]; }
       if (spilled) {
         ulonglong2* ap = reinterpret_cast<ulonglong2*>(&grad_acc[2 * (size_t)i]);
@@ -2303,9 +2303,10 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long*
       // No kernel reads another slot's smooth position after k_reg_accumulate, so the result goes straight to the
       // S record: the reference's parking rows and RegularizeSurfelsCUDAUpdateKernel (:2283-2308) are not needed.
       if (L.dirty8) L.dirty8[i] = 1;
-      S.f(kSmoothX, i) = sp.x - step * grad.x;
-      S.f(kSmoothY, i) = sp.y - step * grad.y;
-      S.f(kSmoothZ, i) = sp.z - step * grad.z;
+      // (ONE 16-byte store, the unused fourth word included: three scalar stores leave four bytes of every record clean, so
+      // no 64-byte sector of the S array is ever fully dirty and every write-back is a partial one -- sparse stores retire
+      // at 21 G/s = 0.7 TB/s on this chip against 5 TB/s for full sectors, profiles/r17_counter_calibration.md)
+      *S.group(kGroupS, i) = make_float4(sp.x - step * grad.x, sp.y - step * grad.y, sp.z - step * grad.z, rs[sub].w);
     }
   }
 }
@@ -2322,9 +2323,8 @@ k_reg_copy_raw(Surfels S, Lists L, const DevState* st) {
     for (uint32_t e = threadIdx.x; e < total; e += kBlock) {
       const uint32_t i = L.recent_list[seg * kSegB + e];
       if (L.dirty8) L.dirty8[i] = 1;
-      S.f(kSmoothX, i) = S.f(kX, i);
-      S.f(kSmoothY, i) = S.f(kY, i);
-      S.f(kSmoothZ, i) = S.f(kZ, i);
+      const float4 p4 = *S.group(kGroupP, i);
+      *S.group(kGroupS, i) = make_float4(p4.x, p4.y, p4.z, 0.0f);
     }
   }
 }

@@ -139,9 +139,9 @@ static void run_pmc() {
   load_idx(4, 0, n);
   hipLaunchKernelGGL(cal_rmw16, dim3(grid), dim3(kBlock), 0, 0, a, idx, n); flush();
   printf("expect cal_rmw16 %zu %zu # one record per 64-byte line (incl. %zu index bytes read)\n", (size_t)n * 16 + (size_t)n * 4, (size_t)n * 16, (size_t)n * 4);
-  load_idx(64, 0, n);   // one byte per 64-byte line of a byte array (idx = byte offsets: stride 64)
+  load_idx(16, 0, n);   // one byte per 16 bytes of a byte array (idx = byte offsets)
   hipLaunchKernelGGL(cal_scatter1, dim3(grid), dim3(kBlock), 0, 0, reinterpret_cast<uint8_t*>(a), idx, n); flush();
-  printf("expect cal_scatter1 %zu %zu # one byte per 64-byte line\n", (size_t)n * 4, (size_t)n);
+  printf("expect cal_scatter1 %zu %zu # one byte per 16 bytes\n", (size_t)n * 4, (size_t)n);
   hipLaunchKernelGGL(cal_stream_write16, dim3(grid), dim3(kBlock), 0, 0, a, g16); flush();
   printf("expect cal_stream_write16 0 %zu\n", g16 * 16);
   hipLaunchKernelGGL(cal_stream_write4, dim3(grid), dim3(kBlock), 0, 0, reinterpret_cast<uint32_t*>(a + g16), g16 * 4); flush();
@@ -213,11 +213,55 @@ static void valu_case(const char* name, int cus) {
   CK(hipFree(out)); CK(hipFree(cyc));
 }
 
+// ---- achievable bandwidth per pattern (calib bw): the same kernels, timed; bytes = what the request counters showed
+// they move (128 bytes per gathered record, 32 per sparse 16-byte store)
+template <class F>
+static double time_ms(F f) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  f(); CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, 0));
+  for (int r = 0; r < 3; ++r) f();
+  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+  float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / 3.0;
+}
+static void run_bw() {
+  const size_t bytes = (size_t)3 << 30;
+  const size_t rec = bytes / 16;
+  uint4* a; uint32_t* out; uint32_t* idx;
+  CK(hipMalloc(&a, bytes)); CK(hipMalloc(&out, 64)); CK(hipMemset(a, 1, bytes));
+  const uint32_t n = 8u << 20;
+  CK(hipMalloc(&idx, (size_t)n * 4));
+  const size_t g16 = ((size_t)1 << 30) / 16;
+  auto load_idx = [&](uint32_t stride, int shape) {
+    const std::vector<uint32_t> h = make_idx(n, stride, rec, shape);
+    CK(hipMemcpy(idx, h.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  };
+  for (int grid : {256 * 8, 256 * 32}) {
+    double ms = time_ms([&] { hipLaunchKernelGGL(cal_stream_read16, dim3(grid), dim3(kBlock), 0, 0, a, g16 * 3, out); });
+    printf("bw grid %5d  stream read 3 GiB            %7.3f ms  %6.2f TB/s\n", grid, ms, 3.0 * 1.0737 / ms);
+    ms = time_ms([&] { hipLaunchKernelGGL(cal_stream_write16, dim3(grid), dim3(kBlock), 0, 0, a, g16 * 3); });
+    printf("bw grid %5d  stream write 3 GiB           %7.3f ms  %6.2f TB/s\n", grid, ms, 3.0 * 1.0737 / ms);
+    load_idx(8, 0);
+    ms = time_ms([&] { hipLaunchKernelGGL(cal_gather16<1>, dim3(grid), dim3(kBlock), 0, 0, a, idx, n, out); });
+    printf("bw grid %5d  8 Mi shuffled 16 B gathers   %7.3f ms  %6.2f G gathers/s  %6.2f TB/s of 128-byte lines\n", grid, ms, n / ms / 1e6, n * 128.0 / ms / 1e9);
+    ms = time_ms([&] { hipLaunchKernelGGL(cal_scatter16<1>, dim3(grid), dim3(kBlock), 0, 0, a, idx, n); });
+    printf("bw grid %5d  8 Mi shuffled 16 B stores    %7.3f ms  %6.2f G stores/s\n", grid, ms, n / ms / 1e6);
+    ms = time_ms([&] { hipLaunchKernelGGL(cal_rmw16, dim3(grid), dim3(kBlock), 0, 0, a, idx, n); });
+    printf("bw grid %5d  8 Mi shuffled 16 B rmw       %7.3f ms  %6.2f G rmw/s\n", grid, ms, n / ms / 1e6);
+    load_idx(0, 1);
+    ms = time_ms([&] { hipLaunchKernelGGL(cal_gather16<2>, dim3(grid), dim3(kBlock), 0, 0, a, idx, n, out); });
+    printf("bw grid %5d  8 Mi gathers in runs of 48   %7.3f ms  %6.2f G gathers/s  %6.2f TB/s of record bytes\n", grid, ms, n / ms / 1e6, n * 16.0 / ms / 1e9);
+  }
+  CK(hipFree(a)); CK(hipFree(out)); CK(hipFree(idx));
+}
+
 int main(int argc, char** argv) {
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   printf("# device %s, %d CUs, clockRate %d kHz\n", prop.name, prop.multiProcessorCount, prop.clockRate);
   if (argc > 1 && !strcmp(argv[1], "pmc")) { run_pmc(); return 0; }
+  if (argc > 1 && !strcmp(argv[1], "bw")) { run_bw(); return 0; }
   const int cus = prop.multiProcessorCount;
   valu_case<0>("v_fma_f32", cus);
   valu_case<1>("v_pk_fma_f32", cus);
