@@ -434,10 +434,11 @@ def run_integrate(args):
     # the timed region; everything else is measured in separate passes.
     if warm_steps is not None:
         wl.pipe.run_array(*warm_steps)       # the W warm-up frames: directly in front of the timed region
-    if dominant in PRE_STAGES:
-        wl.pipe.profile_begin(PRE_STAGES.index(dominant), K)
-    else:
-        rec.profile_begin(dominant, K)
+    # (the roofline block is the HBM roofline of the longest HBM-side kernel; when a preprocessing stage is the longest kernel
+    # of the frame -- the VALU-bound bilateral filter -- it is named in the block with its VALU fractions, `roofline_valu`)
+    longest = dominant
+    dominant = dominant_hbm
+    rec.profile_begin(dominant, K)
     _lib.check(_lib.load().smx_debug_marker(None, 1))   # delimits the timed region in rocprofv3 kernel traces
     sync_all()
     t_start = time.perf_counter()
@@ -448,7 +449,7 @@ def run_integrate(args):
     fps, elapsed, _ = multistream.aggregate_throughput(K, elapsed_local, world, dist if world > 1 else None, reduce_device(args))
     if world > 1:
         dist.barrier()
-    dom_ms, dom_n = wl.pipe.profile_end() if dominant in PRE_STAGES else rec.profile_end()
+    dom_ms, dom_n = rec.profile_end()
     _lib.check(_lib.load().smx_debug_marker(None, 2))
     rec.debug_set_skip(0)
     P = width * height
@@ -538,9 +539,9 @@ def run_integrate(args):
         dist.all_gather_object(gathered, mine)
         parity_all = gathered
     if rank == 0:
-        result["roofline"] = roofline_block(st, P, dominant, dominant_hbm, dom_ms, dom_n, alone_ms, cal_ms,
-                                            1e3 * elapsed / K, args.config)
         result["roofline_valu"] = bilateral_valu_roofline(wl, api, torch, plan[0][0], cal_ms.get("bilateral"))
+        result["roofline"] = roofline_block(st, P, dominant, longest, dom_ms, dom_n, alone_ms, cal_ms,
+                                            1e3 * elapsed / K, args.config, result["roofline_valu"])
         if parity_all is not None:
             result["parity_check_per_rank"] = parity_all
         if host_pass is not None:
@@ -596,10 +597,12 @@ def pmc_bytes(k):
     return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
 
 
-def roofline_block(st, P, dominant, dominant_hbm, dom_ms, dom_n, alone_ms, in_frame_ms, ms_per_step, config="C2"):
-    """Roofline of the kernel that lasts longest IN THE FRAME (every kernel of the frame is a candidate, the preprocessing
-    stages included): algorithmic bytes per launch (ALG_BYTES) / average launch duration measured with time
-    stamps on its launch stream over the timed region.  `frame` = all kernels of one frame / the measured frame time, by
+def roofline_block(st, P, dominant, longest, dom_ms, dom_n, alone_ms, in_frame_ms, ms_per_step, config="C2", valu=None):
+    """HBM roofline of the HBM-side kernel that lasts longest IN THE FRAME: algorithmic bytes per launch (ALG_BYTES,
+    DESIGN.md) / average launch duration measured with time stamps on its launch stream over the timed region.  Every
+    kernel of the frame is judged (the preprocessing stages included): `longest_kernel_in_frame` names the overall longest
+    one -- the VALU-bound bilateral filter, whose fractions of the packed-FMA peak, alone and in the frame, ride along
+    (`roofline_valu`).  `frame` = all kernels of one frame / the measured frame time, by
     the algorithmic bytes of this run and by the PMC bytes of the committed profile of the same build.  `kernels` = every
     kernel alone (unpipelined pass, the measured cost of an empty pair of time stamps subtracted) and in the frame (the
     short calibration passes in front of the timed region)."""
@@ -645,10 +648,12 @@ def roofline_block(st, P, dominant, dominant_hbm, dom_ms, dom_n, alone_ms, in_fr
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_pmc_raw": raw, "traffic_refused": why,
             "frame": frame, "algorithmic_bytes_per_launch": alg,
             "avg_launch_ms": dom_ms, "launches_timed": dom_n, "surfel_slots": st["surfels_size"],
-            "longest_surfel_kernel_in_frame": dominant_hbm,
-            "note": ("the longest kernel in the frame is a preprocessing stage bound by VALU issue, not by HBM (4 bytes per pixel): "
-                     "its VALU roofline is `roofline_valu`; `longest_surfel_kernel_in_frame` names the longest HBM-side kernel, "
-                     "whose fractions are in `kernels`") if dominant in PRE_STAGES else None,
+            "longest_kernel_in_frame": {"kernel": longest, "in_frame_ms": in_frame_ms.get(longest),
+                                        "bound": "valu_fp32" if longest in PRE_STAGES else "hbm",
+                                        "frac_in_frame": (valu or {}).get("frac_in_frame") if longest == "bilateral" else None,
+                                        "frac_alone": (valu or {}).get("frac") if longest == "bilateral" else None,
+                                        "note": "bound by VALU issue, not by HBM (4 bytes per pixel): see roofline_valu"
+                                                if longest in PRE_STAGES else None},
             "event_overhead_ms": overhead,
             "kernels": per_kernel}
 
