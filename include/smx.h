@@ -123,6 +123,16 @@ int smx_outlier_depth_map_fusion(
     const smx_buffer_desc* input_depth, float fx, float fy, float cx, float cy,
     const smx_buffer_desc* other_depths /*[other_count]*/, const float* others_TR_reference,
     const smx_buffer_desc* output_depth);
+/* BilateralFilteringAndDepthCutoffCUDA (value_to_ignore = 0) followed by OutlierDepthMapFusionCUDA, as the reference's
+ * caller chains them (APP/main.cc:1015-1115), in ONE launch where the shape allows it (eight other frames, filter radius 1..8):
+ * the outlier test of a pixel only needs that pixel's own filtered depth.  Same output image as the two calls; scratch_depth
+ * (the intermediate image of the two-call form) is only written when the shape needs the two launches. */
+int smx_bilateral_outlier_fusion(
+    smx_stream s, float sigma_xy, float sigma_value_factor, float radius_factor, uint16_t max_depth,
+    float depth_valid_region_radius, const smx_buffer_desc* input_depth,
+    int32_t other_count, int32_t required_count, float tolerance, float fx, float fy, float cx, float cy,
+    const smx_buffer_desc* other_depths /*[other_count]*/, const float* others_TR_reference,
+    const smx_buffer_desc* scratch_depth, const smx_buffer_desc* output_depth);
 /* ErodeDepthMapCUDA (radius 1..3), cu:540-579; CopyWithoutBorderCUDA, cu:609-633 */
 int smx_erode_depth_map(smx_stream s, int32_t radius, const smx_buffer_desc* input_depth,
                         const smx_buffer_desc* output_depth);

@@ -223,6 +223,28 @@ void OutlierDepthMapFusionCUDA(cudaStream_t stream, int required_count, float to
                                               depth_fy, depth_cx, depth_cy, others, T, output_depth->desc()));
 }
 
+// BilateralFilteringAndDepthCutoffCUDA (value_to_ignore 0) + OutlierDepthMapFusionCUDA<count, u16> as the reference's caller
+// chains them (APP/main.cc:1015-1115), one launch where the library can fuse them (smx_bilateral_outlier_fusion); required_count
+// < 0 selects the all-must-agree overload.  `scratch` is the intermediate image of the two-call form.
+template <int count>
+void BilateralFilteringAndOutlierFusionCUDA(cudaStream_t stream, float sigma_xy, float sigma_value_factor, float radius_factor,
+                                            u16 max_depth, float depth_valid_region_radius, const CUDABuffer_<u16>& input_depth,
+                                            int required_count, float tolerance, float depth_fx, float depth_fy, float depth_cx,
+                                            float depth_cy, const CUDABuffer_<u16>** other_depths,
+                                            const CUDAMatrix3x4* others_TR_reference, CUDABuffer_<u16>* scratch,
+                                            CUDABuffer_<u16>* output_depth) {
+  smx_buffer_desc others[count - 1];
+  float T[(count - 1) * 12];
+  for (int i = 0; i < count - 1; ++i) {
+    others[i] = *other_depths[i]->desc();
+    for (int k = 0; k < 12; ++k) T[12 * i + k] = others_TR_reference[i].m[k];
+  }
+  SMX_SHIM_CHECK(smx_bilateral_outlier_fusion(stream, sigma_xy, sigma_value_factor, radius_factor, max_depth,
+                                              depth_valid_region_radius, input_depth.desc(), count - 1, required_count, tolerance,
+                                              depth_fx, depth_fy, depth_cx, depth_cy, others, T, scratch->desc(),
+                                              output_depth->desc()));
+}
+
 // Image<u16>::DownscaleUsingMedianWhileExcluding (libvis image.h:1003-1053, --pyramid_level's depth image) on device
 // buffers; the output buffer's size selects the source blocks.
 inline void DownscaleUsingMedianWhileExcludingCUDA(cudaStream_t stream, u16 value_to_ignore,

@@ -218,6 +218,22 @@ def OutlierDepthMapFusionCUDA(stream, tolerance, input_depth, depth_fx, depth_fy
         descs, T.ctypes.data_as(C.c_void_p), _d(output_depth)))
 
 
+def BilateralFilteringAndOutlierFusionCUDA(stream, sigma_xy, sigma_value_factor, radius_factor, max_depth,
+                                           depth_valid_region_radius, input_depth, tolerance, depth_fx, depth_fy, depth_cx,
+                                           depth_cy, other_depths, others_TR_reference, scratch_depth, output_depth,
+                                           required_count=-1):
+    """BilateralFilteringAndDepthCutoffCUDA (value_to_ignore 0) + OutlierDepthMapFusionCUDA as the reference's caller chains
+    them (APP/main.cc:1015-1115): one launch where the library can fuse them (smx_bilateral_outlier_fusion), same output."""
+    n = len(other_depths)
+    descs = (BufferDesc * n)(*[b.ToCUDA() if isinstance(b, CUDABuffer) else b for b in other_depths])
+    T = np.ascontiguousarray(np.asarray(others_TR_reference, np.float32).reshape(n, 12))
+    _lib.check(_lib.load().smx_bilateral_outlier_fusion(
+        _sv(stream), C.c_float(sigma_xy), C.c_float(sigma_value_factor), C.c_float(radius_factor), C.c_uint16(int(max_depth)),
+        C.c_float(depth_valid_region_radius), _d(input_depth), C.c_int32(n), C.c_int32(required_count), C.c_float(tolerance),
+        C.c_float(depth_fx), C.c_float(depth_fy), C.c_float(depth_cx), C.c_float(depth_cy),
+        descs, T.ctypes.data_as(C.c_void_p), _d(scratch_depth), _d(output_depth)))
+
+
 def ErodeDepthMapCUDA(stream, radius, input_depth, output_depth):
     _lib.check(_lib.load().smx_erode_depth_map(_sv(stream), C.c_int32(radius), _d(input_depth), _d(output_depth)))
 

@@ -193,10 +193,53 @@ constexpr int bil_half_width(int R, int dy) {
   return hw;
 }
 
-template <int R>
+struct OutlierParams {
+  Mat34 T[8];
+  Img<const uint16_t> others[8];
+};
+// everything the outlier test of one pixel needs besides the pixel (also an argument of the fused bilateral kernel)
+struct OutlierArgs {
+  int required_count; float max_tol, min_tol; float fx, fy, cx, cy; Unproj up; OutlierParams p;
+};
+// OutlierDepthMapFusionCUDAKernel for ONE pixel (both overloads, cu:168-227 and :337-397): depth d of pixel (x, y) -> d or 0
+template <int kOthers>
+__device__ __forceinline__ uint16_t outlier_pixel(uint16_t d, int x, int y, int W, int H, const OutlierArgs& a) {
+  if (d == 0) return 0;
+  const float fd = (float)d;
+  Vec3 rp;
+  rp.x = fd * (a.up.fx_inv * (float)x + a.up.cx_inv);
+  rp.y = fd * (a.up.fy_inv * (float)y + a.up.cy_inv);
+  rp.z = fd;
+  int ok_count = 0;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < kOthers; ++k) {
+    const Vec3 o = mul(a.p.T[k], rp);
+    bool good = false;
+    if (o.z > 0) {
+      const float u = a.fx * (o.x / o.z) + a.cx, v = a.fy * (o.y / o.z) + a.cy;
+      if (u > -1.0f && v > -1.0f && u < (float)W && v < (float)H) {
+        const int px = (int)u, py = (int)v;
+        const uint16_t od = a.p.others[k](py, px);
+        const float fod = (float)od;
+        if (!(od == 0 || fod > a.max_tol * o.z || fod < a.min_tol * o.z)) good = true;
+      }
+    }
+    if (good) ++ok_count;
+    else ok = false;
+  }
+  if (a.required_count < 0) return ok ? d : (uint16_t)0;
+  return (ok_count >= a.required_count) ? d : (uint16_t)0;
+}
+
+// kOthers > 0: the multi-frame outlier cull of the filtered pixel rides in the same launch (smx_bilateral_outlier_fusion):
+// it is a per-pixel test of the pixel's own filtered depth against the RAW depths of the other frames, so it needs nothing
+// the filter's other pixels produce -- and inside this kernel it runs on a CU the filter holds to itself anyway, instead of as a
+// thin kernel of its own on the SIMDs of the memory-bound surfel kernels (profiles/r17_ab_notes.md: r17p, r17q).
+template <int R, int kOthers = 0>
 __global__ void __launch_bounds__(kThreads)
 k_bilateral_p(float denom_xy, float sigma_value_factor, uint16_t value_to_ignore, uint16_t max_depth, float region_r2,
-              Img<const uint16_t> in, Img<uint16_t> out, int tiles_x, int n_tiles) {
+              Img<const uint16_t> in, Img<uint16_t> out, int tiles_x, int n_tiles, OutlierArgs oa) {
   constexpr int TW = kBilTileW + 2 * R, TH = kBilTileH + 2 * R;
   __shared__ float tile[TH * TW];
   __shared__ float spatial[R * R + 1];
@@ -276,7 +319,8 @@ k_bilateral_p(float denom_xy, float sigma_value_factor, uint16_t value_to_ignore
         sum += p[dx].y; weight += w[dx].y;
       }
     }
-    out(y, x) = (weight == 0) ? value_to_ignore : f2u16(sum / weight + 0.5f);
+    const uint16_t filtered = (weight == 0) ? value_to_ignore : f2u16(sum / weight + 0.5f);
+    out(y, x) = kOthers > 0 ? outlier_pixel<kOthers>(filtered, x, y, W, H, oa) : filtered;   // (fused: value_to_ignore is 0, what the cull calls "no depth")
   }
 }
 
@@ -284,45 +328,14 @@ k_bilateral_p(float denom_xy, float sigma_value_factor, uint16_t value_to_ignore
 // Multi-frame outlier cull.  Reference: OutlierDepthMapFusionCUDAKernel (both overloads),
 // cuda_depth_processing.cu:168-227 and :337-397.  Matrices and image descriptors travel in the
 // kernel-argument segment (SGPR-resident), the 8 scattered u16 probes hit L2 (9 x 600 KB).
-struct OutlierParams {
-  Mat34 T[8];
-  Img<const uint16_t> others[8];
-};
 template <int kOthers>
 __global__ void __launch_bounds__(kThreads)
-k_outlier(int required_count, float max_tol, float min_tol, Img<const uint16_t> in,
-          float fx, float fy, float cx, float cy, Unproj up, OutlierParams p, Img<uint16_t> out) {
+k_outlier(Img<const uint16_t> in, OutlierArgs a, Img<uint16_t> out) {
   const int x = blockIdx.x * kTileW + (threadIdx.x & (kTileW - 1));
   const int y = blockIdx.y * (kThreads / kTileW) + threadIdx.x / kTileW;
   const int W = out.width, H = out.height;
   if (x >= W || y >= H) return;
-  const uint16_t d = in(y, x);
-  if (d == 0) { out(y, x) = 0; return; }
-  const float fd = (float)d;
-  Vec3 rp;
-  rp.x = fd * (up.fx_inv * (float)x + up.cx_inv);
-  rp.y = fd * (up.fy_inv * (float)y + up.cy_inv);
-  rp.z = fd;
-  int ok_count = 0;
-  bool ok = true;
-#pragma unroll
-  for (int k = 0; k < kOthers; ++k) {
-    const Vec3 o = mul(p.T[k], rp);
-    bool good = false;
-    if (o.z > 0) {
-      const float u = fx * (o.x / o.z) + cx, v = fy * (o.y / o.z) + cy;
-      if (u > -1.0f && v > -1.0f && u < (float)W && v < (float)H) {
-        const int px = (int)u, py = (int)v;
-        const uint16_t od = p.others[k](py, px);
-        const float fod = (float)od;
-        if (!(od == 0 || fod > max_tol * o.z || fod < min_tol * o.z)) good = true;
-      }
-    }
-    if (good) ++ok_count;
-    else ok = false;
-  }
-  if (required_count < 0) out(y, x) = ok ? d : (uint16_t)0;
-  else out(y, x) = (ok_count >= required_count) ? d : (uint16_t)0;
+  out(y, x) = outlier_pixel<kOthers>(in(y, x), x, y, W, H, a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -653,10 +666,29 @@ inline dim3 grid_rows(int W, int H) { return dim3(div_up(W, kTileW), div_up(H, k
 
 extern "C" {
 
-int smx_bilateral_filtering_and_depth_cutoff(
-    smx_stream s, float sigma_xy, float sigma_value_factor, uint16_t value_to_ignore,
-    float radius_factor, uint16_t max_depth, float depth_valid_region_radius,
-    const smx_buffer_desc* input_depth, const smx_buffer_desc* output_depth) {
+namespace {
+int fill_outlier_args(OutlierArgs* oa, int32_t other_count, int32_t required_count, float tolerance, float fx, float fy,
+                      float cx, float cy, const smx_buffer_desc* other_depths, const float* others_TR_reference,
+                      const smx_buffer_desc* output_depth) {
+  SMX_CHECK_ARG(other_depths && others_TR_reference);
+  SMX_CHECK_ARG(other_count == 2 || other_count == 4 || other_count == 6 || other_count == 8);  // main.cc:1076-1086
+  memset(oa, 0, sizeof(*oa));
+  for (int i = 0; i < other_count; ++i) {
+    memcpy(oa->p.T[i].m, others_TR_reference + 12 * i, sizeof(float) * 12);
+    oa->p.others[i] = as_img<const uint16_t>(&other_depths[i]);
+    SMX_CHECK_ARG(other_depths[i].width == output_depth->width && other_depths[i].height == output_depth->height);
+  }
+  oa->required_count = required_count;
+  oa->max_tol = 1 + tolerance; oa->min_tol = 1 - tolerance;                        // cu:255-256
+  oa->fx = fx; oa->fy = fy; oa->cx = cx; oa->cy = cy;
+  oa->up = make_unproj(fx, fy, cx, cy);
+  return SMX_OK;
+}
+
+// (other_count = 0: the filter alone)
+int launch_bilateral(smx_stream s, float sigma_xy, float sigma_value_factor, uint16_t value_to_ignore, float radius_factor,
+                     uint16_t max_depth, float depth_valid_region_radius, const smx_buffer_desc* input_depth,
+                     const smx_buffer_desc* output_depth, int other_count, const OutlierArgs& oa) {
   SMX_CHECK_ARG(input_depth && output_depth);
   SMX_CHECK_ARG(input_depth->width == output_depth->width && input_depth->height == output_depth->height);
   const int radius = (int)(radius_factor * sigma_xy + 0.5f);                       // cu:135
@@ -672,21 +704,39 @@ int smx_bilateral_filtering_and_depth_cutoff(
   const float denom_xy = 2.0f * sigma_xy * sigma_xy, region_r2 = depth_valid_region_radius * depth_valid_region_radius;
   const Img<const uint16_t> src = as_img<const uint16_t>(input_depth);
   const Img<uint16_t> dst = as_img<uint16_t>(output_depth);
-#define SMX_BILATERAL(R)                                                                                          \
-  case R:                                                                                                         \
-    hipLaunchKernelGGL(k_bilateral_p<R>, grid, dim3(kThreads), 0, (hipStream_t)s, denom_xy, sigma_value_factor,   \
-                       value_to_ignore, max_depth, region_r2, src, dst, tiles_x, n_tiles);                        \
+#define SMX_BILATERAL_N(R, N)                                                                                        \
+  hipLaunchKernelGGL((k_bilateral_p<R, N>), grid, dim3(kThreads), 0, (hipStream_t)s, denom_xy, sigma_value_factor,   \
+                     value_to_ignore, max_depth, region_r2, src, dst, tiles_x, n_tiles, oa)
+#define SMX_BILATERAL(R)                                                                                             \
+  case R:                                                                                                            \
+    if (other_count == 0) SMX_BILATERAL_N(R, 0);                                                                     \
+    else SMX_BILATERAL_N(R, 8);                                                                                      \
     break
+  // (the fused form exists for eight other frames, the reference's default; smx_bilateral_outlier_fusion takes the two
+  // launches for every other count)
   switch (radius) {
     SMX_BILATERAL(1); SMX_BILATERAL(2); SMX_BILATERAL(3); SMX_BILATERAL(4);
     SMX_BILATERAL(5); SMX_BILATERAL(6); SMX_BILATERAL(7); SMX_BILATERAL(8);
     default:  // radius 0: the generic kernel
+      SMX_CHECK_ARG(other_count == 0);
       hipLaunchKernelGGL(k_bilateral, grid, dim3(kThreads), 0, (hipStream_t)s, denom_xy, sigma_value_factor, radius,
                          radius * radius, value_to_ignore, max_depth, region_r2, src, dst, tiles_x, n_tiles);
   }
 #undef SMX_BILATERAL
+#undef SMX_BILATERAL_N
   SMX_LAUNCH_CHECK();
   return SMX_OK;
+}
+}  // namespace
+
+int smx_bilateral_filtering_and_depth_cutoff(
+    smx_stream s, float sigma_xy, float sigma_value_factor, uint16_t value_to_ignore,
+    float radius_factor, uint16_t max_depth, float depth_valid_region_radius,
+    const smx_buffer_desc* input_depth, const smx_buffer_desc* output_depth) {
+  OutlierArgs oa;
+  memset(&oa, 0, sizeof(oa));
+  return launch_bilateral(s, sigma_xy, sigma_value_factor, value_to_ignore, radius_factor, max_depth, depth_valid_region_radius,
+                          input_depth, output_depth, 0, oa);
 }
 
 int smx_outlier_depth_map_fusion(
@@ -694,22 +744,13 @@ int smx_outlier_depth_map_fusion(
     const smx_buffer_desc* input_depth, float fx, float fy, float cx, float cy,
     const smx_buffer_desc* other_depths, const float* others_TR_reference,
     const smx_buffer_desc* output_depth) {
-  SMX_CHECK_ARG(input_depth && output_depth && other_depths && others_TR_reference);
-  SMX_CHECK_ARG(other_count == 2 || other_count == 4 || other_count == 6 || other_count == 8);  // main.cc:1076-1086
-  OutlierParams p;
-  memset(&p, 0, sizeof(p));
-  for (int i = 0; i < other_count; ++i) {
-    memcpy(p.T[i].m, others_TR_reference + 12 * i, sizeof(float) * 12);
-    p.others[i] = as_img<const uint16_t>(&other_depths[i]);
-    SMX_CHECK_ARG(other_depths[i].width == output_depth->width && other_depths[i].height == output_depth->height);
-  }
-  const float max_tol = 1 + tolerance, min_tol = 1 - tolerance;                    // cu:255-256
-  const Unproj up = make_unproj(fx, fy, cx, cy);
+  SMX_CHECK_ARG(input_depth && output_depth);
+  OutlierArgs oa;
+  { const int rc = fill_outlier_args(&oa, other_count, required_count, tolerance, fx, fy, cx, cy, other_depths, others_TR_reference, output_depth);
+    if (rc != SMX_OK) return rc; }
   dim3 grid = grid_rows(output_depth->width, output_depth->height);
   hipStream_t st = (hipStream_t)s;
-#define SMX_OUTLIER(N)                                                                                      \
-  hipLaunchKernelGGL(k_outlier<N>, grid, dim3(kThreads), 0, st, required_count, max_tol, min_tol,          \
-                     as_img<const uint16_t>(input_depth), fx, fy, cx, cy, up, p, as_img<uint16_t>(output_depth))
+#define SMX_OUTLIER(N) hipLaunchKernelGGL(k_outlier<N>, grid, dim3(kThreads), 0, st, as_img<const uint16_t>(input_depth), oa, as_img<uint16_t>(output_depth))
   switch (other_count) {
     case 2: SMX_OUTLIER(2); break;
     case 4: SMX_OUTLIER(4); break;
@@ -719,6 +760,29 @@ int smx_outlier_depth_map_fusion(
 #undef SMX_OUTLIER
   SMX_LAUNCH_CHECK();
   return SMX_OK;
+}
+
+int smx_bilateral_outlier_fusion(
+    smx_stream s, float sigma_xy, float sigma_value_factor, float radius_factor, uint16_t max_depth,
+    float depth_valid_region_radius, const smx_buffer_desc* input_depth,
+    int32_t other_count, int32_t required_count, float tolerance, float fx, float fy, float cx, float cy,
+    const smx_buffer_desc* other_depths, const float* others_TR_reference,
+    const smx_buffer_desc* scratch_depth, const smx_buffer_desc* output_depth) {
+  SMX_CHECK_ARG(input_depth && output_depth);
+  OutlierArgs oa;
+  { const int rc = fill_outlier_args(&oa, other_count, required_count, tolerance, fx, fy, cx, cy, other_depths, others_TR_reference, output_depth);
+    if (rc != SMX_OK) return rc; }
+  const int radius = (int)(radius_factor * sigma_xy + 0.5f);
+  if (other_count == 8 && radius >= 1 && radius <= kMaxBilateralRadius)   // one launch
+    return launch_bilateral(s, sigma_xy, sigma_value_factor, /*value_to_ignore*/ 0, radius_factor, max_depth, depth_valid_region_radius,
+                            input_depth, output_depth, 8, oa);
+  // any other shape: the two launches, through the scratch image
+  SMX_CHECK_ARG(scratch_depth != nullptr);
+  { const int rc = smx_bilateral_filtering_and_depth_cutoff(s, sigma_xy, sigma_value_factor, 0, radius_factor, max_depth,
+                                                            depth_valid_region_radius, input_depth, scratch_depth);
+    if (rc != SMX_OK) return rc; }
+  return smx_outlier_depth_map_fusion(s, other_count, required_count, tolerance, scratch_depth, fx, fy, cx, cy, other_depths,
+                                      others_TR_reference, output_depth);
 }
 
 int smx_erode_depth_map(smx_stream s, int32_t radius, const smx_buffer_desc* input_depth,

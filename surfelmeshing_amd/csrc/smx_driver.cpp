@@ -49,6 +49,7 @@ struct smx_driver_s {
   bool overlap = true;
   bool run_ahead = false;  // smx_driver_run: preprocessing two steps ahead, dependencies routed off the caller's stream (A/B: -1 %)
   bool fuse_tail = true;   // erosion + normals + radii as one launch (A/B: smx_driver_set_fused_tail)
+  bool fuse_head = true;   // bilateral filter + outlier cull as one launch (A/B: smx_driver_set_fused_head)
   unsigned long long frame_counter = 0;
   // smx_driver_debug_prepare: work sets preprocessed ahead of time, consumed in order by the next runs (measurement)
   std::vector<std::unique_ptr<WorkSet>> prepared;
@@ -100,8 +101,10 @@ static int preprocess_frame(smx_driver d, cudaStream_t stream, const smx_driver_
   it->second->last_reader = d->frame_counter;   // (run_one has already counted this step)
   const float* cam = d->camera.parameters();
 
+  const u16 max_depth_u16 = (u16)(c.depth_scaling * c.max_depth > 65535.f ? 65535.f : c.depth_scaling * c.max_depth);
+  const bool fused_head = d->fuse_head && st.other_count > 0;
   // Bilateral filtering and depth cutoff (:1015-1024)
-  { StageTimer t_(d, stream, 0);
+  if (!fused_head) { StageTimer t_(d, stream, 0);
   BilateralFilteringAndDepthCutoffCUDA(stream, c.bilateral_filter_sigma_xy, c.bilateral_filter_sigma_depth_factor,
                                        /*value_to_ignore*/ 0, c.bilateral_filter_radius_factor,
                                        (u16)(c.depth_scaling * c.max_depth > 65535.f ? 65535.f : c.depth_scaling * c.max_depth),
@@ -132,14 +135,22 @@ static int preprocess_frame(smx_driver d, cudaStream_t stream, const smx_driver_
                                                cam[0], cam[1], cam[2], cam[3], other_depths, others_TR_reference,      \
                                                &dst->ToCUDA());                                                        \
   } while (0)
-    StageTimer t_(d, stream, 1);
+    // (fused head: the filter and the cull of its own output pixel in one launch -- timed as stage 0)
+#define SMX_CALL_FUSED_HEAD(n)                                                                                          \
+  BilateralFilteringAndOutlierFusionCUDA<n + 1>(stream, c.bilateral_filter_sigma_xy, c.bilateral_filter_sigma_depth_factor,  \
+                                                c.bilateral_filter_radius_factor, max_depth_u16, c.depth_valid_region_radius,   \
+                                                depth_buffer.ToCUDA(), all ? -1 : req, c.outlier_filtering_depth_tolerance_factor, \
+                                                cam[0], cam[1], cam[2], cam[3], other_depths, others_TR_reference,           \
+                                                &src->ToCUDA(), &dst->ToCUDA())
+    StageTimer t_(d, stream, fused_head ? 0 : 1);
     switch (st.other_count) {
-      case 2: SMX_CALL_OUTLIER_FUSION(2); break;
-      case 4: SMX_CALL_OUTLIER_FUSION(4); break;
-      case 6: SMX_CALL_OUTLIER_FUSION(6); break;
-      case 8: SMX_CALL_OUTLIER_FUSION(8); break;
+      case 2: if (fused_head) SMX_CALL_FUSED_HEAD(2); else SMX_CALL_OUTLIER_FUSION(2); break;
+      case 4: if (fused_head) SMX_CALL_FUSED_HEAD(4); else SMX_CALL_OUTLIER_FUSION(4); break;
+      case 6: if (fused_head) SMX_CALL_FUSED_HEAD(6); else SMX_CALL_OUTLIER_FUSION(6); break;
+      case 8: if (fused_head) SMX_CALL_FUSED_HEAD(8); else SMX_CALL_OUTLIER_FUSION(8); break;
       default: return fail("Unsupported value for outlier_filtering_frame_count");  // main.cc:1084
     }
+#undef SMX_CALL_FUSED_HEAD
 #undef SMX_CALL_OUTLIER_FUSION
     std::swap(src, dst);
   }
@@ -442,6 +453,12 @@ int smx_driver_set_overlap(smx_driver d, int32_t enabled) {
 int smx_driver_set_run_ahead(smx_driver d, int32_t enabled) {
   if (!d) return fail("null argument");
   d->run_ahead = enabled != 0;
+  return SMX_OK;
+}
+
+int smx_driver_set_fused_head(smx_driver d, int32_t enabled) {
+  if (!d) return fail("null argument");
+  d->fuse_head = enabled != 0;
   return SMX_OK;
 }
 

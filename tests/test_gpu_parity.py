@@ -63,6 +63,11 @@ def test_depth_stages_bit_exact(smx, w, h):
             smx.OutlierDepthMapFusionCUDA(stream, 0.02, A, s.fx, s.fy, s.cx, s.cy, [bufs[g] for g in others], T, B, required_count=req)
             oo = orc.outlier_depth_map_fusion(o, [raw[g] for g in others], T, s.fx, s.fy, s.cx, s.cy, 0.02, req)
             assert np.array_equal(B.Download(), oo), (count, req)
+            # the filter and the cull as ONE call (one launch for eight other frames, two through the scratch image otherwise)
+            S2, B2 = smx.CUDABuffer(h, w, np.uint16), smx.CUDABuffer(h, w, np.uint16)
+            smx.BilateralFilteringAndOutlierFusionCUDA(stream, 3.0, 0.05, 2.0, pre.max_depth_u16(), pre.depth_valid_region_radius, bufs[f],
+                                                       0.02, s.fx, s.fy, s.cx, s.cy, [bufs[g] for g in others], T, S2, B2, required_count=req)
+            assert np.array_equal(B2.Download(), oo), ("fused", count, req)
     for radius in (0, 1, 2, 3):
         if radius == 0:
             smx.CopyWithoutBorderCUDA(stream, B, A)
