@@ -287,7 +287,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="A/B: no frame pipelining inside Integrate")
     ap.add_argument("--caller-stream", choices=["null", "plain", "high", "low"], default="null",
                     help="A/B: the stream Integrate is called on (null = the legacy default stream)")
-    ap.add_argument("--no-fused-head", action="store_true", help="A/B: bilateral filter and outlier cull as two launches (same images)")
+    ap.add_argument("--fused-head", action="store_true", help="A/B: bilateral filter and outlier cull in one launch (same images; slower)")
     ap.add_argument("--run-ahead", action="store_true", help="A/B: preprocessing two steps ahead, waits routed off the caller's stream")
     ap.add_argument("--scan-mode", type=int, default=0, help="A/B: smx_recon_set_scan_mode bits (1 = all-slot scans, 2 = multi-launch blend, 4 = no hot-group filter in pass B)")
     ap.add_argument("--ub", default="", help="TIMING-ONLY upper bounds, comma list of: hoist-pre (every timed frame preprocessed "
@@ -386,8 +386,8 @@ def run_integrate(args):
     rec.set_stats_enabled(False)   # the distribution counters are single-address atomics: off while timing
     if args.run_ahead:
         wl.pipe.set_run_ahead(True)
-    if args.no_fused_head:
-        wl.pipe.set_fused_head(False)
+    if args.fused_head:
+        wl.pipe.set_fused_head(True)
     if args.scan_mode:
         rec.set_scan_mode(args.scan_mode)
     settle_steps = wl.steps(plan[:W])

@@ -74,8 +74,9 @@ int smx_driver_run_streamed(smx_driver d, smx_stream s, const smx_driver_step* s
 /* Overlap of the depth preprocessing of later frames (own stream, further sets of work images) with Integrate(f);
  * default on.  Results are identical either way. */
 int smx_driver_set_overlap(smx_driver d, int32_t enabled);
-/* A/B switch: bilateral filter + outlier cull as one fused launch where the library has one (default) or as the reference's
- * two calls; same images. */
+/* A/B switch: bilateral filter + outlier cull as one fused launch where the library has one, or (default) as the reference's
+ * two calls; same images.  The fused launch is the slower one on the loaded chip (profiles/r17_ab_notes.md, r17q: the cull's
+ * gathers have nothing to hide behind in a kernel that runs one 310-register wavefront per SIMD). */
 int smx_driver_set_fused_head(smx_driver d, int32_t enabled);
 /* A/B switch: erosion + normals + radii as one fused launch (default) or as the reference's three calls; same images. */
 int smx_driver_set_fused_tail(smx_driver d, int32_t enabled);

@@ -49,7 +49,7 @@ struct smx_driver_s {
   bool overlap = true;
   bool run_ahead = false;  // smx_driver_run: preprocessing two steps ahead, dependencies routed off the caller's stream (A/B: -1 %)
   bool fuse_tail = true;   // erosion + normals + radii as one launch (A/B: smx_driver_set_fused_tail)
-  bool fuse_head = true;   // bilateral filter + outlier cull as one launch (A/B: smx_driver_set_fused_head)
+  bool fuse_head = false;  // bilateral filter + outlier cull as one launch (A/B: smx_driver_set_fused_head; measured slower, see smx_driver.h)
   unsigned long long frame_counter = 0;
   // smx_driver_debug_prepare: work sets preprocessed ahead of time, consumed in order by the next runs (measurement)
   std::vector<std::unique_ptr<WorkSet>> prepared;

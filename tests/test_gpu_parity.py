@@ -799,11 +799,11 @@ def test_get_timings_are_consistent(smx):
     rec.set_timing_enabled(0)
 
 
-@pytest.mark.parametrize("run_ahead", [False, True])
-def test_native_driver_matches_oracle(smx, run_ahead):
+@pytest.mark.parametrize("run_ahead,fused_head", [(False, False), (True, False), (False, True)])
+def test_native_driver_matches_oracle(smx, run_ahead, fused_head):
     """The C++ frame loop (include/smx_driver.h, written against the shim classes of smx_shim.hpp) produces the
     same state as the oracle; many frames are enqueued by one call.  run_ahead: the preprocessing two steps ahead with
-    its dependencies routed through smx_recon_integrate_hooks."""
+    its dependencies routed through smx_recon_integrate_hooks.  fused_head: bilateral filter + outlier cull in one launch."""
     from surfelmeshing_amd.pipeline import NativeFramePipeline
     from surfelmeshing_amd._lib import IntegrateParams
     s = small_stream(obstacle_until=8)
@@ -811,6 +811,7 @@ def test_native_driver_matches_oracle(smx, run_ahead):
     po = OraclePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, 60000, pre)
     pn = NativeFramePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, 60000, pre, IntegrateParams.defaults())
     pn.set_run_ahead(run_ahead)
+    pn.set_fused_head(fused_head)
     frames = list(range(4, 20))
     for f in range(0, 24):
         d, c = s.frame(f)
