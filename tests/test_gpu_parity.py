@@ -836,6 +836,43 @@ def test_native_driver_matches_oracle(smx, run_ahead, fused_head):
         pn.download_frame(10)
 
 
+def test_native_driver_prepared_steps_and_stage_timing(smx):
+    """The measurement hooks of the driver leave the results alone: smx_driver_debug_prepare (bench.py --ub hoist-pre:
+    the steps preprocessed up front into work images of their own, the run integrates those) gives the map of the plain
+    run, and smx_driver_profile_begin/_end (the in-frame stage durations of the bench line) report a positive average
+    over the frames they saw."""
+    from surfelmeshing_amd.pipeline import NativeFramePipeline, DriverStep
+    from surfelmeshing_amd._lib import IntegrateParams
+    s = small_stream(obstacle_until=8)
+    pre = small_pre(s.width)
+    pipes = [NativeFramePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, 60000, pre, IntegrateParams.defaults()) for _ in range(2)]
+    for f in range(0, 24):
+        d, c = s.frame(f)
+        for p in pipes:
+            p.upload(f, d, c)
+    steps = [pipes[0].make_step(f, s.outlier_frames(f), s.others_TR_reference(f), s.pose(f)) for f in range(4, 17)]
+    arr = (DriverStep * len(steps))(*steps)
+    pipes[0].run_array(arr, len(steps))
+    pipes[1].prepare_array(arr, len(steps))
+    pipes[1].profile_begin(1, 8)
+    pipes[1].run_array(arr, len(steps))
+    ms_prepared, n_prepared = pipes[1].profile_end()
+    assert n_prepared == 0        # nothing preprocessed while the prepared steps ran
+    n = pipes[0].reconstruction.surfels_size()
+    assert n > 1000 and pipes[1].reconstruction.surfels_size() == n
+    assert_surfels_match(pipes[1].reconstruction.debug_download_surfels(n), pipes[0].reconstruction.debug_download_surfels(n), n,
+                         exact=True)
+    for a, b in zip(pipes[0].download_work(), pipes[1].download_work()):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    # a plain continuation with the stage timer on: one more frame per stage, each seen
+    for stage, f in enumerate((17, 18, 19)):
+        one = (DriverStep * 1)(pipes[0].make_step(f, s.outlier_frames(f), s.others_TR_reference(f), s.pose(f)))
+        pipes[0].profile_begin(stage, 8)
+        pipes[0].run_array(one, 1)
+        ms, seen = pipes[0].profile_end()
+        assert seen == 1 and 0.0005 < ms < 50.0, (stage, ms, seen)
+
+
 @pytest.mark.parametrize("overlap", [True, False])
 def test_native_driver_streamed_uploads(smx, overlap):
     """smx_driver_run_streamed: the frames arrive from (page-locked) host memory with the frame loop
