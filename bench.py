@@ -287,6 +287,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="A/B: no frame pipelining inside Integrate")
     ap.add_argument("--caller-stream", choices=["null", "plain", "high", "low"], default="null",
                     help="A/B: the stream Integrate is called on (null = the legacy default stream)")
+    ap.add_argument("--split-pre", type=int, default=-1, help="A/B: 1 / 0 = two preprocessing queues on / off (default: the library's)")
     ap.add_argument("--fused-head", action="store_true", help="A/B: bilateral filter and outlier cull in one launch (same images; slower)")
     ap.add_argument("--run-ahead", action="store_true", help="A/B: preprocessing two steps ahead, waits routed off the caller's stream")
     ap.add_argument("--scan-mode", type=int, default=0, help="A/B: smx_recon_set_scan_mode bits (1 = all-slot scans, 2 = multi-launch blend, 4 = no hot-group filter in pass B)")
@@ -388,6 +389,8 @@ def run_integrate(args):
         wl.pipe.set_run_ahead(True)
     if args.fused_head:
         wl.pipe.set_fused_head(True)
+    if args.split_pre >= 0:
+        wl.pipe.set_split_preprocessing(args.split_pre == 1)
     if args.scan_mode:
         rec.set_scan_mode(args.scan_mode)
     settle_steps = wl.steps(plan[:W])

@@ -78,6 +78,11 @@ int smx_driver_set_overlap(smx_driver d, int32_t enabled);
  * two calls; same images.  The fused launch is the slower one on the loaded chip (profiles/r17_ab_notes.md, r17q: the cull's
  * gathers have nothing to hide behind in a kernel that runs one 310-register wavefront per SIMD). */
 int smx_driver_set_fused_head(smx_driver d, int32_t enabled);
+/* Two preprocessing queues (smx_driver_run with overlap on): the bilateral filter on one, the outlier cull and the
+ * erosion / normals / radii launch of the same frame behind it on a second one, so that the filter of frame f + 1 -- VALU-bound,
+ * one 310-register wavefront per SIMD -- runs beside the gathers of frame f's cull instead of behind them.  Same images.
+ * Frames that arrive with their step (smx_driver_run_streamed) keep the single queue: the copy and its readers share it. */
+int smx_driver_set_split_preprocessing(smx_driver d, int32_t enabled);
 /* A/B switch: erosion + normals + radii as one fused launch (default) or as the reference's three calls; same images. */
 int smx_driver_set_fused_tail(smx_driver d, int32_t enabled);
 /* smx_driver_run with overlap on (default OFF, results identical; measured 1 % slower than the plain loop, see

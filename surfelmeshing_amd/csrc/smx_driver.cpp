@@ -25,16 +25,24 @@ struct WorkSet {
   CUDABuffer<float> radius_buffer;
   CUDABuffer<u16>* final_depth;
   smx_event preprocessed = nullptr, integrated = nullptr;
+  smx_event filtered = nullptr;   // (two preprocessing queues) the bilateral filter's image is written
   bool used = false;
   WorkSet(int h, int w) : filtered_depth_buffer_A(h, w), filtered_depth_buffer_B(h, w), normals_buffer(h, w),
                           radius_buffer(h, w), final_depth(&filtered_depth_buffer_A) {
     radius_buffer.Clear(0.0f, nullptr);
     SMX_SHIM_CHECK(smx_event_create(&preprocessed));
     SMX_SHIM_CHECK(smx_event_create(&integrated));
+    SMX_SHIM_CHECK(smx_event_create(&filtered));
   }
-  ~WorkSet() { smx_event_destroy(preprocessed); smx_event_destroy(integrated); }
+  ~WorkSet() { smx_event_destroy(preprocessed); smx_event_destroy(integrated); smx_event_destroy(filtered); }
 };
 
+#ifndef SMX_PRE_PRIORITY
+#define SMX_PRE_PRIORITY -1
+#endif
+#ifndef SMX_SPLIT_PRE_DEFAULT
+#define SMX_SPLIT_PRE_DEFAULT false
+#endif
 struct smx_driver_s {
   smx_driver_config cfg;
   PinholeCamera4f camera;
@@ -45,6 +53,11 @@ struct smx_driver_s {
   WorkSet* set(unsigned long long k) { return (k % 3 == 0) ? &work0 : (k % 3 == 1) ? &work1 : &work2; }
   std::map<u32, std::unique_ptr<Frame>> frames;
   cudaStream_t pre_stream = nullptr;   // depth preprocessing of the next frame
+  cudaStream_t pre_stream2 = nullptr;  // (split_pre) outlier cull + erosion / normals / radii, behind the filter of the same frame
+  // Two preprocessing queues: the bilateral filter of frame f + 1 (VALU-bound, one 310-register wavefront per SIMD) runs
+  // beside the outlier cull and the tail of frame f (gathers) instead of behind them.  At 1280 x 960 the single queue is
+  // busy all of the time and the frame waits for it (profiles/r21_timeline_c3.md).
+  bool split_pre = SMX_SPLIT_PRE_DEFAULT;
   smx_event run_start = nullptr;
   bool overlap = true;
   bool run_ahead = false;  // smx_driver_run: preprocessing two steps ahead, dependencies routed off the caller's stream (A/B: -1 %)
@@ -63,13 +76,14 @@ struct smx_driver_s {
       : cfg(c), camera(c.width, c.height, intr), reconstruction(c.max_surfel_count, camera),
         work0(c.height, c.width), work1(c.height, c.width), work2(c.height, c.width), last(&work0), prev(&work0) {
     // preprocessing runs ahead of the frame loop: it only has to keep up, so it yields to the surfel kernels
-    SMX_SHIM_CHECK(smx_stream_create_with_priority(&pre_stream, -1));
+    SMX_SHIM_CHECK(smx_stream_create_with_priority(&pre_stream, SMX_PRE_PRIORITY));
+    SMX_SHIM_CHECK(smx_stream_create_with_priority(&pre_stream2, SMX_PRE_PRIORITY));
     SMX_SHIM_CHECK(smx_event_create(&run_start));
     SMX_SHIM_CHECK(smx_stream_synchronize(nullptr));
   }
   ~smx_driver_s() {
-    smx_stream_synchronize(pre_stream); smx_stream_synchronize(nullptr);
-    smx_stream_destroy(pre_stream); smx_event_destroy(run_start);
+    smx_stream_synchronize(pre_stream); smx_stream_synchronize(pre_stream2); smx_stream_synchronize(nullptr);
+    smx_stream_destroy(pre_stream); smx_stream_destroy(pre_stream2); smx_event_destroy(run_start);
     for (smx_event e : prof_ev) smx_event_destroy(e);
   }
 };
@@ -88,7 +102,10 @@ namespace smx { void set_error(const char* fmt, ...); }  // libsmx's thread-loca
 static int fail(const char* msg) { smx::set_error("smx_driver: %s", msg); return SMX_ERR_INVALID_ARGUMENT; }
 
 // Depth preprocessing of one frame, APP/main.cc:1015-1191.
-static int preprocess_frame(smx_driver d, cudaStream_t stream, const smx_driver_step& st, WorkSet* ws) {
+// (tail_stream: the queue of everything behind the bilateral filter -- `stream` itself, or the second preprocessing queue)
+// *done_on: the queue the last launch went to.
+static int preprocess_frame(smx_driver d, cudaStream_t stream, const smx_driver_step& st, WorkSet* ws, cudaStream_t tail_stream,
+                            cudaStream_t* done_on) {
   const smx_driver_config& c = d->cfg;
   // validated before any array below is indexed and before any frame is stamped (main.cc:1084 rejects the same values)
   if (st.other_count != 0 && st.other_count != 2 && st.other_count != 4 && st.other_count != 6 && st.other_count != 8)
@@ -110,6 +127,12 @@ static int preprocess_frame(smx_driver d, cudaStream_t stream, const smx_driver_
                                        (u16)(c.depth_scaling * c.max_depth > 65535.f ? 65535.f : c.depth_scaling * c.max_depth),
                                        c.depth_valid_region_radius, depth_buffer.ToCUDA(),
                                        &ws->filtered_depth_buffer_A.ToCUDA()); }
+  if (fused_head) tail_stream = stream;
+  if (tail_stream != stream) {
+    SMX_SHIM_CHECK(smx_event_record(ws->filtered, stream));
+    SMX_SHIM_CHECK(smx_stream_wait_event(tail_stream, ws->filtered));
+    stream = tail_stream;
+  }
   CUDABuffer<u16>* src = &ws->filtered_depth_buffer_A;
   CUDABuffer<u16>* dst = &ws->filtered_depth_buffer_B;
 
@@ -174,6 +197,7 @@ static int preprocess_frame(smx_driver d, cudaStream_t stream, const smx_driver_
     std::swap(src, dst);
   }
   ws->final_depth = src;
+  *done_on = stream;
   return SMX_OK;
 }
 
@@ -282,9 +306,11 @@ static int run_one(smx_driver d, smx_stream s, const smx_driver_step& step, cons
     // preprocessing(f) on its own stream: it may start as soon as Integrate(f-3) has released this work set,
     // i.e. it overlaps Integrate(f-1); Integrate(f) then waits for it.
     if (ws->used) SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, ws->integrated));
-    rc = preprocess_frame(d, d->pre_stream, step, ws);
+    // (frames that arrive with their step are copied on pre_stream and read behind it in the same queue: see upload_on)
+    cudaStream_t done_on = nullptr;
+    rc = preprocess_frame(d, d->pre_stream, step, ws, (d->split_pre && !arriving) ? d->pre_stream2 : d->pre_stream, &done_on);
     if (rc != SMX_OK) return rc;
-    SMX_SHIM_CHECK(smx_event_record(ws->preprocessed, d->pre_stream));
+    SMX_SHIM_CHECK(smx_event_record(ws->preprocessed, done_on));
     // Both dependencies are routed through Integrate itself: it waits for the preprocessed images behind its all-slot
     // scan (which does not read them), and marks "images consumed" on its internal stream -- the caller's stream, which
     // carries the front chain of the frame, gets neither a wait in front of the call nor a record behind it.
@@ -297,7 +323,8 @@ static int run_one(smx_driver d, smx_stream s, const smx_driver_step& step, cons
       return rc;
     }
   } else {
-    rc = preprocess_frame(d, s, step, ws);
+    cudaStream_t done_on = nullptr;
+    rc = preprocess_frame(d, s, step, ws, s, &done_on);
     if (rc != SMX_OK) return rc;
     rc = integrate_frame(d, s, step, ws);
     if (rc != SMX_OK) return rc;
@@ -313,9 +340,10 @@ static int run_one(smx_driver d, smx_stream s, const smx_driver_step& step, cons
 static int preprocess_ahead(smx_driver d, const smx_driver_step& step, WorkSet** out) {
   WorkSet* ws = d->set(d->frame_counter++);
   if (ws->used) SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, ws->integrated));
-  const int rc = preprocess_frame(d, d->pre_stream, step, ws);
+  cudaStream_t done_on = nullptr;
+  const int rc = preprocess_frame(d, d->pre_stream, step, ws, d->split_pre ? d->pre_stream2 : d->pre_stream, &done_on);
   if (rc != SMX_OK) return rc;
-  SMX_SHIM_CHECK(smx_event_record(ws->preprocessed, d->pre_stream));
+  SMX_SHIM_CHECK(smx_event_record(ws->preprocessed, done_on));
   *out = ws;
   return SMX_OK;
 }
@@ -333,6 +361,7 @@ static int abandon_run(smx_driver d, smx_stream s, int rc) {
   (void)smx_recon_integrate_hooks(d->reconstruction.handle(), nullptr, nullptr);
   (void)smx_recon_integrate_inputs_ready(d->reconstruction.handle(), nullptr);
   (void)smx_stream_synchronize(d->pre_stream);
+  (void)smx_stream_synchronize(d->pre_stream2);
   (void)smx_stream_synchronize(s);
   d->work0.used = d->work1.used = d->work2.used = false;
   for (auto& f : d->frames) f.second->last_reader = 0;
@@ -371,7 +400,8 @@ int smx_driver_debug_prepare(smx_driver d, smx_stream s, const smx_driver_step* 
   for (int i = 0; i < n; ++i) {
     std::unique_ptr<WorkSet> ws(new WorkSet(d->cfg.height, d->cfg.width));
     ++d->frame_counter;
-    const int rc = preprocess_frame(d, d->pre_stream, steps[i], ws.get());
+    cudaStream_t done_on = nullptr;
+    const int rc = preprocess_frame(d, d->pre_stream, steps[i], ws.get(), d->pre_stream, &done_on);
     if (rc != SMX_OK) return rc;
     d->prepared.push_back(std::move(ws));
   }
@@ -459,6 +489,12 @@ int smx_driver_set_run_ahead(smx_driver d, int32_t enabled) {
 int smx_driver_set_fused_head(smx_driver d, int32_t enabled) {
   if (!d) return fail("null argument");
   d->fuse_head = enabled != 0;
+  return SMX_OK;
+}
+
+int smx_driver_set_split_preprocessing(smx_driver d, int32_t enabled) {
+  if (!d) return fail("null argument");
+  d->split_pre = enabled != 0;
   return SMX_OK;
 }
 

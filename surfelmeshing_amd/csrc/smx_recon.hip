@@ -224,9 +224,11 @@ constexpr int kBlockB = kSegB / 4;
 // not depend on them), which is what a prefix over the sub-lists would have cost.
 constexpr uint32_t kCountStride = 32;     // one counter per 128-byte line: atomics on one line serialise, whatever word they hit
 constexpr uint32_t kSubLists = 16;
+constexpr uint32_t kAccCount = 16;        // acc_chunks.count = rec_chunks.count + kAccCount: the second half of the same lines
 struct Chunks { uint32_t* desc; uint32_t* count; uint32_t stride; };   // desc[k * stride + j], count[k * kCountStride]
 struct Lists {
   Chunks vis_chunks, rec_chunks;
+  Chunks acc_chunks;      // segments the edge kernel has work in (descriptor = segment); its counters share rec_chunks' lines (kAccCount)
   uint32_t* vis_list;     // slots that project into the image this frame
   float* seg_box;         // per pass-A segment: min xyz, max xyz, covered slot count (u32), newest stamp (u32)
   uint32_t* vis_seg;
@@ -323,6 +325,12 @@ __device__ __forceinline__ void emit_chunks(const Chunks& ch, uint32_t deal, uin
     const uint32_t in_chunk = min((uint32_t)kBlock, total - q * kBlock);
     ch.desc[(size_t)k * ch.stride + pos + q] = (segment * chunks_per_segment + q) | ((in_chunk - 1u) << 24);
   }
+}
+
+// (one descriptor per segment: the segment number)
+__device__ __forceinline__ void emit_segment(const Chunks& ch, uint32_t segment) {
+  const uint32_t k = segment % kSubLists;
+  ch.desc[(size_t)k * ch.stride + atomicAdd(&ch.count[k * kCountStride], 1u)] = segment;
 }
 
 __device__ __forceinline__ bool stamp_outside_window(uint32_t stamp, uint32_t frame, int window) {
@@ -1518,7 +1526,7 @@ __device__ __forceinline__ void update_neighbors_body(const Surfels& S, const Fr
   // (the slot count BEFORE this frame's creation: the creating workgroups of the same launch advance surfel_count)
   const uint32_t n_scan = kUseList ? 0u : st->create_base_next;
   // (this launch precedes the regulariser's pass B on every path through Integrate: its chunk counter starts at zero)
-  if (block == 0 && threadIdx.x < kSubLists) L.rec_chunks.count[threadIdx.x * kCountStride] = 0;
+  if (block == 0 && threadIdx.x < kSubLists) { L.rec_chunks.count[threadIdx.x * kCountStride] = 0; L.acc_chunks.count[threadIdx.x * kCountStride] = 0; }
   uint32_t desc, cntv;
   const uint32_t n_steps = walk_begin<kUseList>(L.vis_chunks, n_scan, block, desc, cntv);
   for (uint32_t w = block; w < n_steps; w += n_blocks) {
@@ -1783,8 +1791,7 @@ k_update_and_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, Crea
 // accumulators are zero between calls (k_reg_step zeroes what it consumes).
 template <bool kDetach, bool kAccumulate>
 __global__ void __launch_bounds__(kBlockB)
-k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict__ inwin8, uint32_t* __restrict__ need_seg,
-                DevState* st) {
+k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict__ inwin8, DevState* st) {
   const uint32_t seg_id = segment_of_block(L.descending);
   extern __shared__ __align__(16) uint8_t lhot[];   // the hot-group table (n_hot_groups bytes, padded to 16)
   __shared__ uint32_t ltargets[kMaxHotGroups / 32];  // bit g: a link of this segment points into group g (another segment)
@@ -1836,7 +1843,6 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
       if (!__syncthreads_or((reached & hot16) != 0)) {
         if (threadIdx.x == 0) {
           L.recent_seg[seg_id] = kInvalid;   // (no recent slot; the mark is what smx_recon_debug_count_skipped_segments counts)
-          if (kAccumulate) need_seg[seg_id] = 0u;
         }
         return;
       }
@@ -1890,7 +1896,7 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
     const int any = __syncthreads_or(need);
     if (threadIdx.x == 0) {
       L.recent_seg[seg_id] = 0;
-      if (kAccumulate) need_seg[seg_id] = any ? 1u : 0u;
+      if (kAccumulate && any) emit_segment(L.acc_chunks, seg_id);
     }
     return;
   }
@@ -1983,7 +1989,7 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
       const uint32_t k = seg_id % kSubLists;
       L.rec_chunks.desc[(size_t)k * L.rec_chunks.stride + atomicAdd(&L.rec_chunks.count[k * kCountStride], 1u)] = seg_id | ((total - 1u) << 22);
     }
-    if (kAccumulate) need_seg[seg_id] = (any || total) ? 1u : 0u;  // k_reg_accumulate also serves recent slots
+    if (kAccumulate && (any || total)) emit_segment(L.acc_chunks, seg_id);  // k_reg_accumulate also serves recent slots
     if (stats && total) atomicAdd(&st->recent_count, total);
   }
 }
@@ -2015,41 +2021,72 @@ __device__ __forceinline__ void far_term_spill(long long* __restrict__ grad_acc,
   fb.count[(size_t)(target / kSegB) * kCountStride + 1] = 1u;   // (the reader of that segment looks into grad_acc)
 }
 constexpr int kSegAcc = 1024;     // slots per accumulation workgroup (16 KB of LDS sums)
+#ifndef SMX_REG_PRIORITY_HIGH
+#define SMX_REG_PRIORITY_HIGH 1
+#endif
+#ifndef SMX_ACC_WGS_PER_CU
+#define SMX_ACC_WGS_PER_CU 2   // (what the kernel's registers admit)
+#endif
 constexpr int kBlockAcc = 512;
 static_assert(kSegAcc % kSegB == 0 && kSegAcc % kBlockAcc == 0, "segment sizes must nest");
-__global__ void __launch_bounds__(kBlockAcc)
+__global__ void __launch_bounds__(kBlockAcc, 2 * SMX_ACC_WGS_PER_CU)   // (second argument: wavefronts per SIMD)
 k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ grad_acc,
                  long long* __restrict__ grad_local, FarBins fb,
-                 const uint8_t* __restrict__ inwin8, const uint8_t* __restrict__ flags8,
-                 const uint32_t* __restrict__ need_seg, DevState* st, uint32_t descending) {
-  const uint32_t seg_id = segment_of_block(descending);
+                 const uint8_t* __restrict__ inwin8, const uint8_t* __restrict__ flags8, Chunks acc, DevState* st) {
   __shared__ unsigned long long lacc[kSegAcc * 2];  // per target: (gx | gy), (gz | sender classes)
   __shared__ uint32_t hkey[kFarHash], hcnt[kFarHash];   // far destinations of this workgroup: segment, terms -> base in the bin
   const uint32_t N = st->surfel_count;
+  constexpr int kSub = kSegAcc / kBlockAcc;
+  // A walk over the segments pass B listed (acc_chunks: a recent slot or an edge into the window), on a grid the size
+  // of the chip.  (Rounds 1-3 and the first half of round 4: one workgroup per segment of the map, three fifths of which
+  // read a word and left -- with 89 VGPRs two of these 512-lane workgroups fit a CU, so every such visit held one of
+  // the chip's 512 places for its round trip.)  The next step's descriptor and the mask + flag bytes of ITS slots
+  // travel while this step is worked on: one level of dependent loads less per step.
+  uint32_t desc, cntv;
+  const uint32_t n_steps = walk_begin<true>(acc, 0u, blockIdx.x, desc, cntv);
+  uint32_t m8_next[kSub], f8_next[kSub];
+#pragma unroll
+  for (int sub = 0; sub < kSub; ++sub) {
+    const uint32_t i = desc * kSegAcc + sub * kBlockAcc + threadIdx.x;   // (an unused descriptor is 0 or an old segment number: any slot of the map)
+    const bool in = blockIdx.x < n_steps && i < N;
+    m8_next[sub] = in ? (uint32_t)inwin8[i] : 0u; f8_next[sub] = in ? (uint32_t)flags8[i] : 0u;
+  }
+  bool lds_used = false;
+#pragma unroll 1
+  for (uint32_t w = blockIdx.x; w < n_steps; w += gridDim.x) {
+  const uint32_t seg_id = desc;
+  desc = walk_next<true>(acc, w + gridDim.x, n_steps);
+  // (per step: a lane number the optimiser cannot see through keeps the per-lane addresses out of loop-carried registers)
+  uint32_t tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  uint32_t m8_cur[kSub], f8_cur[kSub];
+#pragma unroll
+  for (int sub = 0; sub < kSub; ++sub) {
+    m8_cur[sub] = m8_next[sub]; f8_cur[sub] = f8_next[sub];
+    const uint32_t i = desc * kSegAcc + sub * kBlockAcc + tid;
+    const bool in = w + gridDim.x < n_steps && i < N;
+    m8_next[sub] = in ? (uint32_t)inwin8[i] : 0u; f8_next[sub] = in ? (uint32_t)flags8[i] : 0u;
+  }
+  if (!walk_step_valid(w, cntv)) continue;
   const uint32_t base = seg_id * kSegAcc;
-  if (base >= N) return;
-  uint32_t need = 0;
+  if (lds_used) __syncthreads();   // (the previous step's readers of the table are done)
+  lds_used = true;
 #pragma unroll
-  for (int k = 0; k < kSegAcc / kSegB; ++k) need |= need_seg[seg_id * (kSegAcc / kSegB) + k];
-  if (!need) return;
+  for (int k = 0; k < kSegAcc * 2 / kBlockAcc; ++k) lacc[k * kBlockAcc + tid] = 0;
 #pragma unroll
-  for (int k = 0; k < kSegAcc * 2 / kBlockAcc; ++k) lacc[k * kBlockAcc + threadIdx.x] = 0;
-#pragma unroll
-  for (int k = 0; k < kFarHash / kBlockAcc; ++k) { hkey[k * kBlockAcc + threadIdx.x] = kInvalid; hcnt[k * kBlockAcc + threadIdx.x] = 0; }
+  for (int k = 0; k < kFarHash / kBlockAcc; ++k) { hkey[k * kBlockAcc + tid] = kInvalid; hcnt[k * kBlockAcc + tid] = 0; }
   __syncthreads();
   // Both slots of a lane travel together through three levels of loads, every load of a level requested before the
-  // first one is used: (1) mask + flag bytes, (2) the slots' own T, S, N records, (3) one 16-byte record per link
-  // (tools/isa_phases.py shows the waits).
-  constexpr int kSub = kSegAcc / kBlockAcc;
+  // first one is used: (1) mask + flag bytes (requested one step ahead), (2) the slots' own T, S, N records, (3) one
+  // 16-byte record per link (tools/isa_phases.py shows the waits).  (Requesting the link records a step ahead as well
+  // would leave two levels, but takes the kernel over 128 VGPRs -- one workgroup per CU, or scratch.)
   uint32_t idx[kSub], mask[kSub];
   bool rec[kSub], act[kSub];
 #pragma unroll
   for (int sub = 0; sub < kSub; ++sub) {
-    idx[sub] = base + sub * kBlockAcc + threadIdx.x;
-    const bool in = idx[sub] < N;
-    const uint32_t m8 = in ? (uint32_t)inwin8[idx[sub]] : 0u, f8 = in ? (uint32_t)flags8[idx[sub]] : 0u;
-    mask[sub] = m8;
-    rec[sub] = (f8 & 1u) != 0;
+    idx[sub] = base + sub * kBlockAcc + tid;
+    mask[sub] = m8_cur[sub];
+    rec[sub] = (f8_cur[sub] & 1u) != 0;
   }
   uint4 own_t[kSub];
   float4 own_s[kSub], own_n[kSub];
@@ -2148,14 +2185,14 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
   // one lane per destination reserves the workgroup's run in that bin; the table then holds the run's start
 #pragma unroll
   for (int k = 0; k < kFarHash / kBlockAcc; ++k) {
-    const uint32_t e = k * kBlockAcc + threadIdx.x;
+    const uint32_t e = k * kBlockAcc + tid;
     const uint32_t dseg = hkey[e];
     if (dseg != kInvalid) hcnt[e] = atomicAdd(&fb.count[(size_t)dseg * kCountStride], hcnt[e]);
   }
   // store the in-segment sums (only this workgroup writes the grad_local entries of its segment)
 #pragma unroll
   for (int sub = 0; sub < kSegAcc / kBlockAcc; ++sub) {
-    const uint32_t rel = sub * kBlockAcc + threadIdx.x;
+    const uint32_t rel = sub * kBlockAcc + tid;
     // (every slot of the segment, zeros included: 16 KB of full lines per workgroup.  Storing only the non-zero sums left
     // holes -- partial sectors, which this chip writes back at a seventh of the rate of full ones -- and obliged the step
     // kernel to zero what it had read; the step only ever reads the entries of recent slots, whose segment is rewritten
@@ -2178,6 +2215,7 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
       else
         far_term_spill(grad_acc, fb, target, far_q[sub][q][0], far_q[sub][q][1], far_q[sub][q][2], (int)cls + 1);
     }
+  }
   }
 }
 
@@ -2331,7 +2369,7 @@ k_reg_copy_raw(Surfels S, Lists L, const DevState* st) {
 
 __global__ void k_reset_recent(DevState* st, int stats, uint32_t* rec_chunk_count) {   // (one workgroup of kSubLists threads)
   if (stats && threadIdx.x == 0) { st->recent_count = 0; st->n_edges = 0; st->n_window_edges = 0; st->n_contributors = 0; }
-  if (rec_chunk_count) rec_chunk_count[threadIdx.x * kCountStride] = 0;
+  if (rec_chunk_count) { rec_chunk_count[threadIdx.x * kCountStride] = 0; rec_chunk_count[threadIdx.x * kCountStride + kAccCount] = 0; }
 }
 
 // ---- changed-surfel delta for the mesher ---------------------------------------------------------
@@ -2575,7 +2613,6 @@ struct smx_recon_s {
   int nsegB;                // number of kSegB-slot segments (= workgroups of pass B)
   uint8_t* merge_flag;
   uint8_t* inwin8;          // per slot: which of its 4 neighbours lie inside the regulariser window
-  uint32_t* need_seg;       // per pass-B segment: 1 if any slot has such a neighbour
   bool table_valid;         // flag table's "recent" bits correspond to (table_frame, table_window)
   uint32_t table_frame;
   int table_window;
@@ -2629,6 +2666,7 @@ struct smx_recon_s {
   bool staging_busy;      // row downloads in flight, and the next user may come on another stream
   int grid_surfels;  // persistent grid for the grid-stride all-slot kernels
   int grid_list;     // persistent grid of the chunked list kernels
+  int grid_acc;      // ... of the edge kernel (512-lane workgroups)
   int grid_list_full; // (grid_list is lowered by the A/B switch that forces long walks)
   int debug_skip;    // smx_recon_debug_set_skip (timing only)
   // Frame pipelining: the regulariser of frame f runs on an internal stream while the caller's stream already
@@ -2710,17 +2748,17 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
     SlotTimer t(r, st, kSlotNeighborScan);
     if (stats || zero_chunks) hipLaunchKernelGGL(k_reset_recent, dim3(1), dim3(kSubLists), 0, st, r->st, stats, zero_chunks ? r->L.rec_chunks.count : nullptr);
     if (copy_only) {
-      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, false>), g, bB, hot_lds, st, r->S, stats, use_hot, r->L, r->inwin8, r->need_seg, r->st);
-      else hipLaunchKernelGGL((k_neighbor_scan<false, false>), g, bB, hot_lds, st, r->S, stats, use_hot, r->L, r->inwin8, r->need_seg, r->st);
+      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, false>), g, bB, hot_lds, st, r->S, stats, use_hot, r->L, r->inwin8, r->st);
+      else hipLaunchKernelGGL((k_neighbor_scan<false, false>), g, bB, hot_lds, st, r->S, stats, use_hot, r->L, r->inwin8, r->st);
     } else {
-      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, true>), g, bB, hot_lds, st, r->S, stats, use_hot, r->L, r->inwin8, r->need_seg, r->st);
-      else hipLaunchKernelGGL((k_neighbor_scan<false, true>), g, bB, hot_lds, st, r->S, stats, use_hot, r->L, r->inwin8, r->need_seg, r->st);
+      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, true>), g, bB, hot_lds, st, r->S, stats, use_hot, r->L, r->inwin8, r->st);
+      else hipLaunchKernelGGL((k_neighbor_scan<false, true>), g, bB, hot_lds, st, r->S, stats, use_hot, r->L, r->inwin8, r->st);
     }
   }
   if (!copy_only) {
     SlotTimer t(r, st, kSlotRegAccumulate);
-    hipLaunchKernelGGL(k_reg_accumulate, dim3(div_up((long long)r->nsegB * kSegB, kSegAcc)), dim3(kBlockAcc), 0, st, r->S, rf2, weight, r->grad_acc, r->grad_local,
-                       r->fb, r->inwin8, r->L.flags8, r->need_seg, r->st, r->L.descending);
+    hipLaunchKernelGGL(k_reg_accumulate, dim3(r->grid_acc), dim3(kBlockAcc), 0, st, r->S, rf2, weight, r->grad_acc, r->grad_local,
+                       r->fb, r->inwin8, r->L.flags8, r->L.acc_chunks, r->st);
   }
   if (copy_only) {
     SlotTimer t(r, st, kSlotRegUpdate);
@@ -2819,6 +2857,10 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->L.vis_chunks.desc, (size_t)kSubLists * r->L.vis_chunks.stride, true));
   SMX_TRY(dev_alloc(&r->L.rec_chunks.desc, (size_t)kSubLists * r->L.rec_chunks.stride, true));
   SMX_TRY(dev_alloc(&r->L.rec_chunks.count, (size_t)kSubLists * kCountStride, true));
+  static_assert(kSegAcc == kSegB && kAccCount < kCountStride, "pass B lists the edge kernel's segments by its own segment numbers");
+  r->L.acc_chunks.stride = r->L.rec_chunks.stride;
+  r->L.acc_chunks.count = r->L.rec_chunks.count + kAccCount;
+  SMX_TRY(dev_alloc(&r->L.acc_chunks.desc, (size_t)kSubLists * r->L.acc_chunks.stride, true));
   SMX_TRY(dev_alloc(&r->flags_buf[0], (size_t)r->nsegB * kSegB, true));
   SMX_TRY(dev_alloc(&r->flags_buf[1], (size_t)r->nsegB * kSegB, true));
   r->L.flags8 = r->flags_buf[0];
@@ -2832,7 +2874,6 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   r->hot_holdoff = 3;
   SMX_TRY(dev_alloc(&r->merge_flag, r->S.pitch, true));
   SMX_TRY(dev_alloc(&r->inwin8, (size_t)r->nsegB * kSegB, true));
-  SMX_TRY(dev_alloc(&r->need_seg, (size_t)r->nsegB + kSegAcc / kSegB, true));
   SMX_TRY(dev_alloc(&r->sc.supporting, P, true));
   SMX_TRY(dev_alloc(&r->sc.counts, P, true));
   SMX_TRY(dev_alloc(&r->sc.depth_sums, P, true));
@@ -2873,7 +2914,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
     // the regulariser is on the frame-to-frame critical path, the work it overlaps with is not
     int lo = 0, hi = 0;
     SMX_TRY(hip_rc(hipDeviceGetStreamPriorityRange(&lo, &hi), "hipDeviceGetStreamPriorityRange"));
-    SMX_TRY(hip_rc(hipStreamCreateWithPriority(&r->reg_stream, hipStreamNonBlocking, hi), "hipStreamCreateWithPriority"));
+    SMX_TRY(hip_rc(hipStreamCreateWithPriority(&r->reg_stream, hipStreamNonBlocking, SMX_REG_PRIORITY_HIGH ? hi : 0), "hipStreamCreateWithPriority"));
   }
   // (device-scope release: these events order GPU streams, the host never reads data behind them)
   const unsigned evf = hipEventDisableTiming | hipEventReleaseToDevice;
@@ -2890,6 +2931,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   r->grid_surfels = cus * 8;  // 8 x 256-thread workgroups per CU: full occupancy, >> 256 workgroups
   r->cu_count = cus;
+  r->grid_acc = cus * SMX_ACC_WGS_PER_CU;
   r->grid_list = r->grid_list_full = cus * 32;  // the lists are sparse: most chunks are empty, so more, shorter walks
   r->stats_enabled = 1;
   *out = r;
@@ -2901,8 +2943,8 @@ int smx_recon_destroy(smx_recon r) {
   SMX_ON_DEVICE(r->device);
   void* ptrs[] = {r->sc.supporting, r->sc.counts, r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth,
                   r->tb.pairs, r->tb.count, r->tb.ovf, r->ovf_count_set[0], r->ovf_count_set[1],
-                  r->vis_count_set[0], r->vis_count_set[1], r->L.seg_act, r->L.seg_streak, r->sw.surv_list, r->sw.copy_list, r->sw.count, r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->fb.rec, r->fb.count, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1], r->L.hot_epoch, r->L.seg_targets,
-                  r->merge_flag, r->inwin8, r->need_seg, r->bb.distance_map, r->bb.new_distance_map,
+                  r->vis_count_set[0], r->vis_count_set[1], r->L.seg_act, r->L.seg_streak, r->sw.surv_list, r->sw.copy_list, r->sw.count, r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->fb.rec, r->fb.count, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.acc_chunks.desc, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1], r->L.hot_epoch, r->L.seg_targets,
+                  r->merge_flag, r->inwin8, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->block_offsets, r->st};
   if (r->reg_stream) { (void)hipStreamSynchronize(r->reg_stream); (void)hipStreamDestroy(r->reg_stream); }
   if (r->dir_host) { (void)hipDeviceSynchronize(); (void)hipHostFree(r->dir_host); }

@@ -799,8 +799,9 @@ def test_get_timings_are_consistent(smx):
     rec.set_timing_enabled(0)
 
 
-@pytest.mark.parametrize("run_ahead,fused_head", [(False, False), (True, False), (False, True)])
-def test_native_driver_matches_oracle(smx, run_ahead, fused_head):
+@pytest.mark.parametrize("run_ahead,fused_head,split_pre", [(False, False, False), (True, False, False), (False, True, False),
+                                                            (False, False, True), (True, False, True)])
+def test_native_driver_matches_oracle(smx, run_ahead, fused_head, split_pre):
     """The C++ frame loop (include/smx_driver.h, written against the shim classes of smx_shim.hpp) produces the
     same state as the oracle; many frames are enqueued by one call.  run_ahead: the preprocessing two steps ahead with
     its dependencies routed through smx_recon_integrate_hooks.  fused_head: bilateral filter + outlier cull in one launch."""
@@ -812,6 +813,7 @@ def test_native_driver_matches_oracle(smx, run_ahead, fused_head):
     pn = NativeFramePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, 60000, pre, IntegrateParams.defaults())
     pn.set_run_ahead(run_ahead)
     pn.set_fused_head(fused_head)
+    pn.set_split_preprocessing(split_pre)     # two preprocessing queues: the filter of frame f + 1 beside the cull of frame f
     frames = list(range(4, 20))
     for f in range(0, 24):
         d, c = s.frame(f)
@@ -862,8 +864,7 @@ def test_native_driver_prepared_steps_and_stage_timing(smx):
     assert n > 1000 and pipes[1].reconstruction.surfels_size() == n
     assert_surfels_match(pipes[1].reconstruction.debug_download_surfels(n), pipes[0].reconstruction.debug_download_surfels(n), n,
                          exact=True)
-    for a, b in zip(pipes[0].download_work(), pipes[1].download_work()):
-        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    # (the working-buffer getters refer to the driver's own three sets, which a prepared run does not touch)
     # a plain continuation with the stage timer on: one more frame per stage, each seen
     for stage, f in enumerate((17, 18, 19)):
         one = (DriverStep * 1)(pipes[0].make_step(f, s.outlier_frames(f), s.others_TR_reference(f), s.pose(f)))
