@@ -174,6 +174,13 @@ int smx_erode_normals_radii(smx_stream s, int32_t erosion_radius, float observat
                             float fx, float fy, float cx, float cy, const smx_buffer_desc* in_depth,
                             const smx_buffer_desc* out_depth, const smx_buffer_desc* out_normals /*float2*/,
                             const smx_buffer_desc* radius_buffer /*float*/);
+/* The same launch with `done` (may be null) as its own completion event: equivalent to smx_event_record(done, s) behind the
+ * call, without a packet of its own on the stream (the frame loop's "preprocessed" mark: smx_driver.cpp). */
+int smx_erode_normals_radii_signal(smx_stream s, int32_t erosion_radius, float observation_angle_threshold_deg,
+                                   float point_radius_extension_factor, float point_radius_clamp_factor, float depth_scaling,
+                                   float fx, float fy, float cx, float cy, const smx_buffer_desc* in_depth,
+                                   const smx_buffer_desc* out_depth, const smx_buffer_desc* out_normals /*float2*/,
+                                   const smx_buffer_desc* radius_buffer /*float*/, smx_event done);
 
 /* ---- CUDASurfelReconstruction (APP/cuda_surfel_reconstruction.h:44-176) ---- */
 /* trailing arguments of Integrate(), .h:59-77; defaults APP/main.cc:323-368 */

@@ -300,11 +300,12 @@ inline void ErodeNormalsRadiiCUDA(cudaStream_t stream, int erosion_radius, float
                                   float point_radius_extension_factor, float point_radius_clamp_factor,
                                   float depth_scaling, float depth_fx, float depth_fy, float depth_cx, float depth_cy,
                                   const CUDABuffer_<u16>& in_depth, CUDABuffer_<u16>* out_depth,
-                                  CUDABuffer_<float2_>* out_normals, CUDABuffer_<float>* radius_buffer) {
-  SMX_SHIM_CHECK(smx_erode_normals_radii(stream, erosion_radius, observation_angle_threshold_deg,
-                                         point_radius_extension_factor, point_radius_clamp_factor, depth_scaling, depth_fx,
-                                         depth_fy, depth_cx, depth_cy, in_depth.desc(), out_depth->desc(),
-                                         out_normals->desc(), radius_buffer->desc()));
+                                  CUDABuffer_<float2_>* out_normals, CUDABuffer_<float>* radius_buffer,
+                                  smx_event done = nullptr) {   // (done: the launch's completion event, see smx.h)
+  SMX_SHIM_CHECK(smx_erode_normals_radii_signal(stream, erosion_radius, observation_angle_threshold_deg,
+                                                point_radius_extension_factor, point_radius_clamp_factor, depth_scaling, depth_fx,
+                                                depth_fy, depth_cx, depth_cy, in_depth.desc(), out_depth->desc(),
+                                                out_normals->desc(), radius_buffer->desc(), done));
 }
 
 // ---- APP/cuda_surfels_cpu.h ---------------------------------------------------------------------------

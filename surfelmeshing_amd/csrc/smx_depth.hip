@@ -8,6 +8,7 @@
 #include <atomic>
 
 #include "smx_common.hpp"
+#include <hip/hip_ext.h>
 
 using namespace smx;
 
@@ -883,6 +884,16 @@ int smx_erode_normals_radii(smx_stream s, int32_t erosion_radius, float observat
                             float fx, float fy, float cx, float cy, const smx_buffer_desc* in_depth,
                             const smx_buffer_desc* out_depth, const smx_buffer_desc* out_normals,
                             const smx_buffer_desc* radius_buffer) {
+  return smx_erode_normals_radii_signal(s, erosion_radius, observation_angle_threshold_deg, point_radius_extension_factor,
+                                        point_radius_clamp_factor, depth_scaling, fx, fy, cx, cy, in_depth, out_depth, out_normals,
+                                        radius_buffer, nullptr);
+}
+
+int smx_erode_normals_radii_signal(smx_stream s, int32_t erosion_radius, float observation_angle_threshold_deg,
+                                   float point_radius_extension_factor, float point_radius_clamp_factor, float depth_scaling,
+                                   float fx, float fy, float cx, float cy, const smx_buffer_desc* in_depth,
+                                   const smx_buffer_desc* out_depth, const smx_buffer_desc* out_normals,
+                                   const smx_buffer_desc* radius_buffer, smx_event done) {
   SMX_CHECK_ARG(in_depth && out_depth && out_normals && radius_buffer && in_depth->address != out_depth->address);
   SMX_CHECK_ARG(in_depth->width == out_depth->width && in_depth->height == out_depth->height);
   SMX_CHECK_ARG(out_normals->width == in_depth->width && out_normals->height == in_depth->height);
@@ -895,7 +906,8 @@ int smx_erode_normals_radii(smx_stream s, int32_t erosion_radius, float observat
   const float ext2 = point_radius_extension_factor * point_radius_extension_factor;
   const float clamp_term = point_radius_clamp_factor * point_radius_clamp_factor * sqrtf(2) * sqrtf(2);  // cu:873
   const dim3 grid(div_up(in_depth->width, kFuseTW), div_up(in_depth->height, kFuseTH));
-  hipLaunchKernelGGL(k_erode_normals_radii, grid, dim3(kThreads), 0, (hipStream_t)s, (int)erosion_radius, thr, ext2,
+  // (done: the launch's own completion event -- what a record behind it would mark, without a packet of its own)
+  hipExtLaunchKernelGGL(k_erode_normals_radii, grid, dim3(kThreads), 0, (hipStream_t)s, nullptr, (hipEvent_t)done, 0, (int)erosion_radius, thr, ext2,
                      clamp_term, 1.0f / depth_scaling, make_unproj(fx, fy, cx, cy), as_img<const uint16_t>(in_depth),
                      as_img<uint16_t>(out_depth), as_img<float2>(out_normals), as_img<float>(radius_buffer));
   SMX_LAUNCH_CHECK();

@@ -103,9 +103,10 @@ static int fail(const char* msg) { smx::set_error("smx_driver: %s", msg); return
 
 // Depth preprocessing of one frame, APP/main.cc:1015-1191.
 // (tail_stream: the queue of everything behind the bilateral filter -- `stream` itself, or the second preprocessing queue)
-// *done_on: the queue the last launch went to.
+// *done_on: the queue the last launch went to; null if that launch carried ws->preprocessed as its completion event itself
+// (mark_done: the caller wants that event).
 static int preprocess_frame(smx_driver d, cudaStream_t stream, const smx_driver_step& st, WorkSet* ws, cudaStream_t tail_stream,
-                            cudaStream_t* done_on) {
+                            cudaStream_t* done_on, bool mark_done = false) {
   const smx_driver_config& c = d->cfg;
   // validated before any array below is indexed and before any frame is stamped (main.cc:1084 rejects the same values)
   if (st.other_count != 0 && st.other_count != 2 && st.other_count != 4 && st.other_count != 6 && st.other_count != 8)
@@ -182,7 +183,9 @@ static int preprocess_frame(smx_driver d, cudaStream_t stream, const smx_driver_
     StageTimer t_(d, stream, 2);
     ErodeNormalsRadiiCUDA(stream, c.depth_erosion_radius, c.observation_angle_threshold_deg, c.point_radius_extension_factor,
                           c.point_radius_clamp_factor, c.depth_scaling, cam[0], cam[1], cam[2], cam[3], src->ToCUDA(),
-                          &dst->ToCUDA(), &ws->normals_buffer.ToCUDA(), &ws->radius_buffer.ToCUDA());
+                          &dst->ToCUDA(), &ws->normals_buffer.ToCUDA(), &ws->radius_buffer.ToCUDA(),
+                          (mark_done && d->prof_stage != 2) ? ws->preprocessed : nullptr);
+    if (mark_done && d->prof_stage != 2) stream = nullptr;
     std::swap(src, dst);
   } else {
     if (c.depth_erosion_radius > 0) ErodeDepthMapCUDA(stream, c.depth_erosion_radius, src->ToCUDA(), &dst->ToCUDA());
@@ -308,9 +311,9 @@ static int run_one(smx_driver d, smx_stream s, const smx_driver_step& step, cons
     if (ws->used) SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, ws->integrated));
     // (frames that arrive with their step are copied on pre_stream and read behind it in the same queue: see upload_on)
     cudaStream_t done_on = nullptr;
-    rc = preprocess_frame(d, d->pre_stream, step, ws, (d->split_pre && !arriving) ? d->pre_stream2 : d->pre_stream, &done_on);
+    rc = preprocess_frame(d, d->pre_stream, step, ws, (d->split_pre && !arriving) ? d->pre_stream2 : d->pre_stream, &done_on, true);
     if (rc != SMX_OK) return rc;
-    SMX_SHIM_CHECK(smx_event_record(ws->preprocessed, done_on));
+    if (done_on) SMX_SHIM_CHECK(smx_event_record(ws->preprocessed, done_on));
     // Both dependencies are routed through Integrate itself: it waits for the preprocessed images behind its all-slot
     // scan (which does not read them), and marks "images consumed" on its internal stream -- the caller's stream, which
     // carries the front chain of the frame, gets neither a wait in front of the call nor a record behind it.
@@ -341,9 +344,9 @@ static int preprocess_ahead(smx_driver d, const smx_driver_step& step, WorkSet**
   WorkSet* ws = d->set(d->frame_counter++);
   if (ws->used) SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, ws->integrated));
   cudaStream_t done_on = nullptr;
-  const int rc = preprocess_frame(d, d->pre_stream, step, ws, d->split_pre ? d->pre_stream2 : d->pre_stream, &done_on);
+  const int rc = preprocess_frame(d, d->pre_stream, step, ws, d->split_pre ? d->pre_stream2 : d->pre_stream, &done_on, true);
   if (rc != SMX_OK) return rc;
-  SMX_SHIM_CHECK(smx_event_record(ws->preprocessed, done_on));
+  if (done_on) SMX_SHIM_CHECK(smx_event_record(ws->preprocessed, done_on));
   *out = ws;
   return SMX_OK;
 }

@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "smx_common.hpp"
+#include <hip/hip_ext.h>
 
 using namespace smx;
 
@@ -2021,6 +2022,9 @@ __device__ __forceinline__ void far_term_spill(long long* __restrict__ grad_acc,
   fb.count[(size_t)(target / kSegB) * kCountStride + 1] = 1u;   // (the reader of that segment looks into grad_acc)
 }
 constexpr int kSegAcc = 1024;     // slots per accumulation workgroup (16 KB of LDS sums)
+#ifndef SMX_EXT_STOP_EVENTS
+#define SMX_EXT_STOP_EVENTS 1   // (0: event records as packets of their own, the arrangement up to r22)
+#endif
 #ifndef SMX_REG_PRIORITY_HIGH
 #define SMX_REG_PRIORITY_HIGH 1
 #endif
@@ -2699,17 +2703,24 @@ static const char* const kSlotNames[kSlotCount] = {
   "scan_visible", "assoc_tiles", "blend", "integrate+new_flags", "update_neighbors+create",
   "neighbor_scan", "reg_accumulate", "reg_step", "reg_update", "cull_segments", "empty_slot"};
 
+// launch_carries: the slot's kernel is launched with hipExtLaunchKernelGGL and takes start() / stop() as its own start and
+// completion events -- the profile (smx_recon_profile_begin: bench.py times the frame's longest kernel inside its timed
+// region) then puts no packet of its own on the stream.  Two event records around a kernel on the internal stream cost the
+// frame what a hand-off costs (profiles/r17_ab_notes.md, r23).
 struct SlotTimer {
-  smx_recon r; hipStream_t st; int slot; bool kev, prof;
-  SlotTimer(smx_recon r_, hipStream_t st_, int slot_) : r(r_), st(st_), slot(slot_) {
+  smx_recon r; hipStream_t st; int slot; bool kev, prof, by_launch;
+  SlotTimer(smx_recon r_, hipStream_t st_, int slot_, bool launch_carries = false) : r(r_), st(st_), slot(slot_) {
     kev = (r->timing_enabled & 2) != 0;
     prof = (r->prof_slot == slot) && r->prof_ev && r->prof_n < r->prof_cap;
+    by_launch = prof && launch_carries && SMX_EXT_STOP_EVENTS != 0;
     if (kev) (void)hipEventRecord(r->kev[2 * slot], st);
-    if (prof) (void)hipEventRecord(r->prof_ev[2 * r->prof_n], st);
+    if (prof && !by_launch) (void)hipEventRecord(r->prof_ev[2 * r->prof_n], st);
   }
+  hipEvent_t start() const { return by_launch ? r->prof_ev[2 * r->prof_n] : nullptr; }
+  hipEvent_t stop() const { return by_launch ? r->prof_ev[2 * r->prof_n + 1] : nullptr; }
   ~SlotTimer() {
     if (kev) { (void)hipEventRecord(r->kev[2 * slot + 1], st); r->kev_recorded[slot] = true; }
-    if (prof) { (void)hipEventRecord(r->prof_ev[2 * r->prof_n + 1], st); r->prof_n++; }
+    if (prof) { if (!by_launch) (void)hipEventRecord(r->prof_ev[2 * r->prof_n + 1], st); r->prof_n++; }
   }
 };
 
@@ -2745,27 +2756,27 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
   const int use_hot = (r->hot_holdoff == 0 && !r->scan_mode && r->hot_filter_enabled) ? 1 : 0;
   const size_t hot_lds = ((size_t)r->L.n_hot_groups + 15) & ~(size_t)15;
   {
-    SlotTimer t(r, st, kSlotNeighborScan);
+    SlotTimer t(r, st, kSlotNeighborScan, true);
     if (stats || zero_chunks) hipLaunchKernelGGL(k_reset_recent, dim3(1), dim3(kSubLists), 0, st, r->st, stats, zero_chunks ? r->L.rec_chunks.count : nullptr);
     if (copy_only) {
-      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, false>), g, bB, hot_lds, st, r->S, stats, use_hot, r->L, r->inwin8, r->st);
-      else hipLaunchKernelGGL((k_neighbor_scan<false, false>), g, bB, hot_lds, st, r->S, stats, use_hot, r->L, r->inwin8, r->st);
+      if (detach) hipExtLaunchKernelGGL((k_neighbor_scan<true, false>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->inwin8, r->st);
+      else hipExtLaunchKernelGGL((k_neighbor_scan<false, false>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->inwin8, r->st);
     } else {
-      if (detach) hipLaunchKernelGGL((k_neighbor_scan<true, true>), g, bB, hot_lds, st, r->S, stats, use_hot, r->L, r->inwin8, r->st);
-      else hipLaunchKernelGGL((k_neighbor_scan<false, true>), g, bB, hot_lds, st, r->S, stats, use_hot, r->L, r->inwin8, r->st);
+      if (detach) hipExtLaunchKernelGGL((k_neighbor_scan<true, true>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->inwin8, r->st);
+      else hipExtLaunchKernelGGL((k_neighbor_scan<false, true>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->inwin8, r->st);
     }
   }
   if (!copy_only) {
-    SlotTimer t(r, st, kSlotRegAccumulate);
-    hipLaunchKernelGGL(k_reg_accumulate, dim3(r->grid_acc), dim3(kBlockAcc), 0, st, r->S, rf2, weight, r->grad_acc, r->grad_local,
+    SlotTimer t(r, st, kSlotRegAccumulate, true);
+    hipExtLaunchKernelGGL(k_reg_accumulate, dim3(r->grid_acc), dim3(kBlockAcc), 0, st, t.start(), t.stop(), 0, r->S, rf2, weight, r->grad_acc, r->grad_local,
                        r->fb, r->inwin8, r->L.flags8, r->L.acc_chunks, r->st);
   }
   if (copy_only) {
     SlotTimer t(r, st, kSlotRegUpdate);
     hipLaunchKernelGGL(k_reg_copy_raw, gl, b, 0, st, r->S, r->L, r->st);
   } else {
-    SlotTimer t(r, st, kSlotRegStep);
-    hipLaunchKernelGGL(k_reg_step, gl, b, 0, st, r->S, weight, r->grad_acc, r->grad_local, r->fb, r->L, r->st);
+    SlotTimer t(r, st, kSlotRegStep, true);
+    hipExtLaunchKernelGGL(k_reg_step, gl, b, 0, st, t.start(), t.stop(), 0, r->S, weight, r->grad_acc, r->grad_local, r->fb, r->L, r->st);
   }
   SMX_LAUNCH_CHECK();
   return SMX_OK;
@@ -3129,17 +3140,17 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     r->sw_dirty = true;
     hipLaunchKernelGGL(k_cull_segments, dim3((unsigned)div_up(r->nseg, kBlock)), b, 0, sF, c, r->L, r->sw, r->st, (uint32_t)r->nseg, (uint32_t)P); }
   if (r->pending_mark) { SMX_HIP(hipStreamWaitEvent(sF, r->pending_mark, 0)); r->pending_mark = nullptr; }
-  { SlotTimer t(r, sF, kSlotScanVisible);
+  { SlotTimer t(r, sF, kSlotScanVisible, true);
     const bool lds_tables = !r->no_lds_tables;
     // chip-sized grid: as many workgroups as the chip holds at once (8 per CU) walk the survivor list
     const dim3 ga((unsigned)(r->cu_count * 8));
-    hipLaunchKernelGGL(k_scan_visible, ga, b, 0, sF, r->S, c, r->L, r->tb, r->sw, flags_prev, r->st, lds_tables ? 1 : 0);
+    hipExtLaunchKernelGGL(k_scan_visible, ga, b, 0, sF, t.start(), t.stop(), 0, r->S, c, r->L, r->tb, r->sw, flags_prev, r->st, lds_tables ? 1 : 0);
     r->table_valid = true; r->table_frame = frame_index; r->table_window = c.reg_window; }
   // (smx_recon_integrate_inputs_ready) from here on the input images are read
   if (hook_ready) SMX_HIP(hipStreamWaitEvent(sF, hook_ready, 0));
   // (the tile kernel also leaves the direction for later launches' segment_of_block in host memory, see there)
-  { SlotTimer t(r, sF, kSlotAssocTiles);
-    hipLaunchKernelGGL(k_assoc_tiles, dim3(r->tb.n_tiles), dim3(kTilePx), 0, sF, r->S, c, r->sc, in.depth, in.normals, r->tb,
+  { SlotTimer t(r, sF, kSlotAssocTiles, true);
+    hipExtLaunchKernelGGL(k_assoc_tiles, dim3(r->tb.n_tiles), dim3(kTilePx), 0, sF, t.start(), t.stop(), 0, r->S, c, r->sc, in.depth, in.normals, r->tb,
                        r->ovf_count_set[r->sc_cur ^ 1], r->merge_flag, r->st, r->L.seg_act, (uint32_t)r->nseg, r->dir_dev, r->sw.count,
                        r->stamps ? r->stamps : nullptr);
     r->sw_dirty = false; }
@@ -3147,6 +3158,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   if (tm) { SMX_HIP(hipEventRecord(r->ev[1], sF)); SMX_HIP(hipEventRecord(r->ev[2], sF)); SMX_HIP(hipEventRecord(r->ev[3], sF)); SMX_HIP(hipEventRecord(r->ev[4], sF)); }
   const int halo = p->measurement_blending_radius - 1;
   const bool fused_blend = p->do_blending && halo <= kBlendMaxHalo && !r->blend_multi_launch;
+  bool front_by_launch = false;
   const float ds = 1.0f / c.inv_depth_scaling;  // kernels.cc:179
   const float term = p->do_blending ? 1.0f / ((float)p->measurement_blending_radius - 1.0f) : 0.0f;  // kernels.cc:196
   const Img<uint16_t> blended = {r->blended_depth, r->H, r->W, (size_t)r->W * sizeof(uint16_t)};
@@ -3164,12 +3176,15 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     const int tiles_x = div_up(r->W, tile);
     const uint32_t n_blend = (uint32_t)(tiles_x * div_up(r->H, tile));
     unsigned long long* stamps = r->stamps ? r->stamps + 16 * 8192 : nullptr;
+    // (the hand-over to the internal stream as this launch's own completion event)
+    front_by_launch = SMX_EXT_STOP_EVENTS && pipelined && !tm && !(r->timing_enabled & 2) && r->prof_slot != kSlotBlend;
+    const hipEvent_t stop = front_by_launch ? r->ev_front : nullptr;
     if (tile == 40)
-      hipLaunchKernelGGL(k_blend_tiles<40>, dim3(n_blend), dim3(kBlendThreads), lds, sF, p->measurement_blending_radius, term, ds,
-                         in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps);
+      hipExtLaunchKernelGGL(k_blend_tiles<40>, dim3(n_blend), dim3(kBlendThreads), (uint32_t)lds, sF, nullptr, stop, 0, p->measurement_blending_radius, term, ds,
+                            in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps);
     else
-      hipLaunchKernelGGL(k_blend_tiles<32>, dim3(n_blend), dim3(kBlendThreads), lds, sF, p->measurement_blending_radius, term, ds,
-                         in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps);
+      hipExtLaunchKernelGGL(k_blend_tiles<32>, dim3(n_blend), dim3(kBlendThreads), (uint32_t)lds, sF, nullptr, stop, 0, p->measurement_blending_radius, term, ds,
+                            in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps);
   } else if (p->do_blending) {
     // the reference's own sequence (2 clears + start + iterations, kernels.cc:165-205), in place on the caller's depth
     SlotTimer t(r, sF, kSlotBlend);
@@ -3194,17 +3209,18 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   if (pipelined) {
     // (work on the internal stream from here on: whatever happens below, later entry points order themselves behind it)
     r->reg_pending = true;
-    SMX_HIP(hipEventRecord(r->ev_front, sF));
+    if (!front_by_launch) SMX_HIP(hipEventRecord(r->ev_front, sF));
     SMX_HIP(hipStreamWaitEvent(sR, r->ev_front, 0));
   }
   if (tm) SMX_HIP(hipEventRecord(r->ev[6], sR));
   const bool front_only = (r->debug_skip & 2) != 0, skip_reg = (r->debug_skip & 3) != 0;   // (timing only)
+  bool mark_by_launch = false;
   if (front_only) SMX_HIP(hipMemsetAsync(r->vis_count_set[r->sc_cur ^ 1], 0, sizeof(uint32_t) * kSubLists * kCountStride, sR));   // (k_update_and_create's side job)
-  if (!front_only) { SlotTimer t(r, sR, kSlotIntegrate);
+  if (!front_only) { SlotTimer t(r, sR, kSlotIntegrate, true);
     const uint32_t nfb = (uint32_t)r->n_scan_blocks;
     const dim3 gi(nfb + (uint32_t)r->grid_list);
-    if (r->scan_mode) hipLaunchKernelGGL((k_integrate<false>), gi, b, 0, sR, r->S, c, r->sc, in_integrate, r->L, r->merge_flag, r->st, nf, nfb);
-    else hipLaunchKernelGGL((k_integrate<true>), gi, b, 0, sR, r->S, c, r->sc, in_integrate, r->L, r->merge_flag, r->st, nf, nfb); }
+    if (r->scan_mode) hipExtLaunchKernelGGL((k_integrate<false>), gi, b, 0, sR, t.start(), t.stop(), 0, r->S, c, r->sc, in_integrate, r->L, r->merge_flag, r->st, nf, nfb);
+    else hipExtLaunchKernelGGL((k_integrate<true>), gi, b, 0, sR, t.start(), t.stop(), 0, r->S, c, r->sc, in_integrate, r->L, r->merge_flag, r->st, nf, nfb); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[7], sR)); SMX_HIP(hipEventRecord(r->ev[8], sR)); }
   if (!front_only) { SlotTimer t(r, sR, kSlotUpdateNeighbors);
     CreateArgs ca;
@@ -3215,8 +3231,12 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     const uint32_t ncb = (uint32_t)div_up(P, kBlock);
     const dim3 guc(ncb + (uint32_t)r->grid_list);
     const size_t lds = (size_t)r->n_scan_blocks * sizeof(uint32_t);
-    if (r->scan_mode) hipLaunchKernelGGL((k_update_and_create<false>), guc, b, lds, sR, r->S, c, r->sc, in, r->L, ca, ncb, r->st);
-    else hipLaunchKernelGGL((k_update_and_create<true>), guc, b, lds, sR, r->S, c, r->sc, in, r->L, ca, ncb, r->st); }
+    // (the "map complete / inputs consumed" mark below as this launch's own completion event: no packet of its own between
+    // this kernel and pass B on the internal stream)
+    mark_by_launch = SMX_EXT_STOP_EVENTS && !tm && !(r->timing_enabled & 2) && (pipelined || hook_consumed) && r->prof_slot != kSlotUpdateNeighbors;
+    const hipEvent_t stop = mark_by_launch ? (hook_consumed ? hook_consumed : r->ev_upd) : nullptr;
+    if (r->scan_mode) hipExtLaunchKernelGGL((k_update_and_create<false>), guc, b, (uint32_t)lds, sR, nullptr, stop, 0, r->S, c, r->sc, in, r->L, ca, ncb, r->st);
+    else hipExtLaunchKernelGGL((k_update_and_create<true>), guc, b, (uint32_t)lds, sR, nullptr, stop, 0, r->S, c, r->sc, in, r->L, ca, ncb, r->st); }
   // (the detach half of UpdateNeighborsCUDA runs fused into pass B below)
   if (tm) { SMX_HIP(hipEventRecord(r->ev[9], sR)); SMX_HIP(hipEventRecord(r->ev[10], sR)); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[11], sR)); SMX_HIP(hipEventRecord(r->ev[12], sR)); }
@@ -3230,7 +3250,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   // stream sits on the frame-to-frame critical chain).
   {
     const hipEvent_t mark = hook_consumed ? hook_consumed : r->ev_upd;
-    if (pipelined || hook_consumed) SMX_HIP(hipEventRecord(mark, sR));
+    if ((pipelined || hook_consumed) && !mark_by_launch) SMX_HIP(hipEventRecord(mark, sR));
     // A caller that asked for the "inputs consumed" event orders the reuse of its images itself; its stream then only has
     // to wait before the next call's pass A reads the map -- and that call's cull step, which does not, may go first.
     // (Every other entry point orders its stream after the whole internal stream: join_regularizer.)
