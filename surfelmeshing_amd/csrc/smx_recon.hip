@@ -2022,6 +2022,9 @@ __device__ __forceinline__ void far_term_spill(long long* __restrict__ grad_acc,
   fb.count[(size_t)(target / kSegB) * kCountStride + 1] = 1u;   // (the reader of that segment looks into grad_acc)
 }
 constexpr int kSegAcc = 1024;     // slots per accumulation workgroup (16 KB of LDS sums)
+#ifndef SMX_PASS_A_WGS_PER_CU
+#define SMX_PASS_A_WGS_PER_CU 8
+#endif
 #ifndef SMX_EXT_STOP_EVENTS
 #define SMX_EXT_STOP_EVENTS 1   // (0: event records as packets of their own, the arrangement up to r22)
 #endif
@@ -3143,7 +3146,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   { SlotTimer t(r, sF, kSlotScanVisible, true);
     const bool lds_tables = !r->no_lds_tables;
     // chip-sized grid: as many workgroups as the chip holds at once (8 per CU) walk the survivor list
-    const dim3 ga((unsigned)(r->cu_count * 8));
+    const dim3 ga((unsigned)(r->cu_count * SMX_PASS_A_WGS_PER_CU));
     hipExtLaunchKernelGGL(k_scan_visible, ga, b, 0, sF, t.start(), t.stop(), 0, r->S, c, r->L, r->tb, r->sw, flags_prev, r->st, lds_tables ? 1 : 0);
     r->table_valid = true; r->table_frame = frame_index; r->table_window = c.reg_window; }
   // (smx_recon_integrate_inputs_ready) from here on the input images are read
