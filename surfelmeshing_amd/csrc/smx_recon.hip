@@ -2022,6 +2022,9 @@ __device__ __forceinline__ void far_term_spill(long long* __restrict__ grad_acc,
   fb.count[(size_t)(target / kSegB) * kCountStride + 1] = 1u;   // (the reader of that segment looks into grad_acc)
 }
 constexpr int kSegAcc = 1024;     // slots per accumulation workgroup (16 KB of LDS sums)
+#ifndef SMX_LIST_WGS_PER_CU
+#define SMX_LIST_WGS_PER_CU 12   // (8 .. 32 measured: profiles/r17_ab_notes.md r26; the chunk lists hold ~3 000 steps at C2, ~10 000 at C3)
+#endif
 #ifndef SMX_PASS_A_WGS_PER_CU
 #define SMX_PASS_A_WGS_PER_CU 8
 #endif
@@ -2946,7 +2949,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   r->grid_surfels = cus * 8;  // 8 x 256-thread workgroups per CU: full occupancy, >> 256 workgroups
   r->cu_count = cus;
   r->grid_acc = cus * SMX_ACC_WGS_PER_CU;
-  r->grid_list = r->grid_list_full = cus * 32;  // the lists are sparse: most chunks are empty, so more, shorter walks
+  r->grid_list = r->grid_list_full = cus * SMX_LIST_WGS_PER_CU;  // (a walk step per listed chunk; workgroups without a step only cost)
   r->stats_enabled = 1;
   *out = r;
   return SMX_OK;
