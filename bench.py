@@ -288,6 +288,7 @@ def main():
     ap.add_argument("--caller-stream", choices=["null", "plain", "high", "low"], default="null",
                     help="A/B: the stream Integrate is called on (null = the legacy default stream)")
     ap.add_argument("--split-pre", type=int, default=-1, help="A/B: 1 / 0 = two preprocessing queues on / off (default: the library's)")
+    ap.add_argument("--stage-timing", action="store_true", help="measurement: leave the 14 stage events of GetTimings on in the timed region (what an API user gets by default)")
     ap.add_argument("--fused-head", action="store_true", help="A/B: bilateral filter and outlier cull in one launch (same images; slower)")
     ap.add_argument("--run-ahead", action="store_true", help="A/B: preprocessing two steps ahead, waits routed off the caller's stream")
     ap.add_argument("--scan-mode", type=int, default=0, help="A/B: smx_recon_set_scan_mode bits (1 = all-slot scans, 2 = multi-launch blend, 4 = no hot-group filter in pass B)")
@@ -389,6 +390,7 @@ def run_integrate(args):
         wl.pipe.set_run_ahead(True)
     if args.fused_head:
         wl.pipe.set_fused_head(True)
+    stage_timing_on = bool(getattr(args, 'stage_timing', False))
     if args.split_pre >= 0:
         wl.pipe.set_split_preprocessing(args.split_pre == 1)
     if args.scan_mode:
@@ -444,6 +446,8 @@ def run_integrate(args):
     # of the frame -- the VALU-bound bilateral filter -- it is named in the block with its VALU fractions, `roofline_valu`)
     longest = dominant
     dominant = dominant_hbm
+    if stage_timing_on:
+        rec.set_timing_enabled(1)
     rec.profile_begin(dominant, K)
     _lib.check(_lib.load().smx_debug_marker(None, 1))   # delimits the timed region in rocprofv3 kernel traces
     sync_all()
@@ -456,6 +460,8 @@ def run_integrate(args):
     if world > 1:
         dist.barrier()
     dom_ms, dom_n = rec.profile_end()
+    if stage_timing_on:
+        rec.set_timing_enabled(0)
     _lib.check(_lib.load().smx_debug_marker(None, 2))
     rec.debug_set_skip(0)
     P = width * height

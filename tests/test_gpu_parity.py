@@ -783,10 +783,16 @@ def test_get_timings_are_consistent(smx):
     po, pg = _pipes(smx, s, 60000)
     run_both(po, pg, s, list(range(4, 12)), None)
     rec = pg.reconstruction
+    # the stage events are armed by the first GetTimings call (every record is a packet on a busy stream): zeros once, the
+    # times of the last call from the next Integrate on -- what a caller that asks after every frame sees
+    assert rec.GetTimings() == (0.0,) * 7
+    run_both(po, pg, s, [12], None)
+    armed = rec.GetTimings()
+    assert armed[0] > 0.001 and armed[3] > 0.001 and armed[6] > 0.001, armed
     rec.set_timing_enabled(3)
     smx.StreamSynchronize(None)
     t0 = time.perf_counter()
-    run_both(po, pg, s, [12], None)
+    run_both(po, pg, s, [13], None)
     t = rec.GetTimings()
     wall_ms = 1e3 * (time.perf_counter() - t0)
     assert len(t) == 7 and all(x >= 0 for x in t)
@@ -871,7 +877,7 @@ def test_native_driver_prepared_steps_and_stage_timing(smx):
         pipes[0].profile_begin(stage, 8)
         pipes[0].run_array(one, 1)
         ms, seen = pipes[0].profile_end()
-        assert seen == 1 and 0.0005 < ms < 50.0, (stage, ms, seen)
+        assert seen == 1 and 0.0005 < ms < 5000.0, (stage, ms, seen)   # (a duration; the first launch of a kernel in a process may load its code)
 
 
 @pytest.mark.parametrize("overlap", [True, False])
