@@ -40,6 +40,9 @@ struct WorkSet {
 #ifndef SMX_PRE_PRIORITY
 #define SMX_PRE_PRIORITY -1
 #endif
+#ifndef SMX_PRE2_PRIORITY
+#define SMX_PRE2_PRIORITY SMX_PRE_PRIORITY
+#endif
 #ifndef SMX_SPLIT_PRE_DEFAULT
 #define SMX_SPLIT_PRE_DEFAULT false
 #endif
@@ -77,7 +80,7 @@ struct smx_driver_s {
         work0(c.height, c.width), work1(c.height, c.width), work2(c.height, c.width), last(&work0), prev(&work0) {
     // preprocessing runs ahead of the frame loop: it only has to keep up, so it yields to the surfel kernels
     SMX_SHIM_CHECK(smx_stream_create_with_priority(&pre_stream, SMX_PRE_PRIORITY));
-    SMX_SHIM_CHECK(smx_stream_create_with_priority(&pre_stream2, SMX_PRE_PRIORITY));
+    SMX_SHIM_CHECK(smx_stream_create_with_priority(&pre_stream2, SMX_PRE2_PRIORITY));
     SMX_SHIM_CHECK(smx_event_create(&run_start));
     SMX_SHIM_CHECK(smx_stream_synchronize(nullptr));
   }
