@@ -405,6 +405,9 @@ int smx_driver_debug_prepare(smx_driver d, smx_stream s, const smx_driver_step* 
   if (d->prepared_next >= d->prepared.size()) { d->prepared.clear(); d->prepared_next = 0; }
   for (int i = 0; i < n; ++i) {
     std::unique_ptr<WorkSet> ws(new WorkSet(d->cfg.height, d->cfg.width));
+    // (the set's constructor clears its radius image on the null stream, which the preprocessing queue is not ordered
+    // behind: without this the clear now and then landed on top of the radii -- an intermittent mismatch of the prepared run)
+    SMX_SHIM_CHECK(smx_stream_synchronize(nullptr));
     ++d->frame_counter;
     cudaStream_t done_on = nullptr;
     const int rc = preprocess_frame(d, d->pre_stream, steps[i], ws.get(), d->pre_stream, &done_on);
