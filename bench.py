@@ -259,6 +259,32 @@ def init_ranks(args):
     return rank, local_rank, world, dist, torch
 
 
+def ensure_world(args):
+    """--gpus N decides the number of ranks however the script was started.  Under a launcher (WORLD_SIZE set) the two
+    must agree; started plainly with --gpus N > 1 the script re-executes itself under torch.distributed.run with N
+    ranks on this node (one rank per device, rendezvous on 127.0.0.1) and returns that job's exit code.  None = go on
+    in this process."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, env_world), file=sys.stderr)
+            return 2
+        return None
+    if args.gpus <= 1:
+        return None
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("# bench.py --gpus %d without a launcher: re-executing under torch.distributed.run" % args.gpus, file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def reduce_device(args):
     return "cpu" if (args.dry_run or args.backend == "gloo") else "cuda"
 
@@ -304,6 +330,9 @@ def main():
     args = ap.parse_args()
     if args.config == "C1":
         return run_c1(args)
+    rc = ensure_world(args)
+    if rc is not None:
+        return rc
     if args.config == "C5":
         return run_c5(args)
     return run_integrate(args)
@@ -335,9 +364,12 @@ def run_integrate(args):
             dist.barrier()
         elapsed_local = max(time.perf_counter() - t0, 1e-9)
         fps, elapsed, units = multistream.aggregate_throughput(K, elapsed_local, world, dist, "cpu")
+        each = multistream.per_rank(K / elapsed_local, world, dist, "cpu")
+        seen = multistream.ranks_seen(world, dist, "cpu")
         if rank == 0:
             print(json.dumps({"dry_run": True, "config": {"workload": args.config}, "n_gpus": world, "steps": K, "warmup": W,
                               "value": fps, "unit": "frames/s (host-side plan generation only)", "units_all_ranks": units,
+                              "per_rank_value": each, "ranks_seen": seen,
                               "seed": assign["seed"], "scaling": "weak"}))
         finish_ranks(world, dist)
         return 0
@@ -457,6 +489,8 @@ def run_integrate(args):
     torch.cuda.synchronize()
     elapsed_local = time.perf_counter() - t_start
     fps, elapsed, _ = multistream.aggregate_throughput(K, elapsed_local, world, dist if world > 1 else None, reduce_device(args))
+    each_rank = multistream.per_rank(K / elapsed_local, world, dist if world > 1 else None, reduce_device(args))
+    seen = multistream.ranks_seen(world, dist if world > 1 else None, reduce_device(args))
     if world > 1:
         dist.barrier()
     dom_ms, dom_n = rec.profile_end()
@@ -524,6 +558,7 @@ def run_integrate(args):
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W_user,
         "ms_per_step": 1e3 * elapsed / K, "host_enqueue_ms_per_step": 1e3 * enqueue_local / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "per_rank_frames_per_s": each_rank, ("rccl_ranks_seen" if args.backend == "nccl" else "gloo_ranks_seen"): seen,
         "config": {"workload": "%s: synthetic room stream %dx%d, full preprocessing + Integrate per frame, "
                                "%d live surfels (%d slots), steady-state re-traversal" %
                                (args.config, width, height, live, st["surfels_size"]),

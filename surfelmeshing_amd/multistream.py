@@ -24,3 +24,25 @@ def aggregate_throughput(local_units, local_seconds, world, dist=None, device="c
     u = torch.tensor([float(local_units)], dtype=torch.float64, device=device)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(u.item()) / float(t.item()), float(t.item()), float(u.item())
+
+
+def per_rank(value, world, dist=None, device="cpu"):
+    """The value of every rank, in rank order (all_gather through the job's process group: RCCL, or gloo)."""
+    if world <= 1 or dist is None:
+        return [float(value)]
+    import torch
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
+def ranks_seen(world, dist=None, device="cpu"):
+    """How many ranks took part in a SUM all-reduce of 1 over the job's process group (= world when every rank of the
+    launch reached the collective: bench.py prints it beside n_gpus)."""
+    if world <= 1 or dist is None:
+        return 1
+    import torch
+    t = torch.ones(1, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(float(t.item())))

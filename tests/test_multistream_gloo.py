@@ -96,6 +96,26 @@ def test_bench_dry_run_single_rank():
     assert d["dry_run"] and d["n_gpus"] == 1 and d["units_all_ranks"] == 4
 
 
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """plain `python bench.py --gpus 2` (no launcher, WORLD_SIZE unset): the script starts its own two ranks; a launcher
+    whose world size disagrees with --gpus is refused."""
+    import json
+    import subprocess
+    import sys
+    from common import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and len(d["per_rank_value"]) == 2 and d["units_all_ranks"] == 10.0
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="1"), cwd=ROOT)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_share_one_gpu_over_gloo():
     """C4 readiness without the 8-GPU node: bench.py's REAL timed path with two ranks under torch.distributed.run, process
@@ -106,10 +126,9 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     import subprocess
     import sys
     from common import ROOT
-    port = _free_port()
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+    # (started plainly: bench.py --gpus 2 launches its own two ranks under torch.distributed.run)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--backend", "gloo", "--surfels", "300000", "--steps", "20", "--warmup", "5",
                         "--cpu-frames", "2", "--host-frames", "0", "--check-all-ranks", "--quiet"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
@@ -119,6 +138,7 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["config"]["backend"] == "gloo" and d["config"]["streams"] == 2
+    assert d["gloo_ranks_seen"] == 2 and len(d["per_rank_frames_per_s"]) == 2 and min(d["per_rank_frames_per_s"]) > 0
     checks = d["parity_check_per_rank"]
     assert len(checks) == 2
     for c in checks:
