@@ -146,7 +146,7 @@ class Workload:
         self.target = target_live
         self.pre = PreprocessParams(max_depth=10.0, depth_valid_region_radius=333.0 * sc)
         self.pipe = NativeFramePipeline(width, height, self.fx, self.fy, self.cx, self.cy, cap_surfels, self.pre)
-        self.pipe.reconstruction.set_timing_enabled(0)
+        # (the stage stamps behind GetTimings stay as the library has them: on)
 
     def render(self, logical, pose_index):
         """Render logical frame `logical` (noise seed) at trajectory position `pose_index` on the GPU."""
@@ -161,16 +161,32 @@ class Workload:
         arr = (DriverStep * len(plans))(*[self.pipe.make_step(*p) for p in plans])
         return arr, len(plans)
 
-    def grow(self, log):
+    def grow(self, log, window=None):
         """Untimed: run the real pipeline along the trajectory until the map holds >= target LIVE surfels
-        (surfel_count() = slots - merged, as BASELINE.json's metric counts them)."""
+        (surfel_count() = slots - merged, as BASELINE.json's metric counts them).
+        window = (warm, frames, callback): the EXPLORING regime, timed -- the last `frames` growth frames before the
+        target is reached (the camera keeps finding new surface: thousands of new surfels a frame, every new slot inside
+        the regulariser window) run exactly like the timed window of the steady state: every step array prepared and every
+        frame rendered beforehand, `warm` untimed frames directly in front, no host synchronisation inside.
+        callback(g, info) is called right behind the window (in-run parity check of the next growth frames)."""
         g = 4
         for f in range(0, 9):
             self.render(f, f)
         live = 0
         rec = self.pipe.reconstruction
         t0 = time.time()
+        rate = None
+        self.growth = None
         while live < self.target and g < 40000:
+            if window is not None and self.growth is None and rate is not None and rate > 0 and \
+                    live + (window[0] + window[1]) * rate * 1.02 >= self.target:
+                # (a small target -- the tests' -- is reached in a few frames: a shorter window, or none)
+                frames = min(window[1], int(0.3 * self.target / rate))
+                if frames >= 20:
+                    g = self._growth_window(g, live, (min(window[0], frames // 4), frames, window[2]))
+                    live = rec.surfel_count()
+                    continue
+                self.growth = {"skipped": "the target is reached within %d frames" % int(self.target / rate)}
             batch = []
             for _ in range(50):
                 batch.append(self.plan(g, g))
@@ -181,13 +197,57 @@ class Workload:
             self.pipe.run_array(*self.steps(batch))
             for f in range(batch[0][0] - 4, batch[-1][0] - 3):
                 self.pipe.release(f)
-            live = rec.surfel_count()
+            prev, live = live, rec.surfel_count()
+            rate = (live - prev) / 50.0
             if log and (g - 4) % 500 == 0:
                 print("# grow: frame %d live surfels %d (%.1fs)" % (g, live, time.time() - t0), file=sys.stderr, flush=True)
         for f in list(self.pipe.resident):
             self.pipe.release(f)
         self.api.StreamSynchronize(None)
         return g, live
+
+    def _growth_window(self, g, live_before, window):
+        import torch
+        warm, frames, callback = window
+        rec = self.pipe.reconstruction
+        n = warm + frames + 1
+        plans = [self.plan(g + j, g + j) for j in range(n)]
+        for f in range(g - 4, g + n + 5):
+            self.render(f, f)
+        warm_steps = self.steps(plans[:warm])
+        timed_steps = self.steps(plans[warm:warm + frames])
+        stats_step = self.steps(plans[warm + frames:n])
+        rec.set_stats_enabled(False)   # (the distribution counters are single-address atomics: off while timing)
+        self.pipe.run_array(*warm_steps)
+        torch.cuda.synchronize()
+        slots1 = rec.surfels_size()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        self.pipe.run_array(*timed_steps)
+        enq = time.perf_counter() - t
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        slots2 = rec.surfels_size()
+        live2 = rec.surfel_count()
+        rec.set_stats_enabled(True)
+        self.pipe.run_array(*stats_step)
+        st = rec.stats()
+        rec.set_stats_enabled(False)
+        self.growth = {"value": frames / dt, "unit": "frames/s", "steps": frames, "warmup": warm, "ms_per_step": 1e3 * dt / frames,
+                       "host_enqueue_ms_per_step": 1e3 * enq / frames,
+                       "new_slots_per_frame": (slots2 - slots1) / float(frames),
+                       "live_surfels_at_start": int(live_before), "live_surfels_at_end": int(live2),
+                       "slots_at_start": int(slots1), "slots_at_end": int(slots2),
+                       "frame_behind_the_window": {k: st[k] for k in ("surfels_size", "n_visible", "n_recent", "n_new", "n_segments_skipped",
+                                                                     "n_merged", "n_window_edges")},
+                       "regime": "exploring: the sweep that grows the map, the last %d frames before the live-surfel target; same "
+                                 "frame loop, inputs resident, step arrays prepared, no host synchronisation inside" % frames}
+        g += n
+        if callback is not None:
+            callback(g, self.growth)
+        for f in range(g - n - 4, g - 4):
+            self.pipe.release(f)
+        return g
 
 
 def host_frames_pass(wl, plan, base, count, api, torch):
@@ -221,6 +281,43 @@ def host_frames_pass(wl, plan, base, count, api, torch):
             "h2d_bytes_per_frame": nbytes, "h2d_GBs": nbytes * n / dt / 1e9,
             "note": "inputs copied from page-locked host memory on the preprocessing stream "
                     "(smx_driver_run_streamed); not the headline value"}
+
+
+STAGES = ["data_association", "surfel_merging", "measurement_blending", "integration",
+          "neighbor_update", "new_surfel_creation", "regularization"]
+
+
+def timing_passes(wl, plan, base, count, torch):
+    """What GetTimings costs the frame loop, each variant over `count` frames (the first fifth untimed) directly behind each
+    other in the same regime: stage stamps on (the library default = the headline's configuration), stamps off, stamps
+    on + the non-waiting read after every Integrate (APP/main.cc:1511 ported with GetTimingsNoWait), and the reference's
+    14 event records."""
+    pipe, rec = wl.pipe, wl.pipe.reconstruction
+    warm = max(2, count // 5)
+    out = {}
+    for k, (name, mode, read) in enumerate((("stamps", 4, 0), ("off", 0, 0), ("stamps_read_every_frame_nowait", 4, 1), ("event_records", 1, 0))):
+        rec.set_timing_enabled(mode)
+        pipe.set_read_timings(read)
+        lo = base + k * count
+        warm_steps, timed_steps = wl.steps(plan[lo:lo + warm]), wl.steps(plan[lo + warm:lo + count])
+        pipe.run_array(*warm_steps)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        pipe.run_array(*timed_steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        out[name] = {"value": (count - warm) / dt, "unit": "frames/s", "steps": count - warm}
+        if read:
+            sums, calls = pipe.timing_sums()
+            out[name]["calls_read"] = calls
+            out[name]["mean_stage_ms"] = dict(zip(STAGES, [x / max(calls, 1) for x in sums]))
+    pipe.set_read_timings(0)
+    rec.set_timing_enabled(4)
+    ref = out["off"]["value"]
+    for name in out:
+        out[name]["vs_off"] = out[name]["value"] / ref
+    out["note"] = "short passes behind the timed window (not the headline); the headline runs with the library default: stamps on"
+    return out
 
 
 def reference_model_bytes(st, P):
@@ -310,11 +407,24 @@ def main():
     ap.add_argument("--host-frames", type=int, default=100,
                     help="frames of the extra pass whose inputs arrive from page-locked host memory (0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the full-size GPU-vs-oracle check")
+    ap.add_argument("--growth-frames", type=int, default=200,
+                    help="frames of the timed EXPLORING-regime window: the last growth frames before the live-surfel target (0 = skip)")
+    ap.add_argument("--timing-frames", type=int, default=100,
+                    help="frames of each of the extra passes that price GetTimings (stamps off / read after every frame / the "
+                         "reference's 14 event records); 0 = skip")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default C2 run at N = 1: do not run the short C3 (1280x960, 20 M) and C5 (50 M-point search) benches "
+                         "whose lines are embedded under other_configs")
     ap.add_argument("--no-overlap", action="store_true", help="A/B: no frame pipelining inside Integrate")
     ap.add_argument("--caller-stream", choices=["null", "plain", "high", "low"], default="null",
                     help="A/B: the stream Integrate is called on (null = the legacy default stream)")
     ap.add_argument("--split-pre", type=int, default=-1, help="A/B: 1 / 0 = two preprocessing queues on / off (default: the library's)")
-    ap.add_argument("--stage-timing", action="store_true", help="measurement: leave the 14 stage events of GetTimings on in the timed region (what an API user gets by default)")
+    ap.add_argument("--stage-timing", choices=["stamps", "off", "events"], default="stamps",
+                    help="GetTimings in the timed region: stamps = the library default (the kernels stamp the stage boundaries "
+                         "themselves), off, events = the reference's 14 event records (measurement)")
+    ap.add_argument("--read-timings", choices=["off", "nowait", "block"], default="off",
+                    help="the frame loop reads GetTimings after every Integrate like APP/main.cc:1511: nowait = "
+                         "GetTimingsNoWait, block = the reference's waiting call")
     ap.add_argument("--fused-head", action="store_true", help="A/B: bilateral filter and outlier cull in one launch (same images; slower)")
     ap.add_argument("--run-ahead", action="store_true", help="A/B: preprocessing two steps ahead, waits routed off the caller's stream")
     ap.add_argument("--scan-mode", type=int, default=0, help="A/B: smx_recon_set_scan_mode bits (1 = all-slot scans, 2 = multi-launch blend, 4 = no hot-group filter in pass B)")
@@ -377,7 +487,27 @@ def run_integrate(args):
     from surfelmeshing_amd import _lib, api
     wl = Workload(api, width, height, target_live, cap, assign["seed"], assign["phase"])
     t0 = time.time()
-    g_end, n_live = wl.grow(log)
+    do_cpu_any = rank == 0 and world == 1 and not args.ub
+
+    def growth_check(g, info):
+        """in-run parity check of the exploring regime: the 8 growth frames behind the timed growth window, GPU against
+        oracle from the same map state (the main pipeline runs the same frames afterwards)"""
+        if not (do_cpu_any and not args.no_check and (args.cpu_frames is None or args.cpu_frames > 0)):
+            return
+        api.StreamSynchronize(None)
+        rec_ = wl.pipe.reconstruction
+        state0 = rec_.debug_download_surfels()
+        merge0 = rec_.surfels_size() - rec_.surfel_count()
+        nchk = 8
+        plans = [wl.plan(g + j, g + j) for j in range(nchk)]
+        for f in range(g - 4, g + nchk + 5):
+            wl.render(f, f)
+        api.StreamSynchronize(None)
+        r = cpu_baseline(wl, plans, 0, nchk, state0, merge0, cap, True, False, time_one_core=False)
+        info["parity_check"] = r.get("parity_check")
+        info["cpu_frames_per_s"] = r["value"]
+
+    g_end, n_live = wl.grow(log, (20, args.growth_frames, growth_check) if args.growth_frames > 0 else None)
     if log:
         print("# grown to %d live surfels in %d frames, %.1fs" % (n_live, g_end, time.time() - t0), file=sys.stderr)
 
@@ -406,7 +536,11 @@ def run_integrate(args):
     do_host = args.host_frames if (rank == 0 and world == 1 and not ub) else 0   # PCIe-inclusive pass: rank 0 at N = 1 only
     do_cpu = rank == 0 and world == 1 and cpu_frames > 0 and not ub   # CPU baseline: rank 0 at N = 1 only
     chk_frames = max(1, cpu_frames) if (world > 1 and args.check_all_ranks) else 0
-    cpu_start = total + 1 + reps + do_host                 # its frames: behind everything else
+    do_timing = args.timing_frames if (rank == 0 and world == 1 and not ub) else 0   # the passes that price GetTimings
+    stamps_start = total + 1 + reps                        # stage times by the stamps (reps frames, like the events' pass)
+    host_start = stamps_start + reps
+    timing_start = host_start + do_host
+    cpu_start = timing_start + 4 * do_timing               # its frames: behind everything else
     n_plan = cpu_start + (cpu_frames if do_cpu else 0) + chk_frames
     for j in range(-4, n_plan + 4):
         wl.render(first + j, 4 + j)
@@ -422,7 +556,7 @@ def run_integrate(args):
         wl.pipe.set_run_ahead(True)
     if args.fused_head:
         wl.pipe.set_fused_head(True)
-    stage_timing_on = bool(getattr(args, 'stage_timing', False))
+    timing_mode = {"stamps": 4, "off": 0, "events": 1}[args.stage_timing]
     if args.split_pre >= 0:
         wl.pipe.set_split_preprocessing(args.split_pre == 1)
     if args.scan_mode:
@@ -478,8 +612,8 @@ def run_integrate(args):
     # of the frame -- the VALU-bound bilateral filter -- it is named in the block with its VALU fractions, `roofline_valu`)
     longest = dominant
     dominant = dominant_hbm
-    if stage_timing_on:
-        rec.set_timing_enabled(1)
+    rec.set_timing_enabled(timing_mode)
+    wl.pipe.set_read_timings({"off": 0, "nowait": 1, "block": 2}[args.read_timings])
     rec.profile_begin(dominant, K)
     _lib.check(_lib.load().smx_debug_marker(None, 1))   # delimits the timed region in rocprofv3 kernel traces
     sync_all()
@@ -494,8 +628,9 @@ def run_integrate(args):
     if world > 1:
         dist.barrier()
     dom_ms, dom_n = rec.profile_end()
-    if stage_timing_on:
-        rec.set_timing_enabled(0)
+    wl.pipe.set_read_timings(0)
+    read_sums, read_calls = wl.pipe.timing_sums()
+    rec.set_timing_enabled(4)
     _lib.check(_lib.load().smx_debug_marker(None, 2))
     rec.debug_set_skip(0)
     P = width * height
@@ -540,14 +675,25 @@ def run_integrate(args):
         pre_alone[PRE_STAGES[which]].append(wl.pipe.profile_end()[0])
     stage_ms /= reps
     kernel_ms /= reps
-    rec.set_timing_enabled(0)
+    # the same stages by the stage stamps (what GetTimings serves by default), the same way: un-pipelined, one frame at a time
+    rec.set_timing_enabled(4)
+    stage_ms_stamps = np.zeros(7)
+    for j in range(stamps_start, stamps_start + reps):
+        wl.pipe.run_array(*wl.steps(plan[j:j + 1]))
+        stage_ms_stamps += np.array(rec.GetTimings())
+    stage_ms_stamps /= reps
     alone_ms = dict(zip(names, [float(x) for x in kernel_ms]))
     alone_ms.update({n: float(np.mean(v)) for n, v in pre_alone.items() if v})
 
     host_pass = None
     if do_host > 0:
         rec.set_overlap(not args.no_overlap)
-        host_pass = host_frames_pass(wl, plan, total + 1 + reps, do_host, api, torch)
+        host_pass = host_frames_pass(wl, plan, host_start, do_host, api, torch)
+        rec.set_overlap(False)
+    timing_cost = None
+    if do_timing > 0:
+        rec.set_overlap(not args.no_overlap)
+        timing_cost = timing_passes(wl, plan, timing_start, do_timing, torch)
         rec.set_overlap(False)
 
     ref_bytes = reference_model_bytes(st, P)
@@ -568,8 +714,15 @@ def run_integrate(args):
         "steady_state": {"settle_frames": SETTLE, "note": "untimed frames of the re-traversal in front of the calibration passes, the --warmup frames and the timed window",
                          "frame_before_timed_window": {k: st_before[k] for k in ("surfels_size", "n_visible", "n_recent", "n_new")},
                          "frame_after_timed_window": {k: st[k] for k in ("surfels_size", "n_visible", "n_recent", "n_new")}},
-        "stage_ms": dict(zip(["data_association", "surfel_merging", "measurement_blending", "integration",
-                              "neighbor_update", "new_surfel_creation", "regularization"], [float(x) for x in stage_ms])),
+        "stage_ms": dict(zip(STAGES, [float(x) for x in stage_ms_stamps])),
+        "stage_ms_by_event_records": dict(zip(STAGES, [float(x) for x in stage_ms])),
+        "stage_ms_note": "GetTimings, un-pipelined, one frame at a time, %d frames each: by the kernels' own stage stamps (the "
+                         "library default) and by the reference's 14 event records (measurement mode); stages fused into another "
+                         "stage's launch report 0 by stamps" % reps,
+        "stage_timing_in_timed_region": {"mode": args.stage_timing, "read_every_frame": args.read_timings,
+                                         "calls_read": read_calls,
+                                         "mean_stage_ms_read": dict(zip(STAGES, [x / max(read_calls, 1) for x in read_sums])) if read_calls else None},
+        "growth_phase": getattr(wl, "growth", None),
         "reference_model_bytes_per_frame": ref_bytes,
         "reference_model_GBs": ref_bytes * (K / elapsed) / 1e9,
     }
@@ -581,7 +734,7 @@ def run_integrate(args):
         state0 = rec.debug_download_surfels()
         merge0 = rec.surfels_size() - rec.surfel_count()
         nchk = max(1, cpu_frames)
-        mine = cpu_baseline(wl, plan, total + 1 + reps, nchk, state0, merge0, cap, True, False, time_one_core=False).get("parity_check")
+        mine = cpu_baseline(wl, plan, cpu_start, nchk, state0, merge0, cap, True, False, time_one_core=False).get("parity_check")
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
         parity_all = gathered
@@ -594,15 +747,61 @@ def run_integrate(args):
             result["parity_check_per_rank"] = parity_all
         if host_pass is not None:
             result["host_frames"] = host_pass
+        if timing_cost is not None:
+            result["stage_timing_cost"] = timing_cost
         if do_cpu:
             api.StreamSynchronize(None)
             state0 = rec.debug_download_surfels()
             merge0 = rec.surfels_size() - rec.surfel_count()
             result["cpu_baseline"] = cpu_baseline(wl, plan, cpu_start, cpu_frames, state0, merge0, cap,
                                                   not args.no_check, log)
+        if (args.config == "C2" and world == 1 and not args.no_other_configs and not args.surfels and not args.width
+                and not args.height and not args.scan_mode and do_cpu):
+            result["other_configs"] = other_configs(args, log)
         print(json.dumps(result))
     finish_ranks(world, dist)
     return 0
+
+
+def other_configs(args, log):
+    """BASELINE.json's other single-GPU configurations, short runs of this same script in processes of their own behind the
+    C2 work (this process keeps its ~2 GB map; the chip has 288 GB): C3 = 1280x960 stream / 20 M surfel cap, C5 = 50 M-point
+    radius search.  Their lines -- value, roofline, in-run parity check against the oracle, CPU leg -- are embedded."""
+    import subprocess
+    runs = {"C3": ["--config", "C3", "--steps", "60", "--warmup", "10", "--cpu-frames", "2", "--host-frames", "0",
+                   "--timing-frames", "0", "--growth-frames", "100"],
+            "C5": ["--config", "C5", "--steps", "3", "--warmup", "1"]}
+    out = {}
+    for name, extra in runs.items():
+        t0 = time.time()
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--quiet", "--no-other-configs"] + extra
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[name] = {"error": "rc %d: %s" % (r.returncode, r.stderr[-600:])}
+                continue
+            d = json.loads(lines[-1])
+        except (subprocess.TimeoutExpired, ValueError) as e:
+            out[name] = {"error": repr(e)[:600]}
+            continue
+        roof = dict(d.get("roofline") or {})
+        roof.pop("kernels", None)
+        roof.pop("traffic_pmc_raw", None)
+        cb = d.get("cpu_baseline") or {}
+        out[name] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "warmup": d["warmup"],
+                     "ms_per_step": d["ms_per_step"], "config": d["config"], "roofline": roof,
+                     "roofline_valu": {k: v for k, v in (d.get("roofline_valu") or {}).items() if k != "note"} or None,
+                     "parity_check": cb.get("parity_check"),
+                     "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")} if cb else None,
+                     "growth_phase": d.get("growth_phase"),
+                     "distributions": {k: d.get("distributions", {}).get(k) for k in ("surfels_size", "n_visible", "n_recent", "n_new",
+                                                                                      "n_points", "mean_results") if k in d.get("distributions", {})},
+                     "command": " ".join(["python", "bench.py"] + cmd[2:]), "wall_s": time.time() - t0}
+        if log:
+            print("# other config %s: %.4g %s (%.0fs)" % (name, d["value"], d["unit"], time.time() - t0), file=sys.stderr, flush=True)
+    return out
 
 
 # kernel-slot name -> kernel name in rocprofv3 output

@@ -270,14 +270,21 @@ int smx_recon_transfer_changed_to_cpu(smx_recon r, smx_stream s, uint32_t frame_
 /* ExportVertices, .h:109-112 / .cc:405-410: position 1 x 3N float, colour 1 x 3N u8 */
 int smx_recon_export_vertices(smx_recon r, smx_stream s, const smx_buffer_desc* position_buffer,
                               const smx_buffer_desc* color_buffer);
-/* GetTimings, .h:115-122 / .cc:412-429: data association, merging, blending,
- * integration, neighbor update, new surfel creation, regularization (ms). */
-/* The 14 stage events behind it are recorded from the FIRST call on (that call returns zeros): each record is a packet
- * between two kernels of a stream that is never idle, and with all of them the frame rate at 640 x 480 drops by a third.
- * A caller that asks after every Integrate gets real times from its second frame, one that never asks pays nothing. */
+/* GetTimings, .h:115-122 / .cc:412-429: data association, merging, blending, integration, neighbor update, new surfel
+ * creation, regularization (ms) of the LAST smx_recon_integrate call; like the reference it waits until that call is
+ * through (cudaEventSynchronize(regularization_end_event_), cc:420).  On from the first call, at no measurable cost: the
+ * stages are not bracketed by event records (each a packet between two kernels of a stream that is never idle: fourteen
+ * of them cost a third of the frame rate here) but stamped by the kernels themselves -- device wall clock, "first
+ * workgroup in" / "last workgroup out" of the launches that begin / end a stage -- into a per-call record.  Stages the
+ * design fuses into another stage's launch report 0: merging (decided in the association kernel, applied by the
+ * integration kernel) and creation (in the neighbour-update launch). */
 int smx_recon_get_timings(smx_recon r, float out_ms[7]);
-/* enabled: bit 0 = the reference's 14 stage events (default off, armed by smx_recon_get_timings), bit 1 = events around
- * every kernel */
+/* The same for a frame loop that must not wait: the stage times of the NEWEST call that is known to be through without
+ * waiting (normally the call before the last one while the pipeline is busy; its 1-based number in *call_number, 0 and
+ * zeros if there is none yet).  Costs the host one 512-byte copy on a stream of its own; orders nothing. */
+int smx_recon_get_timings_nowait(smx_recon r, float out_ms[7], uint64_t* call_number);
+/* enabled: bit 2 = stage stamps (default ON: what smx_recon_get_timings reads), bit 0 = the reference's own 14 stage
+ * events instead (measurement: smx_recon_get_timings then reads those), bit 1 = events around every kernel */
 int smx_recon_set_timing_enabled(smx_recon r, int32_t enabled);
 /* Per-kernel device times of the last Integrate call (needs timing bit 1); slot names from
  * smx_recon_kernel_slot_name(0 .. smx_recon_kernel_slot_count()-1). */
@@ -366,7 +373,14 @@ int smx_recon_set_overlap(smx_recon r, int32_t enabled);
  *                    call orders its integration kernels -- and so every call after that all of its kernels -- after
  *                    that mark: work covered by chain_after is complete before the call AFTER the next one starts to
  *                    read its inputs, without any wait on the caller's stream.
- * With pipelining off both act on the caller's stream at the same points. */
+ * With pipelining off both act on the caller's stream at the same points.
+ * CONTRACT CHANGE for a caller that passes inputs_consumed (pipelining on): the caller's stream no longer waits for the
+ * call's second half (integration, neighbour update, creation) when the call returns -- that wait is deferred into
+ * the NEXT smx_recon_integrate call.  Until then the stream is NOT ordered behind the kernels that write the blended
+ * depths back into the depth image and read the colour image: a caller that touches those four images (or reuses them)
+ * outside another smx_recon_* entry point must first make its stream wait for inputs_consumed itself.  smx_driver does:
+ * every run ends with that wait, and its frame upload / render / work-image download entry points wait for the steps
+ * in flight.  Every other smx_recon_* entry point still orders its stream behind all internal work. */
 int smx_recon_integrate_hooks(smx_recon r, smx_event inputs_consumed, smx_event chain_after);
 /* A third hook of the same kind (one-shot, may be null): `inputs_ready` must have been recorded already (e.g. at the end of
  * the preprocessing of the frame, on the caller's preprocessing stream); the NEXT smx_recon_integrate call waits for it

@@ -98,6 +98,13 @@ int smx_driver_set_run_ahead(smx_driver d, int32_t enabled);
 int smx_driver_debug_prepare(smx_driver d, smx_stream s, const smx_driver_step* steps, int32_t n);
 int smx_driver_profile_begin(smx_driver d, int32_t stage, int32_t max_frames);
 int smx_driver_profile_end(smx_driver d, float* avg_ms, int32_t* frames);
+/* The reference's frame loop reads the seven stage times after EVERY Integrate (APP/main.cc:1511-1524) and adds them to
+ * running sums.  mode 1: every step of smx_driver_run / _run_streamed does the same with GetTimingsNoWait (no stall: the
+ * newest call known to be through; each call is added once); mode 2: with the blocking GetTimings (the reference's
+ * semantics: the host waits for the frame before it enqueues the next); 0 (default): no reads.
+ * smx_driver_timing_sums: the sums in ms and the number of calls in them; reset = 1 zeroes them afterwards. */
+int smx_driver_set_read_timings(smx_driver d, int32_t mode);
+int smx_driver_timing_sums(smx_driver d, double sums_ms[7], uint64_t* calls, int32_t reset);
 /* Working buffers after the last frame: final (blended) depth, normals, radius. */
 int smx_driver_work_descs(smx_driver d, smx_buffer_desc* depth, smx_buffer_desc* normals, smx_buffer_desc* radius);
 

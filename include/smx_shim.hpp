@@ -453,6 +453,18 @@ class CUDASurfelReconstruction {
     *data_association = t[0]; *surfel_merging = t[1]; *measurement_blending = t[2]; *integration = t[3];
     *neighbor_update = t[4]; *new_surfel_creation = t[5]; *regularization = t[6];
   }
+  // Not in the reference: the same seven times without the wait for the last call -- those of the newest call that is
+  // known to be through (smx.h smx_recon_get_timings_nowait); returns that call's 1-based number, 0 = none yet (zeros).
+  // For a frame loop that reads the stage times after every Integrate (APP/main.cc:1511) and must not stall its queue.
+  uint64_t GetTimingsNoWait(float* data_association, float* surfel_merging, float* measurement_blending, float* integration,
+                       float* neighbor_update, float* new_surfel_creation, float* regularization) {
+    float t[7];
+    uint64_t call = 0;
+    SMX_SHIM_CHECK(smx_recon_get_timings_nowait(handle_, t, &call));
+    *data_association = t[0]; *surfel_merging = t[1]; *measurement_blending = t[2]; *integration = t[3];
+    *neighbor_update = t[4]; *new_surfel_creation = t[5]; *regularization = t[6];
+    return call;
+  }
   // Unlike the reference these read the device-side counters (they synchronise the last used stream).
   u32 surfel_count() const { u32 a = 0, b = 0; SMX_SHIM_CHECK(smx_recon_counts(handle_, last_stream_, &a, &b)); return a; }
   u32 surfels_size() const { u32 a = 0, b = 0; SMX_SHIM_CHECK(smx_recon_counts(handle_, last_stream_, &a, &b)); return b; }

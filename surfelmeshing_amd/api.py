@@ -520,6 +520,14 @@ class CUDASurfelReconstruction:
         _lib.check(_lib.load().smx_recon_get_timings(self._h, out))
         return tuple(out)
 
+    def GetTimingsNoWait(self):
+        """(the seven stage times in ms, call number) of the newest Integrate call that is known to be through, without
+        waiting for the last one (smx_recon_get_timings_nowait); call number 0 = none yet."""
+        out = (C.c_float * 7)()
+        call = C.c_uint64(0)
+        _lib.check(_lib.load().smx_recon_get_timings_nowait(self._h, out, C.byref(call)))
+        return tuple(out), int(call.value)
+
     def _counts(self):
         a, b = C.c_uint32(), C.c_uint32()
         _lib.check(_lib.load().smx_recon_counts(self._h, _sv(self._last_stream), C.byref(a), C.byref(b)))

@@ -71,6 +71,9 @@ struct smx_driver_s {
   std::vector<std::unique_ptr<WorkSet>> prepared;
   size_t prepared_next = 0;
   // smx_driver_profile_begin: timed events around one preprocessing stage, one pair per frame
+  int read_timings = 0;            // smx_driver_set_read_timings
+  double timing_sums[7] = {0, 0, 0, 0, 0, 0, 0};
+  uint64_t timing_calls = 0, timing_last_call = 0;
   int prof_stage = -1;
   std::vector<smx_event> prof_ev;
   size_t prof_n = 0;
@@ -242,6 +245,16 @@ int smx_driver_recon(smx_driver d, smx_recon* out) {
   return SMX_OK;
 }
 
+// Integrate marks "inputs consumed / map complete" on its INTERNAL stream and defers the caller's stream's wait for it
+// into the next call (smx_recon_integrate_hooks): after a run the caller's stream is therefore not ordered behind the
+// last steps' second halves -- k_integrate writes the blended depths back into the work set, update + create read the
+// frame's colour.  Whoever touches a work set or a frame image outside the frame loop orders its stream here first.
+static int wait_for_steps_in_flight(smx_driver d, cudaStream_t stream) {
+  if (d->prev != d->last && d->prev->used) SMX_SHIM_CHECK(smx_stream_wait_event(stream, d->prev->integrated));
+  if (d->last->used) SMX_SHIM_CHECK(smx_stream_wait_event(stream, d->last->integrated));
+  return SMX_OK;
+}
+
 static Frame* get_or_make(smx_driver d, uint32_t f) {
   auto& slot = d->frames[f];
   if (!slot) slot.reset(new Frame(d->cfg.height, d->cfg.width));
@@ -251,6 +264,7 @@ static Frame* get_or_make(smx_driver d, uint32_t f) {
 int smx_driver_upload_frame(smx_driver d, smx_stream s, uint32_t frame_index, const uint16_t* depth, const uint8_t* color) {
   if (!d || !depth || !color) return fail("null argument");
   Frame* f = get_or_make(d, frame_index);
+  if (f->last_reader != 0) { const int rc = wait_for_steps_in_flight(d, s); if (rc != SMX_OK) return rc; }
   f->depth.UploadAsync(s, depth);
   f->color.UploadAsync(s, reinterpret_cast<const Vec3u8*>(color));
   return SMX_OK;
@@ -260,6 +274,7 @@ int smx_driver_render_frame(smx_driver d, smx_stream s, uint32_t frame_index, co
                             uint32_t seed, float noise_sigma, float dropout) {
   if (!d || !global_T_frame) return fail("null argument");
   Frame* f = get_or_make(d, frame_index);
+  if (f->last_reader != 0) { const int rc = wait_for_steps_in_flight(d, s); if (rc != SMX_OK) return rc; }
   return smx_synth_render_room(s, f->depth.ToCUDA().desc(), f->color.ToCUDA().desc(), d->cfg.fx, d->cfg.fy, d->cfg.cx,
                                d->cfg.cy, global_T_frame, seed, frame_index, d->cfg.depth_scaling, noise_sigma, dropout);
 }
@@ -339,6 +354,21 @@ static int run_one(smx_driver d, smx_stream s, const smx_driver_step& step, cons
   ws->used = true;
   d->prev = d->last;
   d->last = ws;
+  if (d->read_timings) {   // APP/main.cc:1511-1524
+    float t[7];
+    if (d->read_timings == 2) {
+      d->reconstruction.GetTimings(&t[0], &t[1], &t[2], &t[3], &t[4], &t[5], &t[6]);
+      for (int k = 0; k < 7; ++k) d->timing_sums[k] += t[k];
+      ++d->timing_calls;
+    } else {
+      const uint64_t call = d->reconstruction.GetTimingsNoWait(&t[0], &t[1], &t[2], &t[3], &t[4], &t[5], &t[6]);
+      if (call > d->timing_last_call) {
+        for (int k = 0; k < 7; ++k) d->timing_sums[k] += t[k];
+        ++d->timing_calls;
+        d->timing_last_call = call;
+      }
+    }
+  }
   return SMX_OK;
 }
 
@@ -402,7 +432,13 @@ static int run_ahead(smx_driver d, smx_stream s, const smx_driver_step* steps, i
 int smx_driver_debug_prepare(smx_driver d, smx_stream s, const smx_driver_step* steps, int32_t n) {
   if (!d || (!steps && n > 0)) return fail("null argument");
   SMX_SHIM_CHECK(smx_stream_synchronize(s));
-  if (d->prepared_next >= d->prepared.size()) { d->prepared.clear(); d->prepared_next = 0; }
+  if (d->prepared_next >= d->prepared.size()) {
+    // (the sets are freed: nothing may refer to them any more, and whatever still reads them has to be through)
+    { uint32_t live = 0, slots = 0;   // (joins s with the reconstruction's internal stream and waits for both)
+      SMX_SHIM_CHECK(smx_recon_counts(d->reconstruction.handle(), s, &live, &slots)); }
+    d->last = d->prev = &d->work0;
+    d->prepared.clear(); d->prepared_next = 0;
+  }
   for (int i = 0; i < n; ++i) {
     std::unique_ptr<WorkSet> ws(new WorkSet(d->cfg.height, d->cfg.width));
     // (the set's constructor clears its radius image on the null stream, which the preprocessing queue is not ordered
@@ -449,24 +485,30 @@ int smx_driver_run(smx_driver d, smx_stream s, const smx_driver_step* steps, int
     for (int i = 0; i < n; ++i) {
       if (d->prepared_next >= d->prepared.size()) return fail("fewer prepared work sets than steps");
       WorkSet* ws = d->prepared[d->prepared_next++].get();
+      ++d->frame_counter;
+      // (the same bookkeeping as run_one: "inputs consumed" marked by Integrate itself, the set counts as in flight)
+      SMX_SHIM_CHECK(smx_recon_integrate_hooks(d->reconstruction.handle(), ws->integrated, nullptr));
       const int rc = integrate_frame(d, s, steps[i], ws);
-      if (rc != SMX_OK) return rc;
+      if (rc != SMX_OK) { (void)smx_recon_integrate_hooks(d->reconstruction.handle(), nullptr, nullptr); return rc; }
+      ws->used = true;
       d->prev = d->last;
       d->last = ws;
     }
-    return SMX_OK;
+    return wait_for_steps_in_flight(d, s);
   }
   // Everything already enqueued on s (frame uploads / renders, earlier runs) precedes the first preprocessing.
   if (d->overlap) {
     SMX_SHIM_CHECK(smx_event_record(d->run_start, s));
     SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, d->run_start));
-    if (d->run_ahead) return run_ahead(d, s, steps, n);
+    if (d->run_ahead) { const int rc = run_ahead(d, s, steps, n); return rc != SMX_OK ? rc : wait_for_steps_in_flight(d, s); }
   }
   for (int i = 0; i < n; ++i) {
     const int rc = run_one(d, s, steps[i], nullptr);
     if (rc != SMX_OK) return rc;
   }
-  return SMX_OK;
+  // (one wait per RUN, not per frame: what follows the run on s -- downloads, uploads, other entry points' work on the
+  // work sets -- finds the last steps' second halves complete)
+  return d->overlap ? wait_for_steps_in_flight(d, s) : SMX_OK;
 }
 
 int smx_driver_run_streamed(smx_driver d, smx_stream s, const smx_driver_step* steps,
@@ -480,12 +522,26 @@ int smx_driver_run_streamed(smx_driver d, smx_stream s, const smx_driver_step* s
     const int rc = run_one(d, s, steps[i], &uploads[i]);
     if (rc != SMX_OK) return rc;
   }
-  return SMX_OK;
+  return d->overlap ? wait_for_steps_in_flight(d, s) : SMX_OK;
 }
 
 int smx_driver_set_overlap(smx_driver d, int32_t enabled) {
   if (!d) return fail("null argument");
   d->overlap = enabled != 0;
+  return SMX_OK;
+}
+
+int smx_driver_set_read_timings(smx_driver d, int32_t mode) {
+  if (!d || mode < 0 || mode > 2) return fail("invalid argument");
+  d->read_timings = mode;
+  return SMX_OK;
+}
+
+int smx_driver_timing_sums(smx_driver d, double sums_ms[7], uint64_t* calls, int32_t reset) {
+  if (!d || !sums_ms || !calls) return fail("null argument");
+  for (int k = 0; k < 7; ++k) sums_ms[k] = d->timing_sums[k];
+  *calls = d->timing_calls;
+  if (reset) { for (int k = 0; k < 7; ++k) d->timing_sums[k] = 0; d->timing_calls = 0; }
   return SMX_OK;
 }
 
@@ -532,6 +588,7 @@ int smx_driver_download_frame(smx_driver d, smx_stream s, uint32_t frame_index, 
 
 int smx_driver_download_work(smx_driver d, smx_stream s, uint16_t* depth, float* normals, float* radius) {
   if (!d) return fail("null argument");
+  { const int rc = wait_for_steps_in_flight(d, s); if (rc != SMX_OK) return rc; }
   if (depth) d->last->final_depth->DownloadAsync(s, depth);
   if (normals) d->last->normals_buffer.DownloadAsync(s, reinterpret_cast<float2_*>(normals));
   if (radius) d->last->radius_buffer.DownloadAsync(s, radius);

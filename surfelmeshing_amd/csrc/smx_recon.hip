@@ -119,7 +119,24 @@ struct FrameCtx {
   uint32_t frame;
   int W, H;
   int stats;       // collect the value-distribution counters (single-address atomics: off when timing)
+  unsigned long long* ts;   // this call's stage-stamp record (GetTimings; see StageStamps), or null
 };
+
+// Stage stamps: what GetTimings reports (cuda_surfel_reconstruction.cc:131-319 brackets seven stages with fourteen event
+// records in every Integrate call).  An event record is a packet of its own on the stream, and on streams that are never
+// idle fourteen of them cost a third of the frame rate (profiles/r28_stage_timing_C2.txt).  Here the kernels that begin
+// or end a stage stamp the device's constant-rate wall clock (s_memrealtime) into a small per-call record: "stage begins"
+// = a plain store by the first workgroup dispatched, "stage ends" = the maximum over the workgroups that did work
+// (one fire-and-forget 64-bit atomic max per workgroup at its exit: nobody waits for it).  Records live in a ring
+// (kTsRing calls); the first kernel of a call (k_cull_segments) resets the call's record and writes its sequence number.
+enum : int { kTsCullBegin = 0, kTsTilesEnd, kTsBlendEnd, kTsIntBegin, kTsIntEnd, kTsUpdEnd, kTsRegEnd, kTsSeq, kTsWords };
+constexpr int kTsRing = 8;
+__device__ __forceinline__ void ts_begin(unsigned long long* ts, int k) {
+  if (ts && blockIdx.x == 0 && threadIdx.x == 0) ts[k] = wall_clock64();
+}
+__device__ __forceinline__ void ts_end(unsigned long long* ts, int k) {
+  if (ts && threadIdx.x == 0) atomicMax(&ts[k], (unsigned long long)wall_clock64());
+}
 
 struct Scratch {
   uint32_t* supporting;
@@ -409,9 +426,11 @@ struct BlendBufs {
   uint8_t* distance_map; uint8_t* new_distance_map; float* deltas; float* new_deltas;
 };
 
-__global__ void k_reset_frame_stats(DevState* st) {   // (value-distribution counters: only while statistics are on)
+// (value-distribution counters: only while statistics are on.  Two steps: the cull step's counter in front of it, the
+// others behind the stream's wait for the previous call's second half, whose kernels may still be adding to them)
+__global__ void k_reset_frame_stats(DevState* st, int cull_only) {
+  if (cull_only) { st->n_segments_skipped = 0; return; }
   st->n_visible = 0; st->n_merged = 0; st->n_integrated = 0; st->n_replaced = 0; st->n_conflict_hits = 0;
-  st->n_segments_skipped = 0;
   st->n_pairs = 0; st->n_overflow_pairs = 0; st->max_tile_pairs = 0;
 }
 
@@ -448,7 +467,13 @@ struct SegWork {
   uint32_t* count;       // [0] survivors, [1] copies; zeroed for the next call by k_assoc_tiles
 };
 __global__ void __launch_bounds__(kBlock)
-k_cull_segments(FrameCtx c, Lists L, SegWork sw, DevState* st, uint32_t nseg_alloc, uint32_t max_new_slots) {
+k_cull_segments(FrameCtx c, Lists L, SegWork sw, DevState* st, uint32_t nseg_alloc, uint32_t max_new_slots, unsigned long long ts_seq) {
+  if (c.ts && blockIdx.x == 0 && threadIdx.x == 0) {   // (the call's stage-stamp record: reset, sequence number, first stamp)
+#pragma unroll
+    for (int k = 1; k < kTsSeq; ++k) c.ts[k] = 0;
+    c.ts[kTsSeq] = ts_seq;
+    c.ts[kTsCullBegin] = wall_clock64();
+  }
   const uint32_t seg = blockIdx.x * kBlock + threadIdx.x;
   const bool have_seg = seg < nseg_alloc;
   const uint32_t sidx = have_seg ? seg : 0u;   // (segment 0 stands in: no branch around the loads)
@@ -948,6 +973,7 @@ k_assoc_tiles(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<
     sc.confl_key[k] = t.confl[lane];
   }
   SMX_STAMP(stamps, 5);
+  ts_end(c.ts, kTsTilesEnd);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -957,7 +983,8 @@ __device__ __forceinline__ float depth_sum_avg(const Scratch& sc, size_t k) {
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_blend_start(float ds, Img<uint16_t> depth, Scratch sc, BlendBufs b, int W, int H) {
+k_blend_start(float ds, Img<uint16_t> depth, Scratch sc, BlendBufs b, int W, int H, unsigned long long* ts) {
+  ts_end(ts, kTsBlendEnd);   // (multi-launch fallback: the stage ends with the last workgroup STARTED -- within a microsecond of the end)
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (!(x >= 1 && y >= 1 && x < W - 1 && y < H - 1)) return;
@@ -986,7 +1013,8 @@ k_blend_start(float ds, Img<uint16_t> depth, Scratch sc, BlendBufs b, int W, int
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_blend_iter(int it, float term, float ds, Img<uint16_t> depth, Scratch sc, BlendBufs b, int W, int H) {
+k_blend_iter(int it, float term, float ds, Img<uint16_t> depth, Scratch sc, BlendBufs b, int W, int H, unsigned long long* ts) {
+  ts_end(ts, kTsBlendEnd);
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (!(x >= 1 && y >= 1 && x < W - 1 && y < H - 1)) return;
@@ -1057,7 +1085,10 @@ struct BlendMasks {
 __device__ __forceinline__ unsigned long long dilate_row(unsigned long long m) { return m | (m << 1) | (m >> 1); }
 // lane r gets lane r - 1's / r + 1's value, the first / last lane 0: DPP wave_shr:1 / wave_shl:1, no LDS crossbar trip
 // (GFX9-family encodings; the whole file is written for wave64 on gfx950 -- DESIGN.md -- and the build says so)
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+// What the code needs is wave64, the GFX9 DPP controls and packed fp32 -- gfx90a / gfx942 have all three, and
+// -DSMX_ALLOW_OTHER_GFX9 lets such a build through (untuned: every grid, tile and register budget here is gfx950's).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && \
+    !(defined(SMX_ALLOW_OTHER_GFX9) && (defined(__gfx90a__) || defined(__gfx940__) || defined(__gfx941__) || defined(__gfx942__)))
 #error "libsmx device code is written for gfx950 (wave64, GFX9 DPP controls, packed fp32): build with --offload-arch=gfx950"
 #endif
 __device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v) {
@@ -1083,7 +1114,7 @@ __device__ __forceinline__ unsigned long long row_mask_from_bits(uint32_t bits) 
 template <int kBlendTile>
 __global__ void __launch_bounds__(kBlendThreads)
 k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<uint16_t> out, Scratch sc, int W, int H,
-              int tiles_x, unsigned long long* stamps) {
+              int tiles_x, unsigned long long* stamps, unsigned long long* ts) {
   extern __shared__ __align__(16) unsigned char blend_lds[];
   SMX_STAMP(stamps, 0);
   const int halo = radius - 1;
@@ -1247,6 +1278,7 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
     if (x < W && y < H) out(y, x) = dep[(ty + halo) * rw + (tx + halo)];
   }
   SMX_STAMP(stamps, 5);
+  ts_end(ts, kTsBlendEnd);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1456,7 +1488,8 @@ template <bool kUseList>
 __global__ void __launch_bounds__(kBlock)
 k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
             uint8_t* __restrict__ merge_flag, DevState* st, NewFlagsArgs nf, uint32_t n_flag_blocks) {
-  if (blockIdx.x < n_flag_blocks) { new_flags_scan_body(nf, sc, c.W, c.H, st, blockIdx.x); return; }
+  // (workgroup 0 is always a flag block: the image has pixels)
+  if (blockIdx.x < n_flag_blocks) { ts_begin(c.ts, kTsIntBegin); new_flags_scan_body(nf, sc, c.W, c.H, st, blockIdx.x); ts_end(c.ts, kTsIntEnd); return; }
   const uint32_t block = blockIdx.x - n_flag_blocks, n_blocks = gridDim.x - n_flag_blocks;
   const uint32_t n_scan = kUseList ? 0u : st->surfel_count;
   uint32_t merged_here = 0;
@@ -1516,6 +1549,7 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
     atomicAdd(&st->merge_count, merged_here);
     if (c.stats) atomicAdd(&st->n_merged, merged_here);   // (per-call statistic: reset by k_reset_frame_stats while statistics are on)
   }
+  if (block < n_steps) ts_end(c.ts, kTsIntEnd);   // (workgroups that walked at least one step)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1610,6 +1644,7 @@ __device__ __forceinline__ void update_neighbors_body(const Surfels& S, const Fr
       L.hot_epoch[i >> L.hot_shift] = (uint8_t)L.epoch;   // (new links)
     }
   }
+  if (block < n_steps) ts_end(c.ts, kTsUpdEnd);   // (workgroups that walked at least one step)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1763,6 +1798,7 @@ __device__ __forceinline__ void new_create_body(const Surfels& S, const FrameCtx
     *S.group(kGroupS, i) = make_float4((gp.x + sum.x) / (float)count_plus_1, (gp.y + sum.y) / (float)count_plus_1,
                                        (gp.z + sum.z) / (float)count_plus_1, 0.0f);  // :227-229
   }
+  ts_end(c.ts, kTsUpdEnd);   // (workgroups with a flagged pixel, and workgroup 0)
 }
 
 // UpdateNeighborsCUDAKernel and the creation kernel in ONE launch: both only need the integrated surfels, they
@@ -2245,7 +2281,7 @@ k_rebuild_flags(Surfels S, uint32_t frame, int reg_window, uint8_t* __restrict__
 constexpr int kStepSub = kSegB / kBlock;
 __global__ void __launch_bounds__(kBlock)
 k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long* __restrict__ grad_local,
-           FarBins fb, Lists L, DevState* st) {
+           FarBins fb, Lists L, DevState* st, unsigned long long* ts) {
   __shared__ unsigned long long lfar[kSegB * 2];   // per target of the segment: (gx | gy), (gz | sender classes)
   uint32_t desc, cntv;
   const uint32_t n_steps = walk_begin<true>(L.rec_chunks, 0u, blockIdx.x, desc, cntv);
@@ -2357,13 +2393,15 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long*
       *S.group(kGroupS, i) = make_float4(sp.x - step * grad.x, sp.y - step * grad.y, sp.z - step * grad.z, rs[sub].w);
     }
   }
+  if (blockIdx.x < n_steps) ts_end(ts, kTsRegEnd);   // (workgroups that walked at least one step)
 }
 
 // RegularizeSurfelsCUDACopyOnlyKernel (:2310-2327), over the recent list.
 __global__ void __launch_bounds__(kBlock)
-k_reg_copy_raw(Surfels S, Lists L, const DevState* st) {
+k_reg_copy_raw(Surfels S, Lists L, const DevState* st, unsigned long long* ts) {
   uint32_t desc, cntv;
   const uint32_t n_steps = walk_begin<true>(L.rec_chunks, 0u, blockIdx.x, desc, cntv);
+  if (blockIdx.x < n_steps) ts_end(ts, kTsRegEnd);   // (copy-only regulariser: the last workgroup STARTED)
   for (uint32_t w = blockIdx.x; w < n_steps; w += gridDim.x) {
     desc = walk_next<true>(L.rec_chunks, w, n_steps);
     if (!walk_step_valid(w, cntv)) continue;
@@ -2657,8 +2695,13 @@ struct smx_recon_s {
   int n_scan_blocks;
   DevState* st;
   int scan_mode;
-  int timing_enabled;
+  int timing_enabled;       // bit 0: the reference's 14 stage events, bit 1: events around every kernel, bit 2: stage stamps (default)
   bool have_timings;
+  unsigned long long* ts_ring;   // [kTsRing][kTsWords] stage stamps of the last kTsRing Integrate calls (StageStamps)
+  unsigned long long* ts_host;   // page-locked copy target of the ring
+  unsigned long long ts_seq;     // Integrate calls with stamps so far (a call's record: ts_ring[seq % kTsRing])
+  hipStream_t ts_stream;         // copies of the ring: ordered behind nothing
+  int wall_khz;                  // rate of the device's wall clock (hipDeviceAttributeWallClockRate)
   hipEvent_t ev[14];
   // per-kernel instrumentation (timing_enabled bit 1) and single-kernel profiling over many frames
   hipEvent_t kev[2 * 16];
@@ -2748,7 +2791,7 @@ int join_regularizer(smx_recon r, hipStream_t st) {
 // zero_chunks: pass B appends to the recent list's chunk descriptors; inside Integrate the launch in front of it
 // (k_update_and_create) has reset their counter, everywhere else it is done here.
 int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, float weight, int window,
-                       bool detach, bool copy_only, bool zero_chunks) {
+                       bool detach, bool copy_only, bool zero_chunks, unsigned long long* ts = nullptr) {
   const dim3 g(r->nsegB), bB(kBlockB), gl(r->grid_list), b(kBlock);
   const float rf2 = rf * rf;
   if (!r->table_valid || r->table_frame != frame || r->table_window != window) {
@@ -2779,10 +2822,10 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
   }
   if (copy_only) {
     SlotTimer t(r, st, kSlotRegUpdate);
-    hipLaunchKernelGGL(k_reg_copy_raw, gl, b, 0, st, r->S, r->L, r->st);
+    hipLaunchKernelGGL(k_reg_copy_raw, gl, b, 0, st, r->S, r->L, r->st, ts);
   } else {
     SlotTimer t(r, st, kSlotRegStep, true);
-    hipExtLaunchKernelGGL(k_reg_step, gl, b, 0, st, t.start(), t.stop(), 0, r->S, weight, r->grad_acc, r->grad_local, r->fb, r->L, r->st);
+    hipExtLaunchKernelGGL(k_reg_step, gl, b, 0, st, t.start(), t.stop(), 0, r->S, weight, r->grad_acc, r->grad_local, r->fb, r->L, r->st, ts);
   }
   SMX_LAUNCH_CHECK();
   return SMX_OK;
@@ -2925,6 +2968,11 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->block_sums, (size_t)r->n_scan_blocks, true));
   SMX_TRY(dev_alloc(&r->block_offsets, (size_t)r->n_scan_blocks, true));
   SMX_TRY(dev_alloc(&r->st, 1, true));
+  SMX_TRY(dev_alloc(&r->ts_ring, (size_t)kTsRing * kTsWords, true));
+  SMX_TRY(hip_rc(hipHostMalloc(reinterpret_cast<void**>(&r->ts_host), sizeof(unsigned long long) * kTsRing * kTsWords, hipHostMallocDefault), "hipHostMalloc"));
+  SMX_TRY(hip_rc(hipStreamCreateWithFlags(&r->ts_stream, hipStreamNonBlocking), "hipStreamCreateWithFlags"));
+  SMX_TRY(hip_rc(hipDeviceGetAttribute(&r->wall_khz, hipDeviceAttributeWallClockRate, device), "hipDeviceGetAttribute"));
+  if (r->wall_khz <= 0) r->wall_khz = 100000;   // (s_memrealtime: 100 MHz)
   for (int i = 0; i < 14; ++i) SMX_TRY(hip_rc(hipEventCreate(&r->ev[i]), "hipEventCreate"));
   for (int i = 0; i < 2 * 16; ++i) SMX_TRY(hip_rc(hipEventCreate(&r->kev[i]), "hipEventCreate"));
   {
@@ -2941,7 +2989,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(hip_rc(hipEventCreateWithFlags(&r->ev_staging, hipEventDisableTiming), "hipEventCreateWithFlags"));
   r->overlap_enabled = 1;
   r->prof_slot = -1;
-  r->timing_enabled = 0;   // (the 14 stage events of GetTimings: armed by the first call of it, see smx_recon_get_timings)
+  r->timing_enabled = 4;   // (GetTimings is served by the stage stamps: on from the first call, like the reference's events)
   hipDeviceProp_t prop;
   SMX_TRY(hip_rc(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties"));
 #undef SMX_TRY
@@ -2965,6 +3013,9 @@ int smx_recon_destroy(smx_recon r) {
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->block_offsets, r->st};
   if (r->reg_stream) { (void)hipStreamSynchronize(r->reg_stream); (void)hipStreamDestroy(r->reg_stream); }
   if (r->dir_host) { (void)hipDeviceSynchronize(); (void)hipHostFree(r->dir_host); }
+  if (r->ts_stream) { (void)hipStreamSynchronize(r->ts_stream); (void)hipStreamDestroy(r->ts_stream); }
+  if (r->ts_host) (void)hipHostFree(r->ts_host);
+  if (r->ts_ring) (void)hipFree(r->ts_ring);
   if (r->ev_front) (void)hipEventDestroy(r->ev_front);
   if (r->ev_upd) (void)hipEventDestroy(r->ev_upd);
   if (r->ev_reg) (void)hipEventDestroy(r->ev_reg);
@@ -2978,9 +3029,10 @@ int smx_recon_destroy(smx_recon r) {
 }
 
 int smx_recon_set_timing_enabled(smx_recon r, int32_t enabled) {
-  SMX_CHECK_ARG(r != nullptr && enabled >= 0 && enabled <= 3);
+  SMX_CHECK_ARG(r != nullptr && enabled >= 0 && enabled <= 7);
   SMX_ON_DEVICE(r->device);
   r->timing_enabled = enabled;
+  if (!(enabled & 1)) r->have_timings = false;
   return SMX_OK;
 }
 
@@ -3100,6 +3152,8 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   c.frame = frame_index;
   c.W = r->W; c.H = r->H;
   c.stats = r->stats_enabled;
+  c.ts = nullptr;
+  if (r->timing_enabled & 4) { ++r->ts_seq; c.ts = r->ts_ring + (size_t)(r->ts_seq % kTsRing) * kTsWords; }
   const int P = r->W * r->H;
   const dim3 b(kBlock), gpx(div_up(P, kBlock)), gimg(div_up(r->W, 64), div_up(r->H, 4));
   const dim3 gs(r->nseg), gl(r->grid_list);
@@ -3131,7 +3185,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   // (a caller that comes with another stream than last time: that stream has not waited for the previous call's map yet)
   if (r->reg_pending && r->last_stream != st) { const int rcj = join_regularizer(r, st); if (rcj != SMX_OK) return rcj; }
   r->last_stream = st;
-  if (r->stats_enabled) hipLaunchKernelGGL(k_reset_frame_stats, dim3(1), dim3(1), 0, sF, r->st);
+  if (r->stats_enabled) hipLaunchKernelGGL(k_reset_frame_stats, dim3(1), dim3(1), 0, sF, r->st, 1);
   if (tm) SMX_HIP(hipEventRecord(r->ev[0], sF));
   // two chunk counters / overflow counters in alternation: the kernels of this call read theirs while they reset the
   // next call's (k_update_and_create / k_assoc_tiles)
@@ -3144,8 +3198,9 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     SlotTimer t(r, sF, kSlotCull);
     if (r->sw_dirty) SMX_HIP(hipMemsetAsync(r->sw.count, 0, 2 * sizeof(uint32_t), sF));
     r->sw_dirty = true;
-    hipLaunchKernelGGL(k_cull_segments, dim3((unsigned)div_up(r->nseg, kBlock)), b, 0, sF, c, r->L, r->sw, r->st, (uint32_t)r->nseg, (uint32_t)P); }
+    hipLaunchKernelGGL(k_cull_segments, dim3((unsigned)div_up(r->nseg, kBlock)), b, 0, sF, c, r->L, r->sw, r->st, (uint32_t)r->nseg, (uint32_t)P, r->ts_seq); }
   if (r->pending_mark) { SMX_HIP(hipStreamWaitEvent(sF, r->pending_mark, 0)); r->pending_mark = nullptr; }
+  if (r->stats_enabled) hipLaunchKernelGGL(k_reset_frame_stats, dim3(1), dim3(1), 0, sF, r->st, 0);
   { SlotTimer t(r, sF, kSlotScanVisible, true);
     const bool lds_tables = !r->no_lds_tables;
     // chip-sized grid: as many workgroups as the chip holds at once (8 per CU) walk the survivor list
@@ -3187,18 +3242,18 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     const hipEvent_t stop = front_by_launch ? r->ev_front : nullptr;
     if (tile == 40)
       hipExtLaunchKernelGGL(k_blend_tiles<40>, dim3(n_blend), dim3(kBlendThreads), (uint32_t)lds, sF, nullptr, stop, 0, p->measurement_blending_radius, term, ds,
-                            in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps);
+                            in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps, c.ts);
     else
       hipExtLaunchKernelGGL(k_blend_tiles<32>, dim3(n_blend), dim3(kBlendThreads), (uint32_t)lds, sF, nullptr, stop, 0, p->measurement_blending_radius, term, ds,
-                            in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps);
+                            in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps, c.ts);
   } else if (p->do_blending) {
     // the reference's own sequence (2 clears + start + iterations, kernels.cc:165-205), in place on the caller's depth
     SlotTimer t(r, sF, kSlotBlend);
     SMX_HIP(hipMemsetAsync(r->bb.distance_map, 0, (size_t)P, sF));
     SMX_HIP(hipMemsetAsync(r->bb.new_distance_map, 0, (size_t)P, sF));
-    hipLaunchKernelGGL(k_blend_start, gimg, b, 0, sF, ds, depth_rw, r->sc, r->bb, r->W, r->H);
+    hipLaunchKernelGGL(k_blend_start, gimg, b, 0, sF, ds, depth_rw, r->sc, r->bb, r->W, r->H, c.ts);
     for (int it = 2; it < p->measurement_blending_radius; ++it)
-      hipLaunchKernelGGL(k_blend_iter, gimg, b, 0, sF, it, term, ds, depth_rw, r->sc, r->bb, r->W, r->H);
+      hipLaunchKernelGGL(k_blend_iter, gimg, b, 0, sF, it, term, ds, depth_rw, r->sc, r->bb, r->W, r->H, c.ts);
   }
   if (tm) SMX_HIP(hipEventRecord(r->ev[5], sF));
   // Which pixels spawn a surfel depends only on the association images and the blended depth: the flag + rank pass of
@@ -3266,11 +3321,11 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   if (skip_reg) {
   } else if (iters == 0) {
     rc = enqueue_regularize(r, sR, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
-                            p->regularization_frame_window_size, true, true, false);
+                            p->regularization_frame_window_size, true, true, false, c.ts);
   } else {
     for (int k = 0; k < iters && rc == SMX_OK; ++k)
       rc = enqueue_regularize(r, sR, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
-                              p->regularization_frame_window_size, k == 0, false, k > 0);
+                              p->regularization_frame_window_size, k == 0, false, k > 0, c.ts);
   }
   if (rc != SMX_OK) return rc;
   if (tm) { SMX_HIP(hipEventRecord(r->ev[13], sR)); r->have_timings = true; }
@@ -3548,17 +3603,70 @@ int smx_recon_check_triangles(smx_recon r, smx_stream s, const uint32_t* triangl
   return rc;
 }
 
+namespace {
+// stage times of one stamp record (ms); false if the record is not that call's or the call did not get through
+bool stage_ms_from_stamps(const unsigned long long* t, unsigned long long seq, int khz, float out_ms[7]) {
+  if (t[kTsSeq] != seq || t[kTsCullBegin] == 0 || t[kTsTilesEnd] == 0 || t[kTsIntBegin] == 0) return false;
+  auto ms = [&](unsigned long long a, unsigned long long b) { return (b > a && a != 0) ? (float)((double)(b - a) / (double)khz) : 0.0f; };
+  const unsigned long long int_end = t[kTsIntEnd] ? t[kTsIntEnd] : t[kTsIntBegin];
+  const unsigned long long upd_end = t[kTsUpdEnd] ? t[kTsUpdEnd] : int_end;
+  out_ms[0] = ms(t[kTsCullBegin], t[kTsTilesEnd]);   // data association: cull step, pass A, association tiles
+  out_ms[1] = 0.0f;                                  // surfel merging: decided inside the tile kernel, applied by k_integrate
+  out_ms[2] = ms(t[kTsTilesEnd], t[kTsBlendEnd]);    // measurement blending
+  out_ms[3] = ms(t[kTsIntBegin], int_end);           // integration (+ the new-surfel flag and rank pass)
+  out_ms[4] = ms(int_end, upd_end);                  // neighbour update (+ creation, same launch)
+  out_ms[5] = 0.0f;                                  // new surfel creation: inside the neighbour-update launch
+  out_ms[6] = ms(upd_end, t[kTsRegEnd]);             // regularisation: pass B, edges, step
+  return true;
+}
+int copy_stamp_ring(smx_recon r) {
+  SMX_HIP(hipMemcpyAsync(r->ts_host, r->ts_ring, sizeof(unsigned long long) * kTsRing * kTsWords, hipMemcpyDeviceToHost, r->ts_stream));
+  SMX_HIP(hipStreamSynchronize(r->ts_stream));
+  return SMX_OK;
+}
+}  // namespace
+
 int smx_recon_get_timings(smx_recon r, float out_ms[7]) {
   SMX_CHECK_ARG(r != nullptr && out_ms != nullptr);
   SMX_ON_DEVICE(r->device);
-  // The reference records its 14 stage events in every Integrate (cc:112-320).  Here every record is a packet between two
-  // kernels of a stream that is never idle: with them the frame rate at 640 x 480 is 4 000 instead of 6 000 frames/s
-  // (profiles/r17_ab_notes.md, r28).  So they are recorded from the first call of GetTimings on: a caller that asks after
-  // every Integrate gets zeros once and the stage times of the last call from then on, a caller that never asks pays nothing.
-  if (!(r->timing_enabled & 1)) r->timing_enabled |= 1;
-  if (!r->have_timings) { for (int i = 0; i < 7; ++i) out_ms[i] = 0; return SMX_OK; }
-  SMX_HIP(hipEventSynchronize(r->ev[13]));  // cc:420
-  for (int i = 0; i < 7; ++i) SMX_HIP(hipEventElapsedTime(&out_ms[i], r->ev[2 * i], r->ev[2 * i + 1]));
+  for (int i = 0; i < 7; ++i) out_ms[i] = 0;
+  if (r->timing_enabled & 1) {
+    // (measurement / comparison mode: the reference's own 14 event records, cc:131-319 -- every record a packet between two
+    // kernels of a stream that is never idle: 4 000 instead of 6 000 frames/s at 640 x 480, profiles/r28_stage_timing_C2.txt)
+    if (!r->have_timings) return SMX_OK;
+    SMX_HIP(hipEventSynchronize(r->ev[13]));  // cc:420
+    for (int i = 0; i < 7; ++i) SMX_HIP(hipEventElapsedTime(&out_ms[i], r->ev[2 * i], r->ev[2 * i + 1]));
+    return SMX_OK;
+  }
+  if (!(r->timing_enabled & 4) || r->ts_seq == 0) return SMX_OK;
+  // Like the reference (cudaEventSynchronize(regularization_end_event_), cc:420): wait until the last call is through --
+  // all of its work precedes the end of the internal stream's queue (or of the caller's stream's, not pipelined).
+  if (r->reg_pending) { SMX_HIP(hipEventRecord(r->ev_reg, r->reg_stream)); SMX_HIP(hipEventSynchronize(r->ev_reg)); }
+  if (!r->reg_pending || !r->overlap_enabled) SMX_HIP(hipStreamSynchronize(r->last_stream));
+  { const int rc = copy_stamp_ring(r); if (rc != SMX_OK) return rc; }
+  (void)stage_ms_from_stamps(r->ts_host + (size_t)(r->ts_seq % kTsRing) * kTsWords, r->ts_seq, r->wall_khz, out_ms);
+  return SMX_OK;
+}
+
+int smx_recon_get_timings_nowait(smx_recon r, float out_ms[7], uint64_t* call_number) {
+  SMX_CHECK_ARG(r != nullptr && out_ms != nullptr);
+  SMX_ON_DEVICE(r->device);
+  for (int i = 0; i < 7; ++i) out_ms[i] = 0;
+  if (call_number) *call_number = 0;
+  if (!(r->timing_enabled & 4) || r->ts_seq == 0) return SMX_OK;
+  { const int rc = copy_stamp_ring(r); if (rc != SMX_OK) return rc; }
+  // A call's regulariser is known to be through once a LATER call's integration kernel has started (they follow each other
+  // on one in-order stream): the newest record with such a successor.
+  unsigned long long best = 0;
+  for (int k = 0; k < kTsRing; ++k) {
+    const unsigned long long* t = r->ts_host + (size_t)k * kTsWords;
+    const unsigned long long q = t[kTsSeq];
+    if (q == 0 || q <= best) continue;
+    const unsigned long long* nx = r->ts_host + (size_t)((q + 1) % kTsRing) * kTsWords;
+    if (nx[kTsSeq] == q + 1 && nx[kTsIntBegin] != 0) best = q;
+  }
+  if (best && stage_ms_from_stamps(r->ts_host + (size_t)(best % kTsRing) * kTsWords, best, r->wall_khz, out_ms) && call_number)
+    *call_number = best;
   return SMX_OK;
 }
 

@@ -14,12 +14,12 @@ SUF=""; [ $CFG != C2 ] && SUF="_$CFG"
 PMCJ=$OUT/pmc_traffic$SUF.json
 rm -f $PMCJ
 case $CFG in
-  C2) CMD="python bench.py --steps 300 --warmup 20 --cpu-frames 0 --host-frames 0 --quiet"
-      CMDS="python bench.py --steps 20 --warmup 5 --cpu-frames 0 --host-frames 0 --quiet";;
-  C3) CMD="python bench.py --config C3 --steps 100 --warmup 10 --cpu-frames 0 --host-frames 0 --quiet"
-      CMDS="python bench.py --config C3 --steps 10 --warmup 3 --cpu-frames 0 --host-frames 0 --quiet";;
-  C5) CMD="python bench.py --config C5 --steps 3 --warmup 1 --cpu-frames 0 --quiet"
-      CMDS="python bench.py --config C5 --steps 2 --warmup 1 --cpu-frames 0 --quiet";;
+  C2) CMD="python bench.py --steps 300 --warmup 20 --cpu-frames 0 --host-frames 0 --timing-frames 0 --growth-frames 0 --no-other-configs --quiet"
+      CMDS="python bench.py --steps 20 --warmup 5 --cpu-frames 0 --host-frames 0 --timing-frames 0 --growth-frames 0 --no-other-configs --quiet";;
+  C3) CMD="python bench.py --config C3 --steps 100 --warmup 10 --cpu-frames 0 --host-frames 0 --timing-frames 0 --growth-frames 0 --no-other-configs --quiet"
+      CMDS="python bench.py --config C3 --steps 10 --warmup 3 --cpu-frames 0 --host-frames 0 --timing-frames 0 --growth-frames 0 --no-other-configs --quiet";;
+  C5) CMD="python bench.py --config C5 --steps 3 --warmup 1 --cpu-frames 0 --quiet --no-other-configs"
+      CMDS="python bench.py --config C5 --steps 2 --warmup 1 --cpu-frames 0 --quiet --no-other-configs";;
 esac
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_trace -o run -- $CMD > $OUT/${TAG}${SUF}_bench.log 2>&1
 python tools/prof_summary.py /tmp/prof_trace $OUT/${TAG}${SUF}_bench_timed_region_summary.md > /dev/null
