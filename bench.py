@@ -162,92 +162,77 @@ class Workload:
         return arr, len(plans)
 
     def grow(self, log, window=None):
-        """Untimed: run the real pipeline along the trajectory until the map holds >= target LIVE surfels
-        (surfel_count() = slots - merged, as BASELINE.json's metric counts them).
-        window = (warm, frames, callback): the EXPLORING regime, timed -- the last `frames` growth frames before the
-        target is reached (the camera keeps finding new surface: thousands of new surfels a frame, every new slot inside
-        the regulariser window) run exactly like the timed window of the steady state: every step array prepared and every
-        frame rendered beforehand, `warm` untimed frames directly in front, no host synchronisation inside.
-        callback(g, info) is called right behind the window (in-run parity check of the next growth frames)."""
+        """Run the real pipeline along the trajectory until the map holds >= target LIVE surfels (surfel_count() = slots -
+        merged, as BASELINE.json's metric counts them), in batches of 50 frames.
+        window = (frames, callback): the EXPLORING regime, timed on the way -- the camera keeps finding new surface,
+        thousands of new surfels a frame, every new slot inside the regulariser window.  Every batch runs like the timed
+        window of the steady state (frames rendered and step arrays prepared beforehand, no host synchronisation inside);
+        its first 10 frames are untimed (the device idles between batches while the host renders and counts), the other 40
+        lie between two event records on the caller's stream.  growth_phase = the timed frames of the last batches before
+        the target (`frames` of them), growth_curve = every batch.  callback(g, info) is called when the target is reached
+        (in-run parity check of the next growth frames)."""
+        import torch
         g = 4
         for f in range(0, 9):
             self.render(f, f)
         live = 0
         rec = self.pipe.reconstruction
+        rec.set_stats_enabled(False)   # (the distribution counters are single-address atomics: off while timing)
         t0 = time.time()
-        rate = None
-        self.growth = None
+        curve = []
+        B, WARM = 50, 10
+        slots = rec.surfels_size()
         while live < self.target and g < 40000:
-            if window is not None and self.growth is None and rate is not None and rate > 0 and \
-                    live + (window[0] + window[1]) * rate * 1.02 >= self.target:
-                # (a small target -- the tests' -- is reached in a few frames: a shorter window, or none)
-                frames = min(window[1], int(0.3 * self.target / rate))
-                if frames >= 20:
-                    g = self._growth_window(g, live, (min(window[0], frames // 4), frames, window[2]))
-                    live = rec.surfel_count()
-                    continue
-                self.growth = {"skipped": "the target is reached within %d frames" % int(self.target / rate)}
             batch = []
-            for _ in range(50):
+            for _ in range(B):
                 batch.append(self.plan(g, g))
                 g += 1
             # frames g-4 .. g+4 of every step of the batch must be resident while it runs
             for f in range(batch[0][0] - 4, batch[-1][0] + 5):
                 self.render(f, f)
-            self.pipe.run_array(*self.steps(batch))
+            warm_steps, timed_steps = self.steps(batch[:WARM]), self.steps(batch[WARM:])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.pipe.run_array(*warm_steps)
+            e0.record()
+            self.pipe.run_array(*timed_steps)
+            e1.record()
             for f in range(batch[0][0] - 4, batch[-1][0] - 3):
                 self.pipe.release(f)
-            prev, live = live, rec.surfel_count()
-            rate = (live - prev) / 50.0
+            live = rec.surfel_count()      # (synchronises)
+            prev_slots, slots = slots, rec.surfels_size()
+            ms = e0.elapsed_time(e1)
+            curve.append({"frames_done": g - 4, "live": int(live), "slots": int(slots), "timed_frames": B - WARM, "ms": ms,
+                          "frames_per_s": (B - WARM) / (ms * 1e-3), "new_slots_per_frame": (slots - prev_slots) / float(B)})
             if log and (g - 4) % 500 == 0:
                 print("# grow: frame %d live surfels %d (%.1fs)" % (g, live, time.time() - t0), file=sys.stderr, flush=True)
+        self.growth = None
+        if window is not None and curve:
+            frames, callback = window
+            last = curve[-max(1, frames // (B - WARM)):]
+            n, ms = sum(c["timed_frames"] for c in last), sum(c["ms"] for c in last)
+            rec.set_stats_enabled(True)
+            self.render(g + 4, g + 4)
+            self.pipe.run_array(*self.steps([self.plan(g, g)]))
+            st = rec.stats()
+            rec.set_stats_enabled(False)
+            g += 1
+            self.growth = {"value": n / (ms * 1e-3), "unit": "frames/s", "steps": n, "ms_per_step": ms / n,
+                           "new_slots_per_frame": float(np.mean([c["new_slots_per_frame"] for c in last])),
+                           "live_surfels_at_start": int(curve[-len(last) - 1]["live"]) if len(curve) > len(last) else 0,
+                           "live_surfels_at_end": int(live),
+                           "frame_behind_the_window": {k: st[k] for k in ("surfels_size", "n_visible", "n_recent", "n_new", "n_segments_skipped",
+                                                                         "n_merged", "n_window_edges")},
+                           "regime": "exploring: the sweep that grows the map, the last %d batches of 50 frames before the live-surfel "
+                                     "target (40 timed frames each, between two event records on the caller's stream, behind 10 untimed "
+                                     "ones); same frame loop, inputs resident, step arrays prepared, no host synchronisation inside" % len(last),
+                           "growth_curve": [{k: (round(v, 1) if isinstance(v, float) else v) for k, v in c.items() if k != "timed_frames"}
+                                            for c in curve[::max(1, len(curve) // 12)]]}
+            if callback is not None:
+                callback(g, self.growth)
         for f in list(self.pipe.resident):
             self.pipe.release(f)
         self.api.StreamSynchronize(None)
         return g, live
-
-    def _growth_window(self, g, live_before, window):
-        import torch
-        warm, frames, callback = window
-        rec = self.pipe.reconstruction
-        n = warm + frames + 1
-        plans = [self.plan(g + j, g + j) for j in range(n)]
-        for f in range(g - 4, g + n + 5):
-            self.render(f, f)
-        warm_steps = self.steps(plans[:warm])
-        timed_steps = self.steps(plans[warm:warm + frames])
-        stats_step = self.steps(plans[warm + frames:n])
-        rec.set_stats_enabled(False)   # (the distribution counters are single-address atomics: off while timing)
-        self.pipe.run_array(*warm_steps)
-        torch.cuda.synchronize()
-        slots1 = rec.surfels_size()
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        self.pipe.run_array(*timed_steps)
-        enq = time.perf_counter() - t
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t
-        slots2 = rec.surfels_size()
-        live2 = rec.surfel_count()
-        rec.set_stats_enabled(True)
-        self.pipe.run_array(*stats_step)
-        st = rec.stats()
-        rec.set_stats_enabled(False)
-        self.growth = {"value": frames / dt, "unit": "frames/s", "steps": frames, "warmup": warm, "ms_per_step": 1e3 * dt / frames,
-                       "host_enqueue_ms_per_step": 1e3 * enq / frames,
-                       "new_slots_per_frame": (slots2 - slots1) / float(frames),
-                       "live_surfels_at_start": int(live_before), "live_surfels_at_end": int(live2),
-                       "slots_at_start": int(slots1), "slots_at_end": int(slots2),
-                       "frame_behind_the_window": {k: st[k] for k in ("surfels_size", "n_visible", "n_recent", "n_new", "n_segments_skipped",
-                                                                     "n_merged", "n_window_edges")},
-                       "regime": "exploring: the sweep that grows the map, the last %d frames before the live-surfel target; same "
-                                 "frame loop, inputs resident, step arrays prepared, no host synchronisation inside" % frames}
-        g += n
-        if callback is not None:
-            callback(g, self.growth)
-        for f in range(g - n - 4, g - 4):
-            self.pipe.release(f)
-        return g
 
 
 def host_frames_pass(wl, plan, base, count, api, torch):
@@ -288,35 +273,51 @@ STAGES = ["data_association", "surfel_merging", "measurement_blending", "integra
 
 
 def timing_passes(wl, plan, base, count, torch):
-    """What GetTimings costs the frame loop, each variant over `count` frames (the first fifth untimed) directly behind each
-    other in the same regime: stage stamps on (the library default = the headline's configuration), stamps off, stamps
-    on + the non-waiting read after every Integrate (APP/main.cc:1511 ported with GetTimingsNoWait), and the reference's
-    14 event records."""
+    """What GetTimings costs the frame loop.  Four variants over 4 x `count` frames behind the timed window, INTERLEAVED in
+    chunks of 20 frames (the regime drifts along the trajectory -- visible and recent counts change by tens of percent
+    within a few hundred frames -- so every variant samples the whole stretch): stage stamps on (the library default = the
+    headline's configuration), stamps off, stamps on + the non-waiting read after every Integrate (APP/main.cc:1511 ported
+    with GetTimingsNoWait), and the reference's 14 event records.  No host synchronisation between chunks; a chunk lies
+    between two event records on the caller's stream."""
     pipe, rec = wl.pipe, wl.pipe.reconstruction
-    warm = max(2, count // 5)
-    out = {}
-    for k, (name, mode, read) in enumerate((("stamps", 4, 0), ("off", 0, 0), ("stamps_read_every_frame_nowait", 4, 1), ("event_records", 1, 0))):
+    variants = (("stamps", 4, 0), ("off", 0, 0), ("stamps_read_every_frame_nowait", 4, 1), ("event_records", 1, 0))
+    chunk = 20
+    n_chunks = max(len(variants), (4 * count) // chunk)
+    arrays = [wl.steps(plan[base + k * chunk:base + (k + 1) * chunk]) for k in range(n_chunks)]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_chunks + 1)]
+    reads = {}
+    pipe.timing_sums()
+    warm = wl.steps(plan[base - 10:base]) if base >= 10 else None
+    if warm is not None:
+        pipe.run_array(*warm)
+    marks[0].record()
+    for k in range(n_chunks):
+        name, mode, read = variants[k % len(variants)]
         rec.set_timing_enabled(mode)
         pipe.set_read_timings(read)
-        lo = base + k * count
-        warm_steps, timed_steps = wl.steps(plan[lo:lo + warm]), wl.steps(plan[lo + warm:lo + count])
-        pipe.run_array(*warm_steps)
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        pipe.run_array(*timed_steps)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t
-        out[name] = {"value": (count - warm) / dt, "unit": "frames/s", "steps": count - warm}
+        pipe.run_array(*arrays[k])
+        marks[k + 1].record()
         if read:
             sums, calls = pipe.timing_sums()
-            out[name]["calls_read"] = calls
-            out[name]["mean_stage_ms"] = dict(zip(STAGES, [x / max(calls, 1) for x in sums]))
+            acc = reads.setdefault(name, [np.zeros(7), 0])
+            acc[0] += np.array(sums)
+            acc[1] += calls
+    torch.cuda.synchronize()
     pipe.set_read_timings(0)
     rec.set_timing_enabled(4)
+    out = {}
+    for v, (name, mode, read) in enumerate(variants):
+        ks = [k for k in range(n_chunks) if k % len(variants) == v]
+        ms = sum(marks[k].elapsed_time(marks[k + 1]) for k in ks)
+        out[name] = {"value": chunk * len(ks) / (ms * 1e-3), "unit": "frames/s", "steps": chunk * len(ks)}
+        if name in reads:
+            out[name]["calls_read"] = int(reads[name][1])
+            out[name]["mean_stage_ms"] = dict(zip(STAGES, [float(x) / max(reads[name][1], 1) for x in reads[name][0]]))
     ref = out["off"]["value"]
     for name in out:
         out[name]["vs_off"] = out[name]["value"] / ref
-    out["note"] = "short passes behind the timed window (not the headline); the headline runs with the library default: stamps on"
+    out["note"] = ("interleaved chunks of %d frames behind the timed window (not the headline); the headline runs with the "
+                   "library default: stamps on" % chunk)
     return out
 
 
@@ -507,7 +508,7 @@ def run_integrate(args):
         info["parity_check"] = r.get("parity_check")
         info["cpu_frames_per_s"] = r["value"]
 
-    g_end, n_live = wl.grow(log, (20, args.growth_frames, growth_check) if args.growth_frames > 0 else None)
+    g_end, n_live = wl.grow(log, (args.growth_frames, growth_check) if args.growth_frames > 0 else None)
     if log:
         print("# grown to %d live surfels in %d frames, %.1fs" % (n_live, g_end, time.time() - t0), file=sys.stderr)
 

@@ -274,14 +274,16 @@ int smx_recon_export_vertices(smx_recon r, smx_stream s, const smx_buffer_desc* 
  * creation, regularization (ms) of the LAST smx_recon_integrate call; like the reference it waits until that call is
  * through (cudaEventSynchronize(regularization_end_event_), cc:420).  On from the first call, at no measurable cost: the
  * stages are not bracketed by event records (each a packet between two kernels of a stream that is never idle: fourteen
- * of them cost a third of the frame rate here) but stamped by the kernels themselves -- device wall clock, "first
- * workgroup in" / "last workgroup out" of the launches that begin / end a stage -- into a per-call record.  Stages the
+ * of them cost a third of the frame rate here) but stamped by the kernels themselves -- device wall clock, first
+ * workgroup in of the launch that begins a stage / of the launch that follows it on the same stream, last workgroups out
+ * where nothing follows -- into a per-call record.  Stages the
  * design fuses into another stage's launch report 0: merging (decided in the association kernel, applied by the
  * integration kernel) and creation (in the neighbour-update launch). */
 int smx_recon_get_timings(smx_recon r, float out_ms[7]);
-/* The same for a frame loop that must not wait: the stage times of the NEWEST call that is known to be through without
- * waiting (normally the call before the last one while the pipeline is busy; its 1-based number in *call_number, 0 and
- * zeros if there is none yet).  Costs the host one 512-byte copy on a stream of its own; orders nothing. */
+/* The same for a frame loop that must not wait: the stage times of the NEWEST call whose record has been handed over --
+ * every call copies the record of the call before the previous one (complete by stream order at that point) into
+ * page-locked host memory, so the read lags the queue by two calls and touches neither the device nor any stream.
+ * *call_number: that call's 1-based number, 0 (and zeros) if there is none yet. */
 int smx_recon_get_timings_nowait(smx_recon r, float out_ms[7], uint64_t* call_number);
 /* enabled: bit 2 = stage stamps (default ON: what smx_recon_get_timings reads), bit 0 = the reference's own 14 stage
  * events instead (measurement: smx_recon_get_timings then reads those), bit 1 = events around every kernel */

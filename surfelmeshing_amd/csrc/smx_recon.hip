@@ -124,18 +124,31 @@ struct FrameCtx {
 
 // Stage stamps: what GetTimings reports (cuda_surfel_reconstruction.cc:131-319 brackets seven stages with fourteen event
 // records in every Integrate call).  An event record is a packet of its own on the stream, and on streams that are never
-// idle fourteen of them cost a third of the frame rate (profiles/r28_stage_timing_C2.txt).  Here the kernels that begin
-// or end a stage stamp the device's constant-rate wall clock (s_memrealtime) into a small per-call record: "stage begins"
-// = a plain store by the first workgroup dispatched, "stage ends" = the maximum over the workgroups that did work
-// (one fire-and-forget 64-bit atomic max per workgroup at its exit: nobody waits for it).  Records live in a ring
-// (kTsRing calls); the first kernel of a call (k_cull_segments) resets the call's record and writes its sequence number.
-enum : int { kTsCullBegin = 0, kTsTilesEnd, kTsBlendEnd, kTsIntBegin, kTsIntEnd, kTsUpdEnd, kTsRegEnd, kTsSeq, kTsWords };
+// idle fourteen of them cost a third of the frame rate (profiles/r28_stage_timing_C2.txt).  Here the kernels stamp the
+// device's constant-rate wall clock (s_memrealtime) into a small per-call record, and only a handful of workgroups per
+// launch do (a first version let every workgroup's exit raise an "end" word by a fire-and-forget 64-bit atomic max:
+// ~10 000 per frame, each behind the 1 - 2 us an s_memrealtime takes to return -- 14 % of the frame rate,
+// profiles/r5a_bench_line.json):
+//   * a stage BEGINS with the plain store of the first workgroup dispatched (blockIdx 0);
+//   * a stage that is followed by another launch on the same in-order stream ENDS with that launch's begin stamp;
+//   * where nothing follows on the stream (blend -> hand-over to the internal stream; the last regulariser kernel), and as
+//     the fallback where the follower is switched off, the end is the maximum over the LAST workgroups dispatched
+//     (kTsTail of them: workgroups are dispatched in order, the last ones in are the last ones out to within a
+//     microsecond or two) -- a few dozen atomics per frame.
+// Records live in a ring in device memory (kTsRing calls); the first kernel of a call (k_cull_segments) resets the
+// call's record and writes its sequence number.  For the non-waiting read the tile kernel's first workgroup copies the
+// record of the call before the previous one -- complete by stream order when that kernel runs -- into page-locked host
+// memory (sequence number first and last: a reader that sees both equal has a whole record).
+enum : int { kTsSeq = 0, kTsCullBegin, kTsTilesEnd, kTsBlendBegin, kTsBlendEnd, kTsIntBegin, kTsIntEnd, kTsUpdBegin, kTsUpdEnd,
+             kTsRegBegin, kTsRegEnd, kTsSeqTail = 15, kTsWords = 16 };
 constexpr int kTsRing = 8;
+constexpr uint32_t kTsTail = 32;
 __device__ __forceinline__ void ts_begin(unsigned long long* ts, int k) {
   if (ts && blockIdx.x == 0 && threadIdx.x == 0) ts[k] = wall_clock64();
 }
-__device__ __forceinline__ void ts_end(unsigned long long* ts, int k) {
-  if (ts && threadIdx.x == 0) atomicMax(&ts[k], (unsigned long long)wall_clock64());
+// (block of n_blocks: the workgroup's place in the dispatch order of the part of the launch that does this work)
+__device__ __forceinline__ void ts_end(unsigned long long* ts, int k, uint32_t block, uint32_t n_blocks) {
+  if (ts && threadIdx.x == 0 && block < n_blocks && block + kTsTail >= n_blocks) atomicMax(&ts[k], (unsigned long long)wall_clock64());
 }
 
 struct Scratch {
@@ -470,7 +483,7 @@ __global__ void __launch_bounds__(kBlock)
 k_cull_segments(FrameCtx c, Lists L, SegWork sw, DevState* st, uint32_t nseg_alloc, uint32_t max_new_slots, unsigned long long ts_seq) {
   if (c.ts && blockIdx.x == 0 && threadIdx.x == 0) {   // (the call's stage-stamp record: reset, sequence number, first stamp)
 #pragma unroll
-    for (int k = 1; k < kTsSeq; ++k) c.ts[k] = 0;
+    for (int k = 2; k < kTsWords; ++k) c.ts[k] = 0;
     c.ts[kTsSeq] = ts_seq;
     c.ts[kTsCullBegin] = wall_clock64();
   }
@@ -885,9 +898,29 @@ __global__ void __launch_bounds__(kTilePx)
 k_assoc_tiles(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<const float2> normals, TileBins tb,
               uint32_t* __restrict__ next_ovf_count, uint8_t* __restrict__ merge_flag, DevState* st,
               const uint8_t* __restrict__ seg_act, uint32_t nseg, uint32_t* __restrict__ direction_out, uint32_t* __restrict__ seg_work_count,
-              unsigned long long* stamps) {
+              unsigned long long* stamps, const unsigned long long* __restrict__ ts_ring, volatile unsigned long long* ts_host,
+              unsigned long long ts_seq) {
   __shared__ TileLds t;
   __shared__ uint32_t order_wave_tot[kTilePx / 64];
+  // side job of the first workgroup's second wavefront: the stage-stamp record of the call before the previous one (complete:
+  // that call's regulariser preceded the previous call's integration, whose end this stream has waited for) goes to
+  // page-locked host memory for the non-waiting GetTimings -- sequence number first and last around the data
+  if (blockIdx.x == 0 && threadIdx.x == 64 && ts_host && ts_seq > 2) {
+    const unsigned long long q = ts_seq - 2;
+    const unsigned long long* src = ts_ring + (size_t)(q % kTsRing) * kTsWords;
+    volatile unsigned long long* dst = ts_host + (size_t)(q % kTsRing) * kTsWords;
+    unsigned long long w[kTsWords];
+#pragma unroll
+    for (int k = 0; k < kTsWords; ++k) w[k] = src[k];
+    if (w[kTsSeq] == q) {
+      dst[kTsSeq] = q;
+      __threadfence_system();
+#pragma unroll
+      for (int k = 1; k < kTsSeqTail; ++k) dst[k] = w[k];
+      __threadfence_system();
+      dst[kTsSeqTail] = q;
+    }
+  }
   // side job of the first workgroup: the direction in which the launches that follow walk the segments (segment_of_block)
   if (blockIdx.x == 0) {
     const uint32_t n_used = min(nseg, (st->surfel_count + (uint32_t)kSeg - 1u) / (uint32_t)kSeg);
@@ -973,7 +1006,7 @@ k_assoc_tiles(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<
     sc.confl_key[k] = t.confl[lane];
   }
   SMX_STAMP(stamps, 5);
-  ts_end(c.ts, kTsTilesEnd);
+  ts_end(c.ts, kTsTilesEnd, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -984,7 +1017,8 @@ __device__ __forceinline__ float depth_sum_avg(const Scratch& sc, size_t k) {
 
 __global__ void __launch_bounds__(kBlock)
 k_blend_start(float ds, Img<uint16_t> depth, Scratch sc, BlendBufs b, int W, int H, unsigned long long* ts) {
-  ts_end(ts, kTsBlendEnd);   // (multi-launch fallback: the stage ends with the last workgroup STARTED -- within a microsecond of the end)
+  // (multi-launch fallback: the stage ends with the last workgroups STARTED -- within a microsecond of the end)
+  ts_end(ts, kTsBlendEnd, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (!(x >= 1 && y >= 1 && x < W - 1 && y < H - 1)) return;
@@ -1014,7 +1048,7 @@ k_blend_start(float ds, Img<uint16_t> depth, Scratch sc, BlendBufs b, int W, int
 
 __global__ void __launch_bounds__(kBlock)
 k_blend_iter(int it, float term, float ds, Img<uint16_t> depth, Scratch sc, BlendBufs b, int W, int H, unsigned long long* ts) {
-  ts_end(ts, kTsBlendEnd);
+  ts_end(ts, kTsBlendEnd, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (!(x >= 1 && y >= 1 && x < W - 1 && y < H - 1)) return;
@@ -1116,6 +1150,7 @@ __global__ void __launch_bounds__(kBlendThreads)
 k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<uint16_t> out, Scratch sc, int W, int H,
               int tiles_x, unsigned long long* stamps, unsigned long long* ts) {
   extern __shared__ __align__(16) unsigned char blend_lds[];
+  ts_begin(ts, kTsBlendBegin);
   SMX_STAMP(stamps, 0);
   const int halo = radius - 1;
   const int rw = kBlendTile + 2 * halo;          // region width == height (<= 64)
@@ -1278,7 +1313,7 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
     if (x < W && y < H) out(y, x) = dep[(ty + halo) * rw + (tx + halo)];
   }
   SMX_STAMP(stamps, 5);
-  ts_end(ts, kTsBlendEnd);
+  ts_end(ts, kTsBlendEnd, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1489,7 +1524,7 @@ __global__ void __launch_bounds__(kBlock)
 k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
             uint8_t* __restrict__ merge_flag, DevState* st, NewFlagsArgs nf, uint32_t n_flag_blocks) {
   // (workgroup 0 is always a flag block: the image has pixels)
-  if (blockIdx.x < n_flag_blocks) { ts_begin(c.ts, kTsIntBegin); new_flags_scan_body(nf, sc, c.W, c.H, st, blockIdx.x); ts_end(c.ts, kTsIntEnd); return; }
+  if (blockIdx.x < n_flag_blocks) { ts_begin(c.ts, kTsIntBegin); new_flags_scan_body(nf, sc, c.W, c.H, st, blockIdx.x); return; }
   const uint32_t block = blockIdx.x - n_flag_blocks, n_blocks = gridDim.x - n_flag_blocks;
   const uint32_t n_scan = kUseList ? 0u : st->surfel_count;
   uint32_t merged_here = 0;
@@ -1549,7 +1584,7 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
     atomicAdd(&st->merge_count, merged_here);
     if (c.stats) atomicAdd(&st->n_merged, merged_here);   // (per-call statistic: reset by k_reset_frame_stats while statistics are on)
   }
-  if (block < n_steps) ts_end(c.ts, kTsIntEnd);   // (workgroups that walked at least one step)
+  ts_end(c.ts, kTsIntEnd, block, min(n_blocks, n_steps));   // (the workgroups that walked the last steps of the first round)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1644,7 +1679,7 @@ __device__ __forceinline__ void update_neighbors_body(const Surfels& S, const Fr
       L.hot_epoch[i >> L.hot_shift] = (uint8_t)L.epoch;   // (new links)
     }
   }
-  if (block < n_steps) ts_end(c.ts, kTsUpdEnd);   // (workgroups that walked at least one step)
+  ts_end(c.ts, kTsUpdEnd, block, min(n_blocks, n_steps));   // (the workgroups that walked the last steps of the first round)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1798,7 +1833,6 @@ __device__ __forceinline__ void new_create_body(const Surfels& S, const FrameCtx
     *S.group(kGroupS, i) = make_float4((gp.x + sum.x) / (float)count_plus_1, (gp.y + sum.y) / (float)count_plus_1,
                                        (gp.z + sum.z) / (float)count_plus_1, 0.0f);  // :227-229
   }
-  ts_end(c.ts, kTsUpdEnd);   // (workgroups with a flagged pixel, and workgroup 0)
 }
 
 // UpdateNeighborsCUDAKernel and the creation kernel in ONE launch: both only need the integrated surfels, they
@@ -1809,6 +1843,7 @@ __global__ void __launch_bounds__(kBlock)
 k_update_and_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, CreateArgs a, uint32_t n_create_blocks,
                     DevState* st) {
   if (blockIdx.x < n_create_blocks) {
+    ts_begin(c.ts, kTsUpdBegin);
     new_create_body(S, c, sc, in, a, st, blockIdx.x, n_create_blocks);
   } else {
     const uint32_t block = blockIdx.x - n_create_blocks, n_blocks = gridDim.x - n_create_blocks;
@@ -1828,7 +1863,8 @@ k_update_and_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, Crea
 // accumulators are zero between calls (k_reg_step zeroes what it consumes).
 template <bool kDetach, bool kAccumulate>
 __global__ void __launch_bounds__(kBlockB)
-k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict__ inwin8, DevState* st) {
+k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict__ inwin8, DevState* st, unsigned long long* ts) {
+  ts_begin(ts, kTsRegBegin);
   const uint32_t seg_id = segment_of_block(L.descending);
   extern __shared__ __align__(16) uint8_t lhot[];   // the hot-group table (n_hot_groups bytes, padded to 16)
   __shared__ uint32_t ltargets[kMaxHotGroups / 32];  // bit g: a link of this segment points into group g (another segment)
@@ -2393,7 +2429,7 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long*
       *S.group(kGroupS, i) = make_float4(sp.x - step * grad.x, sp.y - step * grad.y, sp.z - step * grad.z, rs[sub].w);
     }
   }
-  if (blockIdx.x < n_steps) ts_end(ts, kTsRegEnd);   // (workgroups that walked at least one step)
+  ts_end(ts, kTsRegEnd, blockIdx.x, min(gridDim.x, n_steps));   // (the workgroups that walked the last steps of the first round)
 }
 
 // RegularizeSurfelsCUDACopyOnlyKernel (:2310-2327), over the recent list.
@@ -2401,7 +2437,7 @@ __global__ void __launch_bounds__(kBlock)
 k_reg_copy_raw(Surfels S, Lists L, const DevState* st, unsigned long long* ts) {
   uint32_t desc, cntv;
   const uint32_t n_steps = walk_begin<true>(L.rec_chunks, 0u, blockIdx.x, desc, cntv);
-  if (blockIdx.x < n_steps) ts_end(ts, kTsRegEnd);   // (copy-only regulariser: the last workgroup STARTED)
+  ts_end(ts, kTsRegEnd, blockIdx.x, min(gridDim.x, n_steps));   // (copy-only regulariser: the last workgroups STARTED)
   for (uint32_t w = blockIdx.x; w < n_steps; w += gridDim.x) {
     desc = walk_next<true>(L.rec_chunks, w, n_steps);
     if (!walk_step_valid(w, cntv)) continue;
@@ -2698,7 +2734,9 @@ struct smx_recon_s {
   int timing_enabled;       // bit 0: the reference's 14 stage events, bit 1: events around every kernel, bit 2: stage stamps (default)
   bool have_timings;
   unsigned long long* ts_ring;   // [kTsRing][kTsWords] stage stamps of the last kTsRing Integrate calls (StageStamps)
-  unsigned long long* ts_host;   // page-locked copy target of the ring
+  unsigned long long* ts_host;   // page-locked copy target of the ring (the waiting read)
+  volatile unsigned long long* ts_mapped;   // page-locked ring the tile kernel copies complete records into (the non-waiting read)
+  unsigned long long* ts_mapped_dev;        // ... its device alias
   unsigned long long ts_seq;     // Integrate calls with stamps so far (a call's record: ts_ring[seq % kTsRing])
   hipStream_t ts_stream;         // copies of the ring: ordered behind nothing
   int wall_khz;                  // rate of the device's wall clock (hipDeviceAttributeWallClockRate)
@@ -2801,6 +2839,7 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
     // (... and pass A copies the flag bytes of every segment it culls again: the table it would otherwise rely on is this one)
     SMX_HIP(hipMemsetAsync(r->L.seg_streak, 0, (size_t)r->nseg, st));
   }
+  unsigned long long* ts_first = zero_chunks ? nullptr : ts;   // (the first pass B of an Integrate call begins the stage)
   const int stats = r->stats_enabled;
   const int use_hot = (r->hot_holdoff == 0 && !r->scan_mode && r->hot_filter_enabled) ? 1 : 0;
   const size_t hot_lds = ((size_t)r->L.n_hot_groups + 15) & ~(size_t)15;
@@ -2808,11 +2847,11 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
     SlotTimer t(r, st, kSlotNeighborScan, true);
     if (stats || zero_chunks) hipLaunchKernelGGL(k_reset_recent, dim3(1), dim3(kSubLists), 0, st, r->st, stats, zero_chunks ? r->L.rec_chunks.count : nullptr);
     if (copy_only) {
-      if (detach) hipExtLaunchKernelGGL((k_neighbor_scan<true, false>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->inwin8, r->st);
-      else hipExtLaunchKernelGGL((k_neighbor_scan<false, false>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->inwin8, r->st);
+      if (detach) hipExtLaunchKernelGGL((k_neighbor_scan<true, false>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->inwin8, r->st, ts_first);
+      else hipExtLaunchKernelGGL((k_neighbor_scan<false, false>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->inwin8, r->st, ts_first);
     } else {
-      if (detach) hipExtLaunchKernelGGL((k_neighbor_scan<true, true>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->inwin8, r->st);
-      else hipExtLaunchKernelGGL((k_neighbor_scan<false, true>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->inwin8, r->st);
+      if (detach) hipExtLaunchKernelGGL((k_neighbor_scan<true, true>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->inwin8, r->st, ts_first);
+      else hipExtLaunchKernelGGL((k_neighbor_scan<false, true>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->inwin8, r->st, ts_first);
     }
   }
   if (!copy_only) {
@@ -2970,6 +3009,13 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->st, 1, true));
   SMX_TRY(dev_alloc(&r->ts_ring, (size_t)kTsRing * kTsWords, true));
   SMX_TRY(hip_rc(hipHostMalloc(reinterpret_cast<void**>(&r->ts_host), sizeof(unsigned long long) * kTsRing * kTsWords, hipHostMallocDefault), "hipHostMalloc"));
+  {
+    void* m = nullptr;
+    SMX_TRY(hip_rc(hipHostMalloc(&m, sizeof(unsigned long long) * kTsRing * kTsWords, hipHostMallocMapped), "hipHostMalloc"));
+    memset(m, 0, sizeof(unsigned long long) * kTsRing * kTsWords);
+    r->ts_mapped = static_cast<volatile unsigned long long*>(m);
+    SMX_TRY(hip_rc(hipHostGetDevicePointer(reinterpret_cast<void**>(&r->ts_mapped_dev), m, 0), "hipHostGetDevicePointer"));
+  }
   SMX_TRY(hip_rc(hipStreamCreateWithFlags(&r->ts_stream, hipStreamNonBlocking), "hipStreamCreateWithFlags"));
   SMX_TRY(hip_rc(hipDeviceGetAttribute(&r->wall_khz, hipDeviceAttributeWallClockRate, device), "hipDeviceGetAttribute"));
   if (r->wall_khz <= 0) r->wall_khz = 100000;   // (s_memrealtime: 100 MHz)
@@ -3015,6 +3061,7 @@ int smx_recon_destroy(smx_recon r) {
   if (r->dir_host) { (void)hipDeviceSynchronize(); (void)hipHostFree(r->dir_host); }
   if (r->ts_stream) { (void)hipStreamSynchronize(r->ts_stream); (void)hipStreamDestroy(r->ts_stream); }
   if (r->ts_host) (void)hipHostFree(r->ts_host);
+  if (r->ts_mapped) { (void)hipDeviceSynchronize(); (void)hipHostFree(const_cast<unsigned long long*>(r->ts_mapped)); }
   if (r->ts_ring) (void)hipFree(r->ts_ring);
   if (r->ev_front) (void)hipEventDestroy(r->ev_front);
   if (r->ev_upd) (void)hipEventDestroy(r->ev_upd);
@@ -3213,7 +3260,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   { SlotTimer t(r, sF, kSlotAssocTiles, true);
     hipExtLaunchKernelGGL(k_assoc_tiles, dim3(r->tb.n_tiles), dim3(kTilePx), 0, sF, t.start(), t.stop(), 0, r->S, c, r->sc, in.depth, in.normals, r->tb,
                        r->ovf_count_set[r->sc_cur ^ 1], r->merge_flag, r->st, r->L.seg_act, (uint32_t)r->nseg, r->dir_dev, r->sw.count,
-                       r->stamps ? r->stamps : nullptr);
+                       r->stamps ? r->stamps : nullptr, r->ts_ring, c.ts ? r->ts_mapped_dev : nullptr, r->ts_seq);
     r->sw_dirty = false; }
   // (the stage times of GetTimings: data association = pass A + the tile kernel, which also decides the merges)
   if (tm) { SMX_HIP(hipEventRecord(r->ev[1], sF)); SMX_HIP(hipEventRecord(r->ev[2], sF)); SMX_HIP(hipEventRecord(r->ev[3], sF)); SMX_HIP(hipEventRecord(r->ev[4], sF)); }
@@ -3606,13 +3653,16 @@ int smx_recon_check_triangles(smx_recon r, smx_stream s, const uint32_t* triangl
 namespace {
 // stage times of one stamp record (ms); false if the record is not that call's or the call did not get through
 bool stage_ms_from_stamps(const unsigned long long* t, unsigned long long seq, int khz, float out_ms[7]) {
-  if (t[kTsSeq] != seq || t[kTsCullBegin] == 0 || t[kTsTilesEnd] == 0 || t[kTsIntBegin] == 0) return false;
+  if (t[kTsSeq] != seq || t[kTsCullBegin] == 0 || t[kTsIntBegin] == 0) return false;
   auto ms = [&](unsigned long long a, unsigned long long b) { return (b > a && a != 0) ? (float)((double)(b - a) / (double)khz) : 0.0f; };
-  const unsigned long long int_end = t[kTsIntEnd] ? t[kTsIntEnd] : t[kTsIntBegin];
-  const unsigned long long upd_end = t[kTsUpdEnd] ? t[kTsUpdEnd] : int_end;
-  out_ms[0] = ms(t[kTsCullBegin], t[kTsTilesEnd]);   // data association: cull step, pass A, association tiles
+  auto first = [](unsigned long long a, unsigned long long b, unsigned long long c) { return a ? a : (b ? b : c); };
+  // a stage ends where the next launch of its stream begins; the tail workgroups' maximum where there is no such launch
+  const unsigned long long tiles_end = first(t[kTsBlendBegin], t[kTsTilesEnd], t[kTsCullBegin]);
+  const unsigned long long int_end = first(t[kTsUpdBegin], t[kTsIntEnd], t[kTsIntBegin]);
+  const unsigned long long upd_end = first(t[kTsRegBegin], t[kTsUpdEnd], int_end);
+  out_ms[0] = ms(t[kTsCullBegin], tiles_end);        // data association: cull step, pass A, association tiles
   out_ms[1] = 0.0f;                                  // surfel merging: decided inside the tile kernel, applied by k_integrate
-  out_ms[2] = ms(t[kTsTilesEnd], t[kTsBlendEnd]);    // measurement blending
+  out_ms[2] = ms(tiles_end, t[kTsBlendEnd]);         // measurement blending
   out_ms[3] = ms(t[kTsIntBegin], int_end);           // integration (+ the new-surfel flag and rank pass)
   out_ms[4] = ms(int_end, upd_end);                  // neighbour update (+ creation, same launch)
   out_ms[5] = 0.0f;                                  // new surfel creation: inside the neighbour-update launch
@@ -3650,23 +3700,26 @@ int smx_recon_get_timings(smx_recon r, float out_ms[7]) {
 
 int smx_recon_get_timings_nowait(smx_recon r, float out_ms[7], uint64_t* call_number) {
   SMX_CHECK_ARG(r != nullptr && out_ms != nullptr);
-  SMX_ON_DEVICE(r->device);
   for (int i = 0; i < 7; ++i) out_ms[i] = 0;
   if (call_number) *call_number = 0;
-  if (!(r->timing_enabled & 4) || r->ts_seq == 0) return SMX_OK;
-  { const int rc = copy_stamp_ring(r); if (rc != SMX_OK) return rc; }
-  // A call's regulariser is known to be through once a LATER call's integration kernel has started (they follow each other
-  // on one in-order stream): the newest record with such a successor.
-  unsigned long long best = 0;
+  if (!(r->timing_enabled & 4) || r->ts_seq == 0 || !r->ts_mapped) return SMX_OK;
+  // No device operation at all: the records the tile kernel has copied into page-locked memory (every call copies the
+  // record of the call before the previous one), newest whole one.  Reader: tail, data, head -- the writer goes head,
+  // data, tail.
+  unsigned long long best = 0, rec[kTsWords];
   for (int k = 0; k < kTsRing; ++k) {
-    const unsigned long long* t = r->ts_host + (size_t)k * kTsWords;
-    const unsigned long long q = t[kTsSeq];
-    if (q == 0 || q <= best) continue;
-    const unsigned long long* nx = r->ts_host + (size_t)((q + 1) % kTsRing) * kTsWords;
-    if (nx[kTsSeq] == q + 1 && nx[kTsIntBegin] != 0) best = q;
+    volatile unsigned long long* t = r->ts_mapped + (size_t)k * kTsWords;
+    unsigned long long w[kTsWords];
+    w[kTsSeqTail] = t[kTsSeqTail];
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    for (int j = 1; j < kTsSeqTail; ++j) w[j] = t[j];
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    w[kTsSeq] = t[kTsSeq];
+    if (w[kTsSeq] == 0 || w[kTsSeq] != w[kTsSeqTail] || w[kTsSeq] <= best) continue;
+    best = w[kTsSeq];
+    memcpy(rec, w, sizeof(rec));
   }
-  if (best && stage_ms_from_stamps(r->ts_host + (size_t)(best % kTsRing) * kTsWords, best, r->wall_khz, out_ms) && call_number)
-    *call_number = best;
+  if (best && stage_ms_from_stamps(rec, best, r->wall_khz, out_ms) && call_number) *call_number = best;
   return SMX_OK;
 }
 

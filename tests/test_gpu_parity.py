@@ -852,7 +852,7 @@ def test_frame_loop_reads_stage_times_every_frame(smx):
     assert 1 <= calls <= len(frames), calls
     assert sums[0] > 0 and sums[3] > 0 and sums[6] > 0 and sums[1] == 0.0, sums
     t, call = pn.reconstruction.GetTimingsNoWait()
-    assert call == len(frames) - 1 and t[0] > 0       # the last call has no successor yet: the one before it is the newest known complete
+    assert call == len(frames) - 2 and t[0] > 0 and t[6] > 0   # every call hands over the record of the call before the previous one
     pn.set_read_timings(2)
     pn.run([pn.make_step(f, s.outlier_frames(f), s.others_TR_reference(f), s.pose(f)) for f in range(36, 44)])
     sums2, calls2 = pn.timing_sums()
