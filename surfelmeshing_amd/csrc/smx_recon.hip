@@ -2113,10 +2113,11 @@ constexpr int kBlockAcc = 512;
 static_assert(kSegAcc % kSegB == 0 && kSegAcc % kBlockAcc == 0, "segment sizes must nest");
 __global__ void __launch_bounds__(kBlockAcc, 2 * SMX_ACC_WGS_PER_CU)   // (second argument: wavefronts per SIMD)
 k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ grad_acc,
-                 long long* __restrict__ grad_local, FarBins fb,
+                 float4* __restrict__ reg_rec, FarBins fb,
                  const uint8_t* __restrict__ inwin8, const uint8_t* __restrict__ flags8, Chunks acc, DevState* st) {
   __shared__ unsigned long long lacc[kSegAcc * 2];  // per target: (gx | gy), (gz | sender classes)
   __shared__ uint32_t hkey[kFarHash], hcnt[kFarHash];   // far destinations of this workgroup: segment, terms -> base in the bin
+  __shared__ uint32_t rec_wave[kSegAcc / kBlockAcc][kBlockAcc / 64];   // recent slots per (half of the segment, wavefront)
   const uint32_t N = st->surfel_count;
   constexpr int kSub = kSegAcc / kBlockAcc;
   // A walk over the segments pass B listed (acc_chunks: a recent slot or an edge into the window), on a grid the size
@@ -2157,7 +2158,28 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
   for (int k = 0; k < kSegAcc * 2 / kBlockAcc; ++k) lacc[k * kBlockAcc + tid] = 0;
 #pragma unroll
   for (int k = 0; k < kFarHash / kBlockAcc; ++k) { hkey[k * kBlockAcc + tid] = kInvalid; hcnt[k * kBlockAcc + tid] = 0; }
+  // A recent slot's results -- the in-segment sums and its own term -- go to ONE dense 32-byte record at the slot's RANK
+  // among the segment's recent slots, which is its place in the recent list pass B wrote (ascending slots, same flag
+  // bytes): the step kernel reads the records of a segment as one coalesced run.  Rank = recent slots in front of it:
+  // wavefront ballots + the other wavefronts' totals through LDS (the barrier below is there anyway).
+  uint32_t rec_rank[kSub];
+#pragma unroll
+  for (int sub = 0; sub < kSub; ++sub) {
+    const unsigned long long bal = __ballot((f8_cur[sub] & 1u) != 0);
+    rec_rank[sub] = (uint32_t)__popcll(bal & ((1ull << (tid & 63u)) - 1ull));
+    if ((tid & 63u) == 0) rec_wave[sub][tid >> 6] = (uint32_t)__popcll(bal);
+  }
   __syncthreads();
+#pragma unroll
+  for (int sub = 0; sub < kSub; ++sub) {
+#pragma unroll
+    for (int wv = 0; wv < kBlockAcc / 64; ++wv) {
+      const uint32_t n = rec_wave[sub][wv];
+      if ((uint32_t)wv < (tid >> 6)) rec_rank[sub] += n;
+#pragma unroll
+      for (int later = sub + 1; later < kSub; ++later) rec_rank[later] += n;
+    }
+  }
   // Both slots of a lane travel together through three levels of loads, every load of a level requested before the
   // first one is used: (1) mask + flag bytes (requested one step ahead), (2) the slots' own T, S, N records, (3) one
   // 16-byte record per link (tools/isa_phases.py shows the waits).  (Requesting the link records a step ahead as well
@@ -2261,7 +2283,8 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
         rg.x = rg.x - nd * nrm.x; rg.y = rg.y - nd * nrm.y; rg.z = rg.z - nd * nrm.z;
       }
     }
-    if (rec[sub]) *S.group(kGroupG, i) = make_float4(rg.x, rg.y, rg.z, __int_as_float(own_count));
+    // (second half of the slot's dense record; the first half -- the in-segment sums -- follows behind the barrier)
+    if (rec[sub]) reg_rec[2 * (size_t)(base + rec_rank[sub]) + 1] = make_float4(rg.x, rg.y, rg.z, __int_as_float(own_count));
   }
   __syncthreads();
   // one lane per destination reserves the workgroup's run in that bin; the table then holds the run's start
@@ -2271,16 +2294,15 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
     const uint32_t dseg = hkey[e];
     if (dseg != kInvalid) hcnt[e] = atomicAdd(&fb.count[(size_t)dseg * kCountStride], hcnt[e]);
   }
-  // store the in-segment sums (only this workgroup writes the grad_local entries of its segment)
+  // the in-segment sums of the recent slots: first half of their dense records.  (Rounds 3-4 stored the sums of EVERY slot
+  // of the segment, zeros included -- 16 KB of full lines per workgroup, 39 MB a frame at C2, of which the step kernel read
+  // the recent slots' 7 MB: profiles/r31_WRITE_SIZE.md.  Dense records by rank are full lines too, and only what is read.)
 #pragma unroll
-  for (int sub = 0; sub < kSegAcc / kBlockAcc; ++sub) {
+  for (int sub = 0; sub < kSub; ++sub) {
+    if (!rec[sub]) continue;
     const uint32_t rel = sub * kBlockAcc + tid;
-    // (every slot of the segment, zeros included: 16 KB of full lines per workgroup.  Storing only the non-zero sums left
-    // holes -- partial sectors, which this chip writes back at a seventh of the rate of full ones -- and obliged the step
-    // kernel to zero what it had read; the step only ever reads the entries of recent slots, whose segment is rewritten
-    // here in every pass that precedes it.)
     const unsigned long long v0 = lacc[rel], v1 = lacc[kSegAcc + rel];
-    *reinterpret_cast<ulonglong2*>(&grad_local[2 * (size_t)(base + rel)]) = make_ulonglong2(v0, v1);
+    *reinterpret_cast<ulonglong2*>(&reg_rec[2 * (size_t)(base + rec_rank[sub])]) = make_ulonglong2(v0, v1);
   }
   __syncthreads();
 #pragma unroll
@@ -2316,7 +2338,7 @@ k_rebuild_flags(Surfels S, uint32_t frame, int reg_window, uint8_t* __restrict__
 // the bin.
 constexpr int kStepSub = kSegB / kBlock;
 __global__ void __launch_bounds__(kBlock)
-k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long* __restrict__ grad_local,
+k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, const float4* __restrict__ reg_rec,
            FarBins fb, Lists L, DevState* st, unsigned long long* ts) {
   __shared__ unsigned long long lfar[kSegB * 2];   // per target of the segment: (gx | gy), (gz | sender classes)
   uint32_t desc, cntv;
@@ -2345,8 +2367,11 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, long long*
 #pragma unroll
     for (int sub = 0; sub < kStepSub; ++sub) {
       const uint32_t i = idx[sub];
-      rp[sub] = *S.group(kGroupP, i); rs[sub] = *S.group(kGroupS, i); rn[sub] = *S.group(kGroupN, i); rgr[sub] = *S.group(kGroupG, i);
-      rl[sub] = *reinterpret_cast<const ulonglong2*>(&grad_local[2 * (size_t)i]);
+      rp[sub] = *S.group(kGroupP, i); rs[sub] = *S.group(kGroupS, i); rn[sub] = *S.group(kGroupN, i);
+      // the slot's dense record (k_reg_accumulate): in-segment sums, own term + neighbour count -- entry e of the segment
+      const size_t e = (size_t)seg_base + (on[sub] ? (uint32_t)(sub * kBlock) + threadIdx.x : 0u);
+      rl[sub] = *reinterpret_cast<const ulonglong2*>(&reg_rec[2 * e]);
+      rgr[sub] = reg_rec[2 * e + 1];
     }
     if (n_far) {
       if (lds_used) __syncthreads();   // (the previous step's readers are done)
@@ -2690,7 +2715,7 @@ struct smx_recon_s {
   float fx, fy, cx, cy;
   Surfels S;
   long long* grad_acc;      // [slots][2] packed fixed point (see pack_pair), cross-segment contributions (atomics)
-  long long* grad_local;    // [slots][2] in-segment contributions (plain stores)
+  float4* reg_rec;          // [slots][2] dense records of the recent slots, by (segment, rank in its recent list): in-segment sums | own term
   FarBins fb;               // far terms of the regulariser, per destination segment (see FarBins)
   Lists L;
   int nseg;                 // number of kSeg-slot segments (= workgroups of pass A)
@@ -2856,7 +2881,7 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
   }
   if (!copy_only) {
     SlotTimer t(r, st, kSlotRegAccumulate, true);
-    hipExtLaunchKernelGGL(k_reg_accumulate, dim3(r->grid_acc), dim3(kBlockAcc), 0, st, t.start(), t.stop(), 0, r->S, rf2, weight, r->grad_acc, r->grad_local,
+    hipExtLaunchKernelGGL(k_reg_accumulate, dim3(r->grid_acc), dim3(kBlockAcc), 0, st, t.start(), t.stop(), 0, r->S, rf2, weight, r->grad_acc, r->reg_rec,
                        r->fb, r->inwin8, r->L.flags8, r->L.acc_chunks, r->st);
   }
   if (copy_only) {
@@ -2864,7 +2889,7 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
     hipLaunchKernelGGL(k_reg_copy_raw, gl, b, 0, st, r->S, r->L, r->st, ts);
   } else {
     SlotTimer t(r, st, kSlotRegStep, true);
-    hipExtLaunchKernelGGL(k_reg_step, gl, b, 0, st, t.start(), t.stop(), 0, r->S, weight, r->grad_acc, r->grad_local, r->fb, r->L, r->st, ts);
+    hipExtLaunchKernelGGL(k_reg_step, gl, b, 0, st, t.start(), t.stop(), 0, r->S, weight, r->grad_acc, r->reg_rec, r->fb, r->L, r->st, ts);
   }
   SMX_LAUNCH_CHECK();
   return SMX_OK;
@@ -2928,7 +2953,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   // padded tail of every row is defined)
   SMX_TRY(dev_alloc(&r->S.base, (size_t)kQuadsPerSlot * 4 * r->S.pitch, true));
   SMX_TRY(dev_alloc(&r->grad_acc, 2 * ((size_t)r->S.pitch + kSegAcc), true));
-  SMX_TRY(dev_alloc(&r->grad_local, 2 * ((size_t)r->S.pitch + kSegAcc), true));
+  SMX_TRY(dev_alloc(&r->reg_rec, 2 * ((size_t)r->S.pitch + kSegAcc), true));
   r->nseg = div_up((long long)r->S.pitch, kSeg);
   r->nsegB = div_up((long long)r->S.pitch, kSegB);
   r->fb.cap = kFarBinCap; r->fb.hash_mask = (uint32_t)kFarHash - 1u;
@@ -3054,7 +3079,7 @@ int smx_recon_destroy(smx_recon r) {
   SMX_ON_DEVICE(r->device);
   void* ptrs[] = {r->sc.supporting, r->sc.counts, r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth,
                   r->tb.pairs, r->tb.count, r->tb.ovf, r->ovf_count_set[0], r->ovf_count_set[1],
-                  r->vis_count_set[0], r->vis_count_set[1], r->L.seg_act, r->L.seg_streak, r->sw.surv_list, r->sw.copy_list, r->sw.count, r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->grad_local, r->fb.rec, r->fb.count, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.acc_chunks.desc, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1], r->L.hot_epoch, r->L.seg_targets,
+                  r->vis_count_set[0], r->vis_count_set[1], r->L.seg_act, r->L.seg_streak, r->sw.surv_list, r->sw.copy_list, r->sw.count, r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->reg_rec, r->fb.rec, r->fb.count, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.acc_chunks.desc, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1], r->L.hot_epoch, r->L.seg_targets,
                   r->merge_flag, r->inwin8, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->block_offsets, r->st};
   if (r->reg_stream) { (void)hipStreamSynchronize(r->reg_stream); (void)hipStreamDestroy(r->reg_stream); }
@@ -3776,7 +3801,6 @@ int smx_recon_debug_upload_surfels(smx_recon r, smx_stream s, const float* rows,
   h.surfel_count = count; h.merge_count = merge_count;
   SMX_HIP(hipMemcpyAsync(r->st, &h, sizeof(h), hipMemcpyHostToDevice, st));
   SMX_HIP(hipMemsetAsync(r->grad_acc, 0, 2 * r->S.pitch * sizeof(long long), st));
-  SMX_HIP(hipMemsetAsync(r->grad_local, 0, 2 * r->S.pitch * sizeof(long long), st));
   SMX_HIP(hipMemsetAsync(r->fb.count, 0, (size_t)r->nsegB * kCountStride * sizeof(uint32_t), st));
   SMX_HIP(hipMemsetAsync(r->merge_flag, 0, r->S.pitch, st));
   if (r->L.dirty8) SMX_HIP(hipMemsetAsync(r->L.dirty8, 1, (size_t)r->nseg * kSeg, st));
