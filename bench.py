@@ -272,6 +272,34 @@ STAGES = ["data_association", "surfel_merging", "measurement_blending", "integra
           "neighbor_update", "new_surfel_creation", "regularization"]
 
 
+def stamp_timeline(rec):
+    """The pipelined frame as the kernels themselves stamped it (device wall clock, smx_recon_debug_stamp_ring): the last
+    calls of the timed region, mean duration of every launch of Integrate in the frame and of the gaps between them -- no
+    profiler, no event packets, the run that is timed."""
+    ring, khz = rec.debug_stamp_ring()
+    recs = {int(r[0]): r.astype(np.int64) for r in ring if r[0] != 0 and r[15] == 0}
+    (SEQ, CULL, TILES_END, BLEND_B, BLEND_E, INT_B, INT_E, UPD_B, UPD_E, REG_B, REG_E, SCAN_B, TILES_B, ACC_B, STEP_B) = range(15)
+    rows = []
+    for q in sorted(recs):
+        a, nx = recs[q], recs.get(q + 1)
+        if nx is None or min(a[k] for k in (CULL, SCAN_B, TILES_B, BLEND_B, BLEND_E, INT_B, UPD_B, REG_B, ACC_B, STEP_B, REG_E)) == 0:
+            continue
+        us = lambda x, y: (float(y) - float(x)) * 1e3 / khz  # noqa: E731
+        rows.append({"cull (+ wait for the previous call's map)": us(a[CULL], a[SCAN_B]), "scan_visible": us(a[SCAN_B], a[TILES_B]),
+                     "assoc_tiles": us(a[TILES_B], a[BLEND_B]), "blend": us(a[BLEND_B], a[BLEND_E]),
+                     "hand-over to the internal stream (blend end -> integrate begin)": us(a[BLEND_E], a[INT_B]),
+                     "integrate+new_flags": us(a[INT_B], a[UPD_B]), "update_neighbors+create": us(a[UPD_B], a[REG_B]),
+                     "neighbor_scan": us(a[REG_B], a[ACC_B]), "reg_accumulate": us(a[ACC_B], a[STEP_B]), "reg_step": us(a[STEP_B], a[REG_E]),
+                     "internal stream: step end -> next integrate begin": us(a[REG_E], nx[INT_B]),
+                     "front: cull begin -> blend end": us(a[CULL], a[BLEND_E]),
+                     "period (integrate begin -> next integrate begin)": us(a[INT_B], nx[INT_B])})
+    if not rows:
+        return None
+    out = {k: round(float(np.mean([r[k] for r in rows])), 2) for k in rows[0]}
+    out["calls_averaged"] = len(rows)
+    return out
+
+
 def timing_passes(wl, plan, base, count, torch):
     """What GetTimings costs the frame loop.  Four variants over 4 x `count` frames behind the timed window, INTERLEAVED in
     chunks of 20 frames (the regime drifts along the trajectory -- visible and recent counts change by tens of percent
@@ -630,6 +658,7 @@ def run_integrate(args):
         dist.barrier()
     dom_ms, dom_n = rec.profile_end()
     wl.pipe.set_read_timings(0)
+    timeline = stamp_timeline(rec) if timing_mode == 4 else None
     read_sums, read_calls = wl.pipe.timing_sums()
     rec.set_timing_enabled(4)
     _lib.check(_lib.load().smx_debug_marker(None, 2))
@@ -723,6 +752,7 @@ def run_integrate(args):
         "stage_timing_in_timed_region": {"mode": args.stage_timing, "read_every_frame": args.read_timings,
                                          "calls_read": read_calls,
                                          "mean_stage_ms_read": dict(zip(STAGES, [x / max(read_calls, 1) for x in read_sums])) if read_calls else None},
+        "in_frame_timeline_us": timeline,
         "growth_phase": getattr(wl, "growth", None),
         "reference_model_bytes_per_frame": ref_bytes,
         "reference_model_GBs": ref_bytes * (K / elapsed) / 1e9,

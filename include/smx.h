@@ -285,6 +285,12 @@ int smx_recon_get_timings(smx_recon r, float out_ms[7]);
  * page-locked host memory, so the read lags the queue by two calls and touches neither the device nor any stream.
  * *call_number: that call's 1-based number, 0 (and zeros) if there is none yet. */
 int smx_recon_get_timings_nowait(smx_recon r, float out_ms[7], uint64_t* call_number);
+/* Measurement: the raw stage-stamp records of the last 8 smx_recon_integrate calls (8 x 16 words of device wall clock,
+ * rate in *wall_clock_khz; word 0 = the call's number, then: cull begin, tiles end*, blend begin, blend end*, integrate
+ * begin, integrate end*, update begin, update end*, pass B begin, step end*, pass A begin, tiles begin, edge kernel begin,
+ * step begin; * = maximum over the last workgroups dispatched).  bench.py turns them into the in-frame timeline of the
+ * pipelined run -- no profiler, no event packets.  Call after synchronising. */
+int smx_recon_debug_stamp_ring(smx_recon r, uint64_t* out, int32_t capacity_words, int32_t* wall_clock_khz);
 /* enabled: bit 2 = stage stamps (default ON: what smx_recon_get_timings reads), bit 0 = the reference's own 14 stage
  * events instead (measurement: smx_recon_get_timings then reads those), bit 1 = events around every kernel */
 int smx_recon_set_timing_enabled(smx_recon r, int32_t enabled);

@@ -85,7 +85,7 @@ EXPORTS = [
     "smx_copy_without_border", "smx_median_filter_and_densify_depth_map", "smx_downscale_using_median_while_excluding", "smx_color_image_pyramid", "smx_compute_normals_and_drop_bad_pixels",
     "smx_compute_point_radii_and_remove_isolated_pixels", "smx_erode_normals_radii", "smx_erode_normals_radii_signal",
     "smx_recon_create", "smx_recon_destroy", "smx_recon_integrate", "smx_recon_regularize",
-    "smx_recon_transfer_all_to_cpu", "smx_recon_set_delta_tracking", "smx_recon_transfer_changed_to_cpu", "smx_recon_export_vertices", "smx_recon_get_timings", "smx_recon_get_timings_nowait",
+    "smx_recon_transfer_all_to_cpu", "smx_recon_set_delta_tracking", "smx_recon_transfer_changed_to_cpu", "smx_recon_export_vertices", "smx_recon_get_timings", "smx_recon_get_timings_nowait", "smx_recon_debug_stamp_ring",
     "smx_recon_build_neighbor_index", "smx_recon_neighbor_candidates", "smx_recon_check_triangles", "smx_recon_deform_by_creation_frame",
     "smx_recon_set_timing_enabled", "smx_recon_counts", "smx_recon_get_stats", "smx_recon_set_stats_enabled",
     "smx_recon_kernel_slot_count", "smx_recon_kernel_slot_name", "smx_recon_get_kernel_timings",

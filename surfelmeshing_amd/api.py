@@ -520,6 +520,13 @@ class CUDASurfelReconstruction:
         _lib.check(_lib.load().smx_recon_get_timings(self._h, out))
         return tuple(out)
 
+    def debug_stamp_ring(self):
+        """(records [8][16] uint64, wall clock kHz): smx_recon_debug_stamp_ring."""
+        out = np.zeros((8, 16), np.uint64)
+        khz = C.c_int32(0)
+        _lib.check(_lib.load().smx_recon_debug_stamp_ring(self._h, out.ctypes.data_as(C.c_void_p), C.c_int32(out.size), C.byref(khz)))
+        return out, int(khz.value)
+
     def GetTimingsNoWait(self):
         """(the seven stage times in ms, call number) of the newest Integrate call that is known to be through, without
         waiting for the last one (smx_recon_get_timings_nowait); call number 0 = none yet."""

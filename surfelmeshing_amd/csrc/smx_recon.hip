@@ -140,7 +140,9 @@ struct FrameCtx {
 // record of the call before the previous one -- complete by stream order when that kernel runs -- into page-locked host
 // memory (sequence number first and last: a reader that sees both equal has a whole record).
 enum : int { kTsSeq = 0, kTsCullBegin, kTsTilesEnd, kTsBlendBegin, kTsBlendEnd, kTsIntBegin, kTsIntEnd, kTsUpdBegin, kTsUpdEnd,
-             kTsRegBegin, kTsRegEnd, kTsSeqTail = 15, kTsWords = 16 };
+             kTsRegBegin, kTsRegEnd,
+             kTsScanBegin, kTsTilesBegin, kTsAccBegin, kTsStepBegin,   // (not part of GetTimings: smx_recon_debug_stamp_ring)
+             kTsSeqTail = 15, kTsWords = 16 };
 constexpr int kTsRing = 8;
 constexpr uint32_t kTsTail = 32;
 __device__ __forceinline__ void ts_begin(unsigned long long* ts, int k) {
@@ -266,6 +268,7 @@ struct Lists {
   uint8_t* seg_streak;      // per pass-A segment: in how many calls in a row pass A has culled it (k_scan_visible, step 2)
   uint32_t* recent_list;  // slots whose last update stamp lies inside the regulariser window
   uint32_t* recent_seg;
+  uint32_t* act_list;     // per pass-B segment: the slots the edge kernel has work for (ActEntry), ascending
   uint8_t* flags8;        // per slot: bit 0 = stamp inside the regulariser window, bit 1 = detach request
   uint8_t* dirty8;        // delta tracking (null = off): 1 = a transferred attribute of the slot changed since the
                           // last smx_recon_transfer_changed_to_cpu
@@ -358,7 +361,13 @@ __device__ __forceinline__ void emit_chunks(const Chunks& ch, uint32_t deal, uin
   }
 }
 
-// (one descriptor per segment: the segment number)
+// Work-list entry of the edge kernel (k_reg_accumulate), written by pass B: the slot's position in its segment, which of
+// its four links end inside the regulariser window, and whether the slot itself lies inside it.
+__device__ __forceinline__ uint32_t act_entry(uint32_t rel, uint32_t window_mask, uint32_t recent) {
+  return rel | (window_mask << 10) | ((recent ? 1u : 0u) << 14);
+}
+constexpr uint32_t kNoActEntry = 0xFFFFFFFFu;
+// (one descriptor per segment: the segment number [| (entries - 1) << 22])
 __device__ __forceinline__ void emit_segment(const Chunks& ch, uint32_t segment) {
   const uint32_t k = segment % kSubLists;
   ch.desc[(size_t)k * ch.stride + atomicAdd(&ch.count[k * kCountStride], 1u)] = segment;
@@ -380,6 +389,30 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t mine, uint32_t* wav
   for (int off = 1; off < 64; off <<= 1) {
     const uint32_t t = __shfl_up(incl, off);
     if (lane >= (uint32_t)off) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t wave_off = 0;
+  total = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) {
+    if ((uint32_t)w < wave) wave_off += wave_tot[w];
+    total += wave_tot[w];
+  }
+  return wave_off + incl - mine;
+}
+
+// The same for counts that are zero in most wavefronts (pass B's list ranks): a wavefront without any skips the shuffles.
+template <int kWaves = kBlock / 64>
+__device__ __forceinline__ uint32_t block_excl_scan_sparse(uint32_t mine, uint32_t* wave_tot /* LDS [kWaves] */, uint32_t& total) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = mine;
+  if (__ballot(mine != 0) != 0ull) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off);
+      if (lane >= (uint32_t)off) incl += t;
+    }
   }
   if (lane == 63) wave_tot[wave] = incl;
   __syncthreads();
@@ -541,6 +574,7 @@ k_cull_segments(FrameCtx c, Lists L, SegWork sw, DevState* st, uint32_t nseg_all
 __global__ void __launch_bounds__(kBlock, 8)   // (eight workgroups per CU: <= 64 VGPRs)
 k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, SegWork sw, const uint8_t* __restrict__ flags_prev, DevState* st,
                int use_lds_tables) {
+  ts_begin(c.ts, kTsScanBegin);
   __shared__ uint32_t wave_tot[kBlock / 64];
   __shared__ float box_part[kBlock / 64][8];
   // the tiles this workgroup's pairs fall into: open-addressed table keyed by tile number (fixed size: a direct-mapped
@@ -902,6 +936,7 @@ k_assoc_tiles(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<
               unsigned long long ts_seq) {
   __shared__ TileLds t;
   __shared__ uint32_t order_wave_tot[kTilePx / 64];
+  ts_begin(c.ts, kTsTilesBegin);
   // side job of the first workgroup's second wavefront: the stage-stamp record of the call before the previous one (complete:
   // that call's regulariser preceded the previous call's integration, whose end this stream has waited for) goes to
   // page-locked host memory for the non-waiting GetTimings -- sequence number first and last around the data
@@ -1863,7 +1898,7 @@ k_update_and_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, Crea
 // accumulators are zero between calls (k_reg_step zeroes what it consumes).
 template <bool kDetach, bool kAccumulate>
 __global__ void __launch_bounds__(kBlockB)
-k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict__ inwin8, DevState* st, unsigned long long* ts) {
+k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, DevState* st, unsigned long long* ts) {
   ts_begin(ts, kTsRegBegin);
   const uint32_t seg_id = segment_of_block(L.descending);
   extern __shared__ __align__(16) uint8_t lhot[];   // the hot-group table (n_hot_groups bytes, padded to 16)
@@ -1965,17 +2000,24 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
         if (kAccumulate && (f & 1u)) { inw[k >> 2] |= (uint8_t)(1u << (k & 3)); need = 1; }
       }
     }
-    if (kAccumulate && i0 < N) *reinterpret_cast<uchar4*>(&inwin8[i0]) = make_uchar4(inw[0], inw[1], inw[2], inw[3]);
-    const int any = __syncthreads_or(need);
+    // the edge kernel's work list of the segment: one entry per slot with a link into the window (ActEntry), at its rank
+    uint32_t total_act = 0;
+    if (kAccumulate) {
+      const uint32_t nact = (uint32_t)((inw[0] != 0) + (inw[1] != 0) + (inw[2] != 0) + (inw[3] != 0));
+      uint32_t off = base + block_excl_scan_sparse<kBlockB / 64>(need ? nact : 0u, wave_tot, total_act);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (inw[j]) L.act_list[off++] = act_entry(threadIdx.x * 4 + j, inw[j], false);
+    }
     if (threadIdx.x == 0) {
       L.recent_seg[seg_id] = 0;
-      if (kAccumulate && any) emit_segment(L.acc_chunks, seg_id);
+      if (kAccumulate && total_act) emit_segment(L.acc_chunks, seg_id | ((total_act - 1u) << 22));
     }
     return;
   }
   if (threadIdx.x < kMaxHotGroups / 32) ltargets[threadIdx.x] = 0;
   uint32_t recent_bits = 0;
-  int need = 0;
+  uint32_t inw4 = 0;   // the window masks of the lane's four slots, a byte each
   uchar4 own = make_uchar4(0, 0, 0, 0);
   uint4 trec[4];  // the T records (4 neighbour ids) of the lane's 4 slots: 64 contiguous bytes
   if (i0 < N) {
@@ -2039,22 +2081,32 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
         }
         if (rel >= (uint32_t)kSegB) { const uint32_t g = nb >> L.hot_shift; atomicOr(&ltargets[g >> 5], 1u << (g & 31u)); }
         ++edges;
-        if (kAccumulate && (f & 1u)) { inw[j] |= (uint8_t)(1u << q); need = 1; }
+        if (kAccumulate && (f & 1u)) inw[j] |= (uint8_t)(1u << q);
       }
     }
-    if (kAccumulate) *reinterpret_cast<uchar4*>(&inwin8[i0]) = make_uchar4(inw[0], inw[1], inw[2], inw[3]);
+    inw4 = (uint32_t)inw[0] | ((uint32_t)inw[1] << 8) | ((uint32_t)inw[2] << 16) | ((uint32_t)inw[3] << 24);
     if (stats && kAccumulate && edges) {
       atomicAdd(&st->n_edges, edges);
       const uint32_t we = __popc(inw[0]) + __popc(inw[1]) + __popc(inw[2]) + __popc(inw[3]);
       if (we) { atomicAdd(&st->n_window_edges, we); atomicAdd(&st->n_contributors, (uint32_t)((inw[0] != 0) + (inw[1] != 0) + (inw[2] != 0) + (inw[3] != 0))); }
     }
   }
-  uint32_t total;
-  uint32_t off = base + block_excl_scan<kBlockB / 64>((uint32_t)__popc(recent_bits), wave_tot, total);
+  // Two lists per segment, ranks from ONE scan (both counts in one word): the recent slots (the step kernel's list) and the
+  // slots the edge kernel has work for -- recent ones (their own term) and those with a link into the window (ActEntry).
+  uint32_t act_bits = kAccumulate ? recent_bits : 0u;
+  if (kAccumulate) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) if ((inw4 >> (8 * j)) & 255u) act_bits |= 1u << j;
+  }
+  uint32_t total2;
+  const uint32_t off2 = block_excl_scan_sparse<kBlockB / 64>((uint32_t)__popc(recent_bits) | ((uint32_t)__popc(act_bits) << 16), wave_tot, total2);
+  const uint32_t total = total2 & 0xFFFFu, total_act = total2 >> 16;
+  uint32_t off = base + (off2 & 0xFFFFu), off_act = base + (off2 >> 16);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
     if (recent_bits & (1u << j)) L.recent_list[off++] = i0 + j;
-  const int any = __syncthreads_or(need);
+    if (act_bits & (1u << j)) L.act_list[off_act++] = act_entry(threadIdx.x * 4 + j, (inw4 >> (8 * j)) & 15u, (recent_bits >> j) & 1u);
+  }
   L.seg_targets[(size_t)seg_id * kBlockB + threadIdx.x] = (uint16_t)(ltargets[threadIdx.x >> 1] >> (16 * (threadIdx.x & 1)));
   if (threadIdx.x == 0) {
     L.recent_seg[seg_id] = total;
@@ -2062,7 +2114,7 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, uint8_t* __restrict_
       const uint32_t k = seg_id % kSubLists;
       L.rec_chunks.desc[(size_t)k * L.rec_chunks.stride + atomicAdd(&L.rec_chunks.count[k * kCountStride], 1u)] = seg_id | ((total - 1u) << 22);
     }
-    if (kAccumulate && (any || total)) emit_segment(L.acc_chunks, seg_id);  // k_reg_accumulate also serves recent slots
+    if (kAccumulate && total_act) emit_segment(L.acc_chunks, seg_id | ((total_act - 1u) << 22));
     if (stats && total) atomicAdd(&st->recent_count, total);
   }
 }
@@ -2107,143 +2159,112 @@ constexpr int kSegAcc = 1024;     // slots per accumulation workgroup (16 KB of 
 #define SMX_REG_PRIORITY_HIGH 1
 #endif
 #ifndef SMX_ACC_WGS_PER_CU
-#define SMX_ACC_WGS_PER_CU 2   // (what the kernel's registers admit)
+#define SMX_ACC_WGS_PER_CU 6   // (256-lane workgroups, 26 KB of LDS each: six per compute unit while the kernel stays at <= 80 VGPRs)
 #endif
-constexpr int kBlockAcc = 512;
-static_assert(kSegAcc % kSegB == 0 && kSegAcc % kBlockAcc == 0, "segment sizes must nest");
-__global__ void __launch_bounds__(kBlockAcc, 2 * SMX_ACC_WGS_PER_CU)   // (second argument: wavefronts per SIMD)
+constexpr int kBlockAcc = 256;
+static_assert(kSegAcc == kSegB, "the edge kernel's segments are pass B's: it walks pass B's work lists");
+__global__ void __launch_bounds__(kBlockAcc, SMX_ACC_WGS_PER_CU)   // (second argument: wavefronts per SIMD = workgroups per CU here)
 k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ grad_acc,
                  float4* __restrict__ reg_rec, FarBins fb,
-                 const uint8_t* __restrict__ inwin8, const uint8_t* __restrict__ flags8, Chunks acc, DevState* st) {
+                 const uint32_t* __restrict__ act_list, Chunks acc, DevState* st, unsigned long long* ts) {
+  ts_begin(ts, kTsAccBegin);
   __shared__ unsigned long long lacc[kSegAcc * 2];  // per target: (gx | gy), (gz | sender classes)
   __shared__ uint32_t hkey[kFarHash], hcnt[kFarHash];   // far destinations of this workgroup: segment, terms -> base in the bin
-  __shared__ uint32_t rec_wave[kSegAcc / kBlockAcc][kBlockAcc / 64];   // recent slots per (half of the segment, wavefront)
-  const uint32_t N = st->surfel_count;
-  constexpr int kSub = kSegAcc / kBlockAcc;
+  __shared__ uint16_t lrank[kSegAcc];                // per slot of the segment: its rank among the recent slots, or 0xFFFF
+  __shared__ uint32_t rec_wave[kBlockAcc / 64];      // recent entries per wavefront of the chunk
   // A walk over the segments pass B listed (acc_chunks: a recent slot or an edge into the window), on a grid the size
-  // of the chip.  (Rounds 1-3 and the first half of round 4: one workgroup per segment of the map, three fifths of which
-  // read a word and left -- with 89 VGPRs two of these 512-lane workgroups fit a CU, so every such visit held one of
-  // the chip's 512 places for its round trip.)  The next step's descriptor and the mask + flag bytes of ITS slots
-  // travel while this step is worked on: one level of dependent loads less per step.
+  // of the chip.  Round 5: a step no longer visits the segment's 1024 slots (512 lanes x 2, four fifths of them idle in
+  // the typical listed segment) but the ENTRIES of the work list pass B wrote for it -- the slots that have work, dense,
+  // one per lane, 256 at a time -- so the kernel needs half the registers per lane and three times as many steps are in
+  // flight per compute unit; the mask and flag bytes (2 KB per step) shrink to 4 bytes per entry.  The next step's
+  // descriptor and the first entries of ITS list travel while this step is worked on.
   uint32_t desc, cntv;
   const uint32_t n_steps = walk_begin<true>(acc, 0u, blockIdx.x, desc, cntv);
-  uint32_t m8_next[kSub], f8_next[kSub];
-#pragma unroll
-  for (int sub = 0; sub < kSub; ++sub) {
-    const uint32_t i = desc * kSegAcc + sub * kBlockAcc + threadIdx.x;   // (an unused descriptor is 0 or an old segment number: any slot of the map)
-    const bool in = blockIdx.x < n_steps && i < N;
-    m8_next[sub] = in ? (uint32_t)inwin8[i] : 0u; f8_next[sub] = in ? (uint32_t)flags8[i] : 0u;
-  }
+  // (an unused descriptor is 0 or an old one: any segment of the map, any entry count -- whatever is read is ignored)
+  uint32_t ent_next = (blockIdx.x < n_steps && threadIdx.x <= (desc >> 22))
+                          ? act_list[(size_t)(desc & 0x003FFFFFu) * kSegAcc + threadIdx.x] : kNoActEntry;
   bool lds_used = false;
 #pragma unroll 1
   for (uint32_t w = blockIdx.x; w < n_steps; w += gridDim.x) {
-  const uint32_t seg_id = desc;
+  const uint32_t cur = desc;
   desc = walk_next<true>(acc, w + gridDim.x, n_steps);
   // (per step: a lane number the optimiser cannot see through keeps the per-lane addresses out of loop-carried registers)
   uint32_t tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
-  uint32_t m8_cur[kSub], f8_cur[kSub];
-#pragma unroll
-  for (int sub = 0; sub < kSub; ++sub) {
-    m8_cur[sub] = m8_next[sub]; f8_cur[sub] = f8_next[sub];
-    const uint32_t i = desc * kSegAcc + sub * kBlockAcc + tid;
-    const bool in = w + gridDim.x < n_steps && i < N;
-    m8_next[sub] = in ? (uint32_t)inwin8[i] : 0u; f8_next[sub] = in ? (uint32_t)flags8[i] : 0u;
-  }
+  const uint32_t ent_first = ent_next;
+  ent_next = (w + gridDim.x < n_steps && tid <= (desc >> 22)) ? act_list[(size_t)(desc & 0x003FFFFFu) * kSegAcc + tid] : kNoActEntry;
   if (!walk_step_valid(w, cntv)) continue;
+  const uint32_t seg_id = cur & 0x003FFFFFu, n_act = (cur >> 22) + 1u;
   const uint32_t base = seg_id * kSegAcc;
-  if (lds_used) __syncthreads();   // (the previous step's readers of the table are done)
+  if (lds_used) __syncthreads();   // (the previous step's readers of the tables are done)
   lds_used = true;
 #pragma unroll
   for (int k = 0; k < kSegAcc * 2 / kBlockAcc; ++k) lacc[k * kBlockAcc + tid] = 0;
 #pragma unroll
-  for (int k = 0; k < kFarHash / kBlockAcc; ++k) { hkey[k * kBlockAcc + tid] = kInvalid; hcnt[k * kBlockAcc + tid] = 0; }
-  // A recent slot's results -- the in-segment sums and its own term -- go to ONE dense 32-byte record at the slot's RANK
-  // among the segment's recent slots, which is its place in the recent list pass B wrote (ascending slots, same flag
-  // bytes): the step kernel reads the records of a segment as one coalesced run.  Rank = recent slots in front of it:
-  // wavefront ballots + the other wavefronts' totals through LDS (the barrier below is there anyway).
-  uint32_t rec_rank[kSub];
+  for (int k = 0; k < kSegAcc / 2 / kBlockAcc; ++k) reinterpret_cast<uint32_t*>(lrank)[k * kBlockAcc + tid] = 0xFFFFFFFFu;
+  uint32_t rec_before = 0;   // recent entries in the chunks in front of this one
+#pragma unroll 1
+  for (uint32_t c0 = 0; c0 < n_act; c0 += kBlockAcc) {
+  if (c0) __syncthreads();   // (the previous chunk's far stores have read the table)
 #pragma unroll
-  for (int sub = 0; sub < kSub; ++sub) {
-    const unsigned long long bal = __ballot((f8_cur[sub] & 1u) != 0);
-    rec_rank[sub] = (uint32_t)__popcll(bal & ((1ull << (tid & 63u)) - 1ull));
-    if ((tid & 63u) == 0) rec_wave[sub][tid >> 6] = (uint32_t)__popcll(bal);
-  }
+  for (int k = 0; k < kFarHash / kBlockAcc; ++k) { hkey[k * kBlockAcc + tid] = kInvalid; hcnt[k * kBlockAcc + tid] = 0; }
+  const uint32_t ent = c0 == 0 ? (tid < n_act ? ent_first : kNoActEntry)
+                               : (c0 + tid < n_act ? act_list[(size_t)base + c0 + tid] : kNoActEntry);
+  const bool act = ent != kNoActEntry;
+  const uint32_t rel_own = act ? (ent & 1023u) : 0u;
+  const uint32_t mask = act ? ((ent >> 10) & 15u) : 0u;
+  const bool rec = act && ((ent >> 14) & 1u);
+  // A recent slot's results -- the in-segment sums and its own term -- go to ONE dense 32-byte record at the slot's RANK
+  // among the segment's recent slots, which is its place in the recent list pass B wrote (both lists ascend by slot):
+  // the step kernel reads the records of a segment as one coalesced run.
+  const unsigned long long bal = __ballot(rec);
+  uint32_t rec_rank = rec_before + (uint32_t)__popcll(bal & ((1ull << (tid & 63u)) - 1ull));
+  if ((tid & 63u) == 0) rec_wave[tid >> 6] = (uint32_t)__popcll(bal);
+  // the slot's own records (idle lanes read the segment's first slot: no branch around the loads)
+  const uint32_t i = base + rel_own;
+  const uint4 own_t = *reinterpret_cast<const uint4*>(S.group(kGroupT, i));
+  const float4 own_s = *S.group(kGroupS, i);
+  const float4 own_n = *S.group(kGroupN, i);
   __syncthreads();
 #pragma unroll
-  for (int sub = 0; sub < kSub; ++sub) {
-#pragma unroll
-    for (int wv = 0; wv < kBlockAcc / 64; ++wv) {
-      const uint32_t n = rec_wave[sub][wv];
-      if ((uint32_t)wv < (tid >> 6)) rec_rank[sub] += n;
-#pragma unroll
-      for (int later = sub + 1; later < kSub; ++later) rec_rank[later] += n;
-    }
+  for (int wv = 0; wv < kBlockAcc / 64; ++wv) {
+    const uint32_t n = rec_wave[wv];
+    if ((uint32_t)wv < (tid >> 6)) rec_rank += n;
+    rec_before += n;
   }
-  // Both slots of a lane travel together through three levels of loads, every load of a level requested before the
-  // first one is used: (1) mask + flag bytes (requested one step ahead), (2) the slots' own T, S, N records, (3) one
-  // 16-byte record per link (tools/isa_phases.py shows the waits).  (Requesting the link records a step ahead as well
-  // would leave two levels, but takes the kernel over 128 VGPRs -- one workgroup per CU, or scratch.)
-  uint32_t idx[kSub], mask[kSub];
-  bool rec[kSub], act[kSub];
+  if (rec) lrank[rel_own] = (uint16_t)rec_rank;
+  const uint32_t nb[4] = {own_t.x, own_t.y, own_t.z, own_t.w};
+  // a recent slot needs every valid neighbour (its own step term, :2238-2256), any other slot only the neighbours inside
+  // the window (the terms it pushes): one 16-byte record per link, all requested before the first is used
+  uint32_t gmask = mask;
+  if (rec) {
 #pragma unroll
-  for (int sub = 0; sub < kSub; ++sub) {
-    idx[sub] = base + sub * kBlockAcc + tid;
-    mask[sub] = m8_cur[sub];
-    rec[sub] = (f8_cur[sub] & 1u) != 0;
+    for (int q = 0; q < 4; ++q) if (nb[q] != kInvalid) gmask |= 1u << q;
   }
-  uint4 own_t[kSub];
-  float4 own_s[kSub], own_n[kSub];
+  float4 ts[4];
 #pragma unroll
-  for (int sub = 0; sub < kSub; ++sub) {
-    act[sub] = mask[sub] != 0 || rec[sub];
-    const uint32_t i = act[sub] ? idx[sub] : base;   // (idle lanes read the segment's first slot: no branch around the loads)
-    own_t[sub] = *reinterpret_cast<const uint4*>(S.group(kGroupT, i));
-    own_s[sub] = *S.group(kGroupS, i);
-    own_n[sub] = *S.group(kGroupN, i);
-  }
-  uint32_t gmask[kSub];
-  float4 ts[kSub][4];
-#pragma unroll
-  for (int sub = 0; sub < kSub; ++sub) {
-    const uint32_t nb[4] = {own_t[sub].x, own_t[sub].y, own_t[sub].z, own_t[sub].w};
-    // a recent slot needs every valid neighbour (its own step term, :2238-2256), any other slot only the
-    // neighbours inside the window (the terms it pushes)
-    uint32_t gm = act[sub] ? mask[sub] : 0u;
-    if (act[sub] && rec[sub]) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) if (nb[q] != kInvalid) gm |= 1u << q;
-    }
-    gmask[sub] = gm;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)   // the neighbour's smooth position; unused links read the slot's own record
-      ts[sub][q] = *S.group(kGroupS, (gm & (1u << q)) ? nb[q] : (act[sub] ? idx[sub] : base));
-  }
+  for (int q = 0; q < 4; ++q)   // the neighbour's smooth position; unused links read the slot's own record
+    ts[q] = *S.group(kGroupS, (gmask & (1u << q)) ? nb[q] : i);
   // far terms wait in registers for their place in the destination's bin: (table entry | rank << 10, target, q22 x 3)
-  uint32_t far_where[kSub][4], far_target[kSub][4];
-  int far_q[kSub][4][3];
+  uint32_t far_where[4], far_target[4];
+  int far_q[4][3];
 #pragma unroll
-  for (int sub = 0; sub < kSub; ++sub) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) far_where[sub][q] = kInvalid;
-    if (!act[sub]) continue;
-    const uint32_t i = idx[sub];
-    const uint32_t nb[4] = {own_t[sub].x, own_t[sub].y, own_t[sub].z, own_t[sub].w};
-    const uint32_t msk = mask[sub];
-    const Vec3 sp = {own_s[sub].x, own_s[sub].y, own_s[sub].z};
-    const Vec3 nrm = {own_n[sub].x, own_n[sub].y, own_n[sub].z};
-    const float r2 = own_n[sub].w;
-    const int neighbor_count = msk ? __popc(msk) : 1;
+  for (int q = 0; q < 4; ++q) far_where[q] = kInvalid;
+  if (act) {
+    const Vec3 sp = {own_s.x, own_s.y, own_s.z};
+    const Vec3 nrm = {own_n.x, own_n.y, own_n.z};
+    const float r2 = own_n.w;
+    const int neighbor_count = mask ? __popc(mask) : 1;
     const float factor = 2 * weight / (float)neighbor_count;  // :2153
     int own_count = 0;
     Vec3 rg = {0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (!(gmask[sub] & (1u << q))) continue;
-      const Vec3 t = {ts[sub][q].x - sp.x, ts[sub][q].y - sp.y, ts[sub][q].z - sp.z};
+      if (!(gmask & (1u << q))) continue;
+      const Vec3 t = {ts[q].x - sp.x, ts[q].y - sp.y, ts[q].z - sp.z};
       const float nd = nrm.x * t.x + nrm.y * t.y + nrm.z * t.z;
       bool pruned = false;
-      if (msk & (1u << q)) {
+      if (mask & (1u << q)) {
         const float f = factor * nd;
         const Vec3 term = {f * nrm.x, f * nrm.y, f * nrm.z};   // (the weight term, :2182, travels as the sender's class)
         // the fixed-point channel carries |component| < 16 m (q22_from_float clamps): a huge regularizer_weight or a
@@ -2269,8 +2290,8 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
           if (where == kInvalid) {
             far_term_spill(grad_acc, fb, nb[q], qx, qy, qz, neighbor_count);
           } else {
-            far_where[sub][q] = where; far_target[sub][q] = nb[q] | ((uint32_t)(neighbor_count - 1) << 30);
-            far_q[sub][q][0] = qx; far_q[sub][q][1] = qy; far_q[sub][q][2] = qz;
+            far_where[q] = where; far_target[q] = nb[q] | ((uint32_t)(neighbor_count - 1) << 30);
+            far_q[q][0] = qx; far_q[q][1] = qy; far_q[q][2] = qz;
           }
         }
         const float d2 = t.x * t.x + t.y * t.y + t.z * t.z;
@@ -2278,13 +2299,13 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
       }
       // the slot's own regulariser term (RegularizeSurfelsCUDAKernel :2238-2256 sees the row after the pruning
       // above): same neighbour positions, same n.t product, so it is formed here and k_reg_step gathers nothing
-      if (rec[sub] && !pruned) {
+      if (rec && !pruned) {
         ++own_count;
         rg.x = rg.x - nd * nrm.x; rg.y = rg.y - nd * nrm.y; rg.z = rg.z - nd * nrm.z;
       }
     }
-    // (second half of the slot's dense record; the first half -- the in-segment sums -- follows behind the barrier)
-    if (rec[sub]) reg_rec[2 * (size_t)(base + rec_rank[sub]) + 1] = make_float4(rg.x, rg.y, rg.z, __int_as_float(own_count));
+    // (second half of the slot's dense record; the first half -- the in-segment sums -- follows when the segment is through)
+    if (rec) reg_rec[2 * (size_t)(base + rec_rank) + 1] = make_float4(rg.x, rg.y, rg.z, __int_as_float(own_count));
   }
   __syncthreads();
   // one lane per destination reserves the workgroup's run in that bin; the table then holds the run's start
@@ -2294,31 +2315,30 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
     const uint32_t dseg = hkey[e];
     if (dseg != kInvalid) hcnt[e] = atomicAdd(&fb.count[(size_t)dseg * kCountStride], hcnt[e]);
   }
-  // the in-segment sums of the recent slots: first half of their dense records.  (Rounds 3-4 stored the sums of EVERY slot
-  // of the segment, zeros included -- 16 KB of full lines per workgroup, 39 MB a frame at C2, of which the step kernel read
-  // the recent slots' 7 MB: profiles/r31_WRITE_SIZE.md.  Dense records by rank are full lines too, and only what is read.)
-#pragma unroll
-  for (int sub = 0; sub < kSub; ++sub) {
-    if (!rec[sub]) continue;
-    const uint32_t rel = sub * kBlockAcc + tid;
-    const unsigned long long v0 = lacc[rel], v1 = lacc[kSegAcc + rel];
-    *reinterpret_cast<ulonglong2*>(&reg_rec[2 * (size_t)(base + rec_rank[sub])]) = make_ulonglong2(v0, v1);
-  }
   __syncthreads();
 #pragma unroll
-  for (int sub = 0; sub < kSub; ++sub) {
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t where = far_where[q];
+    if (where == kInvalid) continue;
+    const uint32_t target = far_target[q] & 0x3FFFFFFFu, cls = far_target[q] >> 30;
+    const uint32_t pos = hcnt[where & 1023u] + (where >> 10);
+    if (pos < fb.cap)
+      fb.rec[(size_t)(target / kSegB) * fb.cap + pos] =
+          make_uint4((target % kSegB) | (cls << 10), (uint32_t)far_q[q][0], (uint32_t)far_q[q][1], (uint32_t)far_q[q][2]);
+    else
+      far_term_spill(grad_acc, fb, target, far_q[q][0], far_q[q][1], far_q[q][2], (int)cls + 1);
+  }
+  }   // chunks
+  // The in-segment sums of the recent slots: first half of their dense records, once every chunk's terms are in (the
+  // barriers above).  (Rounds 3-4 stored the sums of EVERY slot of the segment, zeros included -- 16 KB of full lines per
+  // workgroup, 39 MB a frame at C2, of which the step kernel read the recent slots' 7 MB: profiles/r31_WRITE_SIZE.md.)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t where = far_where[sub][q];
-      if (where == kInvalid) continue;
-      const uint32_t target = far_target[sub][q] & 0x3FFFFFFFu, cls = far_target[sub][q] >> 30;
-      const uint32_t pos = hcnt[where & 1023u] + (where >> 10);
-      if (pos < fb.cap)
-        fb.rec[(size_t)(target / kSegB) * fb.cap + pos] =
-            make_uint4((target % kSegB) | (cls << 10), (uint32_t)far_q[sub][q][0], (uint32_t)far_q[sub][q][1], (uint32_t)far_q[sub][q][2]);
-      else
-        far_term_spill(grad_acc, fb, target, far_q[sub][q][0], far_q[sub][q][1], far_q[sub][q][2], (int)cls + 1);
-    }
+  for (int k = 0; k < kSegAcc / kBlockAcc; ++k) {
+    const uint32_t rel = k * kBlockAcc + tid;
+    const uint32_t rank = lrank[rel];
+    if (rank == 0xFFFFu) continue;
+    const unsigned long long v0 = lacc[rel], v1 = lacc[kSegAcc + rel];
+    *reinterpret_cast<ulonglong2*>(&reg_rec[2 * (size_t)(base + rank)]) = make_ulonglong2(v0, v1);
   }
   }
 }
@@ -2341,6 +2361,7 @@ __global__ void __launch_bounds__(kBlock)
 k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, const float4* __restrict__ reg_rec,
            FarBins fb, Lists L, DevState* st, unsigned long long* ts) {
   __shared__ unsigned long long lfar[kSegB * 2];   // per target of the segment: (gx | gy), (gz | sender classes)
+  ts_begin(ts, kTsStepBegin);
   uint32_t desc, cntv;
   const uint32_t n_steps = walk_begin<true>(L.rec_chunks, 0u, blockIdx.x, desc, cntv);
   bool lds_used = false;
@@ -2721,7 +2742,6 @@ struct smx_recon_s {
   int nseg;                 // number of kSeg-slot segments (= workgroups of pass A)
   int nsegB;                // number of kSegB-slot segments (= workgroups of pass B)
   uint8_t* merge_flag;
-  uint8_t* inwin8;          // per slot: which of its 4 neighbours lie inside the regulariser window
   bool table_valid;         // flag table's "recent" bits correspond to (table_frame, table_window)
   uint32_t table_frame;
   int table_window;
@@ -2872,17 +2892,17 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
     SlotTimer t(r, st, kSlotNeighborScan, true);
     if (stats || zero_chunks) hipLaunchKernelGGL(k_reset_recent, dim3(1), dim3(kSubLists), 0, st, r->st, stats, zero_chunks ? r->L.rec_chunks.count : nullptr);
     if (copy_only) {
-      if (detach) hipExtLaunchKernelGGL((k_neighbor_scan<true, false>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->inwin8, r->st, ts_first);
-      else hipExtLaunchKernelGGL((k_neighbor_scan<false, false>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->inwin8, r->st, ts_first);
+      if (detach) hipExtLaunchKernelGGL((k_neighbor_scan<true, false>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->st, ts_first);
+      else hipExtLaunchKernelGGL((k_neighbor_scan<false, false>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->st, ts_first);
     } else {
-      if (detach) hipExtLaunchKernelGGL((k_neighbor_scan<true, true>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->inwin8, r->st, ts_first);
-      else hipExtLaunchKernelGGL((k_neighbor_scan<false, true>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->inwin8, r->st, ts_first);
+      if (detach) hipExtLaunchKernelGGL((k_neighbor_scan<true, true>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->st, ts_first);
+      else hipExtLaunchKernelGGL((k_neighbor_scan<false, true>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->st, ts_first);
     }
   }
   if (!copy_only) {
     SlotTimer t(r, st, kSlotRegAccumulate, true);
     hipExtLaunchKernelGGL(k_reg_accumulate, dim3(r->grid_acc), dim3(kBlockAcc), 0, st, t.start(), t.stop(), 0, r->S, rf2, weight, r->grad_acc, r->reg_rec,
-                       r->fb, r->inwin8, r->L.flags8, r->L.acc_chunks, r->st);
+                       r->fb, r->L.act_list, r->L.acc_chunks, r->st, ts_first);
   }
   if (copy_only) {
     SlotTimer t(r, st, kSlotRegUpdate);
@@ -2997,7 +3017,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   r->hot_filter_enabled = 1;
   r->hot_holdoff = 3;
   SMX_TRY(dev_alloc(&r->merge_flag, r->S.pitch, true));
-  SMX_TRY(dev_alloc(&r->inwin8, (size_t)r->nsegB * kSegB, true));
+  SMX_TRY(dev_alloc(&r->L.act_list, (size_t)r->nsegB * kSegB, true));
   SMX_TRY(dev_alloc(&r->sc.supporting, P, true));
   SMX_TRY(dev_alloc(&r->sc.counts, P, true));
   SMX_TRY(dev_alloc(&r->sc.depth_sums, P, true));
@@ -3080,7 +3100,7 @@ int smx_recon_destroy(smx_recon r) {
   void* ptrs[] = {r->sc.supporting, r->sc.counts, r->sc.depth_sums, r->sc.confl_key, r->sc.first_depth,
                   r->tb.pairs, r->tb.count, r->tb.ovf, r->ovf_count_set[0], r->ovf_count_set[1],
                   r->vis_count_set[0], r->vis_count_set[1], r->L.seg_act, r->L.seg_streak, r->sw.surv_list, r->sw.copy_list, r->sw.count, r->blended_depth, r->cand_q, r->cand_slots, r->cand_state, r->L.dirty8, r->delta_seg, r->delta_total, r->staging, r->S.base, r->grad_acc, r->reg_rec, r->fb.rec, r->fb.count, r->L.vis_list, r->L.recent_list, r->L.vis_seg, r->L.seg_box, r->L.recent_seg, r->L.vis_chunks.desc, r->L.rec_chunks.desc, r->L.acc_chunks.desc, r->L.rec_chunks.count, r->flags_buf[0], r->flags_buf[1], r->L.hot_epoch, r->L.seg_targets,
-                  r->merge_flag, r->inwin8, r->bb.distance_map, r->bb.new_distance_map,
+                  r->merge_flag, r->L.act_list, r->bb.distance_map, r->bb.new_distance_map,
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->block_offsets, r->st};
   if (r->reg_stream) { (void)hipStreamSynchronize(r->reg_stream); (void)hipStreamDestroy(r->reg_stream); }
   if (r->dir_host) { (void)hipDeviceSynchronize(); (void)hipHostFree(r->dir_host); }
@@ -3720,6 +3740,16 @@ int smx_recon_get_timings(smx_recon r, float out_ms[7]) {
   if (!r->reg_pending || !r->overlap_enabled) SMX_HIP(hipStreamSynchronize(r->last_stream));
   { const int rc = copy_stamp_ring(r); if (rc != SMX_OK) return rc; }
   (void)stage_ms_from_stamps(r->ts_host + (size_t)(r->ts_seq % kTsRing) * kTsWords, r->ts_seq, r->wall_khz, out_ms);
+  return SMX_OK;
+}
+
+int smx_recon_debug_stamp_ring(smx_recon r, uint64_t* out, int32_t capacity_words, int32_t* wall_clock_khz) {
+  SMX_CHECK_ARG(r != nullptr && out != nullptr && capacity_words >= kTsRing * kTsWords);
+  SMX_ON_DEVICE(r->device);
+  // (measurement: the raw stamp records of the last calls, read from the device ring -- the caller has synchronised)
+  { const int rc = copy_stamp_ring(r); if (rc != SMX_OK) return rc; }
+  for (int k = 0; k < kTsRing * kTsWords; ++k) out[k] = r->ts_host[k];
+  if (wall_clock_khz) *wall_clock_khz = r->wall_khz;
   return SMX_OK;
 }
 
