@@ -291,6 +291,7 @@ def stamp_timeline(rec):
                      "integrate+new_flags": us(a[INT_B], a[UPD_B]), "update_neighbors+create": us(a[UPD_B], a[REG_B]),
                      "neighbor_scan": us(a[REG_B], a[ACC_B]), "reg_accumulate": us(a[ACC_B], a[STEP_B]), "reg_step": us(a[STEP_B], a[REG_E]),
                      "internal stream: step end -> next integrate begin": us(a[REG_E], nx[INT_B]),
+                     "hand-over to the caller's stream (update end -> next pass A begin)": us(a[REG_B], nx[SCAN_B]),
                      "front: cull begin -> blend end": us(a[CULL], a[BLEND_E]),
                      "period (integrate begin -> next integrate begin)": us(a[INT_B], nx[INT_B])})
     if not rows:

@@ -2159,7 +2159,7 @@ constexpr int kSegAcc = 1024;     // slots per accumulation workgroup (16 KB of 
 #define SMX_REG_PRIORITY_HIGH 1
 #endif
 #ifndef SMX_ACC_WGS_PER_CU
-#define SMX_ACC_WGS_PER_CU 6   // (256-lane workgroups, 26 KB of LDS each: six per compute unit while the kernel stays at <= 80 VGPRs)
+#define SMX_ACC_WGS_PER_CU 5   // (256-lane workgroups, 26 KB of LDS each; <= 96 VGPRs without scratch. 4 / 5 / 6 measured: profiles/r5_ab_notes.md)
 #endif
 constexpr int kBlockAcc = 256;
 static_assert(kSegAcc == kSegB, "the edge kernel's segments are pass B's: it walks pass B's work lists");
@@ -2203,13 +2203,22 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
 #pragma unroll
   for (int k = 0; k < kSegAcc / 2 / kBlockAcc; ++k) reinterpret_cast<uint32_t*>(lrank)[k * kBlockAcc + tid] = 0xFFFFFFFFu;
   uint32_t rec_before = 0;   // recent entries in the chunks in front of this one
+  // A segment with more than 256 entries takes several chunks, one after the other (they share the LDS sums): the next
+  // chunk's entries are requested at the top of this one, and its slots' own records behind this chunk's first barrier,
+  // so that a chunk waits for its link records and its bin reservations only -- two dependent round trips instead of four
+  // (the dense segments, four chunks each, are what the launch lasts: 40 us alone without this, profiles/r5_ab_notes.md).
+  uint32_t ent = tid < n_act ? ent_first : kNoActEntry;
+  uint4 own_t = *reinterpret_cast<const uint4*>(S.group(kGroupT, base + (ent != kNoActEntry ? (ent & 1023u) : 0u)));
+  float4 own_s = *S.group(kGroupS, base + (ent != kNoActEntry ? (ent & 1023u) : 0u));
+  float4 own_n = *S.group(kGroupN, base + (ent != kNoActEntry ? (ent & 1023u) : 0u));
 #pragma unroll 1
   for (uint32_t c0 = 0; c0 < n_act; c0 += kBlockAcc) {
+  const bool more = c0 + kBlockAcc < n_act;   // (uniform)
+  uint32_t ent_following = kNoActEntry;
+  if (more && c0 + kBlockAcc + tid < n_act) ent_following = act_list[(size_t)base + c0 + kBlockAcc + tid];
   if (c0) __syncthreads();   // (the previous chunk's far stores have read the table)
 #pragma unroll
   for (int k = 0; k < kFarHash / kBlockAcc; ++k) { hkey[k * kBlockAcc + tid] = kInvalid; hcnt[k * kBlockAcc + tid] = 0; }
-  const uint32_t ent = c0 == 0 ? (tid < n_act ? ent_first : kNoActEntry)
-                               : (c0 + tid < n_act ? act_list[(size_t)base + c0 + tid] : kNoActEntry);
   const bool act = ent != kNoActEntry;
   const uint32_t rel_own = act ? (ent & 1023u) : 0u;
   const uint32_t mask = act ? ((ent >> 10) & 15u) : 0u;
@@ -2220,11 +2229,8 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
   const unsigned long long bal = __ballot(rec);
   uint32_t rec_rank = rec_before + (uint32_t)__popcll(bal & ((1ull << (tid & 63u)) - 1ull));
   if ((tid & 63u) == 0) rec_wave[tid >> 6] = (uint32_t)__popcll(bal);
-  // the slot's own records (idle lanes read the segment's first slot: no branch around the loads)
+  // (the slot's own records: requested a chunk ahead; idle lanes hold the segment's first slot's)
   const uint32_t i = base + rel_own;
-  const uint4 own_t = *reinterpret_cast<const uint4*>(S.group(kGroupT, i));
-  const float4 own_s = *S.group(kGroupS, i);
-  const float4 own_n = *S.group(kGroupN, i);
   __syncthreads();
 #pragma unroll
   for (int wv = 0; wv < kBlockAcc / 64; ++wv) {
@@ -2315,6 +2321,14 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
     const uint32_t dseg = hkey[e];
     if (dseg != kInvalid) hcnt[e] = atomicAdd(&fb.count[(size_t)dseg * kCountStride], hcnt[e]);
   }
+  // the next chunk's own records travel while the reservations return and the far records are stored
+  uint4 nxt_t = own_t; float4 nxt_s = own_s, nxt_n = own_n;
+  if (more) {
+    const uint32_t in = base + (ent_following != kNoActEntry ? (ent_following & 1023u) : 0u);
+    nxt_t = *reinterpret_cast<const uint4*>(S.group(kGroupT, in));
+    nxt_s = *S.group(kGroupS, in);
+    nxt_n = *S.group(kGroupN, in);
+  }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -2328,6 +2342,7 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
     else
       far_term_spill(grad_acc, fb, target, far_q[q][0], far_q[q][1], far_q[q][2], (int)cls + 1);
   }
+  ent = ent_following; own_t = nxt_t; own_s = nxt_s; own_n = nxt_n;
   }   // chunks
   // The in-segment sums of the recent slots: first half of their dense records, once every chunk's terms are in (the
   // barriers above).  (Rounds 3-4 stored the sums of EVERY slot of the segment, zeros included -- 16 KB of full lines per

@@ -10,7 +10,9 @@ for v in "$@"; do
 import json
 d = json.load(open("gpurun_out/${T}_${v}_$rep.json"))
 t = d.get("in_frame_timeline_us") or {}
-print("%-8s %7.1f |" % ("$v", d["value"]), " ".join("%s %.1f" % (k.split(" ")[0][:9], v) for k, v in t.items()))
+k = d["roofline"]["kernels"]
+print("%-8s %7.1f |" % ("$v", d["value"]), " ".join("%s %.1f" % (k_.split(" ")[0][:9], v) for k_, v in t.items()),
+      "| alone:", " ".join("%s %.1f" % (n[:9], v["alone_ms"] * 1e3) for n, v in k.items() if n in ("neighbor_scan", "reg_accumulate", "reg_step", "integrate+new_flags", "update_neighbors+create")))
 PY
   done
 done
