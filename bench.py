@@ -433,6 +433,7 @@ def main():
     ap.add_argument("--surfels", type=int, default=0, help="LIVE surfels to reach before timing (C2: 5 M, C3: 20 M)")
     ap.add_argument("--cap", type=int, default=0, help="max_surfel_count (default: surfels * 1.25)")
     ap.add_argument("--points", type=int, default=50_000_000, help="C5: surfel positions in the index")
+    ap.add_argument("--nn-mode", type=int, default=2, help="C5 A/B: smx_nn_set_query_mode (2 = default)")
     ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the CPU baseline sample (0 = skip; C3 default 4)")
     ap.add_argument("--host-frames", type=int, default=100,
                     help="frames of the extra pass whose inputs arrive from page-locked host memory (0 = skip)")
@@ -1154,6 +1155,7 @@ def run_c5(args):
     api.StreamSynchronize(None)
     torch.cuda.synchronize()
     nn = api.SurfelNeighborIndex()
+    nn.set_query_mode(args.nn_mode)
 
     def build():
         _lib.check(L.smx_nn_build(nn._h, None, ptr(bx), ptr(by), ptr(bz), C.c_uint32(n), C.c_float(float(r)), C.c_int32(1)))

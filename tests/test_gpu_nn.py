@@ -265,6 +265,30 @@ def test_workspace_is_reused_and_queries_of_any_size_and_k(smx):
     nn.close()
 
 
+def test_self_queries_in_a_sparse_cloud(smx):
+    """Self-queries over a SPARSE cloud (isolated points and small clusters, bricks far apart: most tiles hold one or two
+    queries): rows identical to the wavefront-per-query kernel and to brute force."""
+    rng = np.random.default_rng(77)
+    n = 20_000
+    pts = rng.uniform(-4, 4, (n, 3)).astype(np.float32)              # ~0.04 points per 5 cm cell: isolated points
+    clusters = rng.uniform(-4, 4, (300, 3)).astype(np.float32)       # ... and small clusters, so that rows are not empty
+    pts[:6000] = (clusters[rng.integers(0, 300, 6000)] + rng.normal(0, 0.03, (6000, 3))).astype(np.float32)
+    r2 = (rng.uniform(0.02, 0.06, n).astype(np.float32)) ** 2
+    nn = smx.SurfelNeighborIndex()
+    nn.Build(pts[:, 0], pts[:, 1], pts[:, 2], 0.05)
+    cs, ds, is_ = nn.FindNearestOfIndexedPoints(n, 32, radius_squared=r2, factor=1.0)
+    nn.set_query_mode(0)
+    c0, d0, i0 = nn.FindNearestOfIndexedPoints(n, 32, radius_squared=r2, factor=1.0)
+    nn.set_query_mode(2)
+    m = np.arange(32)[None, :] < cs[:, None]
+    assert np.array_equal(c0, cs) and np.array_equal(i0[m], is_[m]) and np.array_equal(d0[m].view(np.uint32), ds[m].view(np.uint32))
+    assert cs.min() >= 1 and (cs > 4).sum() > 1000 and (cs == 1).sum() > 1000      # every point finds itself; clusters and loners
+    for j in rng.choice(n, 80, replace=False):
+        c, od2, oidx = orc.nn_bruteforce(pts[:, 0], pts[:, 1], pts[:, 2], pts[j], float(r2[j]), 32)
+        assert cs[j] == c and np.array_equal(is_[j, :c], oidx[:c]) and np.array_equal(ds[j, :c].view(np.uint32), od2[:c].view(np.uint32))
+    nn.close()
+
+
 def test_self_queries_and_kernel_modes_agree(smx):
     """smx_nn_query_self (every indexed point asks for its own neighbourhood; no query keys / sort) and both query
     kernels of smx_nn_query_batch give the same rows; points that are not indexed get count 0; bricks with more than 64
@@ -290,11 +314,12 @@ def test_self_queries_and_kernel_modes_agree(smx):
             rows[mode] = nn.FindNearestSurfelsWithinRadius(pts, r2, 64, state=st, skip_mask=mask)
         # the self-query entry point under the other tile kernel as well (the first call ran the default, mode 2:
         # one lane per query, with the dense clump's queries -- more than 32 matches -- redone by the tile kernel)
-        nn.set_query_mode(0)
-        c0, d0, i0 = nn.FindNearestOfIndexedPoints(n, 64, radius_squared=r2, factor=1.0, state=st, skip_mask=mask)
-        nn.set_query_mode(2)
         m0 = np.arange(64)[None, :] < cs[:, None]
-        assert np.array_equal(c0, cs) and np.array_equal(i0[m0], is_[m0]) and np.array_equal(d0[m0].view(np.uint32), ds[m0].view(np.uint32))
+        for self_mode in (0,):
+            nn.set_query_mode(self_mode)
+            c0, d0, i0 = nn.FindNearestOfIndexedPoints(n, 64, radius_squared=r2, factor=1.0, state=st, skip_mask=mask)
+            assert np.array_equal(c0, cs) and np.array_equal(i0[m0], is_[m0]) and np.array_equal(d0[m0].view(np.uint32), ds[m0].view(np.uint32)), self_mode
+        nn.set_query_mode(2)
         assert (cs > 32).sum() > 100 and (cs < 32).sum() > 1000        # both paths of mode 2 were taken
         for mode in (0, 1, 2):
             cb, db, ib = rows[mode]
