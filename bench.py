@@ -292,6 +292,9 @@ def stamp_timeline(rec):
                      "neighbor_scan": us(a[REG_B], a[ACC_B]), "reg_accumulate": us(a[ACC_B], a[STEP_B]), "reg_step": us(a[STEP_B], a[REG_E]),
                      "internal stream: step end -> next integrate begin": us(a[REG_E], nx[INT_B]),
                      "hand-over to the caller's stream (update end -> next pass A begin)": us(a[REG_B], nx[SCAN_B]),
+                     "gap integrate end* -> update begin": us(a[INT_E], a[UPD_B]),
+                     "gap update end* -> pass B begin": us(a[UPD_E], a[REG_B]),
+                     "gap tiles end* -> blend begin": us(a[TILES_END], a[BLEND_B]),
                      "front: cull begin -> blend end": us(a[CULL], a[BLEND_E]),
                      "period (integrate begin -> next integrate begin)": us(a[INT_B], nx[INT_B])})
     if not rows:

@@ -309,22 +309,29 @@ inline void ErodeNormalsRadiiCUDA(cudaStream_t stream, int erosion_radius, float
 }
 
 // ---- APP/cuda_surfels_cpu.h ---------------------------------------------------------------------------
+// (SMX_SHIM_PAGELOCKED_SURFEL_BUFFERS -- define it in front of this header -- takes the eight arrays from page-locked
+// memory (smx_host_alloc) instead of new[]: the eight row copies of TransferAllToCPU then run asynchronously to the host,
+// as cudaMemcpyAsync only does from and to page-locked memory, and at the full PCIe rate.  Off by default: the
+// reference allocates with new[] (cuda_surfels_cpu.h:42-51), and page-locking 8 x max_surfel_count x 4 bytes per buffer
+// set is a decision for the application.)
 struct CUDASurfelBuffersCPU {
   explicit CUDASurfelBuffersCPU(usize max_surfel_count) {
-    surfel_x_buffer = new float[max_surfel_count];
-    surfel_y_buffer = new float[max_surfel_count];
-    surfel_z_buffer = new float[max_surfel_count];
-    surfel_radius_squared_buffer = new float[max_surfel_count];
-    surfel_normal_x_buffer = new float[max_surfel_count];
-    surfel_normal_y_buffer = new float[max_surfel_count];
-    surfel_normal_z_buffer = new float[max_surfel_count];
-    surfel_last_update_stamp_buffer = new u32[max_surfel_count];
+    surfel_x_buffer = alloc<float>(max_surfel_count);
+    surfel_y_buffer = alloc<float>(max_surfel_count);
+    surfel_z_buffer = alloc<float>(max_surfel_count);
+    surfel_radius_squared_buffer = alloc<float>(max_surfel_count);
+    surfel_normal_x_buffer = alloc<float>(max_surfel_count);
+    surfel_normal_y_buffer = alloc<float>(max_surfel_count);
+    surfel_normal_z_buffer = alloc<float>(max_surfel_count);
+    surfel_last_update_stamp_buffer = alloc<u32>(max_surfel_count);
   }
   ~CUDASurfelBuffersCPU() {
-    delete[] surfel_x_buffer; delete[] surfel_y_buffer; delete[] surfel_z_buffer;
-    delete[] surfel_radius_squared_buffer; delete[] surfel_normal_x_buffer; delete[] surfel_normal_y_buffer;
-    delete[] surfel_normal_z_buffer; delete[] surfel_last_update_stamp_buffer;
+    release(surfel_x_buffer); release(surfel_y_buffer); release(surfel_z_buffer);
+    release(surfel_radius_squared_buffer); release(surfel_normal_x_buffer); release(surfel_normal_y_buffer);
+    release(surfel_normal_z_buffer); release(surfel_last_update_stamp_buffer);
   }
+  CUDASurfelBuffersCPU(const CUDASurfelBuffersCPU&) = delete;
+  CUDASurfelBuffersCPU& operator=(const CUDASurfelBuffersCPU&) = delete;
   u32 frame_index = 0;
   usize surfel_count = 0;
   float* surfel_x_buffer;
@@ -335,6 +342,18 @@ struct CUDASurfelBuffersCPU {
   float* surfel_normal_y_buffer;
   float* surfel_normal_z_buffer;
   u32* surfel_last_update_stamp_buffer;
+ private:
+#ifdef SMX_SHIM_PAGELOCKED_SURFEL_BUFFERS
+  template <typename T> static T* alloc(usize n) {
+    void* p = nullptr;
+    SMX_SHIM_CHECK(smx_host_alloc(&p, (n ? n : 1) * sizeof(T), /*write_combined*/ 0));   // (the mesher reads these arrays)
+    return static_cast<T*>(p);
+  }
+  template <typename T> static void release(T* p) { (void)smx_host_free(p); }
+#else
+  template <typename T> static T* alloc(usize n) { return new T[n]; }
+  template <typename T> static void release(T* p) { delete[] p; }
+#endif
 };
 
 class CUDASurfelsCPU {

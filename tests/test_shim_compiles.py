@@ -122,6 +122,7 @@ int frame(cudaStream_t stream, CUDASurfelReconstruction& reconstruction, CUDASur
   reconstruction.ExportVertices(stream, &position_buffer, &color_out);
   float t[7];
   reconstruction.GetTimings(&t[0], &t[1], &t[2], &t[3], &t[4], &t[5], &t[6]);
+  const uint64_t timed_call = reconstruction.GetTimingsNoWait(&t[0], &t[1], &t[2], &t[3], &t[4], &t[5], &t[6]);
   // additions (SURVEY.md 8f)
   reconstruction.SetDeltaTracking(stream, true);
   CUDASurfelDeltaCPU delta(1000);
@@ -157,3 +158,9 @@ def test_reference_style_host_code_compiles_and_links(tmp_path):
     # the pose conversions are pure host code: run them (libsmx.so is only loaded, no entry point is called)
     r = subprocess.run([str(exe), "check"], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    # ... and with the shim's option that takes CUDASurfelBuffersCPU from page-locked memory (smx_host_alloc)
+    r = subprocess.run(["g++", "-std=c++14", "-Wall", "-Werror", "-Wno-unused-variable", "-DSMX_SHIM_PAGELOCKED_SURFEL_BUFFERS",
+                        "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe) + "_pl", "-L", lib_dir, "-l:libsmx.so",
+                        "-Wl,-rpath," + lib_dir, "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # (GetTimingsNoWait is in the GetTimings block of the caller above)
