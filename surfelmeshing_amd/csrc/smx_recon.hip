@@ -2158,6 +2158,9 @@ constexpr int kSegAcc = 1024;     // slots per accumulation workgroup (16 KB of 
 #ifndef SMX_REG_PRIORITY_HIGH
 #define SMX_REG_PRIORITY_HIGH 1
 #endif
+#ifndef SMX_READY_WAIT_EARLY
+#define SMX_READY_WAIT_EARLY 1   // (1: +0.5 % at C2, 4 of 4 pairs, profiles/r5_ab_notes.md; 0: the wait between pass A and the tile kernel)
+#endif
 #ifndef SMX_ACC_WGS_PER_CU
 #define SMX_ACC_WGS_PER_CU 5   // (256-lane workgroups, 26 KB of LDS each; <= 96 VGPRs without scratch. 4 / 5 / 6 measured: profiles/r5_ab_notes.md)
 #endif
@@ -3307,6 +3310,11 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     r->sw_dirty = true;
     hipLaunchKernelGGL(k_cull_segments, dim3((unsigned)div_up(r->nseg, kBlock)), b, 0, sF, c, r->L, r->sw, r->st, (uint32_t)r->nseg, (uint32_t)P, r->ts_seq); }
   if (r->pending_mark) { SMX_HIP(hipStreamWaitEvent(sF, r->pending_mark, 0)); r->pending_mark = nullptr; }
+#if SMX_READY_WAIT_EARLY
+  // (the wait for the input images next to the wait for the map: pass A and the tile kernel then follow each other without
+  // a barrier packet between them -- 38 -> 31 us from pass A's first workgroup to the tile kernel's at C2)
+  if (hook_ready) SMX_HIP(hipStreamWaitEvent(sF, hook_ready, 0));
+#endif
   if (r->stats_enabled) hipLaunchKernelGGL(k_reset_frame_stats, dim3(1), dim3(1), 0, sF, r->st, 0);
   { SlotTimer t(r, sF, kSlotScanVisible, true);
     const bool lds_tables = !r->no_lds_tables;
@@ -3315,7 +3323,9 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     hipExtLaunchKernelGGL(k_scan_visible, ga, b, 0, sF, t.start(), t.stop(), 0, r->S, c, r->L, r->tb, r->sw, flags_prev, r->st, lds_tables ? 1 : 0);
     r->table_valid = true; r->table_frame = frame_index; r->table_window = c.reg_window; }
   // (smx_recon_integrate_inputs_ready) from here on the input images are read
+#if !SMX_READY_WAIT_EARLY
   if (hook_ready) SMX_HIP(hipStreamWaitEvent(sF, hook_ready, 0));
+#endif
   // (the tile kernel also leaves the direction for later launches' segment_of_block in host memory, see there)
   { SlotTimer t(r, sF, kSlotAssocTiles, true);
     hipExtLaunchKernelGGL(k_assoc_tiles, dim3(r->tb.n_tiles), dim3(kTilePx), 0, sF, t.start(), t.stop(), 0, r->S, c, r->sc, in.depth, in.normals, r->tb,
