@@ -45,17 +45,19 @@ ALG_BYTES = {
     # calls after a segment drops out of view: not counted), 16 B of chunk descriptors per segment read, list + pairs
     "scan_visible": lambda st, P: (18.0 + 16.0 / 1024.0) * (st["surfels_size"] - 1024.0 * st.get("n_segments_skipped", 0))
                                   + (4.0 + 1.9 * 8.0) * st["n_visible"],
-    # T records + flag and mask bytes of the segments that are read (18 B per slot), the hot table + the target-group
-    # bitmap (4.5 KB) of the ones that are skipped, one flag byte per link, the recent list
-    "neighbor_scan": lambda st, P: 18.0 * (st["surfels_size"] - 1024.0 * st.get("n_link_segments_skipped", 0))
-                                   + 4608.0 * st.get("n_link_segments_skipped", 0) + 1.0 * st["n_edges"] + 4.0 * st["n_recent"],
-    # slots served: contributors and recent slots (mostly the same slots): 50 B own records each; per link into the
-    # window the target's S record (16 B) and, for the 29 % of them that leave the segment (tools/far_terms_hist.py), a
-    # 16 B record in the target segment's bin; per recent slot the in-segment sums (16 B) and the own-term record (16 B)
-    "reg_accumulate": lambda st, P: 50.0 * max(st["n_contributors"], st["n_recent"]) + (16.0 + 0.29 * 16.0) * st["n_window_edges"]
+    # T records + flag bytes of the segments that are read (17 B per slot), the hot table + the target-group bitmap (4.5 KB) of
+    # the ones that are skipped, one flag byte per link, the recent list and the edge kernel's work list (4 B per entry)
+    "neighbor_scan": lambda st, P: 17.0 * (st["surfels_size"] - 1024.0 * st.get("n_link_segments_skipped", 0))
+                                   + 4608.0 * st.get("n_link_segments_skipped", 0) + 1.0 * st["n_edges"] + 4.0 * st["n_recent"]
+                                   + 4.0 * max(st["n_contributors"], st["n_recent"]),
+    # entries served: contributors and recent slots (mostly the same slots): the entry (4 B) + T, S, N records (48 B) each;
+    # per link into the window the target's S record (16 B) and, for the 29 % of them that leave the segment
+    # (tools/far_terms_hist.py), a 16 B record in the target segment's bin; per recent slot its dense record (32 B: in-segment
+    # sums | own term)
+    "reg_accumulate": lambda st, P: 52.0 * max(st["n_contributors"], st["n_recent"]) + (16.0 + 0.29 * 16.0) * st["n_window_edges"]
                                     + 32.0 * st["n_recent"],
-    # P, S, N, own-term record, in-segment sums (read + re-zeroed), S store: 112 B per recent slot; the bins' records
-    "reg_step": lambda st, P: 112.0 * st["n_recent"] + 0.29 * 16.0 * st["n_window_edges"],
+    # list entry, P, S, N, the dense record, S store: 100 B per recent slot; the bins' records
+    "reg_step": lambda st, P: 100.0 * st["n_recent"] + 0.29 * 16.0 * st["n_window_edges"],
     "reg_update": lambda st, P: 36.0 * st["n_recent"],
     # association tiles: per pair (~1.9 per visible slot) 8 B + the slot's P and N records (32 B); per pixel the
     # measurement (10 B) and the five images written (24 B); the merge phase's supported-surfel records (32 B per visible slot)
