@@ -2168,7 +2168,7 @@ constexpr int kBlockAcc = 256;
 static_assert(kSegAcc == kSegB, "the edge kernel's segments are pass B's: it walks pass B's work lists");
 __global__ void __launch_bounds__(kBlockAcc, SMX_ACC_WGS_PER_CU)   // (second argument: wavefronts per SIMD = workgroups per CU here)
 k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ grad_acc,
-                 float4* __restrict__ reg_rec, FarBins fb,
+                 float4* __restrict__ reg_rec, size_t rec_own_offset, FarBins fb,
                  const uint32_t* __restrict__ act_list, Chunks acc, DevState* st, unsigned long long* ts) {
   ts_begin(ts, kTsAccBegin);
   __shared__ unsigned long long lacc[kSegAcc * 2];  // per target: (gx | gy), (gz | sender classes)
@@ -2226,9 +2226,11 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
   const uint32_t rel_own = act ? (ent & 1023u) : 0u;
   const uint32_t mask = act ? ((ent >> 10) & 15u) : 0u;
   const bool rec = act && ((ent >> 14) & 1u);
-  // A recent slot's results -- the in-segment sums and its own term -- go to ONE dense 32-byte record at the slot's RANK
-  // among the segment's recent slots, which is its place in the recent list pass B wrote (both lists ascend by slot):
-  // the step kernel reads the records of a segment as one coalesced run.
+  // A recent slot's results -- the in-segment sums and its own term -- go to two dense arrays at the slot's RANK among the
+  // segment's recent slots, which is its place in the recent list pass B wrote (both lists ascend by slot): the step
+  // kernel reads the records of a segment as coalesced runs.  (Two arrays of 16-byte records, not one of 32-byte records:
+  // the two halves are ready at different times, and a 16-byte store into a 32-byte record is a partial sector write --
+  // WRITE_SIZE booked 32 bytes for each, 30 MB a frame at C2 instead of 15, profiles/r40_WRITE_SIZE.md.)
   const unsigned long long bal = __ballot(rec);
   uint32_t rec_rank = rec_before + (uint32_t)__popcll(bal & ((1ull << (tid & 63u)) - 1ull));
   if ((tid & 63u) == 0) rec_wave[tid >> 6] = (uint32_t)__popcll(bal);
@@ -2314,7 +2316,7 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
       }
     }
     // (second half of the slot's dense record; the first half -- the in-segment sums -- follows when the segment is through)
-    if (rec) reg_rec[2 * (size_t)(base + rec_rank) + 1] = make_float4(rg.x, rg.y, rg.z, __int_as_float(own_count));
+    if (rec) reg_rec[rec_own_offset + (size_t)(base + rec_rank)] = make_float4(rg.x, rg.y, rg.z, __int_as_float(own_count));
   }
   __syncthreads();
   // one lane per destination reserves the workgroup's run in that bin; the table then holds the run's start
@@ -2356,7 +2358,7 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
     const uint32_t rank = lrank[rel];
     if (rank == 0xFFFFu) continue;
     const unsigned long long v0 = lacc[rel], v1 = lacc[kSegAcc + rel];
-    *reinterpret_cast<ulonglong2*>(&reg_rec[2 * (size_t)(base + rank)]) = make_ulonglong2(v0, v1);
+    *reinterpret_cast<ulonglong2*>(&reg_rec[(size_t)(base + rank)]) = make_ulonglong2(v0, v1);
   }
   }
 }
@@ -2376,7 +2378,7 @@ k_rebuild_flags(Surfels S, uint32_t frame, int reg_window, uint8_t* __restrict__
 // the bin.
 constexpr int kStepSub = kSegB / kBlock;
 __global__ void __launch_bounds__(kBlock)
-k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, const float4* __restrict__ reg_rec,
+k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, const float4* __restrict__ reg_rec, size_t rec_own_offset,
            FarBins fb, Lists L, DevState* st, unsigned long long* ts) {
   __shared__ unsigned long long lfar[kSegB * 2];   // per target of the segment: (gx | gy), (gz | sender classes)
   ts_begin(ts, kTsStepBegin);
@@ -2409,8 +2411,8 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, const floa
       rp[sub] = *S.group(kGroupP, i); rs[sub] = *S.group(kGroupS, i); rn[sub] = *S.group(kGroupN, i);
       // the slot's dense record (k_reg_accumulate): in-segment sums, own term + neighbour count -- entry e of the segment
       const size_t e = (size_t)seg_base + (on[sub] ? (uint32_t)(sub * kBlock) + threadIdx.x : 0u);
-      rl[sub] = *reinterpret_cast<const ulonglong2*>(&reg_rec[2 * e]);
-      rgr[sub] = reg_rec[2 * e + 1];
+      rl[sub] = *reinterpret_cast<const ulonglong2*>(&reg_rec[e]);
+      rgr[sub] = reg_rec[rec_own_offset + e];
     }
     if (n_far) {
       if (lds_used) __syncthreads();   // (the previous step's readers are done)
@@ -2754,7 +2756,8 @@ struct smx_recon_s {
   float fx, fy, cx, cy;
   Surfels S;
   long long* grad_acc;      // [slots][2] packed fixed point (see pack_pair), cross-segment contributions (atomics)
-  float4* reg_rec;          // [slots][2] dense records of the recent slots, by (segment, rank in its recent list): in-segment sums | own term
+  float4* reg_rec;          // two dense arrays [slots + kSegAcc] of the recent slots' results, by (segment, rank in its recent list):
+                            // the in-segment sums, then the own terms (each written by ONE store instruction per chunk: full sectors)
   FarBins fb;               // far terms of the regulariser, per destination segment (see FarBins)
   Lists L;
   int nseg;                 // number of kSeg-slot segments (= workgroups of pass A)
@@ -2919,7 +2922,7 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
   }
   if (!copy_only) {
     SlotTimer t(r, st, kSlotRegAccumulate, true);
-    hipExtLaunchKernelGGL(k_reg_accumulate, dim3(r->grid_acc), dim3(kBlockAcc), 0, st, t.start(), t.stop(), 0, r->S, rf2, weight, r->grad_acc, r->reg_rec,
+    hipExtLaunchKernelGGL(k_reg_accumulate, dim3(r->grid_acc), dim3(kBlockAcc), 0, st, t.start(), t.stop(), 0, r->S, rf2, weight, r->grad_acc, r->reg_rec, (size_t)r->S.pitch + kSegAcc,
                        r->fb, r->L.act_list, r->L.acc_chunks, r->st, ts_first);
   }
   if (copy_only) {
@@ -2927,7 +2930,7 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
     hipLaunchKernelGGL(k_reg_copy_raw, gl, b, 0, st, r->S, r->L, r->st, ts);
   } else {
     SlotTimer t(r, st, kSlotRegStep, true);
-    hipExtLaunchKernelGGL(k_reg_step, gl, b, 0, st, t.start(), t.stop(), 0, r->S, weight, r->grad_acc, r->reg_rec, r->fb, r->L, r->st, ts);
+    hipExtLaunchKernelGGL(k_reg_step, gl, b, 0, st, t.start(), t.stop(), 0, r->S, weight, r->grad_acc, r->reg_rec, (size_t)r->S.pitch + kSegAcc, r->fb, r->L, r->st, ts);
   }
   SMX_LAUNCH_CHECK();
   return SMX_OK;
