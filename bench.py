@@ -47,9 +47,12 @@ ALG_BYTES = {
                                   + (4.0 + 1.9 * 8.0) * st["n_visible"],
     # T records + flag bytes of the segments that are read (17 B per slot), the hot table + the target-group bitmap (4.5 KB) of
     # the ones that are skipped, one flag byte per link, the recent list and the edge kernel's work list (4 B per entry)
+    # (fused -- the default: the segment's workgroup does the edge work itself, the work list stays in LDS -- the launch also
+    # moves the edge kernel's bytes, minus the list's 4 + 4 per entry)
     "neighbor_scan": lambda st, P: 17.0 * (st["surfels_size"] - 1024.0 * st.get("n_link_segments_skipped", 0))
                                    + 4608.0 * st.get("n_link_segments_skipped", 0) + 1.0 * st["n_edges"] + 4.0 * st["n_recent"]
-                                   + 4.0 * max(st["n_contributors"], st["n_recent"]),
+                                   + (ALG_BYTES["reg_accumulate"](st, P) - 4.0 * max(st["n_contributors"], st["n_recent"]) if st.get("fused_edges")
+                                      else 4.0 * max(st["n_contributors"], st["n_recent"])),
     # entries served: contributors and recent slots (mostly the same slots): the entry (4 B) + T, S, N records (48 B) each;
     # per link into the window the target's S record (16 B) and, for the 29 % of them that leave the segment
     # (tools/far_terms_hist.py), a 16 B record in the target segment's bin; per recent slot its dense record (32 B: in-segment
@@ -284,14 +287,15 @@ def stamp_timeline(rec):
     rows = []
     for q in sorted(recs):
         a, nx = recs[q], recs.get(q + 1)
-        if nx is None or min(a[k] for k in (CULL, SCAN_B, TILES_B, BLEND_B, BLEND_E, INT_B, UPD_B, REG_B, ACC_B, STEP_B, REG_E)) == 0:
+        if nx is None or min(a[k] for k in (CULL, SCAN_B, TILES_B, BLEND_B, BLEND_E, INT_B, UPD_B, REG_B, STEP_B, REG_E)) == 0:
             continue
+        acc_b = a[ACC_B] if a[ACC_B] else a[STEP_B]   # (fused: pass B does the edge work, there is no edge launch)
         us = lambda x, y: (float(y) - float(x)) * 1e3 / khz  # noqa: E731
         rows.append({"cull (+ wait for the previous call's map)": us(a[CULL], a[SCAN_B]), "scan_visible": us(a[SCAN_B], a[TILES_B]),
                      "assoc_tiles": us(a[TILES_B], a[BLEND_B]), "blend": us(a[BLEND_B], a[BLEND_E]),
                      "hand-over to the internal stream (blend end -> integrate begin)": us(a[BLEND_E], a[INT_B]),
                      "integrate+new_flags": us(a[INT_B], a[UPD_B]), "update_neighbors+create": us(a[UPD_B], a[REG_B]),
-                     "neighbor_scan": us(a[REG_B], a[ACC_B]), "reg_accumulate": us(a[ACC_B], a[STEP_B]), "reg_step": us(a[STEP_B], a[REG_E]),
+                     "neighbor_scan": us(a[REG_B], acc_b), "reg_accumulate": us(acc_b, a[STEP_B]), "reg_step": us(a[STEP_B], a[REG_E]),
                      "internal stream: step end -> next integrate begin": us(a[REG_E], nx[INT_B]),
                      "hand-over to the caller's stream (update end -> next pass A begin)": us(a[REG_B], nx[SCAN_B]),
                      "gap integrate end* -> update begin": us(a[INT_E], a[UPD_B]),
@@ -463,7 +467,7 @@ def main():
                          "GetTimingsNoWait, block = the reference's waiting call")
     ap.add_argument("--fused-head", action="store_true", help="A/B: bilateral filter and outlier cull in one launch (same images; slower)")
     ap.add_argument("--run-ahead", action="store_true", help="A/B: preprocessing two steps ahead, waits routed off the caller's stream")
-    ap.add_argument("--scan-mode", type=int, default=0, help="A/B: smx_recon_set_scan_mode bits (1 = all-slot scans, 2 = multi-launch blend, 4 = no hot-group filter in pass B)")
+    ap.add_argument("--scan-mode", type=int, default=0, help="A/B: smx_recon_set_scan_mode bits (1 = all-slot scans, 2 = multi-launch blend, 4 = no hot-group filter in pass B, 512 = pass B and the edge kernel fused into one launch)")
     ap.add_argument("--ub", default="", help="TIMING-ONLY upper bounds, comma list of: hoist-pre (every timed frame preprocessed "
                     "before the timed region: same results), no-reg (regulariser left out: WRONG map), front-only (pass A + "
                     "association tiles + blend only: WRONG map).  No parity check, no CPU leg; the line carries 'upper_bound'")
@@ -721,6 +725,9 @@ def run_integrate(args):
     stage_ms_stamps /= reps
     alone_ms = dict(zip(names, [float(x) for x in kernel_ms]))
     alone_ms.update({n: float(np.mean(v)) for n, v in pre_alone.items() if v})
+    if alone_ms.get("reg_accumulate", 0.0) <= 0.0:   # (no edge launch: pass B carries its work and its bytes)
+        st["fused_edges"] = 1
+        st_before["fused_edges"] = 1
 
     host_pass = None
     if do_host > 0:
@@ -843,7 +850,7 @@ def other_configs(args, log):
 
 
 # kernel-slot name -> kernel name in rocprofv3 output
-SLOT_KERNEL = {"cull_segments": "k_cull_segments", "reg_accumulate": "k_reg_accumulate", "reg_step": "k_reg_step", "neighbor_scan": "k_neighbor_scan<true, true>",
+SLOT_KERNEL = {"cull_segments": "k_cull_segments", "reg_accumulate": "k_reg_accumulate", "reg_step": "k_reg_step", "neighbor_scan": "k_neighbor_scan<true, true",
                "scan_visible": "k_scan_visible", "assoc_tiles": "k_assoc_tiles", "blend": "k_blend_tiles",
                "integrate+new_flags": "k_integrate<true>", "update_neighbors+create": "k_update_and_create<true>",}
 
@@ -921,7 +928,9 @@ def roofline_block(st, P, dominant, longest, dom_ms, dom_n, alone_ms, in_frame_m
         if not at or abs(at - st["surfels_size"]) > 0.1 * st["surfels_size"]:
             pmc, why = None, "collected at %s surfel slots, this run has %d" % (at, st["surfels_size"])
     if pmc is not None:
-        k = pmc.get(SLOT_KERNEL.get(dominant, ""), {})
+        # (template instances: the kernel of the slot is the entry whose name begins with the slot's kernel name)
+        pref = SLOT_KERNEL.get(dominant, "\0")
+        k = max((v for n, v in pmc.items() if n != "_meta" and n.startswith(pref)), key=lambda v: v.get("launches", 0), default={})
         traffic = pmc_bytes(k)
         # like for like: the algorithmic bytes of the PMC run's own counts (its window differs from this run's)
         own = pmc.get("_meta", {}).get("distributions_of_the_pmc_run") or {}

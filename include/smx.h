@@ -359,7 +359,10 @@ int smx_recon_debug_count_skipped_segments(smx_recon r, smx_stream s, uint32_t* 
  * per destination segment, bit 6: a sender workgroup addresses 2 destination segments through the bins -- the other far
  * terms take the atomic accumulators (the overflow paths of those bins); bit 7: the blend's other tile size (the
  * library picks 32 x 32 or 40 x 40 pixels by the number of tiles per compute unit; this bit swaps the choice);
- * bit 8: the list kernels run on a grid of four workgroups, so that every workgroup walks many steps. */
+ * bit 8: the list kernels run on a grid of four workgroups, so that every workgroup walks many steps;
+ * bit 9: the regulariser's pass B and its edge kernel as ONE launch (the workgroup of a segment does the segment's edge work
+ * itself, the work list stays in LDS) instead of two (pass B writes the work lists to memory, k_reg_accumulate walks
+ * them: the default -- the fused launch is shorter alone and longer in the frame). */
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode);
 /* TIMING ONLY -- the map is WRONG afterwards: leaves launches of smx_recon_integrate out, for the upper-bound runs of
  * bench.py --ub (what would the frame rate be without this chain?).  bit 0: no regulariser (pass B, edges, step);

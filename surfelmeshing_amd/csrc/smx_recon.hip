@@ -1896,11 +1896,49 @@ k_update_and_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, Crea
 // neighbour's colour word (:1430) and stamp (:2132) are replaced by ONE byte gather from the flag table
 // (L2-resident: 1 B/slot).  The gradient clear (kernels.cu:2099-2113) is gone: the fixed-point
 // accumulators are zero between calls (k_reg_step zeroes what it consumes).
-template <bool kDetach, bool kAccumulate>
-__global__ void __launch_bounds__(kBlockB)
-k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, DevState* st, unsigned long long* ts) {
+struct EdgeArgs {
+  float rf2, weight;
+  long long* grad_acc;
+  float4* reg_rec; size_t rec_own_offset;
+  FarBins fb;
+};
+struct EdgeLds {
+  unsigned long long* lacc;   // [kSegAcc * 2] per target: (gx | gy), (gz | sender classes)
+  uint32_t* hkey; uint32_t* hcnt;   // [kFarHash] far destinations of this workgroup: segment, terms -> base in the bin
+  uint16_t* lrank;            // [kSegAcc] per slot of the segment: its rank among the recent slots, or 0xFFFF
+  uint32_t* rec_wave;         // [kBlockAcc / 64] recent entries per wavefront of the chunk
+};
+constexpr int kSegAcc = 1024;     // slots per accumulation workgroup (16 KB of LDS sums)
+constexpr int kBlockAcc = 256;
+static_assert(kSegAcc == kSegB && kBlockAcc == kBlockB, "the edge work runs on pass B's segments and workgroups (fused, or over its work lists)");
+__device__ __forceinline__ void edge_segment(const Surfels& S, const EdgeArgs& ea, DevState* st, uint32_t base, uint32_t n_act,
+                                             uint32_t ent_first, const uint32_t* later_entries, const EdgeLds& lds, uint32_t tid);
+#ifndef SMX_FUSE_EDGES
+#define SMX_FUSE_EDGES 0   // (default of the run-time switch; smx_recon_set_scan_mode bit 9 turns the fusion ON.  Measured: the fused
+                           // launch is shorter alone -- 58 us against 28 + 36 -- and LONGER in the frame, 90 us (heavy segments first) /
+                           // 72 us (last) against 34 + 42: C2 6150 / 6249 -> 5852 / 5825 frames/s, profiles/r5_ab_notes.md)
+#endif
+#ifndef SMX_FUSED_HEAVY_FIRST
+#define SMX_FUSED_HEAVY_FIRST 1
+#endif
+#ifndef SMX_FUSED_WGS_PER_CU
+#define SMX_FUSED_WGS_PER_CU 4   // (fused pass B: 36 KB of LDS per workgroup)
+#endif
+// kFused (A/B, off by default): the workgroup that finds work for the edge kernel in its segment does that work at once, from
+// the entries it has just ranked (in LDS instead of the global work list) -- one launch and its boundary less on the internal
+// stream, whose five launches a frame spend ~34 of their 154 us between kernels.  It loses in the frame (see SMX_FUSE_EDGES):
+// 36 KB of LDS and 86 VGPRs for EVERY segment's workgroup, the streaming ones included, and the chip shared with the front.
+template <bool kDetach, bool kAccumulate, bool kFused = false>
+__global__ void __launch_bounds__(kBlockB, kFused ? SMX_FUSED_WGS_PER_CU : 1)
+k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, DevState* st, unsigned long long* ts, EdgeArgs ea, uint32_t descending) {
   ts_begin(ts, kTsRegBegin);
-  const uint32_t seg_id = segment_of_block(L.descending);
+  static_assert(!kFused || kAccumulate, "the fused edge work belongs to the accumulating pass");
+  __shared__ unsigned long long e_lacc[kFused ? kSegAcc * 2 : 1];
+  __shared__ uint32_t e_hkey[kFused ? kFarHash : 1], e_hcnt[kFused ? kFarHash : 1];
+  __shared__ uint16_t e_lrank[kFused ? kSegAcc : 2];
+  __shared__ uint32_t e_rec_wave[kBlockAcc / 64];
+  __shared__ uint32_t lent[kFused ? kSegAcc : 1];   // the segment's work-list entries (fused: LDS instead of L.act_list)
+  const uint32_t seg_id = segment_of_block(descending);
   extern __shared__ __align__(16) uint8_t lhot[];   // the hot-group table (n_hot_groups bytes, padded to 16)
   __shared__ uint32_t ltargets[kMaxHotGroups / 32];  // bit g: a link of this segment points into group g (another segment)
   // B1: pure streaming.  Per slot: detach (:1430-1433), which of its neighbours lie inside the regulariser
@@ -2007,11 +2045,16 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, DevState* st, unsign
       uint32_t off = base + block_excl_scan_sparse<kBlockB / 64>(need ? nact : 0u, wave_tot, total_act);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (inw[j]) L.act_list[off++] = act_entry(threadIdx.x * 4 + j, inw[j], false);
+        if (inw[j]) { (kFused ? lent[off - base] : L.act_list[off]) = act_entry(threadIdx.x * 4 + j, inw[j], false); ++off; }
     }
     if (threadIdx.x == 0) {
       L.recent_seg[seg_id] = 0;
-      if (kAccumulate && total_act) emit_segment(L.acc_chunks, seg_id | ((total_act - 1u) << 22));
+      if (kAccumulate && !kFused && total_act) emit_segment(L.acc_chunks, seg_id | ((total_act - 1u) << 22));
+    }
+    if (kFused && total_act) {   // (uniform)
+      __syncthreads();
+      EdgeLds lds; lds.lacc = e_lacc; lds.hkey = e_hkey; lds.hcnt = e_hcnt; lds.lrank = e_lrank; lds.rec_wave = e_rec_wave;
+      edge_segment(S, ea, st, base, total_act, threadIdx.x < total_act ? lent[threadIdx.x] : kNoActEntry, lent, lds, threadIdx.x);
     }
     return;
   }
@@ -2105,7 +2148,10 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, DevState* st, unsign
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     if (recent_bits & (1u << j)) L.recent_list[off++] = i0 + j;
-    if (act_bits & (1u << j)) L.act_list[off_act++] = act_entry(threadIdx.x * 4 + j, (inw4 >> (8 * j)) & 15u, (recent_bits >> j) & 1u);
+    if (act_bits & (1u << j)) {
+      (kFused ? lent[off_act - base] : L.act_list[off_act]) = act_entry(threadIdx.x * 4 + j, (inw4 >> (8 * j)) & 15u, (recent_bits >> j) & 1u);
+      ++off_act;
+    }
   }
   L.seg_targets[(size_t)seg_id * kBlockB + threadIdx.x] = (uint16_t)(ltargets[threadIdx.x >> 1] >> (16 * (threadIdx.x & 1)));
   if (threadIdx.x == 0) {
@@ -2114,8 +2160,13 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, DevState* st, unsign
       const uint32_t k = seg_id % kSubLists;
       L.rec_chunks.desc[(size_t)k * L.rec_chunks.stride + atomicAdd(&L.rec_chunks.count[k * kCountStride], 1u)] = seg_id | ((total - 1u) << 22);
     }
-    if (kAccumulate && total_act) emit_segment(L.acc_chunks, seg_id | ((total_act - 1u) << 22));
+    if (kAccumulate && !kFused && total_act) emit_segment(L.acc_chunks, seg_id | ((total_act - 1u) << 22));
     if (stats && total) atomicAdd(&st->recent_count, total);
+  }
+  if (kFused && total_act) {   // (uniform)
+    __syncthreads();
+    EdgeLds lds; lds.lacc = e_lacc; lds.hkey = e_hkey; lds.hcnt = e_hcnt; lds.lrank = e_lrank; lds.rec_wave = e_rec_wave;
+    edge_segment(S, ea, st, base, total_act, threadIdx.x < total_act ? lent[threadIdx.x] : kNoActEntry, lent, lds, threadIdx.x);
   }
 }
 
@@ -2145,7 +2196,6 @@ __device__ __forceinline__ void far_term_spill(long long* __restrict__ grad_acc,
   atomicAdd(&a[1], pack_pair(qz, 1 << (8 * (neighbor_count - 1))));
   fb.count[(size_t)(target / kSegB) * kCountStride + 1] = 1u;   // (the reader of that segment looks into grad_acc)
 }
-constexpr int kSegAcc = 1024;     // slots per accumulation workgroup (16 KB of LDS sums)
 #ifndef SMX_LIST_WGS_PER_CU
 #define SMX_LIST_WGS_PER_CU 12   // (8 .. 32 measured: profiles/r17_ab_notes.md r26; the chunk lists hold ~3 000 steps at C2, ~10 000 at C3)
 #endif
@@ -2164,43 +2214,18 @@ constexpr int kSegAcc = 1024;     // slots per accumulation workgroup (16 KB of 
 #ifndef SMX_ACC_WGS_PER_CU
 #define SMX_ACC_WGS_PER_CU 5   // (256-lane workgroups, 26 KB of LDS each; <= 96 VGPRs without scratch. 4 / 5 / 6 measured: profiles/r5_ab_notes.md)
 #endif
-constexpr int kBlockAcc = 256;
-static_assert(kSegAcc == kSegB, "the edge kernel's segments are pass B's: it walks pass B's work lists");
-__global__ void __launch_bounds__(kBlockAcc, SMX_ACC_WGS_PER_CU)   // (second argument: wavefronts per SIMD = workgroups per CU here)
-k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ grad_acc,
-                 float4* __restrict__ reg_rec, size_t rec_own_offset, FarBins fb,
-                 const uint32_t* __restrict__ act_list, Chunks acc, DevState* st, unsigned long long* ts) {
-  ts_begin(ts, kTsAccBegin);
-  __shared__ unsigned long long lacc[kSegAcc * 2];  // per target: (gx | gy), (gz | sender classes)
-  __shared__ uint32_t hkey[kFarHash], hcnt[kFarHash];   // far destinations of this workgroup: segment, terms -> base in the bin
-  __shared__ uint16_t lrank[kSegAcc];                // per slot of the segment: its rank among the recent slots, or 0xFFFF
-  __shared__ uint32_t rec_wave[kBlockAcc / 64];      // recent entries per wavefront of the chunk
-  // A walk over the segments pass B listed (acc_chunks: a recent slot or an edge into the window), on a grid the size
-  // of the chip.  Round 5: a step no longer visits the segment's 1024 slots (512 lanes x 2, four fifths of them idle in
-  // the typical listed segment) but the ENTRIES of the work list pass B wrote for it -- the slots that have work, dense,
-  // one per lane, 256 at a time -- so the kernel needs half the registers per lane and three times as many steps are in
-  // flight per compute unit; the mask and flag bytes (2 KB per step) shrink to 4 bytes per entry.  The next step's
-  // descriptor and the first entries of ITS list travel while this step is worked on.
-  uint32_t desc, cntv;
-  const uint32_t n_steps = walk_begin<true>(acc, 0u, blockIdx.x, desc, cntv);
-  // (an unused descriptor is 0 or an old one: any segment of the map, any entry count -- whatever is read is ignored)
-  uint32_t ent_next = (blockIdx.x < n_steps && threadIdx.x <= (desc >> 22))
-                          ? act_list[(size_t)(desc & 0x003FFFFFu) * kSegAcc + threadIdx.x] : kNoActEntry;
-  bool lds_used = false;
-#pragma unroll 1
-  for (uint32_t w = blockIdx.x; w < n_steps; w += gridDim.x) {
-  const uint32_t cur = desc;
-  desc = walk_next<true>(acc, w + gridDim.x, n_steps);
-  // (per step: a lane number the optimiser cannot see through keeps the per-lane addresses out of loop-carried registers)
-  uint32_t tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));
-  const uint32_t ent_first = ent_next;
-  ent_next = (w + gridDim.x < n_steps && tid <= (desc >> 22)) ? act_list[(size_t)(desc & 0x003FFFFFu) * kSegAcc + tid] : kNoActEntry;
-  if (!walk_step_valid(w, cntv)) continue;
-  const uint32_t seg_id = cur & 0x003FFFFFu, n_act = (cur >> 22) + 1u;
-  const uint32_t base = seg_id * kSegAcc;
-  if (lds_used) __syncthreads();   // (the previous step's readers of the tables are done)
-  lds_used = true;
+// The edge work of ONE segment (k_reg_accumulate's step; also the tail of the fused pass B): n_act entries, the lane's
+// entry of the first chunk in ent_first, the entries of later chunks in later_entries[e] (global work list or LDS).
+__device__ __forceinline__ void edge_segment(const Surfels& S, const EdgeArgs& ea, DevState* st, uint32_t base, uint32_t n_act,
+                                             uint32_t ent_first, const uint32_t* later_entries, const EdgeLds& lds, uint32_t tid) {
+  unsigned long long* const lacc = lds.lacc;
+  uint32_t* const hkey = lds.hkey; uint32_t* const hcnt = lds.hcnt;
+  uint16_t* const lrank = lds.lrank; uint32_t* const rec_wave = lds.rec_wave;
+  const float rf2 = ea.rf2, weight = ea.weight;
+  long long* const grad_acc = ea.grad_acc;
+  float4* const reg_rec = ea.reg_rec;
+  const size_t rec_own_offset = ea.rec_own_offset;
+  const FarBins& fb = ea.fb;
 #pragma unroll
   for (int k = 0; k < kSegAcc * 2 / kBlockAcc; ++k) lacc[k * kBlockAcc + tid] = 0;
 #pragma unroll
@@ -2218,7 +2243,7 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
   for (uint32_t c0 = 0; c0 < n_act; c0 += kBlockAcc) {
   const bool more = c0 + kBlockAcc < n_act;   // (uniform)
   uint32_t ent_following = kNoActEntry;
-  if (more && c0 + kBlockAcc + tid < n_act) ent_following = act_list[(size_t)base + c0 + kBlockAcc + tid];
+  if (more && c0 + kBlockAcc + tid < n_act) ent_following = later_entries[c0 + kBlockAcc + tid];
   if (c0) __syncthreads();   // (the previous chunk's far stores have read the table)
 #pragma unroll
   for (int k = 0; k < kFarHash / kBlockAcc; ++k) { hkey[k * kBlockAcc + tid] = kInvalid; hcnt[k * kBlockAcc + tid] = 0; }
@@ -2359,6 +2384,48 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
     if (rank == 0xFFFFu) continue;
     const unsigned long long v0 = lacc[rel], v1 = lacc[kSegAcc + rel];
     *reinterpret_cast<ulonglong2*>(&reg_rec[(size_t)(base + rank)]) = make_ulonglong2(v0, v1);
+  }
+}
+
+__global__ void __launch_bounds__(kBlockAcc, SMX_ACC_WGS_PER_CU)   // (second argument: wavefronts per SIMD = workgroups per CU here)
+k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ grad_acc,
+                 float4* __restrict__ reg_rec, size_t rec_own_offset, FarBins fb,
+                 const uint32_t* __restrict__ act_list, Chunks acc, DevState* st, unsigned long long* ts) {
+  ts_begin(ts, kTsAccBegin);
+  __shared__ unsigned long long lacc[kSegAcc * 2];  // per target: (gx | gy), (gz | sender classes)
+  __shared__ uint32_t hkey[kFarHash], hcnt[kFarHash];   // far destinations of this workgroup: segment, terms -> base in the bin
+  __shared__ uint16_t lrank[kSegAcc];                // per slot of the segment: its rank among the recent slots, or 0xFFFF
+  __shared__ uint32_t rec_wave[kBlockAcc / 64];      // recent entries per wavefront of the chunk
+  // A walk over the segments pass B listed (acc_chunks: a recent slot or an edge into the window), on a grid the size
+  // of the chip.  Round 5: a step no longer visits the segment's 1024 slots (512 lanes x 2, four fifths of them idle in
+  // the typical listed segment) but the ENTRIES of the work list pass B wrote for it -- the slots that have work, dense,
+  // one per lane, 256 at a time -- so the kernel needs half the registers per lane and three times as many steps are in
+  // flight per compute unit; the mask and flag bytes (2 KB per step) shrink to 4 bytes per entry.  The next step's
+  // descriptor and the first entries of ITS list travel while this step is worked on.
+  uint32_t desc, cntv;
+  const uint32_t n_steps = walk_begin<true>(acc, 0u, blockIdx.x, desc, cntv);
+  // (an unused descriptor is 0 or an old one: any segment of the map, any entry count -- whatever is read is ignored)
+  uint32_t ent_next = (blockIdx.x < n_steps && threadIdx.x <= (desc >> 22))
+                          ? act_list[(size_t)(desc & 0x003FFFFFu) * kSegAcc + threadIdx.x] : kNoActEntry;
+  bool lds_used = false;
+#pragma unroll 1
+  for (uint32_t w = blockIdx.x; w < n_steps; w += gridDim.x) {
+  const uint32_t cur = desc;
+  desc = walk_next<true>(acc, w + gridDim.x, n_steps);
+  // (per step: a lane number the optimiser cannot see through keeps the per-lane addresses out of loop-carried registers)
+  uint32_t tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const uint32_t ent_first = ent_next;
+  ent_next = (w + gridDim.x < n_steps && tid <= (desc >> 22)) ? act_list[(size_t)(desc & 0x003FFFFFu) * kSegAcc + tid] : kNoActEntry;
+  if (!walk_step_valid(w, cntv)) continue;
+  const uint32_t seg_id = cur & 0x003FFFFFu, n_act = (cur >> 22) + 1u;
+  const uint32_t base = seg_id * kSegAcc;
+  if (lds_used) __syncthreads();   // (the previous step's readers of the tables are done)
+  lds_used = true;
+  {
+    EdgeArgs ea; ea.rf2 = rf2; ea.weight = weight; ea.grad_acc = grad_acc; ea.reg_rec = reg_rec; ea.rec_own_offset = rec_own_offset; ea.fb = fb;
+    EdgeLds lds; lds.lacc = lacc; lds.hkey = hkey; lds.hcnt = hcnt; lds.lrank = lrank; lds.rec_wave = rec_wave;
+    edge_segment(S, ea, st, base, n_act, ent_first, act_list + (size_t)base, lds, tid);
   }
   }
 }
@@ -2787,6 +2854,7 @@ struct smx_recon_s {
   int sc_cur;
   int hot_holdoff;          // > 0: pass B does not use the hot-group table (decremented per Integrate call)
   int hot_filter_enabled;   // A/B switch (smx_recon_set_scan_mode bit 2 clears it)
+  int fuse_edges;           // pass B does the edge work of its segment itself (one launch less); scan mode bit 9 sets it
   uint16_t* blended_depth;  // [H][W] output of the fused blend (stored into the caller's depth by k_new_flags_scan)
   BlendBufs bb;
   uint8_t* new_flags;
@@ -2912,15 +2980,21 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
   {
     SlotTimer t(r, st, kSlotNeighborScan, true);
     if (stats || zero_chunks) hipLaunchKernelGGL(k_reset_recent, dim3(1), dim3(kSubLists), 0, st, r->st, stats, zero_chunks ? r->L.rec_chunks.count : nullptr);
-    if (copy_only) {
-      if (detach) hipExtLaunchKernelGGL((k_neighbor_scan<true, false>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->st, ts_first);
-      else hipExtLaunchKernelGGL((k_neighbor_scan<false, false>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->st, ts_first);
-    } else {
-      if (detach) hipExtLaunchKernelGGL((k_neighbor_scan<true, true>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->st, ts_first);
-      else hipExtLaunchKernelGGL((k_neighbor_scan<false, true>), g, bB, (uint32_t)hot_lds, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->st, ts_first);
-    }
+    EdgeArgs ea;
+    ea.rf2 = rf2; ea.weight = weight; ea.grad_acc = r->grad_acc; ea.reg_rec = r->reg_rec;
+    ea.rec_own_offset = (size_t)r->S.pitch + kSegAcc; ea.fb = r->fb;
+    const uint32_t lds_b = (uint32_t)hot_lds;
+    const bool fused = !copy_only && r->fuse_edges != 0;
+    // (fused: the heavy segments carry their edge work, the longest chains of the launch -- they go FIRST, the thousands of
+    // workgroups that only stream or skip fill in behind them; not fused: last, see segment_of_block)
+    const uint32_t dir = fused && SMX_FUSED_HEAVY_FIRST ? (r->L.descending ? 0u : 1u) : r->L.descending;
+#define SMX_LAUNCH_PASS_B(D, A, F) hipExtLaunchKernelGGL((k_neighbor_scan<D, A, F>), g, bB, lds_b, st, t.start(), t.stop(), 0, r->S, stats, use_hot, r->L, r->st, ts_first, ea, dir)
+    if (copy_only) { if (detach) SMX_LAUNCH_PASS_B(true, false, false); else SMX_LAUNCH_PASS_B(false, false, false); }
+    else if (fused) { if (detach) SMX_LAUNCH_PASS_B(true, true, true); else SMX_LAUNCH_PASS_B(false, true, true); }
+    else { if (detach) SMX_LAUNCH_PASS_B(true, true, false); else SMX_LAUNCH_PASS_B(false, true, false); }
+#undef SMX_LAUNCH_PASS_B
   }
-  if (!copy_only) {
+  if (!copy_only && !r->fuse_edges) {
     SlotTimer t(r, st, kSlotRegAccumulate, true);
     hipExtLaunchKernelGGL(k_reg_accumulate, dim3(r->grid_acc), dim3(kBlockAcc), 0, st, t.start(), t.stop(), 0, r->S, rf2, weight, r->grad_acc, r->reg_rec, (size_t)r->S.pitch + kSegAcc,
                        r->fb, r->L.act_list, r->L.acc_chunks, r->st, ts_first);
@@ -3036,6 +3110,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->L.seg_targets, (size_t)r->nsegB * kBlockB, true));   // (written by the unfiltered passes of the hold-off calls before anyone reads it)
   r->L.epoch = 128;   // (far from the zeros)
   r->hot_filter_enabled = 1;
+  r->fuse_edges = SMX_FUSE_EDGES;
   r->hot_holdoff = 3;
   SMX_TRY(dev_alloc(&r->merge_flag, r->S.pitch, true));
   SMX_TRY(dev_alloc(&r->L.act_list, (size_t)r->nsegB * kSegB, true));
@@ -3206,7 +3281,7 @@ int smx_recon_set_overlap(smx_recon r, int32_t enabled) {
 }
 
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
-  SMX_CHECK_ARG(r != nullptr && mode >= 0 && mode <= 511);
+  SMX_CHECK_ARG(r != nullptr && mode >= 0 && mode <= 1023);
   SMX_ON_DEVICE(r->device);
   r->grid_list = ((mode >> 8) & 1) ? 4 : r->grid_list_full;   // four workgroups walk every list: many steps each
   r->scan_mode = mode & 1;
@@ -3216,6 +3291,7 @@ int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
   r->no_lds_tables = (mode >> 4) & 1;                     // pass A reserves bin space per pair (the path of a pair that finds no entry in the workgroup's table)
   r->fb.cap = ((mode >> 5) & 1) ? 4u : kFarBinCap;        // 4 records per far-term bin: most far terms spill to grad_acc
   r->fb.hash_mask = ((mode >> 6) & 1) ? 1u : (uint32_t)kFarHash - 1u;   // 2 destinations per sender workgroup: the rest spills
+  r->fuse_edges = ((mode >> 9) & 1) ? 1 : SMX_FUSE_EDGES;   // one launch: the segment's workgroup of pass B does the segment's edge work itself
   r->blend_other_tile = (mode >> 7) & 1;                  // the blend's other tile size (40 x 40 where it would take 32 x 32 and vice versa)
   return SMX_OK;
 }

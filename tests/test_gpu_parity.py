@@ -235,7 +235,7 @@ def test_cuda_buffer_roundtrips(smx):
 
 
 # ---- full pipeline --------------------------------------------------------------------------
-@pytest.mark.parametrize("scan_mode", [0, 1, 2, 3, 4, 8, 16, 24, 32, 64, 96, 128, 256, 256 + 64, 256 + 96])   # (256: the list kernels on a grid of four workgroups, every one of them walks many steps -- with 64 / 96 the regulariser step then meets segments whose far terms ALL spilled to the atomic accumulators, walk step after walk step; 4: pass B without its hot-group filter; 8: association bins of 16 pairs, the rest through the overflow list; 16: bin space reserved pair by pair; 32: far-term bins of 4 records, 64: two destinations per sender workgroup -- the rest of the regulariser's far terms through the atomic accumulators; 128: the blend's other tile size, 40 x 40 pixels here)
+@pytest.mark.parametrize("scan_mode", [0, 1, 2, 3, 4, 8, 16, 24, 32, 64, 96, 128, 256, 256 + 64, 256 + 96, 512, 512 + 96, 512 + 256 + 96])   # (512: pass B and the edge kernel fused into one launch -- the work list in LDS -- alone and with the spill paths; 256: the list kernels on a grid of four workgroups, every one of them walks many steps -- with 64 / 96 the regulariser step then meets segments whose far terms ALL spilled to the atomic accumulators, walk step after walk step; 4: pass B without its hot-group filter; 8: association bins of 16 pairs, the rest through the overflow list; 16: bin space reserved pair by pair; 32: far-term bins of 4 records, 64: two destinations per sender workgroup -- the rest of the regulariser's far terms through the atomic accumulators; 128: the blend's other tile size, 40 x 40 pixels here)
 def test_stream_parity_every_frame(smx, scan_mode):
     s = small_stream(obstacle_until=10)               # vanishing obstacle -> conflicts and replacements
     po, pg = _pipes(smx, s, 60000, scan_mode=scan_mode)
