@@ -138,13 +138,14 @@ struct FrameCtx {
 // Records live in a ring in device memory (kTsRing calls); the first kernel of a call (k_cull_segments) resets the
 // call's record and writes its sequence number.  For the non-waiting read the tile kernel's first workgroup copies the
 // record of the call before the previous one -- complete by stream order when that kernel runs -- into page-locked host
-// memory (sequence number first and last: a reader that sees both equal has a whole record).
+// memory (with a check word over the record: a reader that meets a record in the middle of being rewritten drops it).
 enum : int { kTsSeq = 0, kTsCullBegin, kTsTilesEnd, kTsBlendBegin, kTsBlendEnd, kTsIntBegin, kTsIntEnd, kTsUpdBegin, kTsUpdEnd,
              kTsRegBegin, kTsRegEnd,
              kTsScanBegin, kTsTilesBegin, kTsAccBegin, kTsStepBegin,   // (not part of GetTimings: smx_recon_debug_stamp_ring)
              kTsSeqTail = 15, kTsWords = 16 };
 constexpr int kTsRing = 8;
 constexpr uint32_t kTsTail = 32;
+constexpr unsigned long long kTsCheckSalt = 0x5EED5EED5EED5EEDull;
 __device__ __forceinline__ void ts_begin(unsigned long long* ts, int k) {
   if (ts && blockIdx.x == 0 && threadIdx.x == 0) ts[k] = wall_clock64();
 }
@@ -939,7 +940,7 @@ k_assoc_tiles(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<
   ts_begin(c.ts, kTsTilesBegin);
   // side job of the first workgroup's second wavefront: the stage-stamp record of the call before the previous one (complete:
   // that call's regulariser preceded the previous call's integration, whose end this stream has waited for) goes to
-  // page-locked host memory for the non-waiting GetTimings -- sequence number first and last around the data
+  // page-locked host memory for the non-waiting GetTimings
   if (blockIdx.x == 0 && threadIdx.x == 64 && ts_host && ts_seq > 2) {
     const unsigned long long q = ts_seq - 2;
     const unsigned long long* src = ts_ring + (size_t)(q % kTsRing) * kTsWords;
@@ -948,12 +949,15 @@ k_assoc_tiles(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<
 #pragma unroll
     for (int k = 0; k < kTsWords; ++k) w[k] = src[k];
     if (w[kTsSeq] == q) {
+      // (no fences: a system-scope fence writes back the L2 of the XCD under every kernel that runs on it.  The record
+      // carries a check word instead -- sequence number x all data words -- and a reader that meets a torn record drops it.)
+      unsigned long long check = q ^ kTsCheckSalt;
+#pragma unroll
+      for (int k = 1; k < kTsSeqTail; ++k) check ^= w[k];
       dst[kTsSeq] = q;
-      __threadfence_system();
 #pragma unroll
       for (int k = 1; k < kTsSeqTail; ++k) dst[k] = w[k];
-      __threadfence_system();
-      dst[kTsSeqTail] = q;
+      dst[kTsSeqTail] = check;
     }
   }
   // side job of the first workgroup: the direction in which the launches that follow walk the segments (segment_of_block)
@@ -3863,18 +3867,15 @@ int smx_recon_get_timings_nowait(smx_recon r, float out_ms[7], uint64_t* call_nu
   if (call_number) *call_number = 0;
   if (!(r->timing_enabled & 4) || r->ts_seq == 0 || !r->ts_mapped) return SMX_OK;
   // No device operation at all: the records the tile kernel has copied into page-locked memory (every call copies the
-  // record of the call before the previous one), newest whole one.  Reader: tail, data, head -- the writer goes head,
-  // data, tail.
+  // record of the call before the previous one), newest whole one.
   unsigned long long best = 0, rec[kTsWords];
   for (int k = 0; k < kTsRing; ++k) {
     volatile unsigned long long* t = r->ts_mapped + (size_t)k * kTsWords;
     unsigned long long w[kTsWords];
-    w[kTsSeqTail] = t[kTsSeqTail];
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    for (int j = 1; j < kTsSeqTail; ++j) w[j] = t[j];
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    w[kTsSeq] = t[kTsSeq];
-    if (w[kTsSeq] == 0 || w[kTsSeq] != w[kTsSeqTail] || w[kTsSeq] <= best) continue;
+    unsigned long long check = kTsCheckSalt;
+    for (int j = 0; j < kTsWords; ++j) w[j] = t[j];
+    for (int j = 0; j < kTsSeqTail; ++j) check ^= w[j];
+    if (w[kTsSeq] == 0 || check != w[kTsSeqTail] || w[kTsSeq] <= best) continue;   // (empty, or torn: being rewritten)
     best = w[kTsSeq];
     memcpy(rec, w, sizeof(rec));
   }
