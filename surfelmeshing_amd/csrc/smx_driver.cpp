@@ -484,8 +484,7 @@ int smx_driver_run(smx_driver d, smx_stream s, const smx_driver_step* steps, int
   if (d->prepared_next < d->prepared.size()) {
     for (int i = 0; i < n; ++i) {
       if (d->prepared_next >= d->prepared.size()) return fail("fewer prepared work sets than steps");
-      WorkSet* ws = d->prepared[d->prepared_next++].get();
-      ++d->frame_counter;
+      WorkSet* ws = d->prepared[d->prepared_next++].get();   // (smx_driver_debug_prepare counted the step when it preprocessed it)
       // (the same bookkeeping as run_one: "inputs consumed" marked by Integrate itself, the set counts as in flight)
       SMX_SHIM_CHECK(smx_recon_integrate_hooks(d->reconstruction.handle(), ws->integrated, nullptr));
       const int rc = integrate_frame(d, s, steps[i], ws);

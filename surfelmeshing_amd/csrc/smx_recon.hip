@@ -3386,6 +3386,11 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   r->sc_cur ^= 1;
   r->L.vis_chunks.count = r->vis_count_set[r->sc_cur];
   r->tb.ovf_count = r->ovf_count_set[r->sc_cur];
+#if SMX_READY_WAIT_EARLY == 2
+  // (A/B: the wait for the input images at the very front of the call -- in a running pipeline they were ready long ago --
+  // so that ONE barrier packet stands between the previous call's update + create and this call's pass A)
+  if (hook_ready) SMX_HIP(hipStreamWaitEvent(sF, hook_ready, 0));
+#endif
   { // the cull step: needs the pose and what the previous pass A left, nothing the previous call's second half writes --
     // so it goes in FRONT of this stream's wait for that half wherever the wait could be deferred (below)
     SlotTimer t(r, sF, kSlotCull);
@@ -3393,7 +3398,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     r->sw_dirty = true;
     hipLaunchKernelGGL(k_cull_segments, dim3((unsigned)div_up(r->nseg, kBlock)), b, 0, sF, c, r->L, r->sw, r->st, (uint32_t)r->nseg, (uint32_t)P, r->ts_seq); }
   if (r->pending_mark) { SMX_HIP(hipStreamWaitEvent(sF, r->pending_mark, 0)); r->pending_mark = nullptr; }
-#if SMX_READY_WAIT_EARLY
+#if SMX_READY_WAIT_EARLY == 1
   // (the wait for the input images next to the wait for the map: pass A and the tile kernel then follow each other without
   // a barrier packet between them -- 38 -> 31 us from pass A's first workgroup to the tile kernel's at C2)
   if (hook_ready) SMX_HIP(hipStreamWaitEvent(sF, hook_ready, 0));
