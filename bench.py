@@ -31,6 +31,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# One hardware queue per busy HIP stream (the runtime's default of 4 lets two of the frame loop's streams share one in about
+# one run out of five: 5 670 instead of 6 380 frames/s, profiles/r5_ab_notes.md).  Read when the HIP runtime initialises, so it
+# is set before torch is imported; libsmx.so raises the same default when it is loaded.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 (vector)

@@ -8,6 +8,9 @@ torch has loaded, so both share one runtime per process.
 import ctypes as C
 import os
 
+# (see smx_buffer.hip smx_runtime_defaults: one hardware queue per busy stream, decided when the HIP runtime initialises --
+# which may be before libsmx.so is loaded if torch touched the GPU first, so the default is raised as early as this import)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (SMX_LIB_PATH: A/B measurements of two builds in one session; the product loads the in-tree library)
 SO_PATH = os.environ.get("SMX_LIB_PATH") or os.path.join(_HERE, "libsmx.so")

@@ -19,6 +19,16 @@ void set_error(const char* fmt, ...) {
 
 }  // namespace smx
 
+// The frame loop keeps three to five HIP streams busy at once (caller's stream, internal stream, one or two preprocessing
+// queues, the stamp copies), at three priorities.  The HIP runtime maps streams onto at most GPU_MAX_HW_QUEUES hardware
+// queues (default 4); when two BUSY streams land on one queue their packets serialise, and the frame falls into a slower
+// mode for the rest of the process -- 3 of 14 runs at C2, 5 670 instead of 6 380 frames/s (period 165 instead of 150 us: the
+// internal stream waits 20 - 35 us for the front), none of 14 with 8 queues (profiles/r5_ab_notes.md).  The variable is read
+// when the runtime initialises, i.e. at the first HIP call of the process: the default is raised here, when the library is
+// loaded (never overriding a value the user has set); a process that has called HIP before it loads libsmx sets the
+// variable itself.
+__attribute__((constructor)) static void smx_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite*/ 0); }
+
 struct smx_buffer_s {
   smx_buffer_desc desc;
   int32_t elem_bytes;
