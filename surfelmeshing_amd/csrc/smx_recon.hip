@@ -2213,7 +2213,9 @@ __device__ __forceinline__ void far_term_spill(long long* __restrict__ grad_acc,
 #define SMX_REG_PRIORITY_HIGH 1
 #endif
 #ifndef SMX_READY_WAIT_EARLY
-#define SMX_READY_WAIT_EARLY 1   // (1: +0.5 % at C2, 4 of 4 pairs, profiles/r5_ab_notes.md; 0: the wait between pass A and the tile kernel)
+#define SMX_READY_WAIT_EARLY 2   // (where the call waits for its input images: 0 = between pass A and the tile kernel (rounds 3-4), 1 = next
+                                 // to the wait for the previous map (+0.5 %), 2 = at the very front of the call, in front of the cull step
+                                 // (+0.9 % on top: ONE barrier packet between the previous update + create and pass A); profiles/r5_ab_notes.md)
 #endif
 #ifndef SMX_ACC_WGS_PER_CU
 #define SMX_ACC_WGS_PER_CU 5   // (256-lane workgroups, 26 KB of LDS each; <= 96 VGPRs without scratch. 4 / 5 / 6 measured: profiles/r5_ab_notes.md)
@@ -3387,8 +3389,9 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   r->L.vis_chunks.count = r->vis_count_set[r->sc_cur];
   r->tb.ovf_count = r->ovf_count_set[r->sc_cur];
 #if SMX_READY_WAIT_EARLY == 2
-  // (A/B: the wait for the input images at the very front of the call -- in a running pipeline they were ready long ago --
-  // so that ONE barrier packet stands between the previous call's update + create and this call's pass A)
+  // (the wait for the input images at the very front of the call -- in a running pipeline they were ready long ago --
+  // so that ONE barrier packet stands between the previous call's update + create and this call's pass A: 12.5 -> 8 us
+  // from update's end to pass A's begin)
   if (hook_ready) SMX_HIP(hipStreamWaitEvent(sF, hook_ready, 0));
 #endif
   { // the cull step: needs the pose and what the previous pass A left, nothing the previous call's second half writes --
