@@ -69,3 +69,21 @@ def test_headers_are_plain_c_and_pod_sizes_match(tmp_path):
     assert sizes == [ctypes.sizeof(BufferDesc), ctypes.sizeof(IntegrateParams), ctypes.sizeof(SurfelBuffersCPU),
                      ctypes.sizeof(ReconStats), ctypes.sizeof(DriverConfig), ctypes.sizeof(DriverStep),
                      ctypes.sizeof(DriverHostFrame), ctypes.sizeof(SurfelDeltaCPU)]
+
+
+def test_library_raises_the_hardware_queue_default_without_overriding_the_user():
+    """libsmx.so raises GPU_MAX_HW_QUEUES to 8 when it is loaded (smx_buffer.hip: smx_runtime_defaults -- two busy HIP streams on
+    one hardware queue make the frame loop a tenth slower) and never overrides a value the user has set.  Checked in fresh
+    processes at the C level (os.environ is a snapshot)."""
+    import subprocess
+    import sys
+    from surfelmeshing_amd import _lib
+    code = ("import ctypes, os, sys\n"
+            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
+            "ctypes.CDLL(sys.argv[1])\n"
+            "print(libc.getenv(b'GPU_MAX_HW_QUEUES').decode())\n")
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    r = subprocess.run([sys.executable, "-c", code, _lib.SO_PATH], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout.strip() == "8", (r.stdout, r.stderr[-500:])
+    r = subprocess.run([sys.executable, "-c", code, _lib.SO_PATH], capture_output=True, text=True, env=dict(env, GPU_MAX_HW_QUEUES="2"))
+    assert r.returncode == 0 and r.stdout.strip() == "2", (r.stdout, r.stderr[-500:])
