@@ -448,6 +448,8 @@ def main():
     ap.add_argument("--points", type=int, default=50_000_000, help="C5: surfel positions in the index")
     ap.add_argument("--nn-mode", type=int, default=2, help="C5 A/B: smx_nn_set_query_mode (2 = default)")
     ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the CPU baseline sample (0 = skip; C3 default 4)")
+    ap.add_argument("--copy-engine-uploads", action="store_true", help="A/B of the PCIe-inclusive pass: the frames are copied by the copy "
+                    "engine in front of their step's preprocessing, in the same queue (rounds 1-4), instead of by kernels on a staging queue")
     ap.add_argument("--host-frames", type=int, default=100,
                     help="frames of the extra pass whose inputs arrive from page-locked host memory (0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the full-size GPU-vs-oracle check")
@@ -736,7 +738,9 @@ def run_integrate(args):
     host_pass = None
     if do_host > 0:
         rec.set_overlap(not args.no_overlap)
+        wl.pipe.set_staged_uploads(not args.copy_engine_uploads)
         host_pass = host_frames_pass(wl, plan, host_start, do_host, api, torch)
+        host_pass["uploads"] = "copy engine, in the preprocessing queue" if args.copy_engine_uploads else "copy kernels on a staging queue"
         rec.set_overlap(False)
     timing_cost = None
     if do_timing > 0:

@@ -99,6 +99,13 @@ int smx_buffer_destroy(smx_buffer b);
 int smx_buffer_get_desc(smx_buffer b, smx_buffer_desc* out);
 /* UploadAsync / UploadPitchedAsync (src_pitch = 0: dense rows of width*elem_bytes) */
 int smx_buffer_upload(smx_buffer b, smx_stream s, const void* src, size_t src_pitch);
+/* The same copy done by a KERNEL that reads the page-locked source over the bus (src must come from smx_host_alloc /
+ * hipHostMalloc; otherwise SMX_ERR_INVALID_ARGUMENT) -- an addition for callers that stage uploads on a stream of their own:
+ * a kernel's stores reach later kernels on other streams through the ordinary event ordering, whereas a copy-engine write
+ * followed by a cross-stream wait that the runtime finds already satisfied is dropped together with the cache invalidation
+ * the consumer needs (measured: stale reads now and then).  Few workgroups (the copy is bound by the bus, not the chip).
+ * done: optional completion event of the launch (no packet of its own on the stream). */
+int smx_buffer_upload_by_kernel(smx_buffer b, smx_stream s, const void* src_pagelocked, size_t src_pitch, smx_event done);
 /* DownloadAsync / DownloadPitchedAsync */
 int smx_buffer_download(smx_buffer b, smx_stream s, void* dst, size_t dst_pitch);
 /* UploadPartAsync / DownloadPartAsync: byte range [start, start+length) of the allocation */

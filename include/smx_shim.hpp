@@ -159,6 +159,10 @@ class CUDABuffer {
   ~CUDABuffer() { SMX_SHIM_CHECK(smx_buffer_destroy(handle_)); }
 
   void UploadAsync(cudaStream_t stream, const T* data) { SMX_SHIM_CHECK(smx_buffer_upload(handle_, stream, data, 0)); }
+  // (an addition: the copy as a kernel that reads page-locked memory over the bus; false if `data` is not page-locked)
+  bool UploadByKernelAsync(cudaStream_t stream, const T* data, smx_event done = nullptr) {
+    return smx_buffer_upload_by_kernel(handle_, stream, data, 0, done) == SMX_OK;
+  }
   void UploadPitchedAsync(cudaStream_t stream, size_t pitch, const T* data) { SMX_SHIM_CHECK(smx_buffer_upload(handle_, stream, data, pitch)); }
   void UploadPartAsync(size_t start, size_t length, cudaStream_t stream, const T* data) { SMX_SHIM_CHECK(smx_buffer_upload_part(handle_, stream, start, length, data)); }
   void DownloadAsync(cudaStream_t stream, T* data) const { SMX_SHIM_CHECK(smx_buffer_download(handle_, stream, data, 0)); }

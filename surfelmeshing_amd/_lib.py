@@ -82,7 +82,7 @@ EXPORTS = [
     "smx_last_error", "smx_device_count", "smx_set_device", "smx_device_name",
     "smx_stream_create", "smx_stream_create_with_priority", "smx_host_alloc", "smx_host_free", "smx_stream_destroy", "smx_stream_synchronize", "smx_debug_marker",
     "smx_event_create", "smx_event_create_timed", "smx_event_elapsed_ms", "smx_event_destroy", "smx_event_record", "smx_stream_wait_event",
-    "smx_buffer_create", "smx_buffer_destroy", "smx_buffer_get_desc", "smx_buffer_upload", "smx_buffer_download",
+    "smx_buffer_create", "smx_buffer_destroy", "smx_buffer_get_desc", "smx_buffer_upload", "smx_buffer_upload_by_kernel", "smx_buffer_download",
     "smx_buffer_upload_part", "smx_buffer_download_part", "smx_buffer_clear", "smx_buffer_set_to",
     "smx_bilateral_filtering_and_depth_cutoff", "smx_outlier_depth_map_fusion", "smx_bilateral_outlier_fusion", "smx_erode_depth_map",
     "smx_copy_without_border", "smx_median_filter_and_densify_depth_map", "smx_downscale_using_median_while_excluding", "smx_color_image_pyramid", "smx_compute_normals_and_drop_bad_pixels",

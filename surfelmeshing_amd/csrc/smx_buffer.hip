@@ -5,6 +5,7 @@
 
 #include <stdlib.h>
 #include "smx_common.hpp"
+#include <hip/hip_ext.h>
 
 namespace smx {
 
@@ -23,7 +24,8 @@ void set_error(const char* fmt, ...) {
 // queues, the stamp copies), at three priorities.  The HIP runtime maps streams onto at most GPU_MAX_HW_QUEUES hardware
 // queues (default 4); when two BUSY streams land on one queue their packets serialise, and the frame falls into a slower
 // mode for the rest of the process -- 3 of 14 runs at C2, 5 670 instead of 6 380 frames/s (period 165 instead of 150 us: the
-// internal stream waits 20 - 35 us for the front), none of 14 with 8 queues (profiles/r5_ab_notes.md).  The variable is read
+// internal stream waits 20 - 35 us for the front), 4 of 128 with 8 queues (profiles/r5_ab_notes.md: the rate also rises with
+// every stream the process creates, busy or not -- which is why the library creates none it can do without).  The variable is read
 // when the runtime initialises, i.e. at the first HIP call of the process: the default is raised here, when the library is
 // loaded (never overriding a value the user has set); a process that has called HIP before it loads libsmx sets the
 // variable itself.
@@ -206,6 +208,44 @@ int smx_buffer_upload(smx_buffer b, smx_stream s, const void* src, size_t src_pi
   if (src_pitch == 0) src_pitch = row_bytes;
   SMX_HIP(hipMemcpy2DAsync(b->desc.address, b->desc.pitch, src, src_pitch, row_bytes, b->desc.height,
                            hipMemcpyHostToDevice, (hipStream_t)s));
+  return SMX_OK;
+}
+
+// (rows of row_bytes bytes: 16 bytes per lane where source, destination and both pitches allow, single bytes otherwise)
+__global__ void __launch_bounds__(256) k_copy_rows(char* __restrict__ dst, size_t dst_pitch, const char* __restrict__ src, size_t src_pitch,
+                                                   size_t row_bytes, int height, int wide) {
+  if (wide) {
+    const size_t per_row = row_bytes / 16, total = per_row * (size_t)height;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (size_t)gridDim.x * blockDim.x) {
+      const size_t y = k / per_row, x = k - y * per_row;
+      *reinterpret_cast<uint4*>(dst + y * dst_pitch + 16 * x) = *reinterpret_cast<const uint4*>(src + y * src_pitch + 16 * x);
+    }
+  } else {
+    const size_t total = row_bytes * (size_t)height;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (size_t)gridDim.x * blockDim.x) {
+      const size_t y = k / row_bytes, x = k - y * row_bytes;
+      dst[y * dst_pitch + x] = src[y * src_pitch + x];
+    }
+  }
+}
+
+int smx_buffer_upload_by_kernel(smx_buffer b, smx_stream s, const void* src, size_t src_pitch, smx_event done) {
+  SMX_CHECK_ARG(b != nullptr && src != nullptr);
+  const size_t row_bytes = (size_t)b->desc.width * b->elem_bytes;
+  if (src_pitch == 0) src_pitch = row_bytes;
+  void* dsrc = nullptr;
+  if (hipHostGetDevicePointer(&dsrc, const_cast<void*>(src), 0) != hipSuccess || dsrc == nullptr) {
+    (void)hipGetLastError();
+    set_error("smx_buffer_upload_by_kernel: the source is not page-locked (smx_host_alloc) memory");
+    return SMX_ERR_INVALID_ARGUMENT;
+  }
+  const int wide = (row_bytes % 16 == 0 && src_pitch % 16 == 0 && b->desc.pitch % 16 == 0 &&
+                    reinterpret_cast<uintptr_t>(dsrc) % 16 == 0 && reinterpret_cast<uintptr_t>(b->desc.address) % 16 == 0) ? 1 : 0;
+  // 32 workgroups: 128 KB of 16-byte loads in flight cover the bus latency; the copy must not take the chip from the frame
+  hipExtLaunchKernelGGL(k_copy_rows, dim3(32), dim3(256), 0, (hipStream_t)s, nullptr, (hipEvent_t)done, 0,
+                        static_cast<char*>(b->desc.address), b->desc.pitch, static_cast<const char*>(dsrc), src_pitch, row_bytes,
+                        b->desc.height, wide);
+  SMX_LAUNCH_CHECK();
   return SMX_OK;
 }
 

@@ -14,7 +14,9 @@ struct Frame {
   CUDABuffer<u16> depth;
   CUDABuffer<Vec3u8> color;
   unsigned long long last_reader = 0;   // 1 + index of the last enqueued step that reads this frame (0 = none)
+  smx_event uploaded = nullptr;         // (staged uploads) completion of the copy kernels that filled the frame
   Frame(int h, int w) : depth(h, w), color(h, w) {}
+  ~Frame() { if (uploaded) smx_event_destroy(uploaded); }
 };
 
 // The per-frame work images (main.cc:801-812).  Three sets: the preprocessing of frames f+1 and f+2 runs on its own
@@ -57,6 +59,15 @@ struct smx_driver_s {
   std::map<u32, std::unique_ptr<Frame>> frames;
   cudaStream_t pre_stream = nullptr;   // depth preprocessing of the next frame
   cudaStream_t pre_stream2 = nullptr;  // (split_pre) outlier cull + erosion / normals / radii, behind the filter of the same frame
+  // Frames that arrive with their step (smx_driver_run_streamed) are copied by KERNELS on a staging queue of its own (round 5):
+  // the copy of step i + 1's frame then runs beside the preprocessing of step i instead of in front of it in the same queue
+  // (55 us of bus time in front of 125 us of preprocessing made that queue the pace-maker of the streamed loop: 5 200
+  // against 6 100 frames/s), and a kernel's stores reach the preprocessing queue through an ordinary event -- the copy
+  // ENGINE's do not when the runtime finds the event already complete (upload_on).
+  // The staging queue is the second preprocessing queue, which is idle unless smx_driver_set_split_preprocessing is on (then
+  // the uploads take the old route): a stream of its own for it made the slow mode of smx_runtime_defaults come back for
+  // every run of the process, the resident ones included (4 of 14: profiles/r5_ab_notes.md).
+  bool staged_uploads = true;
   // Two preprocessing queues: the bilateral filter of frame f + 1 (VALU-bound, one 310-register wavefront per SIMD) runs
   // beside the outlier cull and the tail of frame f (gathers) instead of behind them.  At 1280 x 960 the single queue is
   // busy all of the time and the frame waits for it (profiles/r21_timeline_c3.md).
@@ -314,13 +325,41 @@ static int upload_on(smx_driver d, cudaStream_t stream, const smx_driver_host_fr
   return SMX_OK;
 }
 
+// The staged form: both images copied by kernels on the staging queue (page-locked sources only: false = not page-locked,
+// nothing enqueued); `consumer` -- the queue whose next kernels read the frame -- waits for the copy's completion event.
+static int upload_staged(smx_driver d, cudaStream_t consumer, const smx_driver_host_frame& u, bool* staged) {
+  *staged = false;
+  if (u.depth == nullptr) { *staged = true; return SMX_OK; }
+  if (u.color == nullptr) return fail("upload without a colour image");
+  Frame* f = get_or_make(d, u.frame_index);
+  if (!f->uploaded) SMX_SHIM_CHECK(smx_event_create(&f->uploaded));
+  if (f->last_reader != 0) {
+    WorkSet* w = (f->last_reader >= d->frame_counter) ? d->last : d->prev;
+    if (w->used) SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream2, w->integrated));
+  }
+  if (!f->depth.UploadByKernelAsync(d->pre_stream2, u.depth)) return SMX_OK;   // (the caller falls back to upload_on)
+  if (!f->color.UploadByKernelAsync(d->pre_stream2, reinterpret_cast<const Vec3u8*>(u.color), f->uploaded)) {
+    // (depth page-locked, colour not: finish with the copy engine on the same queue and mark the end with a record)
+    f->color.UploadAsync(d->pre_stream2, reinterpret_cast<const Vec3u8*>(u.color));
+    SMX_SHIM_CHECK(smx_event_record(f->uploaded, d->pre_stream2));
+    SMX_SHIM_CHECK(smx_stream_synchronize(d->pre_stream2));   // (a copy-engine write: see upload_on -- rare path, keep it simple and safe)
+  }
+  SMX_SHIM_CHECK(smx_stream_wait_event(consumer, f->uploaded));
+  *staged = true;
+  return SMX_OK;
+}
+
 // One frame of the loop: [copy of a frame that arrives with this step] + preprocessing (own stream when
 // overlapping) + Integrate.
 static int run_one(smx_driver d, smx_stream s, const smx_driver_step& step, const smx_driver_host_frame* arriving) {
   int rc;
   if (arriving) {
-    rc = upload_on(d, d->overlap ? d->pre_stream : (cudaStream_t)s, *arriving);
-    if (rc != SMX_OK) return rc;
+    bool staged = false;
+    if (d->overlap && d->staged_uploads && !d->split_pre) { rc = upload_staged(d, d->pre_stream, *arriving, &staged); if (rc != SMX_OK) return rc; }
+    if (!staged) {
+      rc = upload_on(d, d->overlap ? d->pre_stream : (cudaStream_t)s, *arriving);
+      if (rc != SMX_OK) return rc;
+    }
   }
   WorkSet* ws = d->set(d->frame_counter++);
   if (d->overlap) {
@@ -516,6 +555,7 @@ int smx_driver_run_streamed(smx_driver d, smx_stream s, const smx_driver_step* s
   if (d->overlap) {
     SMX_SHIM_CHECK(smx_event_record(d->run_start, s));
     SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream, d->run_start));
+    SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream2, d->run_start));
   }
   for (int i = 0; i < n; ++i) {
     const int rc = run_one(d, s, steps[i], &uploads[i]);
@@ -541,6 +581,12 @@ int smx_driver_timing_sums(smx_driver d, double sums_ms[7], uint64_t* calls, int
   for (int k = 0; k < 7; ++k) sums_ms[k] = d->timing_sums[k];
   *calls = d->timing_calls;
   if (reset) { for (int k = 0; k < 7; ++k) d->timing_sums[k] = 0; d->timing_calls = 0; }
+  return SMX_OK;
+}
+
+int smx_driver_set_staged_uploads(smx_driver d, int32_t enabled) {
+  if (!d) return fail("null argument");
+  d->staged_uploads = enabled != 0;
   return SMX_OK;
 }
 

@@ -2878,7 +2878,6 @@ struct smx_recon_s {
   volatile unsigned long long* ts_mapped;   // page-locked ring the tile kernel copies complete records into (the non-waiting read)
   unsigned long long* ts_mapped_dev;        // ... its device alias
   unsigned long long ts_seq;     // Integrate calls with stamps so far (a call's record: ts_ring[seq % kTsRing])
-  hipStream_t ts_stream;         // copies of the ring: ordered behind nothing
   int wall_khz;                  // rate of the device's wall clock (hipDeviceAttributeWallClockRate)
   hipEvent_t ev[14];
   // per-kernel instrumentation (timing_enabled bit 1) and single-kernel profiling over many frames
@@ -3163,7 +3162,6 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
     r->ts_mapped = static_cast<volatile unsigned long long*>(m);
     SMX_TRY(hip_rc(hipHostGetDevicePointer(reinterpret_cast<void**>(&r->ts_mapped_dev), m, 0), "hipHostGetDevicePointer"));
   }
-  SMX_TRY(hip_rc(hipStreamCreateWithFlags(&r->ts_stream, hipStreamNonBlocking), "hipStreamCreateWithFlags"));
   SMX_TRY(hip_rc(hipDeviceGetAttribute(&r->wall_khz, hipDeviceAttributeWallClockRate, device), "hipDeviceGetAttribute"));
   if (r->wall_khz <= 0) r->wall_khz = 100000;   // (s_memrealtime: 100 MHz)
   for (int i = 0; i < 14; ++i) SMX_TRY(hip_rc(hipEventCreate(&r->ev[i]), "hipEventCreate"));
@@ -3206,7 +3204,6 @@ int smx_recon_destroy(smx_recon r) {
                   r->bb.deltas, r->bb.new_deltas, r->new_flags, r->new_ranks, r->tmp_u32, r->block_sums, r->block_offsets, r->st};
   if (r->reg_stream) { (void)hipStreamSynchronize(r->reg_stream); (void)hipStreamDestroy(r->reg_stream); }
   if (r->dir_host) { (void)hipDeviceSynchronize(); (void)hipHostFree(r->dir_host); }
-  if (r->ts_stream) { (void)hipStreamSynchronize(r->ts_stream); (void)hipStreamDestroy(r->ts_stream); }
   if (r->ts_host) (void)hipHostFree(r->ts_host);
   if (r->ts_mapped) { (void)hipDeviceSynchronize(); (void)hipHostFree(const_cast<unsigned long long*>(r->ts_mapped)); }
   if (r->ts_ring) (void)hipFree(r->ts_ring);
@@ -3830,9 +3827,10 @@ bool stage_ms_from_stamps(const unsigned long long* t, unsigned long long seq, i
   out_ms[6] = ms(upd_end, t[kTsRegEnd]);             // regularisation: pass B, edges, step
   return true;
 }
+// (a plain synchronous copy: both callers have waited for the work they ask about, and the object creates no stream it
+// does not need -- every queue more raises the odds of the slow mode of smx_buffer.hip: smx_runtime_defaults)
 int copy_stamp_ring(smx_recon r) {
-  SMX_HIP(hipMemcpyAsync(r->ts_host, r->ts_ring, sizeof(unsigned long long) * kTsRing * kTsWords, hipMemcpyDeviceToHost, r->ts_stream));
-  SMX_HIP(hipStreamSynchronize(r->ts_stream));
+  SMX_HIP(hipMemcpy(r->ts_host, r->ts_ring, sizeof(unsigned long long) * kTsRing * kTsWords, hipMemcpyDeviceToHost));
   return SMX_OK;
 }
 }  // namespace

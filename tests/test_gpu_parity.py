@@ -936,11 +936,12 @@ def test_native_driver_prepared_steps_and_stage_timing(smx):
         assert seen == 1 and 0.0005 < ms < 5000.0, (stage, ms, seen)   # (a duration; the first launch of a kernel in a process may load its code)
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_native_driver_streamed_uploads(smx, overlap):
+@pytest.mark.parametrize("overlap,staged", [(True, True), (True, False), (False, True)])
+def test_native_driver_streamed_uploads(smx, overlap, staged):
     """smx_driver_run_streamed: the frames arrive from (page-locked) host memory with the frame loop
     (APP/main.cc:905-984).  Frame f+4 is copied in for the step of frame f -- the first one over a slot that holds
-    zeros, one over a slot that the steps in flight read -- and the map equals the oracle's."""
+    zeros, one over a slot that the steps in flight read -- and the map equals the oracle's.  staged: the copies are kernels
+    on a staging queue of their own (page-locked sources; pageable ones fall back to the copy engine in the step's queue)."""
     from surfelmeshing_amd.pipeline import NativeFramePipeline
     from surfelmeshing_amd._lib import IntegrateParams
     s = small_stream(obstacle_until=8)
@@ -948,6 +949,7 @@ def test_native_driver_streamed_uploads(smx, overlap):
     po = OraclePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, 60000, pre)
     pn = NativeFramePipeline(s.width, s.height, s.fx, s.fy, s.cx, s.cy, 60000, pre, IntegrateParams.defaults())
     pn.set_overlap(overlap)
+    pn.set_staged_uploads(staged)
     for f in range(0, 30):
         d, c = s.frame(f)
         po.upload(f, d, c)
