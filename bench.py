@@ -281,6 +281,26 @@ STAGES = ["data_association", "surfel_merging", "measurement_blending", "integra
           "neighbor_update", "new_surfel_creation", "regularization"]
 
 
+def handover_probe(wl, n=300):
+    """Mean time of an event hand-over between the frame loop's streams on an otherwise idle chip (smx_debug_handover_probe): the
+    caller's stream <-> the reconstruction's internal stream <-> the preprocessing queue."""
+    import ctypes as C
+    from surfelmeshing_amd import _lib
+    L = _lib.load()
+    internal = C.c_void_p()
+    _lib.check(L.smx_recon_debug_internal_stream(wl.pipe.reconstruction._h, C.byref(internal)))
+    pre = (C.c_void_p * 2)()
+    _lib.check(L.smx_driver_debug_streams(wl.pipe._d, pre))
+    caller = wl.pipe._s()
+    out = {}
+    for name, a, b in (("caller<->internal", caller, internal), ("caller<->preprocessing", caller, C.c_void_p(pre[0])),
+                       ("internal<->preprocessing", internal, C.c_void_p(pre[0]))):
+        us = C.c_float(0)
+        _lib.check(L.smx_debug_handover_probe(a, b, C.c_int32(n), C.byref(us)))
+        out[name] = round(float(us.value), 2)
+    return out
+
+
 def stamp_timeline(rec):
     """The pipelined frame as the kernels themselves stamped it (device wall clock, smx_recon_debug_stamp_ring): the last
     calls of the timed region, mean duration of every launch of Integrate in the frame and of the gaps between them -- no
@@ -553,6 +573,7 @@ def run_integrate(args):
         info["parity_check"] = r.get("parity_check")
         info["cpu_frames_per_s"] = r["value"]
 
+    probe_before = handover_probe(wl)
     g_end, n_live = wl.grow(log, (args.growth_frames, growth_check) if args.growth_frames > 0 else None)
     if log:
         print("# grown to %d live surfels in %d frames, %.1fs" % (n_live, g_end, time.time() - t0), file=sys.stderr)
@@ -775,6 +796,8 @@ def run_integrate(args):
                                          "calls_read": read_calls,
                                          "mean_stage_ms_read": dict(zip(STAGES, [x / max(read_calls, 1) for x in read_sums])) if read_calls else None},
         "in_frame_timeline_us": timeline,
+        "handover_probe_us": {"before_the_run": probe_before, "behind_the_timed_window": handover_probe(wl),
+                              "note": "event hand-over between two of the frame loop's streams, empty kernels, idle chip"},
         "growth_phase": getattr(wl, "growth", None),
         "reference_model_bytes_per_frame": ref_bytes,
         "reference_model_GBs": ref_bytes * (K / elapsed) / 1e9,

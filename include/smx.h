@@ -90,6 +90,9 @@ int smx_event_create_timed(smx_event* out);
 int smx_event_elapsed_ms(smx_event start, smx_event stop, float* ms);
 /* Launches an empty kernel (k_smx_marker) that delimits regions in kernel traces. */
 int smx_debug_marker(smx_stream s, int32_t id);
+/* (measurement) n ping-pongs of an empty kernel between two streams, each leg handed over by an event record + a stream wait:
+ * mean time per leg in microseconds.  Synchronises both streams. */
+int smx_debug_handover_probe(smx_stream a, smx_stream b, int32_t n, float* us_per_handover);
 
 /* ---- CUDABuffer<T>  (VIS/cuda/cuda_buffer.h:45-129, cuda_buffer_inl.h:36-172) ---- */
 /* CUDABuffer(int height, int width): cudaMallocPitch */
@@ -292,6 +295,8 @@ int smx_recon_get_timings(smx_recon r, float out_ms[7]);
  * page-locked host memory, so the read lags the queue by two calls and touches neither the device nor any stream.
  * *call_number: that call's 1-based number, 0 (and zeros) if there is none yet. */
 int smx_recon_get_timings_nowait(smx_recon r, float out_ms[7], uint64_t* call_number);
+/* Measurement: the object's internal stream (for smx_debug_handover_probe; never enqueue work on it). */
+int smx_recon_debug_internal_stream(smx_recon r, smx_stream* out);
 /* Measurement: the raw stage-stamp records of the last 8 smx_recon_integrate calls (8 x 16 words of device wall clock,
  * rate in *wall_clock_khz; word 0 = the call's number, then: cull begin, tiles end*, blend begin, blend end*, integrate
  * begin, integrate end*, update begin, update end*, pass B begin, step end*, pass A begin, tiles begin, edge kernel begin,

@@ -98,6 +98,8 @@ int smx_driver_set_run_ahead(smx_driver d, int32_t enabled);
 int smx_driver_debug_prepare(smx_driver d, smx_stream s, const smx_driver_step* steps, int32_t n);
 int smx_driver_profile_begin(smx_driver d, int32_t stage, int32_t max_frames);
 int smx_driver_profile_end(smx_driver d, float* avg_ms, int32_t* frames);
+/* Measurement: the driver's two preprocessing queues (for smx_debug_handover_probe; never enqueue work on them). */
+int smx_driver_debug_streams(smx_driver d, smx_stream out[2]);
 /* smx_driver_run_streamed with overlap on (default ON; results identical): the frames that arrive with their steps are copied
  * by kernels on a staging queue of its own (page-locked sources: smx_host_alloc), so that the copy for step i + 1 runs beside
  * the preprocessing of step i; 0 = the copy engine in front of the step's preprocessing, in the same queue (rounds 1-4). */

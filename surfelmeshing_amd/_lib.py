@@ -80,7 +80,7 @@ class NNStats(C.Structure):
 # every symbol include/smx.h declares (tests/test_abi.py checks the .so exports them all)
 EXPORTS = [
     "smx_last_error", "smx_device_count", "smx_set_device", "smx_device_name",
-    "smx_stream_create", "smx_stream_create_with_priority", "smx_host_alloc", "smx_host_free", "smx_stream_destroy", "smx_stream_synchronize", "smx_debug_marker",
+    "smx_stream_create", "smx_stream_create_with_priority", "smx_host_alloc", "smx_host_free", "smx_stream_destroy", "smx_stream_synchronize", "smx_debug_marker", "smx_debug_handover_probe",
     "smx_event_create", "smx_event_create_timed", "smx_event_elapsed_ms", "smx_event_destroy", "smx_event_record", "smx_stream_wait_event",
     "smx_buffer_create", "smx_buffer_destroy", "smx_buffer_get_desc", "smx_buffer_upload", "smx_buffer_upload_by_kernel", "smx_buffer_download",
     "smx_buffer_upload_part", "smx_buffer_download_part", "smx_buffer_clear", "smx_buffer_set_to",
@@ -88,7 +88,7 @@ EXPORTS = [
     "smx_copy_without_border", "smx_median_filter_and_densify_depth_map", "smx_downscale_using_median_while_excluding", "smx_color_image_pyramid", "smx_compute_normals_and_drop_bad_pixels",
     "smx_compute_point_radii_and_remove_isolated_pixels", "smx_erode_normals_radii", "smx_erode_normals_radii_signal",
     "smx_recon_create", "smx_recon_destroy", "smx_recon_integrate", "smx_recon_regularize",
-    "smx_recon_transfer_all_to_cpu", "smx_recon_set_delta_tracking", "smx_recon_transfer_changed_to_cpu", "smx_recon_export_vertices", "smx_recon_get_timings", "smx_recon_get_timings_nowait", "smx_recon_debug_stamp_ring",
+    "smx_recon_transfer_all_to_cpu", "smx_recon_set_delta_tracking", "smx_recon_transfer_changed_to_cpu", "smx_recon_export_vertices", "smx_recon_get_timings", "smx_recon_get_timings_nowait", "smx_recon_debug_stamp_ring", "smx_recon_debug_internal_stream",
     "smx_recon_build_neighbor_index", "smx_recon_neighbor_candidates", "smx_recon_check_triangles", "smx_recon_deform_by_creation_frame",
     "smx_recon_set_timing_enabled", "smx_recon_counts", "smx_recon_get_stats", "smx_recon_set_stats_enabled",
     "smx_recon_kernel_slot_count", "smx_recon_kernel_slot_name", "smx_recon_get_kernel_timings",

@@ -106,6 +106,33 @@ int smx_stream_create_with_priority(smx_stream* out, int32_t priority_class) {
 }
 
 // cudaHostAlloc / cudaFreeHost of the caller's upload staging (APP/main.cc:917, 825-829)
+// (measurement) n ping-pongs of an empty kernel between two streams, each leg handed over by an event: mean time per leg.
+int smx_debug_handover_probe(smx_stream sa, smx_stream sb, int32_t n, float* us_per_handover) {
+  SMX_CHECK_ARG(n > 0 && n <= 100000 && us_per_handover != nullptr);
+  hipStream_t a = (hipStream_t)sa, b = (hipStream_t)sb;
+  hipEvent_t t0, t1, ea, eb;
+  SMX_HIP(hipEventCreate(&t0)); SMX_HIP(hipEventCreate(&t1));
+  SMX_HIP(hipEventCreateWithFlags(&ea, hipEventDisableTiming | hipEventReleaseToDevice));
+  SMX_HIP(hipEventCreateWithFlags(&eb, hipEventDisableTiming | hipEventReleaseToDevice));
+  SMX_HIP(hipStreamSynchronize(a)); SMX_HIP(hipStreamSynchronize(b));
+  auto leg = [&](hipStream_t from, hipStream_t to, hipEvent_t e) {
+    hipLaunchKernelGGL(k_smx_marker, dim3(1), dim3(64), 0, from, 0);
+    (void)hipEventRecord(e, from);
+    (void)hipStreamWaitEvent(to, e, 0);
+  };
+  for (int i = 0; i < 8; ++i) { leg(a, b, ea); leg(b, a, eb); }   // (warm-up)
+  SMX_HIP(hipEventRecord(t0, a));
+  for (int i = 0; i < n; ++i) { leg(a, b, ea); leg(b, a, eb); }
+  SMX_HIP(hipEventRecord(t1, a));
+  SMX_HIP(hipEventSynchronize(t1));
+  float ms = 0;
+  SMX_HIP(hipEventElapsedTime(&ms, t0, t1));
+  *us_per_handover = ms * 1e3f / (2.0f * (float)n);
+  (void)hipEventDestroy(t0); (void)hipEventDestroy(t1); (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+  SMX_LAUNCH_CHECK();
+  return SMX_OK;
+}
+
 int smx_host_alloc(void** out, size_t bytes, int32_t write_combined) {
   SMX_CHECK_ARG(out != nullptr && bytes > 0);
   void* p = nullptr;

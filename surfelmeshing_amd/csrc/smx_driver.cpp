@@ -39,8 +39,13 @@ struct WorkSet {
   ~WorkSet() { smx_event_destroy(preprocessed); smx_event_destroy(integrated); smx_event_destroy(filtered); }
 };
 
+// Priority class of the preprocessing queues: 0 = the device's default.  Rounds 2-4 ran them at the LOWEST priority (-1: the
+// preprocessing only has to keep up) -- which is what the frame loop's slow mode hangs on: one run in ten to one in five a
+// tenth slower for its whole length (period 165 instead of 150 us at C2: both stream hand-overs twice as long), 0 of 40 runs
+// with the preprocessing at the default priority, at 1.7 % less than the fast mode (6330 against 6440 frames/s; C3 1810
+// against 1804): the same in expectation, without the tail (profiles/r5_ab_notes.md).
 #ifndef SMX_PRE_PRIORITY
-#define SMX_PRE_PRIORITY -1
+#define SMX_PRE_PRIORITY 0
 #endif
 #ifndef SMX_PRE2_PRIORITY
 #define SMX_PRE2_PRIORITY SMX_PRE_PRIORITY
@@ -92,7 +97,7 @@ struct smx_driver_s {
   explicit smx_driver_s(const smx_driver_config& c, const float* intr)
       : cfg(c), camera(c.width, c.height, intr), reconstruction(c.max_surfel_count, camera),
         work0(c.height, c.width), work1(c.height, c.width), work2(c.height, c.width), last(&work0), prev(&work0) {
-    // preprocessing runs ahead of the frame loop: it only has to keep up, so it yields to the surfel kernels
+    // (preprocessing runs ahead of the frame loop; its priority: see SMX_PRE_PRIORITY)
     SMX_SHIM_CHECK(smx_stream_create_with_priority(&pre_stream, SMX_PRE_PRIORITY));
     SMX_SHIM_CHECK(smx_stream_create_with_priority(&pre_stream2, SMX_PRE2_PRIORITY));
     SMX_SHIM_CHECK(smx_event_create(&run_start));
@@ -581,6 +586,12 @@ int smx_driver_timing_sums(smx_driver d, double sums_ms[7], uint64_t* calls, int
   for (int k = 0; k < 7; ++k) sums_ms[k] = d->timing_sums[k];
   *calls = d->timing_calls;
   if (reset) { for (int k = 0; k < 7; ++k) d->timing_sums[k] = 0; d->timing_calls = 0; }
+  return SMX_OK;
+}
+
+int smx_driver_debug_streams(smx_driver d, smx_stream out[2]) {   // (measurement: the two preprocessing queues)
+  if (!d || !out) return fail("null argument");
+  out[0] = d->pre_stream; out[1] = d->pre_stream2;
   return SMX_OK;
 }
 

@@ -3550,6 +3550,12 @@ int smx_recon_debug_download_stamps(smx_recon r, unsigned long long* out) {   //
 }
 #endif
 
+int smx_recon_debug_internal_stream(smx_recon r, smx_stream* out) {   // (measurement: smx_debug_handover_probe)
+  SMX_CHECK_ARG(r != nullptr && out != nullptr);
+  *out = (smx_stream)r->reg_stream;
+  return SMX_OK;
+}
+
 int smx_recon_integrate_hooks(smx_recon r, smx_event inputs_consumed, smx_event chain_after) {
   SMX_CHECK_ARG(r != nullptr);
   r->hook_consumed = (hipEvent_t)inputs_consumed;
