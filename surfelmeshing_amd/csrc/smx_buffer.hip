@@ -53,6 +53,8 @@ __global__ void k_fill(T* __restrict__ base, size_t pitch, int width, int height
 // Empty kernel whose only purpose is to show up in kernel traces (rocprofv3 --kernel-trace) so that
 // tools/prof_summary.py can cut out the timed region of a benchmark run.
 __global__ void k_smx_marker(int id) { (void)id; }
+// (the hand-over probe's empty kernel: NOT the marker, which the profile summaries look for)
+__global__ void k_smx_probe(int id) { (void)id; }
 
 extern "C" {
 
@@ -116,7 +118,7 @@ int smx_debug_handover_probe(smx_stream sa, smx_stream sb, int32_t n, float* us_
   SMX_HIP(hipEventCreateWithFlags(&eb, hipEventDisableTiming | hipEventReleaseToDevice));
   SMX_HIP(hipStreamSynchronize(a)); SMX_HIP(hipStreamSynchronize(b));
   auto leg = [&](hipStream_t from, hipStream_t to, hipEvent_t e) {
-    hipLaunchKernelGGL(k_smx_marker, dim3(1), dim3(64), 0, from, 0);
+    hipLaunchKernelGGL(k_smx_probe, dim3(1), dim3(64), 0, from, 0);
     (void)hipEventRecord(e, from);
     (void)hipStreamWaitEvent(to, e, 0);
   };
