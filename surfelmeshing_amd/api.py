@@ -136,6 +136,13 @@ class CUDABuffer:
         _lib.check(_lib.load().smx_buffer_upload(self._h, _sv(stream), a.ctypes.data_as(C.c_void_p), C.c_size_t(0)))
         self._keep = a  # keep the host array alive until the caller synchronises
 
+    def UploadByKernelAsync(self, stream, data):
+        """The same copy done by a kernel that reads the page-locked source over the bus (smx_buffer_upload_by_kernel); `data`
+        must be (a view of) a PagelockedArray of the buffer's shape and dtype -- raises SmxError otherwise."""
+        assert data.dtype == self.dtype and data.shape == self._host_shape() and data.flags.c_contiguous
+        _lib.check(_lib.load().smx_buffer_upload_by_kernel(self._h, _sv(stream), data.ctypes.data_as(C.c_void_p), C.c_size_t(0), C.c_void_p(0)))
+        self._keep = data
+
     def UploadPitchedAsync(self, stream, pitch, data):
         _lib.check(_lib.load().smx_buffer_upload(self._h, _sv(stream), data.ctypes.data_as(C.c_void_p), C.c_size_t(pitch)))
         self._keep = data

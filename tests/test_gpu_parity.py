@@ -223,6 +223,18 @@ def test_cuda_buffer_roundtrips(smx):
         val = np.arange(1, ch + 1).astype(dtype)
         b.Clear(val if ch > 1 else val[0])
         assert np.all(b.Download().reshape(-1, ch) == val)
+    # the copy as a kernel that reads page-locked memory over the bus: 16-byte and byte-wise rows; pageable memory is refused
+    for dtype, ch, shape in ((np.uint16, 1, (48, 64)), (np.uint8, 3, (30, 64)), (np.uint8, 3, (7, 13)), (np.float32, 1, (3, 5))):
+        b = smx.CUDABuffer(shape[0], shape[1], dtype, ch)
+        hs = shape + ((ch,) if ch > 1 else ())
+        src = smx.PagelockedArray(hs, dtype)
+        src.array[...] = (rng.random(hs) * 200).astype(dtype)
+        b.Clear(np.zeros(ch, dtype) if ch > 1 else dtype(0))
+        b.UploadByKernelAsync(None, src.array)
+        smx.StreamSynchronize(None)
+        assert np.array_equal(b.Download(), src.array)
+        with pytest.raises(smx.SmxError):
+            b.UploadByKernelAsync(None, np.ascontiguousarray(src.array.copy()))
     # byte-range part transfers on a 1-row buffer (UploadPartAsync / DownloadPartAsync)
     b = smx.CUDABuffer(1, 1000, np.uint32)
     b.Clear(0)
