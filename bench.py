@@ -455,6 +455,156 @@ def finish_ranks(world, dist):
         dist.destroy_process_group()
 
 
+
+# =====================================================================================================================
+# The line the driver reads.  Its record keeps the last 8 000 characters of stdout: the LAST line has to be short (round 5's
+# 24 KB line was cut and the driver's record held no headline at all).  Everything measured goes to bench_detail[_<config>].json
+# next to this script (and to gpurun_out/ when that directory exists, so that it travels back from the GPU box); the last stdout
+# line is compact_line(result): the contract's keys, the two roofline blocks reduced to their figures, the CPU baseline and the
+# in-run parity verdicts.  tests/test_bench_line.py holds its length under 6 000 characters on a canned full result.
+COMPACT_LIMIT = 6000
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _r(x, digits=5):
+    """floats to `digits` significant digits (the detail file keeps the full values)"""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x)) if math.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _r(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, digits) for v in x]
+    return x
+
+
+def _parity_ok(pc):
+    """one verdict per in-run parity block: True / False / None (not run)"""
+    if not pc:
+        return None
+    bad = [k for k, v in pc.items() if (v if k == "rows_not_bit_equal" else (k.endswith("_equal") and v is not True))]
+    return not bad
+
+
+def compact_roofline(roof):
+    if not roof:
+        return None
+    out = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                       "avg_launch_ms", "launches_timed"))
+    out.setdefault("traffic", None)
+    if "avg_launch_ms_by" in roof:
+        out["avg_launch_ms_by"] = "launch start/stop events on the launch stream, this run's timed launches"
+    if roof.get("trace"):
+        out["trace"] = _pick(roof["trace"], ("avg_launch_ms", "launches", "frac", "file"))
+    elif roof.get("trace_refused"):
+        out["trace_refused"] = str(roof["trace_refused"])[:120]
+    raw = roof.get("traffic_pmc_raw") or {}
+    if raw.get("traffic_over_algorithmic") is not None:
+        out["traffic_over_algorithmic"] = raw["traffic_over_algorithmic"]
+    if roof.get("traffic_refused"):
+        out["traffic_refused"] = str(roof["traffic_refused"])[:120]
+    fr = roof.get("frame")
+    if fr:
+        out["frame"] = _pick(fr, ("algorithmic_frac", "frac", "algorithmic_bytes_per_frame", "pmc_bytes_per_frame"))
+    lk = roof.get("longest_kernel_in_frame")
+    if lk:
+        out["longest_kernel_in_frame"] = _pick(lk, ("kernel", "in_frame_ms", "bound", "frac_in_frame"))
+    return out
+
+
+def compact_line(d):
+    """The short form of a result dictionary (C2 / C3 / C5 alike): see the comment above."""
+    out = _pick(d, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "host_enqueue_ms_per_step",
+                    "higher_is_better", "scaling", "dtype", "data", "per_rank_frames_per_s", "rccl_ranks_seen", "gloo_ranks_seen",
+                    "upper_bound"))
+    out["vs_baseline"] = d.get("vs_baseline")
+    out["config"] = _pick(d.get("config", {}), ("workload", "max_surfel_count", "streams", "parallelism", "backend"))
+    out["roofline"] = compact_roofline(d.get("roofline"))
+    rv = d.get("roofline_valu")
+    if rv:
+        out["roofline_valu"] = _pick(rv, ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_in_frame",
+                                          "avg_launch_ms_alone", "avg_launch_ms_in_frame"))
+    cb = d.get("cpu_baseline")
+    if cb:
+        c = _pick(cb, ("value", "unit", "cores", "integrate_cores", "kind"))
+        c["sample"] = str(cb.get("sample", ""))[:230]
+        if cb.get("one_core"):
+            c["one_core_value"] = cb["one_core"].get("value")
+        if cb.get("c1_single_frame"):
+            c["c1_single_frame_ms_all_cores"] = cb["c1_single_frame"].get("ms_all_cores")
+        out["cpu_baseline"] = c
+        if cb.get("parity_check"):
+            out["parity_check"] = dict(cb["parity_check"], ok=_parity_ok(cb["parity_check"]))
+    if d.get("parity_check_per_rank"):
+        out["parity_check_per_rank"] = d["parity_check_per_rank"]
+    if d.get("host_frames"):
+        out["host_frames"] = _pick(d["host_frames"], ("value", "unit", "steps", "h2d_GBs"))
+        out["host_frames"]["note"] = "PCIe-inclusive pass: inputs arrive from page-locked host memory (not the headline)"
+    gp = d.get("growth_phase")
+    if gp:
+        out["growth_phase"] = _pick(gp, ("value", "unit", "steps", "new_slots_per_frame"))
+        if gp.get("parity_check"):
+            out["growth_phase"]["parity_ok"] = _parity_ok(gp["parity_check"])
+    dist = d.get("distributions") or {}
+    out["distributions"] = _pick(dist, ("surfels_size", "merge_count", "n_visible", "n_recent", "n_new", "n_points", "mean_results",
+                                        "distance_tests_per_query"))
+    tl = d.get("in_frame_timeline_us")
+    if tl:
+        out["period_us"] = tl.get("period (integrate begin -> next integrate begin)")
+    for k in ("index_build", "radius_x2", "general_batch_entry_point"):
+        if d.get(k):
+            out[k] = _pick(d[k], ("ms", "queries_per_s", "frac"))
+    oc = d.get("other_configs")
+    if oc:
+        out["other_configs"] = {}
+        for name, o in oc.items():
+            if "error" in o:
+                out["other_configs"][name] = {"error": str(o["error"])[:200]}
+                continue
+            roof = o.get("roofline") or {}
+            fr = roof.get("frame") or {}
+            cbo = o.get("cpu_baseline") or {}
+            e = _pick(o, ("value", "unit", "steps", "warmup", "ms_per_step"))
+            e["workload"] = str((o.get("config") or {}).get("workload", ""))[:140]
+            e["roofline"] = dict(_pick(roof, ("kernel", "frac", "achieved", "traffic", "avg_launch_ms")),
+                                 **({"frame": _pick(fr, ("algorithmic_frac", "frac"))} if fr else {}))
+            if o.get("roofline_valu"):
+                e["roofline_valu"] = _pick(o["roofline_valu"], ("kernel", "frac", "frac_in_frame"))
+            e["parity_ok"] = _parity_ok(o.get("parity_check"))
+            e["cpu_baseline"] = _pick(cbo, ("value", "unit", "cores", "kind"))
+            out["other_configs"][name] = e
+    if d.get("detail"):
+        out["detail"] = d["detail"]
+    line = json.dumps(_r(out))
+    if len(line) > COMPACT_LIMIT:   # (never in the tests; a guard so that the driver's record keeps the headline whatever happens)
+        for k in ("other_configs", "distributions", "growth_phase", "host_frames", "roofline_valu"):
+            out.pop(k, None)
+            line = json.dumps(_r(out))
+            if len(line) <= COMPACT_LIMIT:
+                break
+    return line
+
+
+def emit(result, args):
+    """Full result -> bench_detail[_<config>].json (+ gpurun_out/), compact form -> the last stdout line."""
+    name = "bench_detail.json" if args.config == "C2" else "bench_detail_%s.json" % args.config
+    paths = [args.detail_out] if getattr(args, "detail_out", "") else [os.path.join(ROOT, name)]
+    if not getattr(args, "detail_out", "") and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", name))
+    written = []
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                json.dump(result, f, indent=1)
+            written.append(os.path.relpath(p, ROOT))
+        except OSError as e:   # (a read-only checkout must not cost the run its line)
+            print("# could not write %s: %s" % (p, e), file=sys.stderr)
+    result["detail"] = written[0] if written else None
+    print(json.dumps(result) if getattr(args, "full_line", False) else compact_line(result), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", choices=["C1", "C2", "C3", "C5"], default="C2", help="BASELINE.json config (SURVEY.md 8d)")
@@ -503,6 +653,10 @@ def main():
     ap.add_argument("--check-all-ranks", action="store_true", help="N > 1: every rank runs the in-run parity check (oracle) on its own stream")
     ap.add_argument("--dry-run", action="store_true", help="rank path only (no GPU, gloo): see the module docstring")
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--full-line", action="store_true", help="tools: print the full result as the last line (not for the driver: it "
+                    "keeps 8 000 characters of stdout)")
+    ap.add_argument("--detail-out", default="", help="where the full result goes (default: bench_detail[_<config>].json next to "
+                    "this script, and gpurun_out/ when it exists); the last stdout line is the compact form")
     args = ap.parse_args()
     if args.config == "C1":
         return run_c1(args)
@@ -778,8 +932,8 @@ def run_integrate(args):
         "ms_per_step": 1e3 * elapsed / K, "host_enqueue_ms_per_step": 1e3 * enqueue_local / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "per_rank_frames_per_s": each_rank, ("rccl_ranks_seen" if args.backend == "nccl" else "gloo_ranks_seen"): seen,
-        "config": {"workload": "%s: synthetic room stream %dx%d, full preprocessing + Integrate per frame, "
-                               "%d live surfels (%d slots), steady-state re-traversal" %
+        "config": {"workload": "%s: synthetic room stream %dx%d, raw depth + colour frames resident in HBM, full preprocessing + "
+                               "Integrate per frame, %d live surfels (%d slots), steady-state re-traversal" %
                                (args.config, width, height, live, st["surfels_size"]),
                    "max_surfel_count": cap, "streams": world, "parallelism": "1 independent stream per GPU",
                    "backend": args.backend if world > 1 else None},
@@ -834,7 +988,7 @@ def run_integrate(args):
         if (args.config == "C2" and world == 1 and not args.no_other_configs and not args.surfels and not args.width
                 and not args.height and not args.scan_mode and do_cpu):
             result["other_configs"] = other_configs(args, log)
-        print(json.dumps(result))
+        emit(result, args)
     finish_ranks(world, dist)
     return 0
 
@@ -850,18 +1004,23 @@ def other_configs(args, log):
     out = {}
     for name, extra in runs.items():
         t0 = time.time()
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--quiet", "--no-other-configs"] + extra
+        detail = os.path.join(ROOT, "bench_detail_%s.json" % name)
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--quiet", "--no-other-configs", "--detail-out", detail] + extra
         env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
         try:
+            if os.path.exists(detail):
+                os.remove(detail)
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            if r.returncode != 0 or not lines:
+            if r.returncode != 0 or not os.path.exists(detail):
                 out[name] = {"error": "rc %d: %s" % (r.returncode, r.stderr[-600:])}
                 continue
-            d = json.loads(lines[-1])
-        except (subprocess.TimeoutExpired, ValueError) as e:
+            d = json.load(open(detail))
+        except (subprocess.TimeoutExpired, ValueError, OSError) as e:
             out[name] = {"error": repr(e)[:600]}
             continue
+        gout = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(gout):
+            json.dump(d, open(os.path.join(gout, os.path.basename(detail)), "w"), indent=1)
         roof = dict(d.get("roofline") or {})
         roof.pop("kernels", None)
         roof.pop("traffic_pmc_raw", None)
@@ -874,7 +1033,8 @@ def other_configs(args, log):
                      "growth_phase": d.get("growth_phase"),
                      "distributions": {k: d.get("distributions", {}).get(k) for k in ("surfels_size", "n_visible", "n_recent", "n_new",
                                                                                       "n_points", "mean_results") if k in d.get("distributions", {})},
-                     "command": " ".join(["python", "bench.py"] + cmd[2:]), "wall_s": time.time() - t0}
+                     "command": " ".join(["python", "bench.py"] + cmd[2:]), "detail": os.path.basename(detail),
+                     "wall_s": time.time() - t0}
         if log:
             print("# other config %s: %.4g %s (%.0fs)" % (name, d["value"], d["unit"], time.time() - t0), file=sys.stderr, flush=True)
     return out
@@ -903,6 +1063,34 @@ def pmc_file(config="C2"):
     if meta.get("source_sha") != source_sha():
         return None, "stale: collected on kernel sources %s, this build is %s" % (meta.get("source_sha"), source_sha())
     return d, None
+
+
+def trace_file(config, slot, steps):
+    """The committed rocprofv3 --kernel-trace summary of this same command (profiles/trace_timed_region[_C3].json, written by
+    tools/prof_summary.py through tools/profile_round.sh): average duration of the slot's kernel between the two marker kernels
+    of the timed region, from the trace whose frame count is nearest to this run's.  Refused like the PMC file when it was
+    collected on other kernel sources."""
+    name = "trace_timed_region.json" if config == "C2" else "trace_timed_region_%s.json" % config
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, "no profiles/" + name
+    try:
+        d = json.load(open(path))
+    except (ValueError, OSError) as e:
+        return None, "unreadable: %s" % e
+    meta = d.get("_meta", {})
+    if meta.get("source_sha") != source_sha():
+        return None, "stale: collected on kernel sources %s, this build is %s" % (meta.get("source_sha"), source_sha())
+    runs = [(k, v) for k, v in d.items() if k != "_meta" and v.get("frames")]
+    if not runs:
+        return None, "empty"
+    key, run = min(runs, key=lambda kv: abs(math.log(max(kv[1]["frames"], 1) / max(steps, 1))))
+    pref = SLOT_KERNEL.get(slot, slot)
+    k = max((v for n, v in run["kernels"].items() if n.startswith(pref)), key=lambda v: v["calls"], default=None)
+    if k is None:
+        return None, "no kernel %s in the trace" % pref
+    return {"avg_launch_ms": k["avg_us"] * 1e-3, "launches": k["calls"], "frames_in_trace": run["frames"],
+            "command": meta.get(key), "file": "profiles/" + name}, None
 
 
 PMC_NOTE = ("HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB).  Calibrated on known byte counts in this design's own access patterns "
@@ -975,10 +1163,18 @@ def roofline_block(st, P, dominant, longest, dom_ms, dom_n, alone_ms, in_frame_m
         frame.update({"pmc_bytes_per_frame": total, "GBs": total / (ms_per_step * 1e-3) / 1e9,
                       "frac": total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       "pmc_note": "sum over the kernels of one frame of 2 x FETCH_SIZE + WRITE_SIZE / the measured frame time"})
+    trace, trace_why = trace_file(config, dominant, dom_n)
+    if trace is not None:
+        trace["frac"] = alg / (trace["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        trace["over_this_run"] = trace["avg_launch_ms"] / dom_ms if dom_ms > 0 else None
     return {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_pmc_raw": raw, "traffic_refused": why,
             "frame": frame, "algorithmic_bytes_per_launch": alg,
             "avg_launch_ms": dom_ms, "launches_timed": dom_n, "surfel_slots": st["surfels_size"],
+            "avg_launch_ms_by": "the launch's own start / stop events (hipExtLaunchKernelGGL) on its launch stream, averaged over the "
+                                "timed launches of THIS run; `trace` = the same kernel in the committed rocprofv3 kernel trace of the "
+                                "same command",
+            "trace": trace, "trace_refused": trace_why,
             "longest_kernel_in_frame": {"kernel": longest, "in_frame_ms": in_frame_ms.get(longest),
                                         "bound": "valu_fp32" if longest in PRE_STAGES else "hbm",
                                         "frac_in_frame": (valu or {}).get("frac_in_frame") if longest == "bilateral" else None,
@@ -1308,7 +1504,7 @@ def run_c5(args):
     if rank == 0:
         if world == 1 and (args.cpu_frames is None or args.cpu_frames > 0):
             result["cpu_baseline"] = c5_cpu_baseline(nn, pts, r, Kn, not args.no_check)
-        print(json.dumps(result))
+        emit(result, args)
     nn.close()
     finish_ranks(world, dist)
     return 0

@@ -6,7 +6,7 @@ cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 for rep in $(seq $REPS); do
   for v in "$@"; do
     e="$v"; [ "$v" = "-" ] && e=""
-    env $e timeout 300 python bench.py --steps 300 --warmup 20 --cpu-frames 0 --host-frames 0 --quiet $SMX_BENCH_FLAGS 2>/dev/null | python -c "import sys,json
+    env $e timeout 300 python bench.py --full-line --steps 300 --warmup 20 --cpu-frames 0 --host-frames 0 --quiet $SMX_BENCH_FLAGS 2>/dev/null | python -c "import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); r=d['roofline']; k=r.get('kernels',{}); s=d['distributions']

@@ -8,7 +8,7 @@ for cfg in C2 C3; do
   for rep in $(seq $REPS); do
     for v in "$@"; do
       f="$v"; [ "$v" = "-" ] && f=""
-      timeout 300 python bench.py --config $cfg --steps 300 --warmup 20 --cpu-frames 0 --host-frames 0 --quiet $f 2>/dev/null | python -c "import sys,json
+      timeout 300 python bench.py --full-line --config $cfg --steps 300 --warmup 20 --cpu-frames 0 --host-frames 0 --quiet $f 2>/dev/null | python -c "import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); r=d['roofline']; k=r.get('kernels',{})

@@ -2,9 +2,13 @@
 """Summarises a rocprofv3 --kernel-trace CSV: per-kernel count / total / average duration, restricted to the
 dispatches between the two k_smx_marker kernels bench.py launches around its timed region.
 
-    python tools/prof_summary.py <dir-or-csv> [out.md]
+    python tools/prof_summary.py <dir-or-csv> [out.md] [out.json key]
+
+With `out.json key` the per-kernel averages are also merged into out.json under `key` (profiles/trace_timed_region[_C3].json,
+what bench.py quotes beside the launch's own start / stop events: roofline.trace).
 """
 import csv
+import json
 import glob
 import os
 import re
@@ -47,6 +51,13 @@ def main():
     out = "\n".join(lines) + "\n"
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(out)
+    if len(sys.argv) > 4:
+        path, key = sys.argv[3], sys.argv[4]
+        d = json.load(open(path)) if os.path.exists(path) else {}
+        frames = max((n for name, (n, t) in agg.items() if "k_scan_visible" in name or "k_query_lanes" in name), default=0)
+        d[key] = {"span_ms": span / 1e6, "dispatches": len(sel), "frames": frames,
+                  "kernels": {name: {"calls": n, "avg_us": t / n / 1e3} for name, (n, t) in agg.items()}}
+        json.dump(d, open(path, "w"), indent=1, sort_keys=True)
     print(out)
 
 
