@@ -33,6 +33,15 @@
     }                                                                                            \
   } while (0)
 
+// float2: the reference's callers spell the normals buffer `CUDABuffer<float2>` with CUDA's global vector type
+// (APP/main.cc:804, APP/cuda_surfel_reconstruction.h:64).  Inside a HIP translation unit (or with SMX_SHIM_USE_HIP_TYPES) that
+// is HIP's own ::float2; a plain host compiler without the HIP headers gets a stand-in of the same layout at global scope.
+#if defined(__HIPCC__) || defined(SMX_SHIM_USE_HIP_TYPES)
+#include <hip/hip_vector_types.h>
+#elif !defined(SMX_SHIM_NO_FLOAT2)
+struct float2 { float x, y; };
+#endif
+
 namespace vis {
 
 typedef uint8_t u8;
@@ -41,8 +50,13 @@ typedef uint32_t u32;
 typedef size_t usize;
 typedef smx_stream cudaStream_t;  // a hipStream_t
 
-struct float2_ { float x, y; };
+typedef ::float2 float2_;   // (rounds 1-5 spelled the shim's own stand-in this way; kept for their callers)
+static_assert(sizeof(::float2) == 8, "float2 must be two packed floats");
+// Vec3u8: libvis' Eigen typedef (VIS/eigen.h).  Inside the reference tree define SMX_SHIM_NO_VEC_TYPES and include libvis'
+// header first: the shim then takes vis::Vec3u8 as it finds it (any 3-byte type works: only its size is used).
+#ifndef SMX_SHIM_NO_VEC_TYPES
 struct Vec3u8 { u8 v[3]; };
+#endif
 
 // Row-major 3x4 rigid transform (host part of VIS/cuda/cuda_matrix.cuh:67-116).  As in the reference it is
 // constructible from ANY matrix type with (row, col) element access -- the call sites hand it an Eigen 3x4 from
@@ -170,6 +184,25 @@ class CUDABuffer {
   void DownloadPartAsync(size_t start, size_t length, cudaStream_t stream, T* data) const { SMX_SHIM_CHECK(smx_buffer_download_part(handle_, stream, start, length, data)); }
   void DebugUpload(const T* data) { UploadAsync(nullptr, data); SMX_SHIM_CHECK(smx_stream_synchronize(nullptr)); }
   void DebugDownload(T* data) const { DownloadAsync(nullptr, data); SMX_SHIM_CHECK(smx_stream_synchronize(nullptr)); }
+  // (VIS/cuda/cuda_buffer.h:65, 82: the synchronous forms with a host pitch)
+  void DebugUploadPitched(size_t pitch, const T* data) { UploadPitchedAsync(nullptr, pitch, data); SMX_SHIM_CHECK(smx_stream_synchronize(nullptr)); }
+  void DebugDownloadPitched(size_t pitch, T* data) const {
+    SMX_SHIM_CHECK(smx_buffer_download(handle_, nullptr, data, pitch));
+    SMX_SHIM_CHECK(smx_stream_synchronize(nullptr));
+  }
+  // The Image<T> overloads (VIS/cuda/cuda_buffer.h:69, 86; cuda_buffer_inl.h: a pitched copy with the image's stride) --
+  // what APP/main.cc:1030, 1121, 1147, 1171 call with `&filtered_depth`.  Any image type with data() and stride() (bytes per
+  // row) serves: libvis' Image<T> inside the reference tree, a stand-in elsewhere.  The size has to match like there.
+  template <typename Img, typename = decltype(std::declval<const Img&>().stride()), typename = decltype(std::declval<const Img&>().data())>
+  void UploadAsync(cudaStream_t stream, const Img& data) {
+    check_image_size(data);
+    SMX_SHIM_CHECK(smx_buffer_upload(handle_, stream, data.data(), (size_t)data.stride()));
+  }
+  template <typename Img, typename = decltype(std::declval<Img&>().stride()), typename = decltype(std::declval<Img&>().data())>
+  void DownloadAsync(cudaStream_t stream, Img* data) const {
+    check_image_size(*data);
+    SMX_SHIM_CHECK(smx_buffer_download(handle_, stream, data->data(), (size_t)data->stride()));
+  }
   void Clear(T value, cudaStream_t stream) { SMX_SHIM_CHECK(smx_buffer_clear(handle_, stream, &value)); }
   void SetTo(const CUDABuffer<T>& other, cudaStream_t stream) { SMX_SHIM_CHECK(smx_buffer_set_to(handle_, other.handle_, stream)); }
 
@@ -180,10 +213,19 @@ class CUDABuffer {
   CUDABuffer_<T>& ToCUDA() { return data_; }
 
  private:
+  template <typename Img>
+  void check_image_size(const Img& image) const {   // (the reference: CHECK_EQ on width and height, cuda_buffer_inl.h)
+    if ((int)image.width() != data_.width_ || (int)image.height() != data_.height_) {
+      std::fprintf(stderr, "FATAL %s:%d: image is %d x %d, the buffer %d x %d\n", __FILE__, __LINE__, (int)image.width(),
+                   (int)image.height(), data_.width_, data_.height_);
+      std::abort();
+    }
+  }
   smx_buffer handle_ = nullptr;
   CUDABuffer_<T> data_;
 };
 template <typename T> using CUDABufferPtr = std::shared_ptr<CUDABuffer<T>>;
+template <typename T> using CUDABufferConstPtr = std::shared_ptr<const CUDABuffer<T>>;   // VIS/cuda/cuda_buffer.h:134-135
 
 // ---- APP/cuda_depth_processing.cuh ------------------------------------------------------------------
 inline void BilateralFilteringAndDepthCutoffCUDA(cudaStream_t stream, float sigma_xy, float sigma_value_factor,

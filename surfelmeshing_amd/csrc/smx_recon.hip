@@ -466,6 +466,49 @@ __device__ __forceinline__ void keep(const float2& v) { keep(v.x); keep(v.y); }
 __device__ __forceinline__ void keep(const float4& v) { keep(v.x); keep(v.y); keep(v.z); keep(v.w); }
 __device__ __forceinline__ void keep(const uint4& v) { keep(v.x); keep(v.y); keep(v.z); keep(v.w); }
 
+// Stores of a launch's streaming OUTPUTS -- records no lane of the same launch reads again.  A plain store leaves its line
+// dirty in the XCD's L2, and the launch boundary behind the kernel has to write all of them back before the next launch of
+// the stream may start (MI355X_MICROARCH.md, price table row "boundary": 1.45 - 1.9 us + dirty bytes / 6 TB/s; the edge
+// kernel leaves 30 MB, the frame 79 MB).  Flavours (tools/boundary.hip measures them behind writers of 0 - 64 MB; the
+// in-frame A/Bs are in profiles/r6_ab_notes.md): 0 = plain, 1 = nt (non-temporal: kept in the L2, marked for early
+// eviction), 2 = sc1 (write-through: leaves the L2 while the kernel still runs, the line is dropped), 3 = sc0 sc1.
+// One switch per store site so that each can be judged on its own:
+#ifndef SMX_ST_FARBIN
+#define SMX_ST_FARBIN 0    // k_reg_accumulate: far-term records into the destination segments' bins (sparse 16-byte stores)
+#endif
+#ifndef SMX_ST_REGREC
+#define SMX_ST_REGREC 0    // k_reg_accumulate: the recent slots' dense records (own term; in-segment sums)
+#endif
+#ifndef SMX_ST_STEP
+#define SMX_ST_STEP 0      // k_reg_step: the new smooth positions (scattered 16-byte records)
+#endif
+#ifndef SMX_ST_INT
+#define SMX_ST_INT 0       // k_integrate: the P / N / C records of the slots it changed
+#endif
+#ifndef SMX_ST_IMG
+#define SMX_ST_IMG 0       // k_assoc_tiles: the five association images
+#endif
+typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+template <int kFlavour>
+__device__ __forceinline__ void out_store16(void* p, const v4u_t& w) {
+  if (kFlavour == 1) __builtin_nontemporal_store(w, reinterpret_cast<v4u_t*>(p));
+  else if (kFlavour == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(w) : "memory");
+  else if (kFlavour == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(w) : "memory");
+  else *reinterpret_cast<v4u_t*>(p) = w;
+}
+template <int kFlavour>
+__device__ __forceinline__ void out_store16(void* p, const uint4& v) { const v4u_t w = {v.x, v.y, v.z, v.w}; out_store16<kFlavour>(p, w); }
+template <int kFlavour>
+__device__ __forceinline__ void out_store16(void* p, const float4& v) {
+  const v4u_t w = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  out_store16<kFlavour>(p, w);
+}
+template <int kFlavour>
+__device__ __forceinline__ void out_store16(void* p, unsigned long long a, unsigned long long b) {
+  const v4u_t w = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+  out_store16<kFlavour>(p, w);
+}
+
 // ---------------------------------------------------------------------------------------------
 // The reference's 5 clears (cuda_surfel_reconstruction.cc:134-138) have no counterpart: k_assoc_tiles writes every pixel
 // of the association images with plain stores.  The maps of the multi-launch blend fallback (kernels.cc:165-166):
@@ -1038,11 +1081,19 @@ k_assoc_tiles(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<
   SMX_STAMP(stamps, 4);
   if (in_image) {
     const size_t k = (size_t)y * c.W + x;
+#if SMX_ST_IMG   // (4- and 8-byte stores, full lines per wavefront row: non-temporal only -- a scalar sc1 store is a fabric write of its own)
+    __builtin_nontemporal_store(__int_as_float(t.zmin[lane]), &sc.first_depth[k]);
+    __builtin_nontemporal_store(t.sup[lane], &sc.supporting[k]);
+    __builtin_nontemporal_store(t.cnt[lane], &sc.counts[k]);
+    __builtin_nontemporal_store((long long)t.sum[lane], &sc.depth_sums[k]);
+    __builtin_nontemporal_store(t.confl[lane], &sc.confl_key[k]);
+#else
     sc.first_depth[k] = __int_as_float(t.zmin[lane]);
     sc.supporting[k] = t.sup[lane];
     sc.counts[k] = t.cnt[lane];
     sc.depth_sums[k] = (long long)t.sum[lane];
     sc.confl_key[k] = t.confl[lane];
+#endif
   }
   SMX_STAMP(stamps, 5);
   ts_end(c.ts, kTsTilesEnd, blockIdx.x, gridDim.x);
@@ -1607,7 +1658,8 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
     if (R.dirty) {
       L.hot_epoch[i >> L.hot_shift] = (uint8_t)L.epoch;   // (stamp / colour mark may have changed, a replacement drops the links)
       if (L.dirty8) L.dirty8[i] = 1;
-      *S.group(kGroupP, i) = R.P; *S.group(kGroupN, i) = R.N; *S.group(kGroupC, i) = R.C;
+      out_store16<SMX_ST_INT>(S.group(kGroupP, i), R.P); out_store16<SMX_ST_INT>(S.group(kGroupN, i), R.N);
+      out_store16<SMX_ST_INT>(S.group(kGroupC, i), R.C);
       if (R.replaced) {
         *S.group(kGroupS, i) = make_float4(R.new_smooth.x, R.new_smooth.y, R.new_smooth.z, 0.0f);   // (whole records: see k_reg_step)
         S.set_neighbors(i, make_uint4(kInvalid, kInvalid, kInvalid, kInvalid));
@@ -2347,7 +2399,7 @@ __device__ __forceinline__ void edge_segment(const Surfels& S, const EdgeArgs& e
       }
     }
     // (second half of the slot's dense record; the first half -- the in-segment sums -- follows when the segment is through)
-    if (rec) reg_rec[rec_own_offset + (size_t)(base + rec_rank)] = make_float4(rg.x, rg.y, rg.z, __int_as_float(own_count));
+    if (rec) out_store16<SMX_ST_REGREC>(&reg_rec[rec_own_offset + (size_t)(base + rec_rank)], make_float4(rg.x, rg.y, rg.z, __int_as_float(own_count)));
   }
   __syncthreads();
   // one lane per destination reserves the workgroup's run in that bin; the table then holds the run's start
@@ -2373,8 +2425,8 @@ __device__ __forceinline__ void edge_segment(const Surfels& S, const EdgeArgs& e
     const uint32_t target = far_target[q] & 0x3FFFFFFFu, cls = far_target[q] >> 30;
     const uint32_t pos = hcnt[where & 1023u] + (where >> 10);
     if (pos < fb.cap)
-      fb.rec[(size_t)(target / kSegB) * fb.cap + pos] =
-          make_uint4((target % kSegB) | (cls << 10), (uint32_t)far_q[q][0], (uint32_t)far_q[q][1], (uint32_t)far_q[q][2]);
+      out_store16<SMX_ST_FARBIN>(&fb.rec[(size_t)(target / kSegB) * fb.cap + pos],
+                                 make_uint4((target % kSegB) | (cls << 10), (uint32_t)far_q[q][0], (uint32_t)far_q[q][1], (uint32_t)far_q[q][2]));
     else
       far_term_spill(grad_acc, fb, target, far_q[q][0], far_q[q][1], far_q[q][2], (int)cls + 1);
   }
@@ -2389,7 +2441,7 @@ __device__ __forceinline__ void edge_segment(const Surfels& S, const EdgeArgs& e
     const uint32_t rank = lrank[rel];
     if (rank == 0xFFFFu) continue;
     const unsigned long long v0 = lacc[rel], v1 = lacc[kSegAcc + rel];
-    *reinterpret_cast<ulonglong2*>(&reg_rec[(size_t)(base + rank)]) = make_ulonglong2(v0, v1);
+    out_store16<SMX_ST_REGREC>(&reg_rec[(size_t)(base + rank)], v0, v1);
   }
 }
 
@@ -2565,7 +2617,7 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, const floa
       // (ONE 16-byte store, the unused fourth word included: three scalar stores leave four bytes of every record clean, so
       // no 64-byte sector of the S array is ever fully dirty and every write-back is a partial one -- sparse stores retire
       // at 21 G/s = 0.7 TB/s on this chip against 5 TB/s for full sectors, profiles/r17_counter_calibration.md)
-      *S.group(kGroupS, i) = make_float4(sp.x - step * grad.x, sp.y - step * grad.y, sp.z - step * grad.z, rs[sub].w);
+      out_store16<SMX_ST_STEP>(S.group(kGroupS, i), make_float4(sp.x - step * grad.x, sp.y - step * grad.y, sp.z - step * grad.z, rs[sub].w));
     }
   }
   ts_end(ts, kTsRegEnd, blockIdx.x, min(gridDim.x, n_steps));   // (the workgroups that walked the last steps of the first round)
