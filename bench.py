@@ -261,6 +261,7 @@ def host_frames_pass(wl, plan, base, count, api, torch):
         keep += [pd, pc]
         uploads.append((f, pd.array, pc.array))
     steps = [pipe.make_step(*plan[j]) for j in range(base, base + count)]
+    pipe.upload_counts(reset=True)
     pipe.run_streamed(steps[:warm], uploads[:warm])
     torch.cuda.synchronize()
     t = time.perf_counter()
@@ -271,7 +272,9 @@ def host_frames_pass(wl, plan, base, count, api, torch):
     nbytes = wl.w * wl.h * 5
     for k in keep:
         k.close()
+    staged, copy_engine = pipe.upload_counts(reset=True)
     return {"value": n / dt, "unit": "frames/s", "steps": n, "ms_per_step": 1e3 * dt / n,
+            "frames_staged_by_copy_kernels": staged, "frames_by_copy_engine": copy_engine,
             "h2d_bytes_per_frame": nbytes, "h2d_GBs": nbytes * n / dt / 1e9,
             "note": "inputs copied from page-locked host memory on the preprocessing stream "
                     "(smx_driver_run_streamed); not the headline value"}

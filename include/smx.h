@@ -20,7 +20,8 @@
  *    the reference, Integrate does not block the host (the surfel count lives
  *    in device memory), so counts are read with smx_recon_counts(), which
  *    synchronises the stream.
- *  - single caller thread per object; no process-global state (the reference's
+ *  - single caller thread per object; no process-global state -- the library neither keeps any nor touches the process
+ *    environment (smx_runtime_advice reports what the application should set) -- (the reference's
  *    function-local static buffer at APP/cuda_surfel_reconstruction_kernels.cc:479
  *    is per-object here), so one object per GPU / per stream works.
  *  - camera cx, cy are in the pixel-CORNER convention, as
@@ -60,6 +61,11 @@ typedef struct {
 } smx_buffer_desc;
 
 const char* smx_last_error(void);
+/* Runtime settings the frame loop wants and the library does not make itself (process-global: the application's to set):
+ * returns the number of recommendations (0 = none) and their text.  Today: GPU_MAX_HW_QUEUES >= 8, read by the HIP runtime at
+ * the process's first HIP call (INTEGRATION.md "Streams, queues, priorities").  The first smx_recon_create of a process prints
+ * the text once on stderr unless SMX_QUIET=1. */
+int smx_runtime_advice(char* text, size_t capacity);
 /* Number of visible HIP devices / select one for the calling thread. */
 int smx_device_count(int* count);
 int smx_set_device(int device);
@@ -72,6 +78,10 @@ int smx_stream_create_with_priority(smx_stream* out, int32_t priority_class);
  * upload from and slow for the CPU to read. */
 int smx_host_alloc(void** out, size_t bytes, int32_t write_combined);
 int smx_host_free(void* p);
+/* *yes = 1 if [p, p + bytes) lies inside page-locked memory the device can read (smx_host_alloc / hipHostMalloc /
+ * hipHostRegister), else 0.  What smx_buffer_upload_by_kernel requires of its source; a caller with a choice of routes asks
+ * before it enqueues anything (smx_driver does). */
+int smx_host_is_page_locked(const void* p, size_t bytes, int32_t* yes);
 int smx_stream_destroy(smx_stream s);
 int smx_stream_synchronize(smx_stream s);
 /* Events for cross-stream ordering (hipEvent_t, timing disabled): the frame driver overlaps depth
@@ -282,13 +292,16 @@ int smx_recon_export_vertices(smx_recon r, smx_stream s, const smx_buffer_desc* 
                               const smx_buffer_desc* color_buffer);
 /* GetTimings, .h:115-122 / .cc:412-429: data association, merging, blending, integration, neighbor update, new surfel
  * creation, regularization (ms) of the LAST smx_recon_integrate call; like the reference it waits until that call is
- * through (cudaEventSynchronize(regularization_end_event_), cc:420).  On from the first call, at no measurable cost: the
- * stages are not bracketed by event records (each a packet between two kernels of a stream that is never idle: fourteen
+ * through (cudaEventSynchronize(regularization_end_event_), cc:420).  On from the first call; cost 1.4 - 2.2 % of the frame rate at
+ * 640 x 480 / 5 M surfels, nothing measurable at 1280 x 960 (bench.py: stage_timing_cost; smx_recon_set_timing_enabled(r, 0)
+ * switches the stamps off): the stages are not bracketed by event records (each a packet between two kernels of a stream that is never idle: fourteen
  * of them cost a third of the frame rate here) but stamped by the kernels themselves -- device wall clock, first
  * workgroup in of the launch that begins a stage / of the launch that follows it on the same stream, last workgroups out
  * where nothing follows -- into a per-call record.  Stages the
- * design fuses into another stage's launch report 0: merging (decided in the association kernel, applied by the
- * integration kernel) and creation (in the neighbour-update launch). */
+ * design fuses into another stage's launch report 0 -- out_ms[1] (surfel_merging: decided in the association kernel,
+ * applied by the integration kernel) and out_ms[5] (new_surfel_creation: the first workgroups of the neighbour-update
+ * launch): their time is INSIDE out_ms[0] / out_ms[3] and out_ms[4], so the seven values still add up to the call; a caller
+ * that accumulates the reference's seven columns (APP/main.cc:1511-1530) gets two empty ones. */
 int smx_recon_get_timings(smx_recon r, float out_ms[7]);
 /* The same for a frame loop that must not wait: the stage times of the NEWEST call whose record has been handed over --
  * every call copies the record of the call before the previous one (complete by stream order at that point) into

@@ -104,6 +104,10 @@ int smx_driver_debug_streams(smx_driver d, smx_stream out[2]);
  * by kernels on a staging queue of its own (page-locked sources: smx_host_alloc), so that the copy for step i + 1 runs beside
  * the preprocessing of step i; 0 = the copy engine in front of the step's preprocessing, in the same queue (rounds 1-4). */
 int smx_driver_set_staged_uploads(smx_driver d, int32_t enabled);
+/* How many frames of smx_driver_run_streamed took the staged route and how many the copy engine (pageable source, staging
+ * switched off, no overlap, or two preprocessing queues): a frame loop that believes it stages and does not would otherwise
+ * only show up as a lower frame rate.  reset = 1 zeroes the counters afterwards. */
+int smx_driver_upload_counts(smx_driver d, uint64_t* staged, uint64_t* copy_engine, int32_t reset);
 /* The reference's frame loop reads the seven stage times after EVERY Integrate (APP/main.cc:1511-1524) and adds them to
  * running sums.  mode 1: every step of smx_driver_run / _run_streamed does the same with GetTimingsNoWait (no stall: the
  * newest call known to be through; each call is added once); mode 2: with the blocking GetTimings (the reference's

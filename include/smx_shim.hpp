@@ -44,6 +44,11 @@ struct float2 { float x, y; };
 
 namespace vis {
 
+// Process-level settings the frame loop wants (smx.h: smx_runtime_advice; INTEGRATION.md "Streams, queues, priorities"): call
+// at the top of main(), BEFORE the first HIP call of the process -- the HIP runtime reads the variable when it initialises.
+// Never overrides a value the user exported.  The library itself does not touch the environment.
+inline void SmxSetRecommendedRuntimeDefaults() { setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite*/ 0); }
+
 typedef uint8_t u8;
 typedef uint16_t u16;
 typedef uint32_t u32;
@@ -511,6 +516,11 @@ class CUDASurfelReconstruction {
   void ExportVertices(cudaStream_t stream, CUDABuffer<float>* position_buffer, CUDABuffer<u8>* color_buffer) {
     SMX_SHIM_CHECK(smx_recon_export_vertices(handle_, stream, position_buffer->ToCUDA().desc(), color_buffer->ToCUDA().desc()));
   }
+  // APP/cuda_surfel_reconstruction.cc:412-429.  Two of the reference's seven columns are ALWAYS 0 here, because their work
+  // has no launch of its own: *surfel_merging (the merges are decided in the association kernel and applied by the
+  // integration kernel: its time is inside *data_association and *integration) and *new_surfel_creation (the first
+  // workgroups of the neighbour-update launch: inside *neighbor_update).  The seven values still add up to the call; a
+  // caller that logs per-column sums like APP/main.cc:1511-1530 should fold columns 2 and 6 into their neighbours.
   void GetTimings(float* data_association, float* surfel_merging, float* measurement_blending, float* integration,
                   float* neighbor_update, float* new_surfel_creation, float* regularization) {
     float t[7];

@@ -8,8 +8,9 @@ torch has loaded, so both share one runtime per process.
 import ctypes as C
 import os
 
-# (see smx_buffer.hip smx_runtime_defaults: one hardware queue per busy stream, decided when the HIP runtime initialises --
-# which may be before libsmx.so is loaded if torch touched the GPU first, so the default is raised as early as this import)
+# One hardware queue per busy stream (smx_buffer.hip: runtime_advice): decided when the HIP runtime initialises, i.e. at the
+# process's first HIP call -- possibly torch's -- so this module, the APPLICATION side of the binding, raises the default as
+# early as its import.  libsmx.so itself does not touch the environment (smx_runtime_advice reports instead).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (SMX_LIB_PATH: A/B measurements of two builds in one session; the product loads the in-tree library)
@@ -79,7 +80,7 @@ class NNStats(C.Structure):
 
 # every symbol include/smx.h declares (tests/test_abi.py checks the .so exports them all)
 EXPORTS = [
-    "smx_last_error", "smx_device_count", "smx_set_device", "smx_device_name",
+    "smx_last_error", "smx_runtime_advice", "smx_host_is_page_locked", "smx_device_count", "smx_set_device", "smx_device_name",
     "smx_stream_create", "smx_stream_create_with_priority", "smx_host_alloc", "smx_host_free", "smx_stream_destroy", "smx_stream_synchronize", "smx_debug_marker", "smx_debug_handover_probe",
     "smx_event_create", "smx_event_create_timed", "smx_event_elapsed_ms", "smx_event_destroy", "smx_event_record", "smx_stream_wait_event",
     "smx_buffer_create", "smx_buffer_destroy", "smx_buffer_get_desc", "smx_buffer_upload", "smx_buffer_upload_by_kernel", "smx_buffer_download",

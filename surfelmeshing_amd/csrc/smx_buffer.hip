@@ -25,11 +25,23 @@ void set_error(const char* fmt, ...) {
 // queues (default 4); when two BUSY streams land on one queue their packets serialise, and the frame falls into a slower
 // mode for the rest of the process -- 3 of 14 runs at C2, 5 670 instead of 6 380 frames/s (period 165 instead of 150 us: the
 // internal stream waits 20 - 35 us for the front), 4 of 128 with 8 queues (profiles/r5_ab_notes.md: the rate also rises with
-// every stream the process creates, busy or not -- which is why the library creates none it can do without).  The variable is read
-// when the runtime initialises, i.e. at the first HIP call of the process: the default is raised here, when the library is
-// loaded (never overriding a value the user has set); a process that has called HIP before it loads libsmx sets the
-// variable itself.
-__attribute__((constructor)) static void smx_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite*/ 0); }
+// every stream the process creates, busy or not -- which is why the library creates none it can do without).  The variable is
+// read when the runtime initialises, i.e. at the first HIP call of the PROCESS, so it is the application's to set (rounds 4-5
+// raised it from a constructor of this library: process-global state changed behind the host's back, a setenv racing other
+// threads' getenv, and no effect at all when HIP was already up -- advisor r5).  The library only REPORTS:
+// smx_runtime_advice(), and one line on stderr from the first smx_recon_create of a process that runs without it
+// (SMX_QUIET=1 silences it).  bench.py, the Python binding (_lib.py, before it imports torch) and the shim's
+// vis::SmxSetRecommendedRuntimeDefaults() (called by the application at the top of main) set it.
+static int runtime_advice(char* text, size_t capacity) {
+  const char* q = getenv("GPU_MAX_HW_QUEUES");
+  const int have = q ? atoi(q) : 0;
+  if (have >= 8) { if (text && capacity) text[0] = 0; return 0; }
+  if (text && capacity)
+    snprintf(text, capacity, "GPU_MAX_HW_QUEUES is %s: the HIP runtime multiplexes this library's 4-5 busy streams onto %s hardware "
+             "queues, and about one run in five is a tenth slower; export GPU_MAX_HW_QUEUES=8 before the process's first HIP call",
+             q ? q : "unset", q ? q : "4");
+  return 1;
+}
 
 struct smx_buffer_s {
   smx_buffer_desc desc;
@@ -65,6 +77,8 @@ int smx_debug_marker(smx_stream s, int32_t id) {
 }
 
 const char* smx_last_error(void) { return g_error; }
+
+int smx_runtime_advice(char* text, size_t capacity) { return runtime_advice(text, capacity); }
 
 int smx_device_count(int* count) {
   SMX_CHECK_ARG(count != nullptr);
@@ -112,7 +126,9 @@ int smx_stream_create_with_priority(smx_stream* out, int32_t priority_class) {
 int smx_debug_handover_probe(smx_stream sa, smx_stream sb, int32_t n, float* us_per_handover) {
   SMX_CHECK_ARG(n > 0 && n <= 100000 && us_per_handover != nullptr);
   hipStream_t a = (hipStream_t)sa, b = (hipStream_t)sb;
-  hipEvent_t t0, t1, ea, eb;
+  hipEvent_t t0 = nullptr, t1 = nullptr, ea = nullptr, eb = nullptr;
+  // (every exit destroys what was created: the SMX_HIP early returns used to leak the four events)
+  struct Cleanup { hipEvent_t *a, *b, *c, *d; ~Cleanup() { for (hipEvent_t* e : {a, b, c, d}) if (*e) (void)hipEventDestroy(*e); } } cleanup{&t0, &t1, &ea, &eb};
   SMX_HIP(hipEventCreate(&t0)); SMX_HIP(hipEventCreate(&t1));
   SMX_HIP(hipEventCreateWithFlags(&ea, hipEventDisableTiming | hipEventReleaseToDevice));
   SMX_HIP(hipEventCreateWithFlags(&eb, hipEventDisableTiming | hipEventReleaseToDevice));
@@ -130,7 +146,6 @@ int smx_debug_handover_probe(smx_stream sa, smx_stream sb, int32_t n, float* us_
   float ms = 0;
   SMX_HIP(hipEventElapsedTime(&ms, t0, t1));
   *us_per_handover = ms * 1e3f / (2.0f * (float)n);
-  (void)hipEventDestroy(t0); (void)hipEventDestroy(t1); (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
   SMX_LAUNCH_CHECK();
   return SMX_OK;
 }
@@ -140,6 +155,32 @@ int smx_host_alloc(void** out, size_t bytes, int32_t write_combined) {
   void* p = nullptr;
   SMX_HIP(hipHostMalloc(&p, bytes, write_combined ? hipHostMallocWriteCombined : hipHostMallocDefault));
   *out = p;
+  return SMX_OK;
+}
+
+// (device view of a page-locked host range, or null; *room = bytes of the allocation behind the pointer, SIZE_MAX if unknown)
+static void* pagelocked_device_view(const void* p, size_t* room) {
+  void* dsrc = nullptr;
+  if (p == nullptr || hipHostGetDevicePointer(&dsrc, const_cast<void*>(p), 0) != hipSuccess || dsrc == nullptr) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  *room = SIZE_MAX;
+  if (hipMemGetAddressRange(&base, &size, dsrc) == hipSuccess && base != nullptr && size != 0) {
+    const size_t off = (size_t)(static_cast<char*>(dsrc) - static_cast<char*>(base));
+    *room = off <= size ? size - off : 0;
+  } else {
+    (void)hipGetLastError();   // (no range known -- memory registered by the caller: its size is the caller's word)
+  }
+  return dsrc;
+}
+
+int smx_host_is_page_locked(const void* p, size_t bytes, int32_t* yes) {
+  SMX_CHECK_ARG(yes != nullptr);
+  size_t room = 0;
+  *yes = (pagelocked_device_view(p, &room) != nullptr && bytes <= room) ? 1 : 0;
   return SMX_OK;
 }
 
@@ -262,10 +303,17 @@ int smx_buffer_upload_by_kernel(smx_buffer b, smx_stream s, const void* src, siz
   SMX_CHECK_ARG(b != nullptr && src != nullptr);
   const size_t row_bytes = (size_t)b->desc.width * b->elem_bytes;
   if (src_pitch == 0) src_pitch = row_bytes;
-  void* dsrc = nullptr;
-  if (hipHostGetDevicePointer(&dsrc, const_cast<void*>(src), 0) != hipSuccess || dsrc == nullptr) {
-    (void)hipGetLastError();
+  // The kernel reads height rows of row_bytes at src_pitch: the page-locked allocation has to cover them (the copy engine
+  // would refuse a range that runs past it; a kernel would fault the GPU instead).
+  size_t room = 0;
+  void* dsrc = pagelocked_device_view(src, &room);
+  if (dsrc == nullptr) {
     set_error("smx_buffer_upload_by_kernel: the source is not page-locked (smx_host_alloc) memory");
+    return SMX_ERR_INVALID_ARGUMENT;
+  }
+  const size_t need = b->desc.height > 0 ? (size_t)(b->desc.height - 1) * src_pitch + row_bytes : 0;
+  if (need > room) {
+    set_error("smx_buffer_upload_by_kernel: the source needs %zu bytes, its page-locked allocation holds %zu behind the pointer", need, room);
     return SMX_ERR_INVALID_ARGUMENT;
   }
   const int wide = (row_bytes % 16 == 0 && src_pitch % 16 == 0 && b->desc.pitch % 16 == 0 &&

@@ -73,6 +73,7 @@ struct smx_driver_s {
   // the uploads take the old route): a stream of its own for it made the slow mode of smx_runtime_defaults come back for
   // every run of the process, the resident ones included (4 of 14: profiles/r5_ab_notes.md).
   bool staged_uploads = true;
+  uint64_t uploads_staged = 0, uploads_copy_engine = 0;   // frames of smx_driver_run_streamed by the route they took
   // Two preprocessing queues: the bilateral filter of frame f + 1 (VALU-bound, one 310-register wavefront per SIMD) runs
   // beside the outlier cull and the tail of frame f (gathers) instead of behind them.  At 1280 x 960 the single queue is
   // busy all of the time and the frame waits for it (profiles/r21_timeline_c3.md).
@@ -330,25 +331,29 @@ static int upload_on(smx_driver d, cudaStream_t stream, const smx_driver_host_fr
   return SMX_OK;
 }
 
-// The staged form: both images copied by kernels on the staging queue (page-locked sources only: false = not page-locked,
-// nothing enqueued); `consumer` -- the queue whose next kernels read the frame -- waits for the copy's completion event.
+// The staged form: both images copied by kernels on the staging queue (page-locked sources only); `consumer` -- the queue
+// whose next kernels read the frame -- waits for the copy's completion event.  ONE route per frame: both sources are probed
+// before anything is enqueued, and a frame with a pageable image takes the copy-engine route as a whole (*staged = false,
+// nothing enqueued here; round 5 found out half-way, after the reuse wait and the depth copy were on the staging queue, and
+// finished a mixed frame with a host-side synchronisation inside the loop -- advisor r5).
 static int upload_staged(smx_driver d, cudaStream_t consumer, const smx_driver_host_frame& u, bool* staged) {
   *staged = false;
   if (u.depth == nullptr) { *staged = true; return SMX_OK; }
   if (u.color == nullptr) return fail("upload without a colour image");
+  const size_t px = (size_t)d->cfg.width * d->cfg.height;
+  int32_t depth_ok = 0, color_ok = 0;
+  SMX_SHIM_CHECK(smx_host_is_page_locked(u.depth, px * sizeof(u16), &depth_ok));
+  SMX_SHIM_CHECK(smx_host_is_page_locked(u.color, px * 3, &color_ok));
+  if (!depth_ok || !color_ok) return SMX_OK;   // (the caller falls back to upload_on)
   Frame* f = get_or_make(d, u.frame_index);
   if (!f->uploaded) SMX_SHIM_CHECK(smx_event_create(&f->uploaded));
   if (f->last_reader != 0) {
     WorkSet* w = (f->last_reader >= d->frame_counter) ? d->last : d->prev;
     if (w->used) SMX_SHIM_CHECK(smx_stream_wait_event(d->pre_stream2, w->integrated));
   }
-  if (!f->depth.UploadByKernelAsync(d->pre_stream2, u.depth)) return SMX_OK;   // (the caller falls back to upload_on)
-  if (!f->color.UploadByKernelAsync(d->pre_stream2, reinterpret_cast<const Vec3u8*>(u.color), f->uploaded)) {
-    // (depth page-locked, colour not: finish with the copy engine on the same queue and mark the end with a record)
-    f->color.UploadAsync(d->pre_stream2, reinterpret_cast<const Vec3u8*>(u.color));
-    SMX_SHIM_CHECK(smx_event_record(f->uploaded, d->pre_stream2));
-    SMX_SHIM_CHECK(smx_stream_synchronize(d->pre_stream2));   // (a copy-engine write: see upload_on -- rare path, keep it simple and safe)
-  }
+  if (!f->depth.UploadByKernelAsync(d->pre_stream2, u.depth) ||
+      !f->color.UploadByKernelAsync(d->pre_stream2, reinterpret_cast<const Vec3u8*>(u.color), f->uploaded))
+    return fail("staged upload refused a source that was probed page-locked");
   SMX_SHIM_CHECK(smx_stream_wait_event(consumer, f->uploaded));
   *staged = true;
   return SMX_OK;
@@ -360,7 +365,9 @@ static int run_one(smx_driver d, smx_stream s, const smx_driver_step& step, cons
   int rc;
   if (arriving) {
     bool staged = false;
+    // (with two preprocessing queues the staging queue is the second of them: the copy-engine route, counted below)
     if (d->overlap && d->staged_uploads && !d->split_pre) { rc = upload_staged(d, d->pre_stream, *arriving, &staged); if (rc != SMX_OK) return rc; }
+    if (arriving->depth != nullptr) ++(staged ? d->uploads_staged : d->uploads_copy_engine);
     if (!staged) {
       rc = upload_on(d, d->overlap ? d->pre_stream : (cudaStream_t)s, *arriving);
       if (rc != SMX_OK) return rc;
@@ -598,6 +605,14 @@ int smx_driver_debug_streams(smx_driver d, smx_stream out[2]) {   // (measuremen
 int smx_driver_set_staged_uploads(smx_driver d, int32_t enabled) {
   if (!d) return fail("null argument");
   d->staged_uploads = enabled != 0;
+  return SMX_OK;
+}
+
+int smx_driver_upload_counts(smx_driver d, uint64_t* staged, uint64_t* copy_engine, int32_t reset) {
+  if (!d) return fail("null argument");
+  if (staged) *staged = d->uploads_staged;
+  if (copy_engine) *copy_engine = d->uploads_copy_engine;
+  if (reset) { d->uploads_staged = 0; d->uploads_copy_engine = 0; }
   return SMX_OK;
 }
 

@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #include "smx_common.hpp"
@@ -3112,6 +3113,14 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   int device = 0;
   { const int rcd = resolve_device(device_id, &device); if (rcd != SMX_OK) return rcd; }
   SMX_ON_DEVICE(device);
+  {   // (once per process: what the application should have set before its first HIP call -- smx_runtime_advice)
+    static std::atomic<int> advised{0};
+    char text[512];
+    if (!advised.exchange(1) && smx_runtime_advice(text, sizeof(text)) > 0) {
+      const char* quiet = getenv("SMX_QUIET");
+      if (!(quiet && quiet[0] == '1')) fprintf(stderr, "libsmx: %s\n", text);
+    }
+  }
   smx_recon_s* r = new smx_recon_s();
   memset(r, 0, sizeof(*r));
   r->device = device;
@@ -3274,6 +3283,9 @@ int smx_recon_destroy(smx_recon r) {
 int smx_recon_set_timing_enabled(smx_recon r, int32_t enabled) {
   SMX_CHECK_ARG(r != nullptr && enabled >= 0 && enabled <= 7);
   SMX_ON_DEVICE(r->device);
+  // (bit 1 alone -- events around every kernel, a measurement mode -- keeps the stage stamps on: GetTimings must not go
+  // silent because a tool asked for per-kernel times; 0 switches everything off)
+  if ((enabled & 3) == 2) enabled |= 4;
   r->timing_enabled = enabled;
   if (!(enabled & 1)) r->have_timings = false;
   return SMX_OK;
@@ -3869,12 +3881,14 @@ int smx_recon_check_triangles(smx_recon r, smx_stream s, const uint32_t* triangl
 namespace {
 // stage times of one stamp record (ms); false if the record is not that call's or the call did not get through
 bool stage_ms_from_stamps(const unsigned long long* t, unsigned long long seq, int khz, float out_ms[7]) {
-  if (t[kTsSeq] != seq || t[kTsCullBegin] == 0 || t[kTsIntBegin] == 0) return false;
+  // (a call whose second half was left out -- smx_recon_debug_set_skip front-only -- has no integration stamp: the stages that
+  // ran are reported, the others stay 0)
+  if (t[kTsSeq] != seq || t[kTsCullBegin] == 0) return false;
   auto ms = [&](unsigned long long a, unsigned long long b) { return (b > a && a != 0) ? (float)((double)(b - a) / (double)khz) : 0.0f; };
   auto first = [](unsigned long long a, unsigned long long b, unsigned long long c) { return a ? a : (b ? b : c); };
   // a stage ends where the next launch of its stream begins; the tail workgroups' maximum where there is no such launch
   const unsigned long long tiles_end = first(t[kTsBlendBegin], t[kTsTilesEnd], t[kTsCullBegin]);
-  const unsigned long long int_end = first(t[kTsUpdBegin], t[kTsIntEnd], t[kTsIntBegin]);
+  const unsigned long long int_end = first(t[kTsUpdBegin], t[kTsIntEnd], first(t[kTsIntBegin], t[kTsBlendEnd], tiles_end));
   const unsigned long long upd_end = first(t[kTsRegBegin], t[kTsUpdEnd], int_end);
   out_ms[0] = ms(t[kTsCullBegin], tiles_end);        // data association: cull step, pass A, association tiles
   out_ms[1] = 0.0f;                                  // surfel merging: decided inside the tile kernel, applied by k_integrate

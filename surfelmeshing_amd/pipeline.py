@@ -184,7 +184,7 @@ class DriverStep(_C.Structure):
 DRIVER_EXPORTS = ["smx_driver_create", "smx_driver_destroy", "smx_driver_recon", "smx_driver_upload_frame",
                   "smx_driver_render_frame", "smx_driver_release_frame", "smx_driver_frame_descs", "smx_driver_run",
                   "smx_driver_work_descs", "smx_driver_download_frame", "smx_driver_download_work", "smx_driver_set_overlap", "smx_driver_set_fused_tail", "smx_driver_set_fused_head", "smx_driver_set_run_ahead", "smx_driver_set_split_preprocessing",
-                  "smx_driver_run_streamed", "smx_driver_debug_streams", "smx_driver_set_staged_uploads", "smx_driver_set_read_timings", "smx_driver_timing_sums", "smx_driver_debug_prepare", "smx_driver_profile_begin", "smx_driver_profile_end"]
+                  "smx_driver_run_streamed", "smx_driver_debug_streams", "smx_driver_set_staged_uploads", "smx_driver_upload_counts", "smx_driver_set_read_timings", "smx_driver_timing_sums", "smx_driver_debug_prepare", "smx_driver_profile_begin", "smx_driver_profile_end"]
 
 
 class DriverHostFrame(_C.Structure):
@@ -244,6 +244,12 @@ class NativeFramePipeline:
 
     def set_staged_uploads(self, enabled):
         _smxlib.check(_smxlib.load().smx_driver_set_staged_uploads(self._d, _C.c_int32(1 if enabled else 0)))
+
+    def upload_counts(self, reset=False):
+        """(frames of run_streamed that took the staged route, frames that took the copy engine)"""
+        a, b = _C.c_uint64(0), _C.c_uint64(0)
+        _smxlib.check(_smxlib.load().smx_driver_upload_counts(self._d, _C.byref(a), _C.byref(b), _C.c_int32(1 if reset else 0)))
+        return int(a.value), int(b.value)
 
     def set_read_timings(self, mode):
         """0 = off, 1 = GetTimingsNoWait after every Integrate of the native loop, 2 = the blocking GetTimings (APP/main.cc:1511)."""

@@ -315,10 +315,9 @@ def test_self_queries_and_kernel_modes_agree(smx):
         # the self-query entry point under the other tile kernel as well (the first call ran the default, mode 2:
         # one lane per query, with the dense clump's queries -- more than 32 matches -- redone by the tile kernel)
         m0 = np.arange(64)[None, :] < cs[:, None]
-        for self_mode in (0,):
-            nn.set_query_mode(self_mode)
-            c0, d0, i0 = nn.FindNearestOfIndexedPoints(n, 64, radius_squared=r2, factor=1.0, state=st, skip_mask=mask)
-            assert np.array_equal(c0, cs) and np.array_equal(i0[m0], is_[m0]) and np.array_equal(d0[m0].view(np.uint32), ds[m0].view(np.uint32)), self_mode
+        nn.set_query_mode(0)
+        c0, d0, i0 = nn.FindNearestOfIndexedPoints(n, 64, radius_squared=r2, factor=1.0, state=st, skip_mask=mask)
+        assert np.array_equal(c0, cs) and np.array_equal(i0[m0], is_[m0]) and np.array_equal(d0[m0].view(np.uint32), ds[m0].view(np.uint32))
         nn.set_query_mode(2)
         assert (cs > 32).sum() > 100 and (cs < 32).sum() > 1000        # both paths of mode 2 were taken
         for mode in (0, 1, 2):

@@ -235,6 +235,21 @@ def test_cuda_buffer_roundtrips(smx):
         assert np.array_equal(b.Download(), src.array)
         with pytest.raises(smx.SmxError):
             b.UploadByKernelAsync(None, np.ascontiguousarray(src.array.copy()))
+    # ... and so is a page-locked source that is too small for the rows the kernel would read (advisor r5: it used to fault the GPU)
+    import ctypes as C
+    from surfelmeshing_amd import _lib
+    L = _lib.load()
+    big, small = smx.PagelockedArray((256, 1024), np.uint16), smx.PagelockedArray((16, 1024), np.uint16)
+    yes = C.c_int32(-1)
+    for arr, nbytes, want in ((big.array, big.array.nbytes, 1), (small.array, small.array.nbytes, 1), (small.array, big.array.nbytes, 0),
+                              (np.zeros(64, np.uint16), 128, 0)):
+        _lib.check(L.smx_host_is_page_locked(C.c_void_p(arr.ctypes.data), C.c_size_t(nbytes), C.byref(yes)))
+        assert yes.value == want, (nbytes, want)
+    b = smx.CUDABuffer(256, 1024, np.uint16)
+    rc = L.smx_buffer_upload_by_kernel(b._h, C.c_void_p(0), C.c_void_p(small.array.ctypes.data), C.c_size_t(0), C.c_void_p(0))
+    assert rc != 0 and b"needs" in L.smx_last_error()
+    b.UploadByKernelAsync(None, big.array)
+    smx.StreamSynchronize(None)
     # byte-range part transfers on a 1-row buffer (UploadPartAsync / DownloadPartAsync)
     b = smx.CUDABuffer(1, 1000, np.uint32)
     b.Clear(0)
@@ -980,6 +995,11 @@ def test_native_driver_streamed_uploads(smx, overlap, staged):
         d, c = s.frame(src)
         if f % 3 == 0:                                   # pageable memory works too (the copy then blocks the host)
             hd, hc = np.ascontiguousarray(d), np.ascontiguousarray(c)
+        elif f == 10:                                    # depth page-locked, colour not: the frame takes ONE route (copy engine)
+            pd = smx.PagelockedArray(d.shape, np.uint16)
+            pd.array[...] = d
+            keep.append(pd)
+            hd, hc = pd.array, np.ascontiguousarray(c)
         else:
             pd, pc = smx.PagelockedArray(d.shape, np.uint16, write_combined=(f % 4 == 1)), smx.PagelockedArray(c.shape, np.uint8)
             pd.array[...] = d
@@ -990,6 +1010,9 @@ def test_native_driver_streamed_uploads(smx, overlap, staged):
     pn.run_streamed(steps[:9], uploads[:9])
     pn.run_streamed(steps[9:], uploads[9:])          # a second call continues the stream
     smx.StreamSynchronize(None)
+    # every frame took one route, and the driver says which (a loop that believes it stages and does not would only be slower)
+    pinned = sum(1 for f in range(4, 20) if f % 3 != 0 and f != 10)
+    assert pn.upload_counts() == ((pinned, 16 - pinned) if (overlap and staged) else (0, 16))
     n = po.recon.surfels_size
     assert pn.reconstruction.surfels_size() == n
     assert_surfels_match(pn.reconstruction.debug_download_surfels(n), po.recon.surfels(), n)
