@@ -741,7 +741,7 @@ def run_integrate(args):
     # (round 2: 4144 frames/s at --steps 20 --warmup 5 against 3873 at --steps 300 --warmup 20).
     first = g_end + 10
     ub = set(x for x in args.ub.split(",") if x)
-    assert ub <= {"hoist-pre", "no-reg", "front-only"}, "unknown --ub item"
+    assert ub <= {"hoist-pre", "no-reg", "front-only", "no-front-wait", "no-upd-wait"}, "unknown --ub item"
     rec0 = wl.pipe.reconstruction
     names = rec0.kernel_time_names()
     # kernels judged in the frame: the Integrate slots (not the empty slot that measures the time stamps themselves, not the
@@ -827,7 +827,8 @@ def run_integrate(args):
         if warm_steps is not None:
             wl.pipe.prepare_array(*warm_steps)
         wl.pipe.prepare_array(*timed_steps)
-    rec.debug_set_skip((1 if "no-reg" in ub else 0) | (2 if "front-only" in ub else 0))
+    rec.debug_set_skip((1 if "no-reg" in ub else 0) | (2 if "front-only" in ub else 0) | (4 if "no-front-wait" in ub else 0) |
+                       (8 if "no-upd-wait" in ub else 0))
     # Time stamps around the dominant kernel only (2 records per frame on the stream it is launched on) stay on during
     # the timed region; everything else is measured in separate passes.
     if warm_steps is not None:
@@ -866,7 +867,8 @@ def run_integrate(args):
             print(json.dumps({
                 "metric": "UPPER BOUND (timing only), frames/s", "upper_bound": sorted(ub),
                 "note": "hoist-pre: the timed frames were preprocessed before the timed region (results unchanged); no-reg: "
-                        "pass B / edges / step left out (map WRONG); front-only: pass A + tiles + blend only (map WRONG)",
+                        "pass B / edges / step left out (map WRONG); front-only: pass A + tiles + blend only (map WRONG); "
+                        "no-front-wait / no-upd-wait: the blend -> integrate / update -> pass A hand-over left out (races: map undefined)",
                 "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W_user, "ms_per_step": 1e3 * elapsed / K,
                 "config": {"workload": "%s %dx%d" % (args.config, width, height)},
                 "in_frame_ms_before_the_bound_was_applied": cal_ms,

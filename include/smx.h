@@ -392,7 +392,9 @@ int smx_recon_set_scan_mode(smx_recon r, int32_t mode);
 /* TIMING ONLY -- the map is WRONG afterwards: leaves launches of smx_recon_integrate out, for the upper-bound runs of
  * bench.py --ub (what would the frame rate be without this chain?).  bit 0: no regulariser (pass B, edges, step);
  * bit 1: the front of the frame only (pass A, association tiles, blend): no integration, neighbour update, creation
- * or regulariser either.  The stream hand-offs stay as they are.  0 = off. */
+ * or regulariser either.  bit 2: the internal stream does not wait for the front of the frame (blend -> integrate
+ * hand-over left out), bit 3: the caller's stream does not wait for update + create (-> next pass A): what the two
+ * cross-stream hand-overs cost the frame -- results undefined.  0 = off. */
 int smx_recon_debug_set_skip(smx_recon r, int32_t mask);
 /* Frame pipelining (default on): the regulariser of a frame runs on an internal stream beside the first
  * kernels of the next smx_recon_integrate call (which only read what the regulariser does not write).

@@ -312,6 +312,32 @@ __device__ __forceinline__ bool find_brick(const BrickSlot* __restrict__ table, 
   }
 }
 
+// The same look-up with the first kSpec probe positions requested TOGETHER: a miss (most of the 27 bricks around a surface
+// tile are empty) ends at the first empty slot of its probe sequence, two or three dependent round trips down the line when
+// they are taken one at a time -- and the tile's look-ups last as long as the longest of them.
+template <int kSpec>
+__device__ __forceinline__ bool find_brick_spec(const BrickSlot* __restrict__ table, uint32_t mask, unsigned long long brick,
+                                                uint32_t& start, uint32_t& end) {
+  uint32_t s = hash_brick(brick, mask);
+  uint4 e[kSpec];
+#pragma unroll
+  for (int u = 0; u < kSpec; ++u) e[u] = *reinterpret_cast<const uint4*>(&table[(s + (uint32_t)u) & mask]);
+#pragma unroll
+  for (int u = 0; u < kSpec; ++u) {
+    const unsigned long long key = ((unsigned long long)e[u].y << 32) | e[u].x;
+    if (key == brick + 1ull) { start = e[u].z; end = e[u].w; return true; }
+    if (key == 0ull) return false;
+  }
+  s = (s + (uint32_t)kSpec) & mask;
+  for (;;) {
+    const uint4 f = *reinterpret_cast<const uint4*>(&table[s]);
+    const unsigned long long key = ((unsigned long long)f.y << 32) | f.x;
+    if (key == brick + 1ull) { start = f.z; end = f.w; return true; }
+    if (key == 0ull) return false;
+    s = (s + 1u) & mask;
+  }
+}
+
 struct BuildCounts { uint32_t n_valid, n_bricks; };
 
 // counts of indexed points and of occupied bricks (one partial per workgroup, summed by k_sum_counts)
@@ -410,12 +436,12 @@ k_gather_queries(const uint32_t* __restrict__ order, const float* __restrict__ q
 // Tile boundaries over the sorted queries: a tile is a run of <= 64 queries of one brick.  flag[j] = 1 where a tile starts.
 constexpr int kTile = 64;
 __global__ void __launch_bounds__(kBlock)
-k_tile_flags(const unsigned long long* __restrict__ qkeys, uint32_t nq, uint32_t* __restrict__ flags) {
+k_tile_flags(const unsigned long long* __restrict__ qkeys, uint32_t nq, int shift, uint32_t* __restrict__ flags) {
   // position of the last brick change at or before j, within the workgroup's chunk (chunk starts count as changes)
   __shared__ uint32_t wave_last[kBlock / 64];
   const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
   const bool in = j < nq;
-  const bool change = in && (threadIdx.x == 0 || qkeys[j - 1] != qkeys[j]);
+  const bool change = in && (threadIdx.x == 0 || (qkeys[j - 1] >> shift) != (qkeys[j] >> shift));
   uint32_t last = change ? threadIdx.x : 0u;   // inclusive max-scan over the workgroup
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -500,12 +526,12 @@ k_query_tiles(QueryArgs a) {
   __shared__ uint32_t seg_total;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const Grid& g = a.g;
-  const uint32_t n_tiles = kSelf ? a.mask + 1u : *a.n_tiles;
+  const uint32_t n_tiles = (kSelf && !a.tile_start) ? a.mask + 1u : *a.n_tiles;
   const int K = a.K;
   if (a.redo && *a.redo_flag == 0u) return;   // (uniform) k_query_lanes answered everything
   for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     uint32_t sub_begin, sub_end;
-    if (kSelf) {
+    if (kSelf && !a.tile_start) {
       const uint4 slot = *reinterpret_cast<const uint4*>(&a.table[t]);
       if ((slot.x | slot.y) == 0u) continue;   // (uniform) empty slot
       sub_begin = slot.z; sub_end = slot.w;
@@ -715,7 +741,7 @@ static_assert(kStageL <= 256, "a lane's list holds stage positions as bytes");
 // profiles/r14_c5_stage.txt.  Round 4: the sorted rows leave the registers directly (no parking), the lists hold bytes,
 // the staging loop's two small tables lie over the lists: 6.25 KB, 25 workgroups per CU.
 constexpr int kLaneCap = 32;     // entries of a lane's private list (positions in the stage: 1 byte each)
-constexpr int kLaneStride = kLaneCap + 4;   // bytes: 33 entries (the last one is the spare a full list keeps overwriting), an odd number of 32-bit words per lane
+constexpr int kLaneStride = kLaneCap + 4;   // bytes: 33 entries (the last one is the spare a full list keeps overwriting), entry 34 is the dump byte of the predicated append; an odd number of 32-bit words per lane
 
 // The lane's matches, sorted in registers by Batcher's odd-even merge network over 64-bit keys (dist^2 bits << 32 |
 // index: a non-negative float orders like its bit pattern, so one unsigned 64-bit compare is the (dist^2, index) order),
@@ -752,8 +778,26 @@ __device__ __forceinline__ void sort_lane_matches(const float4* __restrict__ sta
           }
         }
 }
-template <bool kSelf>
-__global__ void __launch_bounds__(64)
+#ifndef SMX_NN_BRANCHFREE
+#define SMX_NN_BRANCHFREE 1   // (the walk's append: 1 = predicated, 0 = a branch per candidate as in rounds 3-5; profiles/r6_ab_notes.md)
+#endif
+// kFilter: the caller passed a state row (skip kFree / kCompleted surfels, APP/octree.cc:330-335) -- a template parameter,
+// because the test sits in the innermost loop: as a run-time (uniform) condition it cost every candidate an exec-mask
+// save, a branch and a restore whether a state row was there or not.
+#ifndef SMX_NN_STAGE_MLP
+#define SMX_NN_STAGE_MLP 6   // (1: 5.67, 2: 6.05, 4: 6.25 G queries/s at C5 with the table-order tiles; 6 on top of the key-order tiles: 6.86 -> 7.05; profiles/r6_ab_notes.md)
+#endif
+#ifndef SMX_NN_SELF_SORTED
+#define SMX_NN_SELF_SORTED 1
+#endif
+#ifndef SMX_NN_PROBE_SPEC
+#define SMX_NN_PROBE_SPEC 1
+#endif
+#ifndef SMX_NN_LANES_WAVES
+#define SMX_NN_LANES_WAVES 1   // (__launch_bounds__'s second argument: 1 = let the compiler have the registers it likes)
+#endif
+template <bool kSelf, bool kFilter>
+__global__ void __launch_bounds__(64, SMX_NN_LANES_WAVES)
 k_query_lanes(QueryArgs a) {
   // one block: the stage, then the lanes' lists; the sorted keys later lie over both (neither is needed any more once
   // every lane holds its keys in registers).  LDS is what limits the wavefronts per CU here.
@@ -766,11 +810,11 @@ k_query_lanes(QueryArgs a) {
   uint32_t* seg_src = seg_end + 64;
   const uint32_t lane = threadIdx.x;
   const Grid& g = a.g;
-  const uint32_t n_tiles = kSelf ? a.mask + 1u : *a.n_tiles;
+  const uint32_t n_tiles = (kSelf && !a.tile_start) ? a.mask + 1u : *a.n_tiles;
   const int K = a.K;
   for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     uint32_t sub_begin, sub_end;
-    if (kSelf) {
+    if (kSelf && !a.tile_start) {
       const uint4 slot = *reinterpret_cast<const uint4*>(&a.table[t]);
       if ((slot.x | slot.y) == 0u) continue;   // (uniform) empty slot
       sub_begin = slot.z; sub_end = slot.w;
@@ -840,7 +884,11 @@ k_query_lanes(QueryArgs a) {
             const int bx = kb[0] + (int)(lane % (uint32_t)bn[0]);
             const int by = kb[1] + (int)((lane / (uint32_t)bn[0]) % (uint32_t)bn[1]);
             const int bz = kb[2] + (int)(lane / ((uint32_t)bn[0] * (uint32_t)bn[1]));
+#if SMX_NN_PROBE_SPEC > 1
+            if (!find_brick_spec<SMX_NN_PROBE_SPEC>(a.table, a.mask, brick_index(g, bx, by, bz), s, e)) { s = 0; e = 0; }
+#else
             if (!find_brick(a.table, a.mask, brick_index(g, bx, by, bz), s, e)) { s = 0; e = 0; }
+#endif
           }
           const uint32_t len = e - s;
           uint32_t incl = len;
@@ -858,6 +906,28 @@ k_query_lanes(QueryArgs a) {
             // still care -- the walk was three quarters of this kernel's instructions.  (A record outside the box fails
             // d2 <= r2 for every query of the tile: cover_radius bounds |dx| of an accepted pair.)
             uint32_t cur = 0, kept = 0;
+#if SMX_NN_STAGE_MLP > 1
+            // (round 6: SMX_NN_STAGE_MLP records per lane requested before the first is looked at -- the loop was a chain of
+            // dependent round trips, one per 64 records, five per tile at C5, in a kernel that is bound by exactly those)
+            for (uint32_t k0 = 0; k0 < total; k0 += 64 * SMX_NN_STAGE_MLP) {
+              float4 v[SMX_NN_STAGE_MLP];
+#pragma unroll
+              for (int u = 0; u < SMX_NN_STAGE_MLP; ++u) {
+                const uint32_t k = min(k0 + 64u * u + lane, total - 1u);
+                while (k >= seg_end[cur]) ++cur;
+                v[u] = a.sorted[seg_src[cur] + k];
+              }
+#pragma unroll
+              for (int u = 0; u < SMX_NN_STAGE_MLP; ++u) {
+                const bool in = k0 + 64u * u + lane < total && v[u].x >= blo[0] && v[u].x <= bhi[0] && v[u].y >= blo[1] && v[u].y <= bhi[1] &&
+                                v[u].z >= blo[2] && v[u].z <= bhi[2];
+                const unsigned long long m = __ballot(in);
+                const uint32_t pos = kept + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (in && pos < (uint32_t)kStageL) stage[pos] = v[u];
+                kept += (uint32_t)__popcll(m);
+              }
+            }
+#else
             for (uint32_t k0 = 0; k0 < total; k0 += 64) {
               const uint32_t k = min(k0 + lane, total - 1u);
               while (k >= seg_end[cur]) ++cur;
@@ -869,6 +939,7 @@ k_query_lanes(QueryArgs a) {
               if (in && pos < (uint32_t)kStageL) stage[pos] = v;
               kept += (uint32_t)__popcll(m);
             }
+#endif
             __syncthreads();
             if (kept > (uint32_t)kStageL) { redo = ball; kept = 0; }   // (more than the stage holds: the other kernel)
             n_staged = total;   // (statistics: records read from the index; n_tests below counts the tests on the kept ones)
@@ -877,6 +948,31 @@ k_query_lanes(QueryArgs a) {
             // before the first test; a match is appended without a branch (a list that is full keeps overwriting its
             // spare last entry; cnt keeps counting and marks the query for the other kernel afterwards).
             const uint32_t lbase = lane * kLaneStride;
+#if SMX_NN_BRANCHFREE
+            // Round 6: no branch in the walk.  A lane without a ball carries r^2 = -1 (no d^2 passes), so the test is the
+            // compare alone; the append is predicated -- a match goes to entry min(cnt, kLaneCap) of the lane's list, a miss
+            // to the list's dump byte (entry kLaneCap + 1; the stride leaves room) -- one byte store per candidate whatever
+            // the outcome, no exec-mask juggling (rounds 3-5: two branches and a dozen scalar instructions per candidate,
+            // as many as the arithmetic).  Whole groups of four first, the tail one at a time.
+            auto test_one = [&](const float4& rc, uint32_t k) {
+              const float dx = rc.x - px, dy = rc.y - py, dz = rc.z - pz;
+              const float d2 = dx * dx + dy * dy + dz * dz;
+              bool ok = d2 <= r2;
+              if (kFilter) { if (ok && (a.state[__float_as_uint(rc.w)] & a.skip_mask)) ok = false; }
+              const uint32_t slot = ok ? min(cnt, (uint32_t)kLaneCap) : (uint32_t)kLaneCap + 1u;
+              l_pos[lbase + slot] = (uint8_t)k;
+              cnt += ok ? 1u : 0u;
+            };
+            uint32_t k0 = 0;
+            for (; k0 + 4 <= kept; k0 += 4) {
+              float4 rec[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) rec[u] = stage[k0 + u];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) test_one(rec[u], k0 + u);
+            }
+            for (; k0 < kept; ++k0) test_one(stage[k0], k0);
+#else
             for (uint32_t k0 = 0; k0 < kept; k0 += 4) {
               float4 rec[4];
 #pragma unroll
@@ -886,7 +982,7 @@ k_query_lanes(QueryArgs a) {
                 const float dx = rec[u].x - px, dy = rec[u].y - py, dz = rec[u].z - pz;
                 const float d2 = dx * dx + dy * dy + dz * dz;
                 bool ok = ball && (k0 + u < kept) && d2 <= r2;
-                if (a.state != nullptr) {   // (uniform; the filter is the rare case)
+                if (kFilter) {
                   if (ok && (a.state[__float_as_uint(rec[u].w)] & a.skip_mask)) ok = false;
                 }
                 if (ok) {
@@ -895,6 +991,7 @@ k_query_lanes(QueryArgs a) {
                 }
               }
             }
+#endif
             if (cnt > (uint32_t)kLaneCap) redo = true;
           }
         }
@@ -1114,7 +1211,10 @@ struct smx_nn_s {
   unsigned long long* qkeys[2];
   uint32_t* qvals[2];
   uint32_t *qflags, *qtile_start;
-  uint8_t *tile_redo_q, *tile_redo_self;   // k_query_lanes' per-tile marks: one per query tile / per table slot
+  uint8_t *tile_redo_q, *tile_redo_self;   // k_query_lanes' per-tile marks: one per query tile / per self tile (or table slot)
+  uint32_t* self_tile_start;    // the self queries' tiles in KEY order: tile t = points [start[t], start[t + 1]) of nn->sorted,
+  uint32_t* self_n_tiles;       // <= 64 points of one brick each (k_tile_flags over the point keys); their number (device word)
+  size_t cap_self_tiles, cap_tile_redo_self;
   float* qrows;         // upload target for host queries [4][cap]
   float4* qrec;         // queries in brick order
   uint8_t* dstate; size_t cap_state;
@@ -1130,7 +1230,7 @@ namespace {
 
 void nn_free(smx_nn nn) {
   void* ptrs[] = {nn->keys[0], nn->keys[1], nn->vals[0], nn->vals[1], nn->rows, nn->sorted, nn->hist, nn->table, nn->bbox,
-                  nn->partial, nn->counts, nn->qkeys[0], nn->qkeys[1], nn->qvals[0], nn->qvals[1], nn->qflags, nn->tile_redo_q, nn->tile_redo_self,
+                  nn->partial, nn->counts, nn->qkeys[0], nn->qkeys[1], nn->qvals[0], nn->qvals[1], nn->qflags, nn->tile_redo_q, nn->tile_redo_self, nn->self_tile_start, nn->self_n_tiles,
                   nn->qtile_start, nn->qrows, nn->qrec, nn->dstate, nn->didx, nn->dd2, nn->dcnt, nn->stat};
   for (void* p : ptrs) if (p) (void)hipFree(p);
 }
@@ -1248,7 +1348,8 @@ int smx_nn_build(smx_nn nn, smx_stream s, const float* x, const float* y, const 
   nn->n = n; nn->n_valid = 0; nn->n_bricks = 0;
   if (n == 0) return SMX_OK;
   int rc = ensure_points(nn, n);
-  if (rc == SMX_OK) rc = ensure_hist(nn, std::max<size_t>(n, nn->cap_queries));
+  const size_t hist_max_n = std::max<size_t>(n, nn->cap_queries);
+  if (rc == SMX_OK) rc = ensure_hist(nn, hist_max_n);
   if (rc != SMX_OK) return rc;
   const float *dx = x, *dy = y, *dz = z;
   if (!rows_on_device) {
@@ -1305,7 +1406,7 @@ int smx_nn_build(smx_nn nn, smx_stream s, const float* x, const float* y, const 
   while (slots < (size_t)h.n_bricks * 2) slots <<= 1;
   if (slots > nn->table_slots) {
     rc = grow(&nn->table, slots);
-    if (rc == SMX_OK) rc = grow(&nn->tile_redo_self, slots);
+    if (rc == SMX_OK && slots > nn->cap_tile_redo_self) { rc = grow(&nn->tile_redo_self, slots); nn->cap_tile_redo_self = rc == SMX_OK ? slots : 0; }
     nn->table_slots = rc == SMX_OK ? slots : 0;
     if (rc != SMX_OK) return rc;
   }
@@ -1313,6 +1414,35 @@ int smx_nn_build(smx_nn nn, smx_stream s, const float* x, const float* y, const 
   SMX_HIP(hipMemsetAsync(nn->table, 0, slots * sizeof(BrickSlot), st));
   hipLaunchKernelGGL(k_brick_insert, dim3(grid), dim3(kBlock), 0, st, nn->keys[0], h.n_valid, nn->table, (uint32_t)(slots - 1));
   hipLaunchKernelGGL(k_brick_ends, dim3(grid), dim3(kBlock), 0, st, nn->keys[0], h.n_valid, nn->table, (uint32_t)(slots - 1));
+#if SMX_NN_SELF_SORTED
+  // The self queries' tiles in KEY order (round 6).  Rounds 2-5 walked the brick TABLE: tile = hash slot -- half of the
+  // slots empty (a round trip each to find out) and neighbouring bricks a random distance apart in the walk, so that each
+  // tile's 27 bricks came from memory anew (PMC traffic 1.78 x the algorithmic bytes).  In key order (brick index, row-major)
+  // the tiles in flight at any moment are a few adjacent rows of bricks, and what one stages its neighbours find in the L2.
+  if (h.n_valid > 0) {
+    const size_t max_tiles = (size_t)h.n_bricks + (size_t)h.n_valid / kTile + 2;
+    if (max_tiles + 1 > nn->cap_self_tiles) {
+      SMX_HIP(hipDeviceSynchronize());
+      rc = grow(&nn->self_tile_start, max_tiles + 1 + max_tiles / 8);
+      if (rc == SMX_OK && !nn->self_n_tiles) rc = grow(&nn->self_n_tiles, 4);
+      nn->cap_self_tiles = rc == SMX_OK ? max_tiles + 1 + max_tiles / 8 : 0;
+      if (rc != SMX_OK) return rc;
+    }
+    if (max_tiles > nn->cap_tile_redo_self) {
+      SMX_HIP(hipDeviceSynchronize());
+      rc = grow(&nn->tile_redo_self, std::max(max_tiles + max_tiles / 8, slots));
+      nn->cap_tile_redo_self = rc == SMX_OK ? std::max(max_tiles + max_tiles / 8, slots) : 0;
+      if (rc != SMX_OK) return rc;
+    }
+    uint32_t* flags = nn->vals[1];   // (scratch of the sort: the order lives in vals[0])
+    hipLaunchKernelGGL(k_tile_flags, dim3((h.n_valid + kBlock - 1) / kBlock), dim3(kBlock), 0, st, nn->keys[0], h.n_valid, kLocalBits, flags);
+    uint32_t* total = nullptr;
+    uint32_t* flag_ws = nn->hist + sort_hist_elems(hist_max_n) + scan_workspace_elems(sort_hist_elems(hist_max_n));
+    exclusive_scan_inplace(flags, h.n_valid, flag_ws, st, &total);
+    hipLaunchKernelGGL(k_tile_starts, dim3(grid), dim3(kBlock), 0, st, flags, h.n_valid, total, nn->self_tile_start);
+    SMX_HIP(hipMemcpyAsync(nn->self_n_tiles, total, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  }
+#endif
   SMX_LAUNCH_CHECK();
   nn->n_valid = h.n_valid; nn->n_bricks = h.n_bricks;
   return SMX_OK;
@@ -1379,7 +1509,7 @@ int smx_nn_query_batch(smx_nn nn, smx_stream s, uint32_t nq, const float* qx, co
   const int cur = radix_sort(nn->qkeys, nn->qvals, nq, nn->grid.brick_bits, nn->hist, st);
   hipLaunchKernelGGL(k_gather_queries, dim3(grid), dim3(kBlock), 0, st, nn->qvals[cur], dqx, dqy, dqz, dqr2, nq, nn->qrec);
   a.qrec = nn->qrec;
-  hipLaunchKernelGGL(k_tile_flags, dim3((nq + kBlock - 1) / kBlock), dim3(kBlock), 0, st, nn->qkeys[cur], nq, nn->qflags);
+  hipLaunchKernelGGL(k_tile_flags, dim3((nq + kBlock - 1) / kBlock), dim3(kBlock), 0, st, nn->qkeys[cur], nq, 0, nn->qflags);
   uint32_t* total = nullptr;
   uint32_t* flag_ws = nn->hist + sort_hist_elems(max_n) + scan_workspace_elems(sort_hist_elems(max_n));
   exclusive_scan_inplace(nn->qflags, nq, flag_ws, st, &total);
@@ -1397,7 +1527,8 @@ int smx_nn_query_batch(smx_nn nn, smx_stream s, uint32_t nq, const float* qx, co
     a.tile_redo = nn->tile_redo_q;
     SMX_HIP(hipMemsetAsync(a.redo_flag, 0, 4, st));
     const unsigned lb = (unsigned)std::min<size_t>((size_t)nn->grid_blocks * 4, (size_t)nq + 1);
-    hipLaunchKernelGGL(k_query_lanes<false>, dim3(lb), dim3(64), 0, st, a);
+    if (a.state) hipLaunchKernelGGL((k_query_lanes<false, true>), dim3(lb), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_query_lanes<false, false>), dim3(lb), dim3(64), 0, st, a);
     a.redo = 1;
     hipLaunchKernelGGL(k_query_tiles<false>, dim3(blocks), dim3(64 * kTileWaves), 0, st, a);
   }
@@ -1428,13 +1559,20 @@ int smx_nn_query_self(smx_nn nn, smx_stream s, const float* radius_squared, floa
   a.out_idx = out_idx; a.out_d2 = out_d2; a.out_count = out_count;
   a.self_r2 = radius_squared; a.self_factor = factor;
   a.stat = nn->stats_enabled ? nn->stat : nullptr;
-  const unsigned blocks = (unsigned)std::min<size_t>((size_t)nn->grid_blocks, nn->table_slots);
+#if SMX_NN_SELF_SORTED
+  a.tile_start = nn->self_tile_start; a.n_tiles = nn->self_n_tiles;   // tiles in key order (smx_nn_build)
+  const size_t tiles_bound = (size_t)nn->n_bricks + (size_t)nn->n_valid / kTile + 2;
+#else
+  const size_t tiles_bound = nn->table_slots;
+#endif
+  const unsigned blocks = (unsigned)std::min<size_t>((size_t)nn->grid_blocks, tiles_bound);
   if (nn->query_mode == 2) {
     a.redo_flag = reinterpret_cast<uint32_t*>(nn->stat + 4);
     a.tile_redo = nn->tile_redo_self;
     SMX_HIP(hipMemsetAsync(a.redo_flag, 0, 4, st));
-    const unsigned lb = (unsigned)std::min<size_t>((size_t)nn->grid_blocks * 4, nn->table_slots);
-    hipLaunchKernelGGL(k_query_lanes<true>, dim3(lb), dim3(64), 0, st, a);
+    const unsigned lb = (unsigned)std::min<size_t>((size_t)nn->grid_blocks * 4, tiles_bound);
+    if (a.state) hipLaunchKernelGGL((k_query_lanes<true, true>), dim3(lb), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_query_lanes<true, false>), dim3(lb), dim3(64), 0, st, a);
     a.redo = 1;
   }
   hipLaunchKernelGGL(k_query_tiles<true>, dim3(blocks), dim3(64 * kTileWaves), 0, st, a);

@@ -3364,7 +3364,7 @@ int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
 }
 
 int smx_recon_debug_set_skip(smx_recon r, int32_t mask) {
-  SMX_CHECK_ARG(r != nullptr && mask >= 0 && mask <= 3);
+  SMX_CHECK_ARG(r != nullptr && mask >= 0 && mask <= 15);
   r->debug_skip = mask;
   return SMX_OK;
 }
@@ -3540,7 +3540,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     // (work on the internal stream from here on: whatever happens below, later entry points order themselves behind it)
     r->reg_pending = true;
     if (!front_by_launch) SMX_HIP(hipEventRecord(r->ev_front, sF));
-    SMX_HIP(hipStreamWaitEvent(sR, r->ev_front, 0));
+    if (!(r->debug_skip & 4)) SMX_HIP(hipStreamWaitEvent(sR, r->ev_front, 0));   // (bit 2: timing only -- what is the hand-over worth?)
   }
   if (tm) SMX_HIP(hipEventRecord(r->ev[6], sR));
   const bool front_only = (r->debug_skip & 2) != 0, skip_reg = (r->debug_skip & 3) != 0;   // (timing only)
@@ -3584,7 +3584,8 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     // A caller that asked for the "inputs consumed" event orders the reuse of its images itself; its stream then only has
     // to wait before the next call's pass A reads the map -- and that call's cull step, which does not, may go first.
     // (Every other entry point orders its stream after the whole internal stream: join_regularizer.)
-    if (pipelined && hook_consumed) r->pending_mark = mark;
+    if (r->debug_skip & 8) { }   // (bit 3: timing only -- the caller's stream does not wait for update + create)
+    else if (pipelined && hook_consumed) r->pending_mark = mark;
     else if (pipelined) SMX_HIP(hipStreamWaitEvent(sF, mark, 0));
   }
   if (skip_reg) {
