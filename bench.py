@@ -520,6 +520,7 @@ def compact_roofline(roof):
 def compact_line(d):
     """The short form of a result dictionary (C2 / C3 / C5 alike): see the comment above."""
     out = _pick(d, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "host_enqueue_ms_per_step",
+                    "host_enqueue_ms_per_step_per_rank", "host_cores",
                     "higher_is_better", "scaling", "dtype", "data", "per_rank_frames_per_s", "rccl_ranks_seen", "gloo_ranks_seen",
                     "upper_bound"))
     out["vs_baseline"] = d.get("vs_baseline")
@@ -701,6 +702,7 @@ def run_integrate(args):
         seen = multistream.ranks_seen(world, dist, "cpu")
         if rank == 0:
             print(json.dumps({"dry_run": True, "config": {"workload": args.config}, "n_gpus": world, "steps": K, "warmup": W,
+                              "host_cores": os.cpu_count(),
                               "value": fps, "unit": "frames/s (host-side plan generation only)", "units_all_ranks": units,
                               "per_rank_value": each, "ranks_seen": seen,
                               "seed": assign["seed"], "scaling": "weak"}))
@@ -741,7 +743,7 @@ def run_integrate(args):
     # (round 2: 4144 frames/s at --steps 20 --warmup 5 against 3873 at --steps 300 --warmup 20).
     first = g_end + 10
     ub = set(x for x in args.ub.split(",") if x)
-    assert ub <= {"hoist-pre", "no-reg", "front-only", "no-front-wait", "no-upd-wait"}, "unknown --ub item"
+    assert ub <= {"hoist-pre", "no-reg", "front-only", "no-front-wait", "no-upd-wait", "split"}, "unknown --ub item"
     rec0 = wl.pipe.reconstruction
     names = rec0.kernel_time_names()
     # kernels judged in the frame: the Integrate slots (not the empty slot that measures the time stamps themselves, not the
@@ -828,7 +830,7 @@ def run_integrate(args):
             wl.pipe.prepare_array(*warm_steps)
         wl.pipe.prepare_array(*timed_steps)
     rec.debug_set_skip((1 if "no-reg" in ub else 0) | (2 if "front-only" in ub else 0) | (4 if "no-front-wait" in ub else 0) |
-                       (8 if "no-upd-wait" in ub else 0))
+                       (8 if "no-upd-wait" in ub else 0) | (16 if "split" in ub else 0))
     # Time stamps around the dominant kernel only (2 records per frame on the stream it is launched on) stay on during
     # the timed region; everything else is measured in separate passes.
     if warm_steps is not None:
@@ -850,6 +852,8 @@ def run_integrate(args):
     fps, elapsed, _ = multistream.aggregate_throughput(K, elapsed_local, world, dist if world > 1 else None, reduce_device(args))
     each_rank = multistream.per_rank(K / elapsed_local, world, dist if world > 1 else None, reduce_device(args))
     seen = multistream.ranks_seen(world, dist if world > 1 else None, reduce_device(args))
+    # (one host core per rank enqueues that rank's frames: 0.06 - 0.08 ms of a 0.16 ms step at C2 -- eight ranks want eight free cores)
+    enqueue_each = multistream.per_rank(1e3 * enqueue_local / K, world, dist if world > 1 else None, reduce_device(args))
     if world > 1:
         dist.barrier()
     dom_ms, dom_n = rec.profile_end()
@@ -934,7 +938,8 @@ def run_integrate(args):
         "metric": "RGB-D frames/s integrated @640x480, 5M live surfels; achieved HBM GB/s" if args.config == "C2" else
                   "RGB-D frames/s integrated @%dx%d, %dM surfel cap; achieved HBM GB/s" % (width, height, target_live // 1000000),
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W_user,
-        "ms_per_step": 1e3 * elapsed / K, "host_enqueue_ms_per_step": 1e3 * enqueue_local / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * elapsed / K, "host_enqueue_ms_per_step": 1e3 * enqueue_local / K,
+        "host_enqueue_ms_per_step_per_rank": enqueue_each, "host_cores": os.cpu_count(), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "per_rank_frames_per_s": each_rank, ("rccl_ranks_seen" if args.backend == "nccl" else "gloo_ranks_seen"): seen,
         "config": {"workload": "%s: synthetic room stream %dx%d, raw depth + colour frames resident in HBM, full preprocessing + "

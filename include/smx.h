@@ -394,7 +394,10 @@ int smx_recon_set_scan_mode(smx_recon r, int32_t mode);
  * bit 1: the front of the frame only (pass A, association tiles, blend): no integration, neighbour update, creation
  * or regulariser either.  bit 2: the internal stream does not wait for the front of the frame (blend -> integrate
  * hand-over left out), bit 3: the caller's stream does not wait for update + create (-> next pass A): what the two
- * cross-stream hand-overs cost the frame -- results undefined.  0 = off. */
+ * cross-stream hand-overs cost the frame -- results undefined; bit 4: another arrangement of the streams (integrate + update
+ * stay on the caller's stream behind the blend and wait for the previous call's edge kernel only, the internal stream keeps
+ * pass B / edges / step and waits for update + create: the step kernel off every cycle, two hand-overs on the critical one) --
+ * measured 5 % slower even as an upper bound, profiles/r6_ab_notes.md.  0 = off. */
 int smx_recon_debug_set_skip(smx_recon r, int32_t mask);
 /* Frame pipelining (default on): the regulariser of a frame runs on an internal stream beside the first
  * kernels of the next smx_recon_integrate call (which only read what the regulariser does not write).

@@ -3021,7 +3021,7 @@ int join_regularizer(smx_recon r, hipStream_t st) {
 // zero_chunks: pass B appends to the recent list's chunk descriptors; inside Integrate the launch in front of it
 // (k_update_and_create) has reset their counter, everywhere else it is done here.
 int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, float weight, int window,
-                       bool detach, bool copy_only, bool zero_chunks, unsigned long long* ts = nullptr) {
+                       bool detach, bool copy_only, bool zero_chunks, unsigned long long* ts = nullptr, hipEvent_t acc_done = nullptr) {
   const dim3 g(r->nsegB), bB(kBlockB), gl(r->grid_list), b(kBlock);
   const float rf2 = rf * rf;
   if (!r->table_valid || r->table_frame != frame || r->table_window != window) {
@@ -3054,8 +3054,10 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
   }
   if (!copy_only && !r->fuse_edges) {
     SlotTimer t(r, st, kSlotRegAccumulate, true);
-    hipExtLaunchKernelGGL(k_reg_accumulate, dim3(r->grid_acc), dim3(kBlockAcc), 0, st, t.start(), t.stop(), 0, r->S, rf2, weight, r->grad_acc, r->reg_rec, (size_t)r->S.pitch + kSegAcc,
+    const bool done_by_launch = acc_done && !t.stop();
+    hipExtLaunchKernelGGL(k_reg_accumulate, dim3(r->grid_acc), dim3(kBlockAcc), 0, st, t.start(), done_by_launch ? acc_done : t.stop(), 0, r->S, rf2, weight, r->grad_acc, r->reg_rec, (size_t)r->S.pitch + kSegAcc,
                        r->fb, r->L.act_list, r->L.acc_chunks, r->st, ts_first);
+    if (acc_done && !done_by_launch) SMX_HIP(hipEventRecord(acc_done, st));
   }
   if (copy_only) {
     SlotTimer t(r, st, kSlotRegUpdate);
@@ -3364,7 +3366,7 @@ int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
 }
 
 int smx_recon_debug_set_skip(smx_recon r, int32_t mask) {
-  SMX_CHECK_ARG(r != nullptr && mask >= 0 && mask <= 15);
+  SMX_CHECK_ARG(r != nullptr && mask >= 0 && mask <= 31);
   r->debug_skip = mask;
   return SMX_OK;
 }
@@ -3438,6 +3440,11 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   const bool pipelined = r->overlap_enabled != 0;
   const hipStream_t sF = st;
   const hipStream_t sR = pipelined ? r->reg_stream : st;
+  // TIMING EXPERIMENT (debug_skip bit 4; results NOT exact -- the step kernel of the previous call still reads P / N records
+  // that this call's integration rewrites): integrate + update stay on the caller's stream behind the blend (no hand-over
+  // there), waiting only for the previous call's EDGE kernel; the internal stream runs pass B / edges / step and waits for
+  // update + create.  The step kernel then sits on no cycle.
+  const bool split = pipelined && (r->debug_skip & 16) != 0;
   // (a caller that comes with another stream than last time: that stream has not waited for the previous call's map yet)
   if (r->reg_pending && r->last_stream != st) { const int rcj = join_regularizer(r, st); if (rcj != SMX_OK) return rcj; }
   r->last_stream = st;
@@ -3507,7 +3514,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     const uint32_t n_blend = (uint32_t)(tiles_x * div_up(r->H, tile));
     unsigned long long* stamps = r->stamps ? r->stamps + 16 * 8192 : nullptr;
     // (the hand-over to the internal stream as this launch's own completion event)
-    front_by_launch = SMX_EXT_STOP_EVENTS && pipelined && !tm && !(r->timing_enabled & 2) && r->prof_slot != kSlotBlend;
+    front_by_launch = SMX_EXT_STOP_EVENTS && pipelined && !split && !tm && !(r->timing_enabled & 2) && r->prof_slot != kSlotBlend;
     const hipEvent_t stop = front_by_launch ? r->ev_front : nullptr;
     if (tile == 40)
       hipExtLaunchKernelGGL(k_blend_tiles<40>, dim3(n_blend), dim3(kBlendThreads), (uint32_t)lds, sF, nullptr, stop, 0, p->measurement_blending_radius, term, ds,
@@ -3536,7 +3543,11 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   in_integrate.depth = nf.depth;
   // Everything up to here only read P and N records; from here on they (and T, S) are written, so the previous
   // call's regulariser has to be done: it is, by stream order -- the rest of the call follows it on the internal stream.
-  if (pipelined) {
+  const hipStream_t sI = split ? sF : sR;   // integrate, update + create
+  if (split) {
+    if (r->reg_pending) SMX_HIP(hipStreamWaitEvent(sF, r->ev_front, 0));   // (here: "the previous call's edge kernel is done")
+    r->reg_pending = true;
+  } else if (pipelined) {
     // (work on the internal stream from here on: whatever happens below, later entry points order themselves behind it)
     r->reg_pending = true;
     if (!front_by_launch) SMX_HIP(hipEventRecord(r->ev_front, sF));
@@ -3546,13 +3557,13 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   const bool front_only = (r->debug_skip & 2) != 0, skip_reg = (r->debug_skip & 3) != 0;   // (timing only)
   bool mark_by_launch = false;
   if (front_only) SMX_HIP(hipMemsetAsync(r->vis_count_set[r->sc_cur ^ 1], 0, sizeof(uint32_t) * kSubLists * kCountStride, sR));   // (k_update_and_create's side job)
-  if (!front_only) { SlotTimer t(r, sR, kSlotIntegrate, true);
+  if (!front_only) { SlotTimer t(r, sI, kSlotIntegrate, true);
     const uint32_t nfb = (uint32_t)r->n_scan_blocks;
     const dim3 gi(nfb + (uint32_t)r->grid_list);
-    if (r->scan_mode) hipExtLaunchKernelGGL((k_integrate<false>), gi, b, 0, sR, t.start(), t.stop(), 0, r->S, c, r->sc, in_integrate, r->L, r->merge_flag, r->st, nf, nfb);
-    else hipExtLaunchKernelGGL((k_integrate<true>), gi, b, 0, sR, t.start(), t.stop(), 0, r->S, c, r->sc, in_integrate, r->L, r->merge_flag, r->st, nf, nfb); }
+    if (r->scan_mode) hipExtLaunchKernelGGL((k_integrate<false>), gi, b, 0, sI, t.start(), t.stop(), 0, r->S, c, r->sc, in_integrate, r->L, r->merge_flag, r->st, nf, nfb);
+    else hipExtLaunchKernelGGL((k_integrate<true>), gi, b, 0, sI, t.start(), t.stop(), 0, r->S, c, r->sc, in_integrate, r->L, r->merge_flag, r->st, nf, nfb); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[7], sR)); SMX_HIP(hipEventRecord(r->ev[8], sR)); }
-  if (!front_only) { SlotTimer t(r, sR, kSlotUpdateNeighbors);
+  if (!front_only) { SlotTimer t(r, sI, kSlotUpdateNeighbors);
     CreateArgs ca;
     ca.flags = r->new_flags; ca.ranks = r->new_ranks; ca.block_sums = r->block_sums; ca.block_offsets_out = r->block_offsets;
     ca.n_scan_blocks = r->n_scan_blocks; ca.max_surfels = r->max_surfels; ca.flags8 = r->L.flags8; ca.dirty8 = r->L.dirty8;
@@ -3565,8 +3576,8 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     // this kernel and pass B on the internal stream)
     mark_by_launch = SMX_EXT_STOP_EVENTS && !tm && !(r->timing_enabled & 2) && (pipelined || hook_consumed) && r->prof_slot != kSlotUpdateNeighbors;
     const hipEvent_t stop = mark_by_launch ? (hook_consumed ? hook_consumed : r->ev_upd) : nullptr;
-    if (r->scan_mode) hipExtLaunchKernelGGL((k_update_and_create<false>), guc, b, (uint32_t)lds, sR, nullptr, stop, 0, r->S, c, r->sc, in, r->L, ca, ncb, r->st);
-    else hipExtLaunchKernelGGL((k_update_and_create<true>), guc, b, (uint32_t)lds, sR, nullptr, stop, 0, r->S, c, r->sc, in, r->L, ca, ncb, r->st); }
+    if (r->scan_mode) hipExtLaunchKernelGGL((k_update_and_create<false>), guc, b, (uint32_t)lds, sI, nullptr, stop, 0, r->S, c, r->sc, in, r->L, ca, ncb, r->st);
+    else hipExtLaunchKernelGGL((k_update_and_create<true>), guc, b, (uint32_t)lds, sI, nullptr, stop, 0, r->S, c, r->sc, in, r->L, ca, ncb, r->st); }
   // (the detach half of UpdateNeighborsCUDA runs fused into pass B below)
   if (tm) { SMX_HIP(hipEventRecord(r->ev[9], sR)); SMX_HIP(hipEventRecord(r->ev[10], sR)); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[11], sR)); SMX_HIP(hipEventRecord(r->ev[12], sR)); }
@@ -3580,11 +3591,12 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   // stream sits on the frame-to-frame critical chain).
   {
     const hipEvent_t mark = hook_consumed ? hook_consumed : r->ev_upd;
-    if ((pipelined || hook_consumed) && !mark_by_launch) SMX_HIP(hipEventRecord(mark, sR));
+    if ((pipelined || hook_consumed) && !mark_by_launch) SMX_HIP(hipEventRecord(mark, sI));
     // A caller that asked for the "inputs consumed" event orders the reuse of its images itself; its stream then only has
     // to wait before the next call's pass A reads the map -- and that call's cull step, which does not, may go first.
     // (Every other entry point orders its stream after the whole internal stream: join_regularizer.)
-    if (r->debug_skip & 8) { }   // (bit 3: timing only -- the caller's stream does not wait for update + create)
+    if (split) SMX_HIP(hipStreamWaitEvent(sR, mark, 0));   // (the internal stream's pass B waits; the caller's stream carries on)
+    else if (r->debug_skip & 8) { }   // (bit 3: timing only -- the caller's stream does not wait for update + create)
     else if (pipelined && hook_consumed) r->pending_mark = mark;
     else if (pipelined) SMX_HIP(hipStreamWaitEvent(sF, mark, 0));
   }
@@ -3595,7 +3607,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   } else {
     for (int k = 0; k < iters && rc == SMX_OK; ++k)
       rc = enqueue_regularize(r, sR, frame_index, p->radius_factor_for_regularization_neighbors, p->regularizer_weight,
-                              p->regularization_frame_window_size, k == 0, false, k > 0, c.ts);
+                              p->regularization_frame_window_size, k == 0, false, k > 0, c.ts, (split && k == iters - 1) ? r->ev_front : nullptr);
   }
   if (rc != SMX_OK) return rc;
   if (tm) { SMX_HIP(hipEventRecord(r->ev[13], sR)); r->have_timings = true; }

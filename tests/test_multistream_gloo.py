@@ -116,6 +116,27 @@ def test_bench_gpus_flag_launches_the_ranks_itself():
     assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
 
 
+def test_bench_gpus_8_dry_run_plain_start():
+    """The driver's 8-GPU command shape, started plainly (`python bench.py --gpus 8 ...`): eight ranks over gloo, eight distinct
+    streams (seeds / start poses), one line from rank 0 with the whole-job aggregate -- the C4 path minus the GPUs (no 8-GPU
+    node was available to any round: SCALE_r0x.json are 'skipped' records)."""
+    import json
+    import subprocess
+    import sys
+    from common import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--dry-run"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and len(d["per_rank_value"]) == 8 and d["units_all_ranks"] == 160.0
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak" and d["value"] > 0
+    from surfelmeshing_amd import multistream
+    assert len({multistream.stream_assignment(r_)["seed"] for r_ in range(8)}) == 8
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_share_one_gpu_over_gloo():
     """C4 readiness without the 8-GPU node: bench.py's REAL timed path with two ranks under torch.distributed.run, process
