@@ -790,6 +790,9 @@ __device__ __forceinline__ void sort_lane_matches(const float4* __restrict__ sta
 #ifndef SMX_NN_SELF_SORTED
 #define SMX_NN_SELF_SORTED 1
 #endif
+#ifndef SMX_NN_XCD_MAP
+#define SMX_NN_XCD_MAP 0   // (measured: 6.82 - 6.92 against 6.89 - 6.95 G queries/s without -- the kernel is not bound by its bytes; profiles/r6_ab_notes.md)
+#endif
 #ifndef SMX_NN_PROBE_SPEC
 #define SMX_NN_PROBE_SPEC 1
 #endif
@@ -812,7 +815,18 @@ k_query_lanes(QueryArgs a) {
   const Grid& g = a.g;
   const uint32_t n_tiles = (kSelf && !a.tile_start) ? a.mask + 1u : *a.n_tiles;
   const int K = a.K;
+#if SMX_NN_XCD_MAP
+  // Workgroup b runs on XCD b % 8, and every XCD has an L2 of its own: with tile = blockIdx + k * gridDim the eight
+  // neighbours of a tile in key order are staged by eight DIFFERENT L2s and each brick is fetched from memory once per XCD
+  // that needs it.  Here every XCD walks a contiguous eighth of the tiles, its workgroups side by side: what a tile stages,
+  // the tiles next to it (same row of bricks) and a row further (a few hundred tiles on) find in that XCD's L2.
+  const uint32_t xcd = blockIdx.x & 7u, wi = blockIdx.x >> 3, per_xcd = (n_tiles + 7u) / 8u, wgs_per_xcd = gridDim.x >> 3;
+  for (uint32_t ti = wi; ti < per_xcd; ti += wgs_per_xcd) {
+    const uint32_t t = xcd * per_xcd + ti;
+    if (t >= n_tiles) break;
+#else
   for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+#endif
     uint32_t sub_begin, sub_end;
     if (kSelf && !a.tile_start) {
       const uint4 slot = *reinterpret_cast<const uint4*>(&a.table[t]);
@@ -1526,7 +1540,7 @@ int smx_nn_query_batch(smx_nn nn, smx_stream s, uint32_t nq, const float* qx, co
     a.redo_flag = reinterpret_cast<uint32_t*>(nn->stat + 4);
     a.tile_redo = nn->tile_redo_q;
     SMX_HIP(hipMemsetAsync(a.redo_flag, 0, 4, st));
-    const unsigned lb = (unsigned)std::min<size_t>((size_t)nn->grid_blocks * 4, (size_t)nq + 1);
+    const unsigned lb = std::max(8u, (unsigned)std::min<size_t>((size_t)nn->grid_blocks * 4, (size_t)nq + 1) & ~7u);   // (a multiple of 8: SMX_NN_XCD_MAP)
     if (a.state) hipLaunchKernelGGL((k_query_lanes<false, true>), dim3(lb), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((k_query_lanes<false, false>), dim3(lb), dim3(64), 0, st, a);
     a.redo = 1;
@@ -1570,7 +1584,7 @@ int smx_nn_query_self(smx_nn nn, smx_stream s, const float* radius_squared, floa
     a.redo_flag = reinterpret_cast<uint32_t*>(nn->stat + 4);
     a.tile_redo = nn->tile_redo_self;
     SMX_HIP(hipMemsetAsync(a.redo_flag, 0, 4, st));
-    const unsigned lb = (unsigned)std::min<size_t>((size_t)nn->grid_blocks * 4, tiles_bound);
+    const unsigned lb = std::max(8u, (unsigned)std::min<size_t>((size_t)nn->grid_blocks * 4, tiles_bound) & ~7u);   // (a multiple of 8: SMX_NN_XCD_MAP)
     if (a.state) hipLaunchKernelGGL((k_query_lanes<true, true>), dim3(lb), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((k_query_lanes<true, false>), dim3(lb), dim3(64), 0, st, a);
     a.redo = 1;
