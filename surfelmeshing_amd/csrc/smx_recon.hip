@@ -89,11 +89,22 @@ __host__ __device__ constexpr int row_sub(int row) {
 // start of each group array in units of pitch x 16 bytes
 __host__ __device__ constexpr int group_start(int g) { return g; }
 constexpr int kQuadsPerSlot = 6;   // 96 bytes per slot
+#ifndef SMX_LAYOUT_NC
+#define SMX_LAYOUT_NC 0
+#endif
 struct Surfels {
   float* base;
   size_t pitch;  // slots per group array (multiple of 64)
   __host__ __device__ __forceinline__ size_t quad(int g, uint32_t i) const {
+#if SMX_LAYOUT_NC
+    // (A/B, VERDICT r5 item 5: N and C of a slot side by side in one 32-byte record -- a visible slot costs the integration two
+    // lines instead of three -- P, S, T, G stay arrays of their own.  Measured: profiles/r6_ab_notes.md)
+    if (g == kGroupN) return (size_t)4 * pitch + 2 * (size_t)i;
+    if (g == kGroupC) return (size_t)4 * pitch + 2 * (size_t)i + 1;
+    return (size_t)(g == kGroupP ? 0 : g == kGroupS ? 1 : g == kGroupT ? 2 : 3) * pitch + (size_t)i;
+#else
     return (size_t)group_start(g) * pitch + (size_t)i;
+#endif
   }
   __device__ __forceinline__ float& f(int row, uint32_t i) const { return base[quad(row_group(row), i) * 4 + row_sub(row)]; }
   __device__ __forceinline__ uint32_t& u(int row, uint32_t i) const {
