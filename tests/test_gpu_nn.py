@@ -251,7 +251,7 @@ def test_workspace_is_reused_and_queries_of_any_size_and_k(smx):
     K <= 16, <= 32, <= 64); more than 64 queries per brick (several tiles per brick), K smaller than the matches."""
     rng = np.random.default_rng(21)
     nn = smx.SurfelNeighborIndex()
-    for n, cell in ((3000, 0.2), (50000, 0.05), (700, 0.5)):
+    for n, cell in ((3000, 0.2), (50000, 0.05), (700, 0.5), (120000, 0.04)):
         pts = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
         nn.Build(pts[:, 0], pts[:, 1], pts[:, 2], cell)
         for nq, k, rad in ((1, 1, 0.3), (70, 5, 0.3), (500, 16, 0.15), (333, 17, 0.2), (900, 33, 0.25), (64, 64, 0.4)):
@@ -262,6 +262,14 @@ def test_workspace_is_reused_and_queries_of_any_size_and_k(smx):
             for j in range(0, nq, max(1, nq // 40)):
                 c, od2, oidx = orc.nn_bruteforce(pts[:, 0], pts[:, 1], pts[:, 2], q[j], float(r2[j]), k)
                 assert cnt[j] == c and np.array_equal(idx[j, :c], oidx[:c]) and np.array_equal(d2[j, :c].view(np.uint32), od2[:c].view(np.uint32)), (n, nq, k, j)
+        # the self queries walk tiles in KEY order that every build cuts anew (round 6): on a handle that has held larger and
+        # smaller indexes they give the rows of the batch entry point over the same points
+        r2s = np.full(n, (0.8 * cell) ** 2, np.float32)
+        cs, ds, is_ = nn.FindNearestOfIndexedPoints(n, 64, radius_squared=r2s, factor=1.0)
+        cb, db, ib = nn.FindNearestSurfelsWithinRadius(pts, r2s, 64)
+        m = np.arange(64)[None, :] < cb[:, None]
+        assert np.array_equal(cs, cb) and np.array_equal(is_[m], ib[m]) and np.array_equal(ds[m].view(np.uint32), db[m].view(np.uint32)), n
+        assert cs.min() >= 1
     nn.close()
 
 
