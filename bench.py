@@ -309,7 +309,7 @@ def stamp_timeline(rec):
     calls of the timed region, mean duration of every launch of Integrate in the frame and of the gaps between them -- no
     profiler, no event packets, the run that is timed."""
     ring, khz = rec.debug_stamp_ring()
-    recs = {int(r[0]): r.astype(np.int64) for r in ring if r[0] != 0}
+    recs = {int(r[0]): r.astype(np.int64) for r in ring if r[0] != 0 and r[15] == 0}
     (SEQ, CULL, TILES_END, BLEND_B, BLEND_E, INT_B, INT_E, UPD_B, UPD_E, REG_B, REG_E, SCAN_B, TILES_B, ACC_B, STEP_B) = range(15)
     rows = []
     for q in sorted(recs):

@@ -297,14 +297,11 @@ int smx_recon_export_vertices(smx_recon r, smx_stream s, const smx_buffer_desc* 
  * switches the stamps off): the stages are not bracketed by event records (each a packet between two kernels of a stream that is never idle: fourteen
  * of them cost a third of the frame rate here) but stamped by the kernels themselves -- device wall clock, first
  * workgroup in of the launch that begins a stage / of the launch that follows it on the same stream, last workgroups out
- * where nothing follows -- into a per-call record.  Two stages have
- * no launch of their own here and get their share of the launch that carries them, taken out of that launch's stage (the
- * seven values add up to the call): out_ms[1], surfel_merging = the association kernel's time x the share of their run its
- * last workgroups spent in the merge phase (the marks are applied inside the integration launch: that part stays in
- * out_ms[3]); out_ms[5], new_surfel_creation = from the begin of the update + create launch until its last CREATING
- * workgroups are through (they are dispatched first; out_ms[4] is what the launch does after that).  With the reference's
- * event records instead (smx_recon_set_timing_enabled bit 0, a measurement mode) both columns hold what lies between two
- * records around nothing: a few microseconds of packet time. */
+ * where nothing follows -- into a per-call record.  Stages the
+ * design fuses into another stage's launch report 0 -- out_ms[1] (surfel_merging: decided in the association kernel,
+ * applied by the integration kernel) and out_ms[5] (new_surfel_creation: the first workgroups of the neighbour-update
+ * launch): their time is INSIDE out_ms[0] / out_ms[3] and out_ms[4], so the seven values still add up to the call; a caller
+ * that accumulates the reference's seven columns (APP/main.cc:1511-1530) gets two empty ones. */
 int smx_recon_get_timings(smx_recon r, float out_ms[7]);
 /* The same for a frame loop that must not wait: the stage times of the NEWEST call whose record has been handed over --
  * every call copies the record of the call before the previous one (complete by stream order at that point) into
@@ -313,10 +310,10 @@ int smx_recon_get_timings(smx_recon r, float out_ms[7]);
 int smx_recon_get_timings_nowait(smx_recon r, float out_ms[7], uint64_t* call_number);
 /* Measurement: the object's internal stream (for smx_debug_handover_probe; never enqueue work on it). */
 int smx_recon_debug_internal_stream(smx_recon r, smx_stream* out);
-/* Measurement: the raw stage-stamp records of the last 8 smx_recon_integrate calls (8 x 20 words of device wall clock,
+/* Measurement: the raw stage-stamp records of the last 8 smx_recon_integrate calls (8 x 16 words of device wall clock,
  * rate in *wall_clock_khz; word 0 = the call's number, then: cull begin, tiles end*, blend begin, blend end*, integrate
  * begin, integrate end*, update begin, update end*, pass B begin, step end*, pass A begin, tiles begin, edge kernel begin,
- * step begin, creation end*, merge-phase time and run time summed over the tile kernel's last workgroups; * = maximum over the last workgroups dispatched).  bench.py turns them into the in-frame timeline of the
+ * step begin; * = maximum over the last workgroups dispatched).  bench.py turns them into the in-frame timeline of the
  * pipelined run -- no profiler, no event packets.  Call after synchronising. */
 int smx_recon_debug_stamp_ring(smx_recon r, uint64_t* out, int32_t capacity_words, int32_t* wall_clock_khz);
 /* enabled: bit 2 = stage stamps (default ON: what smx_recon_get_timings reads), bit 0 = the reference's own 14 stage

@@ -528,8 +528,8 @@ class CUDASurfelReconstruction:
         return tuple(out)
 
     def debug_stamp_ring(self):
-        """(records [8][20] uint64, wall clock kHz): smx_recon_debug_stamp_ring."""
-        out = np.zeros((8, 20), np.uint64)
+        """(records [8][16] uint64, wall clock kHz): smx_recon_debug_stamp_ring."""
+        out = np.zeros((8, 16), np.uint64)
         khz = C.c_int32(0)
         _lib.check(_lib.load().smx_recon_debug_stamp_ring(self._h, out.ctypes.data_as(C.c_void_p), C.c_int32(out.size), C.byref(khz)))
         return out, int(khz.value)

@@ -154,11 +154,7 @@ struct FrameCtx {
 enum : int { kTsSeq = 0, kTsCullBegin, kTsTilesEnd, kTsBlendBegin, kTsBlendEnd, kTsIntBegin, kTsIntEnd, kTsUpdBegin, kTsUpdEnd,
              kTsRegBegin, kTsRegEnd,
              kTsScanBegin, kTsTilesBegin, kTsAccBegin, kTsStepBegin,   // (not part of GetTimings: smx_recon_debug_stamp_ring)
-             // round 6: the two stages that have no launch of their own get their share of the launch that carries them --
-             // creation = until the LAST creating workgroups of the update + create launch are through (they are dispatched
-             // first); merging = the tile kernel's time x the share its last workgroups spent in their merge phase
-             kTsCreateEnd = 15, kTsMergeNum, kTsMergeDen,
-             kTsSeqTail = 19, kTsWords = 20 };
+             kTsSeqTail = 15, kTsWords = 16 };
 constexpr int kTsRing = 8;
 constexpr uint32_t kTsTail = 32;
 constexpr unsigned long long kTsCheckSalt = 0x5EED5EED5EED5EEDull;
@@ -997,11 +993,6 @@ k_assoc_tiles(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<
   __shared__ TileLds t;
   __shared__ uint32_t order_wave_tot[kTilePx / 64];
   ts_begin(c.ts, kTsTilesBegin);
-  // (GetTimings' surfel_merging: the LAST workgroups dispatched time their merge phase and their whole run -- uniform
-  // conditions, scalar clock reads: no vector register -- and the host gives the launch's time that share)
-  const bool ts_tail = c.ts != nullptr && blockIdx.x + kTsTail >= gridDim.x;
-  unsigned long long ts_wg_begin = 0, ts_merge_begin = 0;
-  if (ts_tail) ts_wg_begin = wall_clock64();
   // side job of the first workgroup's second wavefront: the stage-stamp record of the call before the previous one (complete:
   // that call's regulariser preceded the previous call's integration, whose end this stream has waited for) goes to
   // page-locked host memory for the non-waiting GetTimings
@@ -1083,7 +1074,6 @@ k_assoc_tiles(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<
   for_uncached_pairs(S, c, tb, tile, n_binned, overflowed, n_ovf, [&](const PairRec& r) { assoc_stage(t, c, r); });
   __syncthreads();
   SMX_STAMP(stamps, 3);
-  if (ts_tail) ts_merge_begin = wall_clock64();
   // phase 3: merge decisions (the supported surfels' records of all cached pairs are gathered together)
   uint32_t cand[kPairCache];
   float4 cp4[kPairCache], cn4[kPairCache];
@@ -1119,11 +1109,6 @@ k_assoc_tiles(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<
   }
   SMX_STAMP(stamps, 5);
   ts_end(c.ts, kTsTilesEnd, blockIdx.x, gridDim.x);
-  if (ts_tail && threadIdx.x == 0) {
-    const unsigned long long now = wall_clock64();
-    atomicAdd(&c.ts[kTsMergeNum], now - ts_merge_begin);
-    atomicAdd(&c.ts[kTsMergeDen], now - ts_wg_begin);
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1963,7 +1948,6 @@ k_update_and_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, Crea
   if (blockIdx.x < n_create_blocks) {
     ts_begin(c.ts, kTsUpdBegin);
     new_create_body(S, c, sc, in, a, st, blockIdx.x, n_create_blocks);
-    ts_end(c.ts, kTsCreateEnd, blockIdx.x, n_create_blocks);   // (GetTimings' new_surfel_creation: the last creating workgroups out)
   } else {
     const uint32_t block = blockIdx.x - n_create_blocks, n_blocks = gridDim.x - n_create_blocks;
     // (pass A of the next call, which follows this launch, appends to the other chunk counter)
@@ -3930,22 +3914,12 @@ bool stage_ms_from_stamps(const unsigned long long* t, unsigned long long seq, i
   const unsigned long long tiles_end = first(t[kTsBlendBegin], t[kTsTilesEnd], t[kTsCullBegin]);
   const unsigned long long int_end = first(t[kTsUpdBegin], t[kTsIntEnd], first(t[kTsIntBegin], t[kTsBlendEnd], tiles_end));
   const unsigned long long upd_end = first(t[kTsRegBegin], t[kTsUpdEnd], int_end);
-  // Two of the reference's stages have no launch of their own here; each gets its share of the launch that carries it, taken
-  // OUT of that launch's stage, so that the seven values still add up to the call:
-  //   surfel merging   = the tile kernel's time x the share of their run its last workgroups spent in the merge phase
-  //                      (the marks are applied by k_integrate on the side: not separable, stays with the integration);
-  //   surfel creation  = begin of the update + create launch -> the last CREATING workgroups out (they are dispatched first;
-  //                      the neighbour update is what the launch does after that).
-  float merging = 0.0f;
-  if (t[kTsMergeDen] != 0 && t[kTsTilesBegin] != 0 && tiles_end > t[kTsTilesBegin])
-    merging = ms(t[kTsTilesBegin], tiles_end) * (float)((double)t[kTsMergeNum] / (double)t[kTsMergeDen]);
-  const unsigned long long create_end = (t[kTsCreateEnd] > int_end && t[kTsCreateEnd] <= upd_end) ? t[kTsCreateEnd] : int_end;
-  out_ms[0] = ms(t[kTsCullBegin], tiles_end) - merging;   // data association: cull step, pass A, association tiles (- merge phase)
-  out_ms[1] = merging;                                // surfel merging: the merge phase of the tile kernel
+  out_ms[0] = ms(t[kTsCullBegin], tiles_end);        // data association: cull step, pass A, association tiles
+  out_ms[1] = 0.0f;                                  // surfel merging: decided inside the tile kernel, applied by k_integrate
   out_ms[2] = ms(tiles_end, t[kTsBlendEnd]);         // measurement blending
-  out_ms[3] = ms(t[kTsIntBegin], int_end);           // integration (+ the new-surfel flag and rank pass, + the merge marks)
-  out_ms[4] = ms(create_end, upd_end);               // neighbour update: the rest of the update + create launch
-  out_ms[5] = ms(int_end, create_end);               // new surfel creation: its first workgroups
+  out_ms[3] = ms(t[kTsIntBegin], int_end);           // integration (+ the new-surfel flag and rank pass)
+  out_ms[4] = ms(int_end, upd_end);                  // neighbour update (+ creation, same launch)
+  out_ms[5] = 0.0f;                                  // new surfel creation: inside the neighbour-update launch
   out_ms[6] = ms(upd_end, t[kTsRegEnd]);             // regularisation: pass B, edges, step
   return true;
 }
