@@ -266,6 +266,7 @@ def host_frames_pass(wl, plan, base, count, api, torch):
     torch.cuda.synchronize()
     t = time.perf_counter()
     pipe.run_streamed(steps[warm:], uploads[warm:])
+    t_enq = time.perf_counter() - t           # (the host side of the loop: returns without synchronising)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t
     n = count - warm
@@ -275,6 +276,7 @@ def host_frames_pass(wl, plan, base, count, api, torch):
     staged, copy_engine = pipe.upload_counts(reset=True)
     return {"value": n / dt, "unit": "frames/s", "steps": n, "ms_per_step": 1e3 * dt / n,
             "frames_staged_by_copy_kernels": staged, "frames_by_copy_engine": copy_engine,
+            "host_enqueue_ms_per_step": 1e3 * t_enq / n,
             "h2d_bytes_per_frame": nbytes, "h2d_GBs": nbytes * n / dt / 1e9,
             "note": "inputs copied from page-locked host memory on the preprocessing stream "
                     "(smx_driver_run_streamed); not the headline value"}
