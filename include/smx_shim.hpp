@@ -150,17 +150,36 @@ class PinholeCamera4f {
 };
 
 // Device-side view, same members/layout as the reference's CUDABuffer_<T>.
+#if defined(__HIPCC__)
+#define SMX_SHIM_HD __host__ __device__
+#else
+#define SMX_SHIM_HD
+#endif
 template <typename T>
 struct CUDABuffer_ {
   T* address_;
   int height_;
   int width_;
   size_t pitch_;
-  T* address() const { return address_; }
-  int width() const { return width_; }
-  int height() const { return height_; }
-  size_t pitch() const { return pitch_; }
+  SMX_SHIM_HD T* address() const { return address_; }
+  SMX_SHIM_HD int width() const { return width_; }
+  SMX_SHIM_HD int height() const { return height_; }
+  SMX_SHIM_HD size_t pitch() const { return pitch_; }
   const smx_buffer_desc* desc() const { return reinterpret_cast<const smx_buffer_desc*>(this); }
+#if defined(__HIPCC__)
+  // The element accessors of VIS/cuda/cuda_buffer.cuh:58-96, for a maintainer's OWN kernels that take a CUDABuffer_<T> by
+  // value (the reference's visualisation and debug kernels do): element (y, x) at address + y * pitch + x * sizeof(T).
+  __device__ __forceinline__ T& operator()(unsigned int y, unsigned int x) {
+    return *(reinterpret_cast<T*>(reinterpret_cast<char*>(address_) + y * pitch_) + x);
+  }
+  __device__ __forceinline__ const T& operator()(unsigned int y, unsigned int x) const {
+    return *(reinterpret_cast<const T*>(reinterpret_cast<const char*>(address_) + y * pitch_) + x);
+  }
+  __device__ __forceinline__ T& operator()(const int2& pixel) { return operator()(pixel.y, pixel.x); }
+  __device__ __forceinline__ const T& operator()(const int2& pixel) const { return operator()(pixel.y, pixel.x); }
+  __device__ __forceinline__ T& operator()(const uint2& pixel) { return operator()(pixel.y, pixel.x); }
+  __device__ __forceinline__ const T& operator()(const uint2& pixel) const { return operator()(pixel.y, pixel.x); }
+#endif
 };
 static_assert(sizeof(CUDABuffer_<float>) == sizeof(smx_buffer_desc), "CUDABuffer_ must alias smx_buffer_desc");
 

@@ -227,7 +227,17 @@ def test_reference_style_host_code_compiles_and_links(tmp_path):
     # ... and inside a HIP translation unit float2 is HIP's own vector type (what a maintainer building main.cc with hipcc gets);
     # SMX_SHIM_NO_VEC_TYPES takes the caller's Vec3u8 (libvis' Eigen typedef inside the reference tree)
     hip_src = tmp_path / "caller_hip.cc"
-    hip_src.write_text("#include <hip/hip_runtime.h>\nnamespace vis { struct Vec3u8 { unsigned char v[3]; }; }\n" + SRC)
+    # ... with a kernel of the maintainer's own that takes CUDABuffer_<T> by value and uses the reference's accessors
+    # (VIS/cuda/cuda_buffer.cuh:58-96)
+    own_kernel = (
+        "template <typename T> __global__ void k_scale(vis::CUDABuffer_<T> in, vis::CUDABuffer_<float> out, float s) {\n"
+        "  const unsigned x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;\n"
+        "  if (x < (unsigned)in.width() && y < (unsigned)in.height()) out(y, x) = s * (float)in(make_uint2(x, y));\n"
+        "}\n"
+        "void launch_own(hipStream_t st, vis::CUDABuffer<vis::u16>& a, vis::CUDABuffer<float>& b) {\n"
+        "  hipLaunchKernelGGL(k_scale<vis::u16>, dim3((a.width() + 63) / 64, a.height()), dim3(64), 0, st, a.ToCUDA(), b.ToCUDA(), 0.0002f);\n"
+        "}\n")
+    hip_src.write_text("#include <hip/hip_runtime.h>\nnamespace vis { struct Vec3u8 { unsigned char v[3]; }; }\n" + SRC + own_kernel)
     r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-Wall", "-Werror", "-Wno-unused-variable",
                         "-Wno-unused-result", "-DSMX_SHIM_NO_VEC_TYPES", "-x", "hip", "-c", "-I", os.path.join(ROOT, "include"), str(hip_src),
                         "-o", str(tmp_path / "caller_hip.o")], capture_output=True, text=True)
