@@ -459,8 +459,11 @@ class CUDASurfelReconstruction {
   // The three cudaGraphicsResource_t arguments and the render window of the reference's constructor are
   // viewer plumbing (OpenGL interop); pass nullptr.
   // device_id (an addition): the GPU the object lives on, -1 = the calling thread's current device (as in the reference).
-  CUDASurfelReconstruction(usize max_surfel_count, const PinholeCamera4f& depth_camera, void* = nullptr,
-                           void* = nullptr, void* = nullptr, void* = nullptr, int device_id = -1) {
+  // (templates, so that APP/main.cc:835-837 compiles as it stands: whatever the caller's cudaGraphicsResource_t and
+  // shared_ptr<SurfelMeshingRenderWindow> are, they are accepted and ignored)
+  template <typename R1 = void*, typename R2 = void*, typename R3 = void*, typename Window = void*>
+  CUDASurfelReconstruction(usize max_surfel_count, const PinholeCamera4f& depth_camera, const R1& = R1(),
+                           const R2& = R2(), const R3& = R3(), const Window& = Window(), int device_id = -1) {
     const float* p = depth_camera.parameters();
     SMX_SHIM_CHECK(smx_recon_create((uint32_t)max_surfel_count, depth_camera.width(), depth_camera.height(), p[0], p[1],
                                     p[2], p[3], device_id, &handle_));

@@ -196,6 +196,20 @@ void buffers_like_main_cc(cudaStream_t stream, int width, int height, bool debug
   (void)const_color->ToCUDA(); (void)color_buffer_pagelocked; (void)next_color_buffer_pagelocked;
   // Integrate takes the float2 buffer as the reference declares it (APP/cuda_surfel_reconstruction.h:59-77)
   CUDASurfelReconstruction* reconstruction = nullptr;
+  if (debug_depth_preprocessing && width < 0) {
+    // APP/main.cc:835-838, token for token: three cudaGraphicsResource_t and the render window (viewer plumbing: ignored)
+    struct cudaGraphicsResource; typedef cudaGraphicsResource* cudaGraphicsResource_t;
+    struct SurfelMeshingRenderWindow {};
+    cudaGraphicsResource_t vertex_buffer_resource = nullptr, neighbor_index_buffer_resource = nullptr, normal_vertex_buffer_resource = nullptr;
+    shared_ptr<SurfelMeshingRenderWindow> render_window;
+    const float params[4] = {525.f, 525.f, 320.f, 240.f};
+    const PinholeCamera4f depth_camera(width, height, params);
+    usize max_surfel_count = 1000;
+    CUDASurfelReconstruction reconstruction(
+        max_surfel_count, depth_camera, vertex_buffer_resource,
+        neighbor_index_buffer_resource, normal_vertex_buffer_resource, render_window);
+    CUDASurfelsCPU cuda_surfels_cpu_buffers(max_surfel_count);
+  }
   if (reconstruction)
     reconstruction->Integrate(stream, 0, 5000.f, &filtered_depth_buffer_A, normals_buffer, radius_buffer, *color_buffer, SE3f(),
                               0.05f, 5.f, 10.f, 30, true, 1, 1, 2.f, 40.f, 0x7fffffff);
