@@ -60,6 +60,17 @@ __global__ void __launch_bounds__(kBlock) k_follower(const uint4* __restrict__ i
   if (threadIdx.x == 0) { sink[blockIdx.x] = v.x ^ i; stamps[2 * blockIdx.x] = t0; stamps[2 * blockIdx.x + 1] = now(); }
 }
 
+// The same follower with a private-segment (scratch) frame of 20 bytes per lane that is hardly used -- what k_integrate's code
+// object asks for (SGPR spill slots): does a dispatch that needs scratch start later?
+__global__ void __launch_bounds__(kBlock) k_follower_scratch(const uint4* __restrict__ in, uint32_t n, uint32_t stride, uint64_t* __restrict__ stamps, uint32_t* __restrict__ sink) {
+  const uint64_t t0 = now();
+  volatile uint32_t tmp[5];
+  tmp[threadIdx.x % 5u] = threadIdx.x;
+  const uint32_t i = (blockIdx.x * 9973u) % (n ? n : 1u);
+  const uint4 v = n ? in[(size_t)i * stride] : make_uint4(0, 0, 0, 0);
+  if (threadIdx.x == 0) { sink[blockIdx.x] = (v.x ^ i) + (tmp[0] & 0u); stamps[2 * blockIdx.x] = t0; stamps[2 * blockIdx.x + 1] = now(); }
+}
+
 struct Result { double boundary_us, writer_us, pair_period_us; int bad; };
 
 template <int kMode>
@@ -141,5 +152,41 @@ int main() {
                  b.pair_period_us, a.bad + b.bad);
           fflush(stdout);
         }
+  // ---- does a follower that needs scratch start later?  (same stream, plain stores, 0 and 16 MB)
+  printf("# follower with a 20-byte scratch frame vs without (same stream; boundary us, pair period us)\n");
+  for (size_t bytes : {(size_t)0, (size_t)(16u << 20)}) {
+    for (int scratch = 0; scratch < 2; ++scratch) {
+      const uint32_t n = (uint32_t)(bytes / 16);
+      const int wg_w = 256 * 8, wg_f = 256;
+      std::vector<uint64_t> st(2 * (wg_w + wg_f));
+      std::vector<double> bnd;
+      for (int rep = 0; rep < 31; ++rep) {
+        hipLaunchKernelGGL(k_writer<kPlain>, dim3(wg_w), dim3(kBlock), 0, s0, buf, n, 1u, d_st);
+        if (scratch) hipLaunchKernelGGL(k_follower_scratch, dim3(wg_f), dim3(kBlock), 0, s0, buf, n, 1u, d_st + 2 * wg_w, d_sink);
+        else hipLaunchKernelGGL(k_follower, dim3(wg_f), dim3(kBlock), 0, s0, buf, n, 1u, d_st + 2 * wg_w, d_sink);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+        uint64_t w_e = 0, f_b = ~0ull;
+        for (int b = 0; b < wg_w; ++b) w_e = std::max(w_e, st[2 * b + 1]);
+        for (int b = 0; b < wg_f; ++b) f_b = std::min(f_b, st[2 * (wg_w + b)]);
+        bnd.push_back(((double)f_b - (double)w_e) * 0.01);
+      }
+      std::sort(bnd.begin(), bnd.end());
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      CK(hipEventRecord(e0, s0));
+      for (int i = 0; i < 40; ++i) {
+        hipLaunchKernelGGL(k_writer<kPlain>, dim3(wg_w), dim3(kBlock), 0, s0, buf, n, 1u, d_st);
+        if (scratch) hipLaunchKernelGGL(k_follower_scratch, dim3(wg_f), dim3(kBlock), 0, s0, buf, n, 1u, d_st + 2 * wg_w, d_sink);
+        else hipLaunchKernelGGL(k_follower, dim3(wg_f), dim3(kBlock), 0, s0, buf, n, 1u, d_st + 2 * wg_w, d_sink);
+      }
+      CK(hipEventRecord(e1, s0));
+      CK(hipDeviceSynchronize());
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("  %2.0f MB  follower %-12s boundary %6.2f  pair %6.2f\n", bytes / 1048576.0, scratch ? "with scratch" : "plain", bnd[bnd.size() / 2], ms * 1e3 / 40);
+      CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+    }
+  }
   return 0;
 }
