@@ -1016,23 +1016,32 @@ def other_configs(args, log):
     out = {}
     for name, extra in runs.items():
         t0 = time.time()
-        detail = os.path.join(ROOT, "bench_detail_%s.json" % name)
+        # (the child's full result travels through a file in a temporary directory -- the checkout may be read-only -- and is
+        # copied next to this script, and to gpurun_out/, afterwards)
+        import shutil
+        import tempfile
+        tmpdir = tempfile.mkdtemp(prefix="smx_bench_")
+        detail = os.path.join(tmpdir, "bench_detail_%s.json" % name)
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--quiet", "--no-other-configs", "--detail-out", detail] + extra
         env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
         try:
-            if os.path.exists(detail):
-                os.remove(detail)
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
             if r.returncode != 0 or not os.path.exists(detail):
                 out[name] = {"error": "rc %d: %s" % (r.returncode, r.stderr[-600:])}
+                shutil.rmtree(tmpdir, ignore_errors=True)
                 continue
             d = json.load(open(detail))
         except (subprocess.TimeoutExpired, ValueError, OSError) as e:
             out[name] = {"error": repr(e)[:600]}
+            shutil.rmtree(tmpdir, ignore_errors=True)
             continue
-        gout = os.path.join(ROOT, "gpurun_out")
-        if os.path.isdir(gout):
-            json.dump(d, open(os.path.join(gout, os.path.basename(detail)), "w"), indent=1)
+        for dst in (ROOT, os.path.join(ROOT, "gpurun_out")):
+            if os.path.isdir(dst):
+                try:
+                    shutil.copy(detail, os.path.join(dst, os.path.basename(detail)))
+                except OSError:
+                    pass
+        shutil.rmtree(tmpdir, ignore_errors=True)
         roof = dict(d.get("roofline") or {})
         roof.pop("kernels", None)
         roof.pop("traffic_pmc_raw", None)
