@@ -138,6 +138,35 @@ def test_bench_gpus_8_dry_run_plain_start():
 
 
 @pytest.mark.gpu
+def test_bench_line_of_a_real_run_is_compact_and_complete(tmp_path):
+    """The driver's command shape on a small map: ONE stdout line that starts with '{', under 6 000 characters (the driver keeps
+    8 000 of stdout), with the contract's keys, the roofline and CPU-baseline blocks and a green in-run parity check; the full
+    result lands in the detail file."""
+    import json
+    import subprocess
+    import sys
+    from common import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    detail = str(tmp_path / "detail.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                        "--surfels", "300000", "--cpu-frames", "2", "--host-frames", "20", "--growth-frames", "0", "--timing-frames", "0",
+                        "--detail-out", detail], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{") and len(lines[0]) < 6000, (len(lines), len(lines[0]))
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["value"] > 0 and d["vs_baseline"] is None
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["avg_launch_ms"] > 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert d["parity_check"]["ok"] is True and d["host_frames"]["value"] > 0
+    full = json.load(open(detail))
+    assert full["roofline"]["kernels"] and full["host_frames"]["frames_staged_by_copy_kernels"] == 20
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_share_one_gpu_over_gloo():
     """C4 readiness without the 8-GPU node: bench.py's REAL timed path with two ranks under torch.distributed.run, process
     group gloo (RCCL refuses two ranks on one device; the streams are independent, the only collectives are the barrier and
