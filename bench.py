@@ -648,6 +648,8 @@ def main():
                     help="the frame loop reads GetTimings after every Integrate like APP/main.cc:1511: nowait = "
                          "GetTimingsNoWait, block = the reference's waiting call")
     ap.add_argument("--fused-head", action="store_true", help="A/B: bilateral filter and outlier cull in one launch (same images; slower)")
+    ap.add_argument("--pre-cus", type=int, default=0, help="A/B: the preprocessing queues on the first N compute units of the CU mask (N / 8 per XCD); 0 = no partition")
+    ap.add_argument("--cu-exclusive", action="store_true", help="with --pre-cus: the internal stream and the caller's stream on the OTHER compute units")
     ap.add_argument("--run-ahead", action="store_true", help="A/B: preprocessing two steps ahead, waits routed off the caller's stream")
     ap.add_argument("--scan-mode", type=int, default=0, help="A/B: smx_recon_set_scan_mode bits (1 = all-slot scans, 2 = multi-launch blend, 4 = no hot-group filter in pass B, 512 = pass B and the edge kernel fused into one launch)")
     ap.add_argument("--ub", default="", help="TIMING-ONLY upper bounds, comma list of: hoist-pre (every timed frame preprocessed "
@@ -780,6 +782,14 @@ def run_integrate(args):
         api.StreamSynchronize(None)
         wl.pipe.stream = api.Stream({"plain": None, "high": 1, "low": -1}[args.caller_stream])
     rec.set_stats_enabled(False)   # the distribution counters are single-address atomics: off while timing
+    if args.pre_cus:
+        def cu_mask(lo, hi, total=256):
+            return [sum(1 << b for b in range(32) if lo <= 32 * w + b < hi) for w in range(total // 32)]
+        wl.pipe.set_pre_cu_mask(cu_mask(0, args.pre_cus))
+        if args.cu_exclusive:
+            api.StreamSynchronize(None)
+            rec.set_internal_cu_mask(cu_mask(args.pre_cus, 256))
+            wl.pipe.stream = api.Stream(cu_mask=cu_mask(args.pre_cus, 256))
     if args.run_ahead:
         wl.pipe.set_run_ahead(True)
     if args.fused_head:

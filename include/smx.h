@@ -73,6 +73,11 @@ int smx_device_name(int device, char* name, size_t capacity);
 int smx_stream_create(smx_stream* out);
 /* priority_class: -1 = lowest, 0 = default, +1 = highest priority the device offers (cudaStreamCreateWithPriority) */
 int smx_stream_create_with_priority(smx_stream* out, int32_t priority_class);
+/* A stream whose kernels only run on a subset of the compute units (hipExtStreamCreateWithCUMask; no CUDA counterpart):
+ * bit k of mask_words[k / 32] set = compute unit k may be used.  On this part consecutive bits fall on consecutive XCDs
+ * (bit k -> XCD k % 8), so the low n bits are n / 8 compute units of every XCD.  Default priority.  Measured use:
+ * a partition between the preprocessing queue and the surfel queues (profiles/r6_ab_notes.md section 10). */
+int smx_stream_create_with_cu_mask(smx_stream* out, const uint32_t* mask_words, uint32_t n_words);
 /* Page-locked host memory for upload staging (cudaHostAlloc(..., cudaHostAllocWriteCombined) / cudaFreeHost,
  * APP/main.cc:825-829, 917): copies from it are asynchronous to the host.  write_combined memory is fast to
  * upload from and slow for the CPU to read. */
@@ -308,6 +313,9 @@ int smx_recon_get_timings(smx_recon r, float out_ms[7]);
  * page-locked host memory, so the read lags the queue by two calls and touches neither the device nor any stream.
  * *call_number: that call's 1-based number, 0 (and zeros) if there is none yet. */
 int smx_recon_get_timings_nowait(smx_recon r, float out_ms[7], uint64_t* call_number);
+/* Experiment: the object's internal stream re-created on a subset of the compute units (mask as for
+ * smx_stream_create_with_cu_mask; n_words = 0: all of them again, at the highest priority).  Waits for the object's work. */
+int smx_recon_set_internal_cu_mask(smx_recon r, const uint32_t* mask_words, uint32_t n_words);
 /* Measurement: the object's internal stream (for smx_debug_handover_probe; never enqueue work on it). */
 int smx_recon_debug_internal_stream(smx_recon r, smx_stream* out);
 /* Measurement: the raw stage-stamp records of the last 8 smx_recon_integrate calls (8 x 16 words of device wall clock,

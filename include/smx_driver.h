@@ -90,6 +90,9 @@ int smx_driver_set_fused_tail(smx_driver d, int32_t enabled);
  * (three sets of work images) and its dependencies are routed through smx_recon_integrate_hooks, so that from the third
  * step of a call on the caller's stream carries one event record and one wait per frame instead of two and two. */
 int smx_driver_set_run_ahead(smx_driver d, int32_t enabled);
+/* Experiment (results identical): the preprocessing queues re-created on a subset of the compute units (mask as for
+ * smx_stream_create_with_cu_mask; n_words = 0: plain queues again).  Waits for the driver's work. */
+int smx_driver_set_pre_cu_mask(smx_driver d, const uint32_t* mask_words, uint32_t n_words);
 /* Measurement hooks (bench.py).  smx_driver_debug_prepare: preprocess the n steps now, each into work images of its
  * own, and wait; the following smx_driver_run calls integrate those images in order instead of preprocessing (same
  * results; the preprocessing queue stays empty while the frames run).  smx_driver_profile_begin / _end: time stamps

@@ -35,11 +35,15 @@ def _stream(s):
 class Stream:
     """A HIP stream (cudaStream_t in the reference's signatures)."""
 
-    def __init__(self, priority_class=None):
+    def __init__(self, priority_class=None, cu_mask=None):
         """priority_class: None = plain stream; -1 / 0 / +1 = lowest / default / highest device priority
-        (cudaStreamCreateWithPriority)."""
+        (cudaStreamCreateWithPriority).  cu_mask: list of 32-bit words, bit k = compute unit k may be used
+        (smx_stream_create_with_cu_mask; default priority)."""
         self.handle = C.c_void_p()
-        if priority_class is None:
+        if cu_mask:
+            arr = (C.c_uint32 * len(cu_mask))(*cu_mask)
+            _lib.check(_lib.load().smx_stream_create_with_cu_mask(C.byref(self.handle), arr, C.c_uint32(len(cu_mask))))
+        elif priority_class is None:
             _lib.check(_lib.load().smx_stream_create(C.byref(self.handle)))
         else:
             _lib.check(_lib.load().smx_stream_create_with_priority(C.byref(self.handle), C.c_int32(priority_class)))
@@ -588,6 +592,11 @@ class CUDASurfelReconstruction:
 
     def set_scan_mode(self, mode):
         _lib.check(_lib.load().smx_recon_set_scan_mode(self._h, C.c_int32(mode)))
+
+    def set_internal_cu_mask(self, mask_words):
+        """experiment (smx_recon_set_internal_cu_mask): the internal stream on the compute units of the mask (empty = all)"""
+        arr = (C.c_uint32 * max(1, len(mask_words)))(*mask_words)
+        _lib.check(_lib.load().smx_recon_set_internal_cu_mask(self._h, arr, C.c_uint32(len(mask_words))))
 
     def debug_set_skip(self, mask):
         """TIMING ONLY (smx_recon_debug_set_skip): bit 0 = no regulariser, bit 1 = front of the frame only."""

@@ -121,6 +121,17 @@ int smx_stream_create_with_priority(smx_stream* out, int32_t priority_class) {
   return SMX_OK;
 }
 
+int smx_stream_create_with_cu_mask(smx_stream* out, const uint32_t* mask_words, uint32_t n_words) {
+  SMX_CHECK_ARG(out != nullptr && mask_words != nullptr && n_words >= 1 && n_words <= 32);
+  uint32_t any = 0;
+  for (uint32_t k = 0; k < n_words; ++k) any |= mask_words[k];
+  SMX_CHECK_ARG(any != 0);
+  hipStream_t s;
+  SMX_HIP(hipExtStreamCreateWithCUMask(&s, n_words, mask_words));
+  *out = (smx_stream)s;
+  return SMX_OK;
+}
+
 // cudaHostAlloc / cudaFreeHost of the caller's upload staging (APP/main.cc:917, 825-829)
 // (measurement) n ping-pongs of an empty kernel between two streams, each leg handed over by an event: mean time per leg.
 int smx_debug_handover_probe(smx_stream sa, smx_stream sb, int32_t n, float* us_per_handover) {

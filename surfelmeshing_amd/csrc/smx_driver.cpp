@@ -634,6 +634,23 @@ int smx_driver_set_split_preprocessing(smx_driver d, int32_t enabled) {
   return SMX_OK;
 }
 
+int smx_driver_set_pre_cu_mask(smx_driver d, const uint32_t* mask_words, uint32_t n_words) {
+  if (!d || (n_words && !mask_words)) return fail("null argument");
+  SMX_SHIM_CHECK(smx_stream_synchronize(d->pre_stream));
+  SMX_SHIM_CHECK(smx_stream_synchronize(d->pre_stream2));
+  cudaStream_t a = nullptr, b = nullptr;
+  if (n_words) {
+    SMX_SHIM_CHECK(smx_stream_create_with_cu_mask(&a, mask_words, n_words));
+    SMX_SHIM_CHECK(smx_stream_create_with_cu_mask(&b, mask_words, n_words));
+  } else {
+    SMX_SHIM_CHECK(smx_stream_create_with_priority(&a, SMX_PRE_PRIORITY));
+    SMX_SHIM_CHECK(smx_stream_create_with_priority(&b, SMX_PRE2_PRIORITY));
+  }
+  smx_stream_destroy(d->pre_stream); smx_stream_destroy(d->pre_stream2);
+  d->pre_stream = a; d->pre_stream2 = b;
+  return SMX_OK;
+}
+
 int smx_driver_set_fused_tail(smx_driver d, int32_t enabled) {
   if (!d) return fail("null argument");
   d->fuse_tail = enabled != 0;

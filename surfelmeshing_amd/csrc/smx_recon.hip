@@ -3638,6 +3638,24 @@ int smx_recon_debug_download_stamps(smx_recon r, unsigned long long* out) {   //
 }
 #endif
 
+int smx_recon_set_internal_cu_mask(smx_recon r, const uint32_t* mask_words, uint32_t n_words) {
+  SMX_CHECK_ARG(r != nullptr && (n_words == 0 || mask_words != nullptr) && n_words <= 32);
+  SMX_ON_DEVICE(r->device);
+  SMX_HIP(hipStreamSynchronize(r->reg_stream));
+  r->reg_pending = false;
+  hipStream_t s = nullptr;
+  if (n_words) {
+    SMX_HIP(hipExtStreamCreateWithCUMask(&s, n_words, mask_words));
+  } else {
+    int lo = 0, hi = 0;
+    SMX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    SMX_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, SMX_REG_PRIORITY_HIGH ? hi : 0));
+  }
+  (void)hipStreamDestroy(r->reg_stream);
+  r->reg_stream = s;
+  return SMX_OK;
+}
+
 int smx_recon_debug_internal_stream(smx_recon r, smx_stream* out) {   // (measurement: smx_debug_handover_probe)
   SMX_CHECK_ARG(r != nullptr && out != nullptr);
   *out = (smx_stream)r->reg_stream;

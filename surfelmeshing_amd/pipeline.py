@@ -183,7 +183,7 @@ class DriverStep(_C.Structure):
 
 DRIVER_EXPORTS = ["smx_driver_create", "smx_driver_destroy", "smx_driver_recon", "smx_driver_upload_frame",
                   "smx_driver_render_frame", "smx_driver_release_frame", "smx_driver_frame_descs", "smx_driver_run",
-                  "smx_driver_work_descs", "smx_driver_download_frame", "smx_driver_download_work", "smx_driver_set_overlap", "smx_driver_set_fused_tail", "smx_driver_set_fused_head", "smx_driver_set_run_ahead", "smx_driver_set_split_preprocessing",
+                  "smx_driver_work_descs", "smx_driver_download_frame", "smx_driver_download_work", "smx_driver_set_overlap", "smx_driver_set_fused_tail", "smx_driver_set_fused_head", "smx_driver_set_run_ahead", "smx_driver_set_split_preprocessing", "smx_driver_set_pre_cu_mask",
                   "smx_driver_run_streamed", "smx_driver_debug_streams", "smx_driver_set_staged_uploads", "smx_driver_upload_counts", "smx_driver_set_read_timings", "smx_driver_timing_sums", "smx_driver_debug_prepare", "smx_driver_profile_begin", "smx_driver_profile_end"]
 
 
@@ -238,6 +238,11 @@ class NativeFramePipeline:
 
     def set_split_preprocessing(self, enabled):
         _smxlib.check(_smxlib.load().smx_driver_set_split_preprocessing(self._d, _C.c_int32(1 if enabled else 0)))
+
+    def set_pre_cu_mask(self, mask_words):
+        """experiment: the preprocessing queues on the compute units of the mask (list of 32-bit words; empty = all)"""
+        arr = (_C.c_uint32 * max(1, len(mask_words)))(*mask_words)
+        _smxlib.check(_smxlib.load().smx_driver_set_pre_cu_mask(self._d, arr, _C.c_uint32(len(mask_words))))
 
     def set_fused_tail(self, enabled):
         _smxlib.check(_smxlib.load().smx_driver_set_fused_tail(self._d, _C.c_int32(1 if enabled else 0)))
