@@ -1974,7 +1974,7 @@ struct EdgeLds {
   unsigned long long* lacc;   // [kSegAcc * 2] per target: (gx | gy), (gz | sender classes)
   uint32_t* hkey; uint32_t* hcnt;   // [kFarHash] far destinations of this workgroup: segment, terms -> base in the bin
   uint16_t* lrank;            // [kSegAcc] per slot of the segment: its rank among the recent slots, or 0xFFFF
-  uint32_t* rec_wave;         // [kBlockAcc / 64] recent entries per wavefront of the chunk
+  uint32_t* rec_wave;         // [kSegAcc / 64] recent entries per (chunk, wavefront) of the segment
 };
 constexpr int kSegAcc = 1024;     // slots per accumulation workgroup (16 KB of LDS sums)
 constexpr int kBlockAcc = 256;
@@ -2004,7 +2004,7 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, DevState* st, unsign
   __shared__ unsigned long long e_lacc[kFused ? kSegAcc * 2 : 1];
   __shared__ uint32_t e_hkey[kFused ? kFarHash : 1], e_hcnt[kFused ? kFarHash : 1];
   __shared__ uint16_t e_lrank[kFused ? kSegAcc : 2];
-  __shared__ uint32_t e_rec_wave[kBlockAcc / 64];
+  __shared__ uint32_t e_rec_wave[kSegAcc / 64];
   __shared__ uint32_t lent[kFused ? kSegAcc : 1];   // the segment's work-list entries (fused: LDS instead of L.act_list)
   const uint32_t seg_id = segment_of_block(descending);
   extern __shared__ __align__(16) uint8_t lhot[];   // the hot-group table (n_hot_groups bytes, padded to 16)
@@ -2284,6 +2284,235 @@ __device__ __forceinline__ void far_term_spill(long long* __restrict__ grad_acc,
 #ifndef SMX_ACC_WGS_PER_CU
 #define SMX_ACC_WGS_PER_CU 5   // (256-lane workgroups, 26 KB of LDS each; <= 96 VGPRs without scratch. 4 / 5 / 6 measured: profiles/r5_ab_notes.md)
 #endif
+#ifndef SMX_EDGE_ONEPASS
+#define SMX_EDGE_ONEPASS 1   // (0: the chunk-by-chunk form of rounds 5-6, kept for A/B -- profiles/r6_ab_notes.md section 11)
+#endif
+#if SMX_EDGE_ONEPASS
+// The edge work of ONE segment (k_reg_accumulate's step; also the tail of the fused pass B): n_act entries, the lane's
+// entry of the first chunk in ent_first, the entries of later chunks in later_entries[e] (global work list or LDS).
+//
+// A segment with more than 256 entries takes several chunks of 256 (they share the LDS sums).  Rounds 5-6 worked the chunks
+// one after the other, each with the whole chain -- link records, neighbour gathers, a barrier, the returning atomics that
+// reserve the workgroup's runs in the destination bins, a barrier, the far stores -- and the workgroup stamps of
+// tools/stamps.py showed what that costs (profiles/r8c_stamps_alone.txt, C2): every workgroup of the launch starts within
+// 0.4 us, the 320 + 139 segments with up to 256 entries are through after 7 - 10 us, and the 393 dense segments (769 - 1024
+// entries: four chunks) after 24 - 30 us -- the launch lasts as long as four chains in a row while the chip empties.
+// Here the chains of a segment's chunks are taken apart and laid side by side:
+//   1. entries and link records of ALL chunks requested together (one round trip); the recent slots' ranks;
+//   2. the far terms are COUNTED per destination from the link records and the window masks alone (no positions needed) in
+//      the LDS table, and the workgroup's runs in the bins are reserved ONCE per segment -- while the first chunk's
+//      position gathers are already travelling;
+//   3. the chunks' terms are formed one chunk after the other with the next chunk's gathers in flight, and every far term
+//      is stored at once at the place it draws from its destination's run (an LDS counter): no barrier between chunks, no
+//      far term waits in registers.
+// Four barriers per segment instead of three per chunk; the dependent round trips of a dense segment fall from eight to
+// two plus what the gathers of four chunks cannot hide behind each other.  The sums are integer sums and the order of the
+// records inside a bin is of no consequence (k_reg_step adds them up in LDS): results unchanged bit for bit.
+__device__ __forceinline__ void edge_segment(const Surfels& S, const EdgeArgs& ea, DevState* st, uint32_t base, uint32_t n_act,
+                                             uint32_t ent_first, const uint32_t* later_entries, const EdgeLds& lds, uint32_t tid) {
+  constexpr int kCh = kSegAcc / kBlockAcc;   // chunks of a full segment
+  unsigned long long* const lacc = lds.lacc;
+  uint32_t* const hkey = lds.hkey; uint32_t* const hcnt = lds.hcnt;
+  uint16_t* const lrank = lds.lrank; uint32_t* const rec_wave = lds.rec_wave;
+  const float rf2 = ea.rf2, weight = ea.weight;
+  long long* const grad_acc = ea.grad_acc;
+  float4* const reg_rec = ea.reg_rec;
+  const size_t rec_own_offset = ea.rec_own_offset;
+  const FarBins& fb = ea.fb;
+  const uint32_t n_chunks = (n_act + kBlockAcc - 1u) / kBlockAcc;   // (uniform: 1 .. kCh)
+#pragma unroll
+  for (int k = 0; k < kSegAcc * 2 / kBlockAcc; ++k) lacc[k * kBlockAcc + tid] = 0;
+#pragma unroll
+  for (int k = 0; k < kSegAcc / 2 / kBlockAcc; ++k) reinterpret_cast<uint32_t*>(lrank)[k * kBlockAcc + tid] = 0xFFFFFFFFu;
+#pragma unroll
+  for (int k = 0; k < kFarHash / kBlockAcc; ++k) { hkey[k * kBlockAcc + tid] = kInvalid; hcnt[k * kBlockAcc + tid] = 0; }
+  // 1. the lane's entry of every chunk and its link record (idle lanes and chunks: the segment's first slot, no links used)
+  uint32_t entq[kCh];
+  uint4 tq[kCh];
+  entq[0] = tid < n_act ? ent_first : kNoActEntry;
+#pragma unroll
+  for (int c = 1; c < kCh; ++c)
+    entq[c] = ((uint32_t)c < n_chunks && (uint32_t)c * kBlockAcc + tid < n_act) ? later_entries[(uint32_t)c * kBlockAcc + tid] : kNoActEntry;
+#pragma unroll
+  for (int c = 0; c < kCh; ++c)
+    tq[c] = ((uint32_t)c < n_chunks) ? *reinterpret_cast<const uint4*>(S.group(kGroupT, base + (entq[c] != kNoActEntry ? (entq[c] & 1023u) : 0u)))
+                                     : make_uint4(kInvalid, kInvalid, kInvalid, kInvalid);
+  // (what a chunk's terms need: the slot's own S and N records and one S record per link -- a recent slot every valid
+  // neighbour (its own step term, :2238-2256), any other slot only the neighbours inside the window (the terms it pushes);
+  // unused links read the slot's own record)
+  auto gather_mask = [](uint32_t ent, const uint4& t) -> uint32_t {
+    if (ent == kNoActEntry) return 0u;
+    uint32_t g = (ent >> 10) & 15u;
+    if ((ent >> 14) & 1u) g |= (t.x != kInvalid ? 1u : 0u) | (t.y != kInvalid ? 2u : 0u) | (t.z != kInvalid ? 4u : 0u) | (t.w != kInvalid ? 8u : 0u);
+    return g;
+  };
+  float4 cur_s, cur_n, cur_ts[4];
+  {
+    const uint32_t i = base + (entq[0] != kNoActEntry ? (entq[0] & 1023u) : 0u);
+    const uint32_t g = gather_mask(entq[0], tq[0]);
+    const uint32_t nb[4] = {tq[0].x, tq[0].y, tq[0].z, tq[0].w};
+    cur_s = *S.group(kGroupS, i);
+    cur_n = *S.group(kGroupN, i);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cur_ts[q] = *S.group(kGroupS, (g & (1u << q)) ? nb[q] : i);
+  }
+  // A recent slot's results -- the in-segment sums and its own term -- go to two dense arrays at the slot's RANK among the
+  // segment's recent slots, which is its place in the recent list pass B wrote (both lists ascend by slot): the step
+  // kernel reads the records of a segment as coalesced runs.  (Two arrays of 16-byte records, not one of 32-byte records:
+  // the two halves are ready at different times, and a 16-byte store into a 32-byte record is a partial sector write --
+  // WRITE_SIZE booked 32 bytes for each, 30 MB a frame at C2 instead of 15, profiles/r40_WRITE_SIZE.md.)
+  uint32_t rank_in_wave[kCh];
+#pragma unroll
+  for (int c = 0; c < kCh; ++c) {
+    const bool rec = entq[c] != kNoActEntry && ((entq[c] >> 14) & 1u);
+    const unsigned long long bal = __ballot(rec);
+    rank_in_wave[c] = (uint32_t)__popcll(bal & ((1ull << (tid & 63u)) - 1ull));
+    if ((tid & 63u) == 0) rec_wave[c * (kBlockAcc / 64) + (tid >> 6)] = (uint32_t)__popcll(bal);
+  }
+  __syncthreads();   // (the tables are clear, the recent counts of every (chunk, wavefront) in place)
+  {
+    uint32_t before = 0;   // recent entries in the wavefronts in front of this lane's, chunk-major
+#pragma unroll
+    for (int c = 0; c < kCh; ++c) {
+      uint32_t mine = before;
+#pragma unroll
+      for (int wv = 0; wv < kBlockAcc / 64; ++wv) {
+        const uint32_t n = rec_wave[c * (kBlockAcc / 64) + wv];
+        if ((uint32_t)wv < (tid >> 6)) mine += n;
+        before += n;
+      }
+      if (entq[c] != kNoActEntry && ((entq[c] >> 14) & 1u)) lrank[entq[c] & 1023u] = (uint16_t)(mine + rank_in_wave[c]);
+    }
+  }
+  // 2. how many far terms this workgroup has for each destination segment: find (or claim) the destination's entry in the
+  // LDS table and count (the same probe sequence finds the entry again in step 3; a destination that finds no room in the
+  // table -- 16 probes -- is not in it then either, and its terms go to grad_acc)
+#pragma unroll
+  for (int c = 0; c < kCh; ++c) {
+    if ((uint32_t)c >= n_chunks) break;   // (uniform)
+    if (entq[c] == kNoActEntry) continue;
+    const uint32_t mask = (entq[c] >> 10) & 15u;
+    const uint32_t nb[4] = {tq[c].x, tq[c].y, tq[c].z, tq[c].w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!(mask & (1u << q)) || nb[q] - base < (uint32_t)kSegAcc) continue;
+      const uint32_t dseg = nb[q] / kSegB;
+      uint32_t h = (dseg * 2654435761u) >> 16;
+      for (int probe = 0; probe < 16; ++probe) {
+        h &= fb.hash_mask;
+        const uint32_t seen = atomicCAS(&hkey[h], kInvalid, dseg);
+        if (seen == kInvalid || seen == dseg) { atomicAdd(&hcnt[h], 1u); break; }
+        ++h;
+      }
+    }
+  }
+  __syncthreads();
+  // one lane per destination reserves the workgroup's run in that bin; the table then holds the next free place of the run
+#pragma unroll
+  for (int k = 0; k < kFarHash / kBlockAcc; ++k) {
+    const uint32_t e = k * kBlockAcc + tid;
+    const uint32_t dseg = hkey[e];
+    if (dseg != kInvalid) hcnt[e] = atomicAdd(&fb.count[(size_t)dseg * kCountStride], hcnt[e]);
+  }
+  __syncthreads();
+  // 3. the chunks' terms
+#pragma unroll 1
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    const uint32_t ent = entq[0];
+    const uint4 own_t = tq[0];
+    // the next chunk's records travel while this chunk's terms are formed
+    float4 nxt_s = cur_s, nxt_n = cur_n, nxt_ts[4] = {cur_ts[0], cur_ts[1], cur_ts[2], cur_ts[3]};
+    if (c + 1 < n_chunks) {   // (uniform)
+      const uint32_t i1 = base + (entq[1] != kNoActEntry ? (entq[1] & 1023u) : 0u);
+      const uint32_t g1 = gather_mask(entq[1], tq[1]);
+      const uint32_t nb1[4] = {tq[1].x, tq[1].y, tq[1].z, tq[1].w};
+      nxt_s = *S.group(kGroupS, i1);
+      nxt_n = *S.group(kGroupN, i1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) nxt_ts[q] = *S.group(kGroupS, (g1 & (1u << q)) ? nb1[q] : i1);
+    }
+    const bool act = ent != kNoActEntry;
+    const uint32_t rel_own = act ? (ent & 1023u) : 0u;
+    const uint32_t mask = act ? ((ent >> 10) & 15u) : 0u;
+    const bool rec = act && ((ent >> 14) & 1u);
+    const uint32_t i = base + rel_own;
+    const uint32_t nb[4] = {own_t.x, own_t.y, own_t.z, own_t.w};
+    const uint32_t gmask = gather_mask(ent, own_t);
+    if (act) {
+      const Vec3 sp = {cur_s.x, cur_s.y, cur_s.z};
+      const Vec3 nrm = {cur_n.x, cur_n.y, cur_n.z};
+      const float r2 = cur_n.w;
+      const int neighbor_count = mask ? __popc(mask) : 1;
+      const float factor = 2 * weight / (float)neighbor_count;  // :2153
+      int own_count = 0;
+      Vec3 rg = {0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!(gmask & (1u << q))) continue;
+        const Vec3 t = {cur_ts[q].x - sp.x, cur_ts[q].y - sp.y, cur_ts[q].z - sp.z};
+        const float nd = nrm.x * t.x + nrm.y * t.y + nrm.z * t.z;
+        bool pruned = false;
+        if (mask & (1u << q)) {
+          const float f = factor * nd;
+          const Vec3 term = {f * nrm.x, f * nrm.y, f * nrm.z};   // (the weight term, :2182, travels as the sender's class)
+          // the fixed-point channel carries |component| < 16 m (q22_from_float clamps): a huge regularizer_weight or a
+          // corrupt position is reported instead of silently bending the gradient
+          if (!(fabsf(term.x) < 16.0f && fabsf(term.y) < 16.0f && fabsf(term.z) < 16.0f)) st->reg_saturated = 1u;
+          const int qx = q22_from_float(term.x), qy = q22_from_float(term.y), qz = q22_from_float(term.z);
+          const uint32_t rel = nb[q] - base;
+          if (rel < (uint32_t)kSegAcc) {
+            // component-major LDS layout: consecutive lanes (consecutive targets) hit consecutive banks
+            atomicAdd(&lacc[rel], pack_pair(qx, qy));
+            atomicAdd(&lacc[kSegAcc + rel], pack_pair(qz, 1 << (8 * (neighbor_count - 1))));
+          } else {
+            // the destination's entry in the table (step 2 put it there, or found no room), the term's place in the run
+            const uint32_t dseg = nb[q] / kSegB;
+            uint32_t h = (dseg * 2654435761u) >> 16;
+            uint32_t pos = kInvalid;
+            for (int probe = 0; probe < 16; ++probe) {
+              h &= fb.hash_mask;
+              if (hkey[h] == dseg) { pos = atomicAdd(&hcnt[h], 1u); break; }
+              ++h;
+            }
+            if (pos < fb.cap)
+              out_store16<SMX_ST_FARBIN>(&fb.rec[(size_t)dseg * fb.cap + pos],
+                                         make_uint4((nb[q] % kSegB) | ((uint32_t)(neighbor_count - 1) << 10), (uint32_t)qx, (uint32_t)qy, (uint32_t)qz));
+            else
+              far_term_spill(grad_acc, fb, nb[q], qx, qy, qz, neighbor_count);
+          }
+          const float d2 = t.x * t.x + t.y * t.y + t.z * t.z;
+          if (d2 > rf2 * r2) { S.set_neighbor(i, q, kInvalid); pruned = true; }  // :2190-2192
+        }
+        // the slot's own regulariser term (RegularizeSurfelsCUDAKernel :2238-2256 sees the row after the pruning
+        // above): same neighbour positions, same n.t product, so it is formed here and k_reg_step gathers nothing
+        if (rec && !pruned) {
+          ++own_count;
+          rg.x = rg.x - nd * nrm.x; rg.y = rg.y - nd * nrm.y; rg.z = rg.z - nd * nrm.z;
+        }
+      }
+      // (second half of the slot's dense record; the first half -- the in-segment sums -- follows when the segment is through)
+      if (rec) out_store16<SMX_ST_REGREC>(&reg_rec[rec_own_offset + (size_t)(base + lrank[rel_own])], make_float4(rg.x, rg.y, rg.z, __int_as_float(own_count)));
+    }
+#pragma unroll
+    for (int k = 0; k + 1 < kCh; ++k) { entq[k] = entq[k + 1]; tq[k] = tq[k + 1]; }
+    cur_s = nxt_s; cur_n = nxt_n;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cur_ts[q] = nxt_ts[q];
+  }
+  __syncthreads();   // (every chunk's in-segment terms are in)
+  // The in-segment sums of the recent slots: first half of their dense records.  (Rounds 3-4 stored the sums of EVERY slot
+  // of the segment, zeros included -- 16 KB of full lines per workgroup, 39 MB a frame at C2, of which the step kernel read
+  // the recent slots' 7 MB: profiles/r31_WRITE_SIZE.md.)
+#pragma unroll
+  for (int k = 0; k < kSegAcc / kBlockAcc; ++k) {
+    const uint32_t rel = k * kBlockAcc + tid;
+    const uint32_t rank = lrank[rel];
+    if (rank == 0xFFFFu) continue;
+    const unsigned long long v0 = lacc[rel], v1 = lacc[kSegAcc + rel];
+    out_store16<SMX_ST_REGREC>(&reg_rec[(size_t)(base + rank)], v0, v1);
+  }
+}
+#else
 // The edge work of ONE segment (k_reg_accumulate's step; also the tail of the fused pass B): n_act entries, the lane's
 // entry of the first chunk in ent_first, the entries of later chunks in later_entries[e] (global work list or LDS).
 __device__ __forceinline__ void edge_segment(const Surfels& S, const EdgeArgs& ea, DevState* st, uint32_t base, uint32_t n_act,
@@ -2457,15 +2686,21 @@ __device__ __forceinline__ void edge_segment(const Surfels& S, const EdgeArgs& e
   }
 }
 
+#endif   // SMX_EDGE_ONEPASS
 __global__ void __launch_bounds__(kBlockAcc, SMX_ACC_WGS_PER_CU)   // (second argument: wavefronts per SIMD = workgroups per CU here)
 k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ grad_acc,
                  float4* __restrict__ reg_rec, size_t rec_own_offset, FarBins fb,
-                 const uint32_t* __restrict__ act_list, Chunks acc, DevState* st, unsigned long long* ts) {
+                 const uint32_t* __restrict__ act_list, Chunks acc, DevState* st, unsigned long long* ts, unsigned long long* stamps) {
   ts_begin(ts, kTsAccBegin);
+#ifdef SMX_STAMPS
+  // (diagnosis, tools/acc_stamps.py: per workgroup the wall clock at entry and exit, steps, entries, the largest step)
+  const unsigned long long t_in = wall_clock64();
+  uint32_t dbg_steps = 0, dbg_entries = 0, dbg_max = 0;
+#endif
   __shared__ unsigned long long lacc[kSegAcc * 2];  // per target: (gx | gy), (gz | sender classes)
   __shared__ uint32_t hkey[kFarHash], hcnt[kFarHash];   // far destinations of this workgroup: segment, terms -> base in the bin
   __shared__ uint16_t lrank[kSegAcc];                // per slot of the segment: its rank among the recent slots, or 0xFFFF
-  __shared__ uint32_t rec_wave[kBlockAcc / 64];      // recent entries per wavefront of the chunk
+  __shared__ uint32_t rec_wave[kSegAcc / 64];        // recent entries per (chunk, wavefront) of the segment
   // A walk over the segments pass B listed (acc_chunks: a recent slot or an edge into the window), on a grid the size
   // of the chip.  Round 5: a step no longer visits the segment's 1024 slots (512 lanes x 2, four fifths of them idle in
   // the typical listed segment) but the ENTRIES of the work list pass B wrote for it -- the slots that have work, dense,
@@ -2490,6 +2725,9 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
   if (!walk_step_valid(w, cntv)) continue;
   const uint32_t seg_id = cur & 0x003FFFFFu, n_act = (cur >> 22) + 1u;
   const uint32_t base = seg_id * kSegAcc;
+#ifdef SMX_STAMPS
+  ++dbg_steps; dbg_entries += n_act; dbg_max = max(dbg_max, n_act);
+#endif
   if (lds_used) __syncthreads();   // (the previous step's readers of the tables are done)
   lds_used = true;
   {
@@ -2498,6 +2736,12 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
     edge_segment(S, ea, st, base, n_act, ent_first, act_list + (size_t)base, lds, tid);
   }
   }
+#ifdef SMX_STAMPS
+  if (stamps && threadIdx.x == 0 && blockIdx.x < 8192) {
+    unsigned long long* o = stamps + (size_t)blockIdx.x * 16;
+    o[0] = t_in; o[1] = wall_clock64(); o[2] = dbg_steps; o[3] = dbg_entries; o[4] = dbg_max; o[5] = n_steps;
+  }
+#endif
 }
 
 // Rebuilds the flag table for an arbitrary (frame, window): used when Regularize() is called with other
@@ -2913,7 +3157,7 @@ struct smx_recon_s {
   bool sw_dirty;            // a call failed between the cull step and the tile kernel: the lists' counters are not zero
   hipEvent_t pending_mark;  // != null: the caller's stream has not waited for the previous call's update + create yet (smx_recon_integrate)
   uint32_t* ovf_count_set[2];   // overflow counters, alternating by call (the tile kernel zeroes the next call's)
-  unsigned long long* stamps;   // -DSMX_STAMPS builds: [2][8192 workgroups][16] shader clocks (tile kernel, blend kernel)
+  unsigned long long* stamps;   // -DSMX_STAMPS builds: [3][8192 workgroups][16] shader clocks (tile kernel, blend kernel), wall clocks + counts (edge kernel)
   int no_lds_tables;        // A/B switch (scan mode bit 4)
   int blend_other_tile;     // A/B switch (scan mode bit 7)
   int cu_count;             // compute units of the object's device
@@ -3067,7 +3311,7 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
     SlotTimer t(r, st, kSlotRegAccumulate, true);
     const bool done_by_launch = acc_done && !t.stop();
     hipExtLaunchKernelGGL(k_reg_accumulate, dim3(r->grid_acc), dim3(kBlockAcc), 0, st, t.start(), done_by_launch ? acc_done : t.stop(), 0, r->S, rf2, weight, r->grad_acc, r->reg_rec, (size_t)r->S.pitch + kSegAcc,
-                       r->fb, r->L.act_list, r->L.acc_chunks, r->st, ts_first);
+                       r->fb, r->L.act_list, r->L.acc_chunks, r->st, ts_first, r->stamps ? r->stamps + 2 * 16 * 8192 : nullptr);
     if (acc_done && !done_by_launch) SMX_HIP(hipEventRecord(acc_done, st));
   }
   if (copy_only) {
@@ -3213,7 +3457,7 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->tb.ovf, 2 * (size_t)r->S.pitch + 64, false));
   r->tb.ovf_count = r->ovf_count_set[0];
 #ifdef SMX_STAMPS
-  SMX_TRY(dev_alloc(&r->stamps, (size_t)2 * 16 * 8192, true));
+  SMX_TRY(dev_alloc(&r->stamps, (size_t)3 * 16 * 8192, true));
 #endif
   SMX_TRY(dev_alloc(&r->blended_depth, P, true));
   SMX_TRY(dev_alloc(&r->bb.distance_map, P, true));
@@ -3629,11 +3873,11 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
 }
 
 #ifdef SMX_STAMPS
-int smx_recon_debug_download_stamps(smx_recon r, unsigned long long* out) {   // [2][8192][16]
+int smx_recon_debug_download_stamps(smx_recon r, unsigned long long* out) {   // [3][8192][16]
   SMX_CHECK_ARG(r != nullptr && out != nullptr && r->stamps != nullptr);
   SMX_ON_DEVICE(r->device);
   SMX_HIP(hipDeviceSynchronize());
-  SMX_HIP(hipMemcpy(out, r->stamps, sizeof(unsigned long long) * 2 * 16 * 8192, hipMemcpyDeviceToHost));
+  SMX_HIP(hipMemcpy(out, r->stamps, sizeof(unsigned long long) * 3 * 16 * 8192, hipMemcpyDeviceToHost));
   return SMX_OK;
 }
 #endif

@@ -1,9 +1,24 @@
 #!/bin/bash
-# bash tools/build_variant.sh <name> [extra hipcc flags...]: compiles the in-tree smx_recon.hip with extra flags (e.g.
-# -DSMX_STAMPS) and links build/ab/libsmx_<name>.so with the other in-tree objects (A/B runs: SMX_LIB_PATH).
+# A variant build of the library for same-box A/Bs:  bash tools/build_variant.sh <name> "<extra flags>" [sources...]
+#   -> build/ab/libsmx_<name>.so (the listed sources -- default smx_recon.hip -- recompiled with the flags, the other objects
+#   taken from the in-tree build, which must be current: python -m surfelmeshing_amd.build)
 set -e
-N=$1; shift
-R=$(cd "$(dirname "$0")/.." && pwd); C=$R/surfelmeshing_amd/csrc
-mkdir -p $R/build/ab
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -I $R/include -I $C "$@" -c $C/smx_recon.hip -o $R/build/ab/recon_$N.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build/ab/libsmx_$N.so $C/smx_buffer.o $C/smx_depth.o $R/build/ab/recon_$N.o $C/smx_nn.o $C/smx_synth.o $C/smx_driver.o
+NAME=$1; EXTRA=$2; shift; shift
+SRCS=${@:-smx_recon.hip}
+ROOT=$(cd "$(dirname "$0")/.." && pwd); C=$ROOT/surfelmeshing_amd/csrc; O=$ROOT/build/ab/obj_$NAME
+mkdir -p $O
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -I $ROOT/include -I $C"
+OBJS=""
+for s in smx_buffer.hip smx_depth.hip smx_recon.hip smx_nn.hip smx_synth.hip smx_driver.cpp; do
+  b=${s%.*}
+  if echo " $SRCS " | grep -q " $s "; then
+    X=""; [ "${s##*.}" = cpp ] && X="-x hip"
+    /opt/rocm/bin/hipcc $FLAGS $EXTRA $X -c $C/$s -o $O/$b.o &
+    OBJS="$OBJS $O/$b.o"
+  else
+    OBJS="$OBJS $C/$b.o"
+  fi
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/build/ab/libsmx_$NAME.so $OBJS
+echo build/ab/libsmx_$NAME.so
