@@ -648,6 +648,7 @@ def main():
                     help="the frame loop reads GetTimings after every Integrate like APP/main.cc:1511: nowait = "
                          "GetTimingsNoWait, block = the reference's waiting call")
     ap.add_argument("--fused-head", action="store_true", help="A/B: bilateral filter and outlier cull in one launch (same images; slower)")
+    ap.add_argument("--handover", type=int, default=-1, help="A/B: smx_recon_set_handover_mode (1 = device word + gate kernel, 0 = event; default: the library's)")
     ap.add_argument("--pre-cus", type=int, default=0, help="A/B: the preprocessing queues on the first N compute units of the CU mask (N / 8 per XCD); 0 = no partition")
     ap.add_argument("--cu-exclusive", action="store_true", help="with --pre-cus: the internal stream and the caller's stream on the OTHER compute units")
     ap.add_argument("--run-ahead", action="store_true", help="A/B: preprocessing two steps ahead, waits routed off the caller's stream")
@@ -782,6 +783,8 @@ def run_integrate(args):
         api.StreamSynchronize(None)
         wl.pipe.stream = api.Stream({"plain": None, "high": 1, "low": -1}[args.caller_stream])
     rec.set_stats_enabled(False)   # the distribution counters are single-address atomics: off while timing
+    if args.handover >= 0:
+        rec.set_handover_mode(args.handover)
     if args.pre_cus:
         def cu_mask(lo, hi, total=256):
             return [sum(1 << b for b in range(32) if lo <= 32 * w + b < hi) for w in range(total // 32)]

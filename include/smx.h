@@ -313,6 +313,11 @@ int smx_recon_get_timings(smx_recon r, float out_ms[7]);
  * page-locked host memory, so the read lags the queue by two calls and touches neither the device nor any stream.
  * *call_number: that call's 1-based number, 0 (and zeros) if there is none yet. */
 int smx_recon_get_timings_nowait(smx_recon r, float out_ms[7], uint64_t* call_number);
+/* How the front of a pipelined smx_recon_integrate call (pass A .. blend, on the caller's stream) hands over to the
+ * internal stream: 1 = the blend's workgroups count themselves in a device word and a one-wavefront gate kernel in front of the
+ * integration polls it (default; a queue that is found WAITING at an event is woken in ~20 us, the gate in 1 - 2:
+ * profiles/r6_ab_notes.md section 12), 0 = an event (rounds 3 - 6).  Results identical. */
+int smx_recon_set_handover_mode(smx_recon r, int32_t mode);
 /* Experiment: the object's internal stream re-created on a subset of the compute units (mask as for
  * smx_stream_create_with_cu_mask; n_words = 0: all of them again, at the highest priority).  Waits for the object's work. */
 int smx_recon_set_internal_cu_mask(smx_recon r, const uint32_t* mask_words, uint32_t n_words);

@@ -593,6 +593,10 @@ class CUDASurfelReconstruction:
     def set_scan_mode(self, mode):
         _lib.check(_lib.load().smx_recon_set_scan_mode(self._h, C.c_int32(mode)))
 
+    def set_handover_mode(self, mode):
+        """smx_recon_set_handover_mode: 1 = device word + gate kernel (default), 0 = event"""
+        _lib.check(_lib.load().smx_recon_set_handover_mode(self._h, C.c_int32(int(mode))))
+
     def set_internal_cu_mask(self, mask_words):
         """experiment (smx_recon_set_internal_cu_mask): the internal stream on the compute units of the mask (empty = all)"""
         arr = (C.c_uint32 * max(1, len(mask_words)))(*mask_words)

@@ -478,6 +478,23 @@ __device__ __forceinline__ void keep(const float2& v) { keep(v.x); keep(v.y); }
 __device__ __forceinline__ void keep(const float4& v) { keep(v.x); keep(v.y); keep(v.z); keep(v.w); }
 __device__ __forceinline__ void keep(const uint4& v) { keep(v.x); keep(v.y); keep(v.z); keep(v.w); }
 
+// Which groups of loads are pinned together by keep() (bit mask, A/B: profiles/r6_ab_notes.md section 12): 1 = the walk's first
+// descriptor with its counters, 2 = k_integrate's merge mark + records and its pixel loads, 4 = the update kernel's records and
+// pixel loads, 8 = the edge kernel's bin reservations, 16 = pass B's first four loads, 32 = the step kernel's bin state + list
+// entries, 64 = pass A's records + flag bytes + next list entry.
+#ifndef SMX_RT_MASK
+#define SMX_RT_MASK 57
+#endif
+template <int kBit, class T>
+__device__ __forceinline__ void keep_if(const T& v) { if (SMX_RT_MASK & kBit) keep(v); }
+
+// Wave priority of the surfel kernels (s_setprio 0 .. 3; 0 = the default every wavefront starts with).  The instruction arbiter
+// of a SIMD serves the highest priority first and the OLDEST wavefront among equals -- and the oldest wavefront beside these
+// short kernels is the bilateral filter's, which lives for the whole of its tile loop (A/B: profiles/r6_ab_notes.md section 13).
+#ifndef SMX_WAVE_PRIO
+#define SMX_WAVE_PRIO 1
+#endif
+#define SMX_SET_WAVE_PRIO() do { if (SMX_WAVE_PRIO) __builtin_amdgcn_s_setprio(SMX_WAVE_PRIO); } while (0)
 // Stores of a launch's streaming OUTPUTS -- records no lane of the same launch reads again.  A plain store leaves its line
 // dirty in the XCD's L2, and the launch boundary behind the kernel has to write all of them back before the next launch of
 // the stream may start (MI355X_MICROARCH.md, price table row "boundary": 1.45 - 1.9 us + dirty bytes / 6 TB/s; the edge
@@ -570,6 +587,7 @@ struct SegWork {
 };
 __global__ void __launch_bounds__(kBlock)
 k_cull_segments(FrameCtx c, Lists L, SegWork sw, DevState* st, uint32_t nseg_alloc, uint32_t max_new_slots, unsigned long long ts_seq) {
+  SMX_SET_WAVE_PRIO();
   if (c.ts && blockIdx.x == 0 && threadIdx.x == 0) {   // (the call's stage-stamp record: reset, sequence number, first stamp)
 #pragma unroll
     for (int k = 2; k < kTsWords; ++k) c.ts[k] = 0;
@@ -630,6 +648,7 @@ k_cull_segments(FrameCtx c, Lists L, SegWork sw, DevState* st, uint32_t nseg_all
 __global__ void __launch_bounds__(kBlock, 8)   // (eight workgroups per CU: <= 64 VGPRs)
 k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, SegWork sw, const uint8_t* __restrict__ flags_prev, DevState* st,
                int use_lds_tables) {
+  SMX_SET_WAVE_PRIO();
   ts_begin(c.ts, kTsScanBegin);
   __shared__ uint32_t wave_tot[kBlock / 64];
   __shared__ float box_part[kBlock / 64][8];
@@ -656,26 +675,29 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, SegWork sw, const ui
   for (uint32_t e = wg; e < n_surv; e += G) {
     {
       const uint32_t seg_id = next_seg;
-      next_seg = (e + G < n_surv) ? sw.surv_list[e + G] : 0u;
       // (everything below is per segment: a lane number the optimiser cannot see through keeps it from hoisting the
       // per-lane addresses of a dozen arrays out of the loop and holding them in registers across it -- 96 VGPRs instead
       // of 51, five workgroups per CU instead of eight)
       uint32_t tid = threadIdx.x;
       asm volatile("" : "+v"(tid));
-      if (seg_id * (uint32_t)kSeg >= N) continue;   // (the cull step's bound on the slot count was generous)
       const uint32_t base = seg_id * (uint32_t)kSeg;
       const uint32_t i0 = base + tid * 4;
-      const uint32_t in_seg = (N - base < (uint32_t)kSeg) ? N - base : (uint32_t)kSeg;
-      float* box = &L.seg_box[8 * (size_t)seg_id];
       // four consecutive P records (X, Y, Z, stamp) = 64 contiguous bytes per lane, requested first; the group arrays are
       // padded to a multiple of 64 slots, so the loads stay inside the array
-      float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0;
-      uchar4 of = make_uchar4(0, 0, 0, 0);
-      if (i0 < N) {
-        const float4* P = S.group(kGroupP, i0);
-        p0 = P[0]; p1 = P[1]; p2 = P[2]; p3 = P[3];
-        of = *reinterpret_cast<const uchar4*>(&flags_prev[i0]);  // (detach bits carry over)
-      }
+      // (no branch around the loads -- a lane beyond the end reads slot 0 and uses nothing of it -- so that nothing has to be
+      // merged, i.e. waited for, before the next request goes out)
+      const uint32_t il = i0 < N ? i0 : 0u;
+      const float4* P = S.group(kGroupP, il);
+      const float4 p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3];
+      const uint32_t of_word = *reinterpret_cast<const uint32_t*>(&flags_prev[il]);  // (detach bits carry over)
+      next_seg = sw.surv_list[e + G < n_surv ? e + G : e];   // (no branch around the load: this entry again when it is the last)
+      // (the records, the old flag bytes and the next list entry: ONE round trip, pinned -- the compiler had asked for the
+      // next entry and waited, for the flag bytes and waited, and only then for the records: tools/isa_phases.py)
+      keep_if<64>(p0); keep_if<64>(p1); keep_if<64>(p2); keep_if<64>(p3); keep_if<64>(of_word); keep_if<64>(next_seg);
+      if (base >= N) continue;   // (the cull step's bound on the slot count was generous)
+      const uchar4 of = make_uchar4((uint8_t)(of_word & 255u), (uint8_t)((of_word >> 8) & 255u), (uint8_t)((of_word >> 16) & 255u), (uint8_t)(of_word >> 24));
+      const uint32_t in_seg = (N - base < (uint32_t)kSeg) ? N - base : (uint32_t)kSeg;
+      float* box = &L.seg_box[8 * (size_t)seg_id];
       if (!first_segment) __syncthreads();   // (the previous segment's readers of the tables and partials are done)
       first_segment = false;
       if (lds_tables) {
@@ -829,6 +851,9 @@ __device__ __forceinline__ uint32_t walk_begin(const Chunks& ch, uint32_t n_slot
   if (kUseList) {
     desc = ch.desc[(size_t)(first % kSubLists) * ch.stride + first / kSubLists];
     cntv = ch.count[(threadIdx.x % kSubLists) * kCountStride];
+    // (pinned: left to itself the compiler moves the descriptor's load behind the walk's first test -- `no step for this
+    // workgroup' -- and the first step then begins a round trip late: tools/isa_phases.py)
+    keep_if<1>(desc); keep_if<1>(cntv);
     uint32_t longest = cntv;
 #pragma unroll
     for (uint32_t off = kSubLists / 2; off > 0; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, (int)off));
@@ -990,6 +1015,7 @@ k_assoc_tiles(Surfels S, FrameCtx c, Scratch sc, Img<const uint16_t> depth, Img<
               const uint8_t* __restrict__ seg_act, uint32_t nseg, uint32_t* __restrict__ direction_out, uint32_t* __restrict__ seg_work_count,
               unsigned long long* stamps, const unsigned long long* __restrict__ ts_ring, volatile unsigned long long* ts_host,
               unsigned long long ts_seq) {
+  SMX_SET_WAVE_PRIO();
   __shared__ TileLds t;
   __shared__ uint32_t order_wave_tot[kTilePx / 64];
   ts_begin(c.ts, kTsTilesBegin);
@@ -1250,7 +1276,8 @@ __device__ __forceinline__ unsigned long long row_mask_from_bits(uint32_t bits) 
 template <int kBlendTile>
 __global__ void __launch_bounds__(kBlendThreads)
 k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<uint16_t> out, Scratch sc, int W, int H,
-              int tiles_x, unsigned long long* stamps, unsigned long long* ts) {
+              int tiles_x, unsigned long long* stamps, unsigned long long* ts, uint32_t* gate_count) {
+  SMX_SET_WAVE_PRIO();
   extern __shared__ __align__(16) unsigned char blend_lds[];
   ts_begin(ts, kTsBlendBegin);
   SMX_STAMP(stamps, 0);
@@ -1412,10 +1439,44 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
   for (int k = threadIdx.x; k < kBlendTile * kBlendTile; k += kBlendThreads) {
     const int ty = k / kBlendTile, tx = k - ty * kBlendTile;
     const int x = tile_x * kBlendTile + tx, y = tile_y * kBlendTile + ty;
-    if (x < W && y < H) out(y, x) = dep[(ty + halo) * rw + (tx + halo)];
+    if (x < W && y < H) {
+      const uint32_t v = dep[(ty + halo) * rw + (tx + halo)];
+      // (device-word hand-over: the blended depths are the only thing this launch leaves for the integration, and they leave
+      // WRITE-THROUGH -- device-scope stores, complete when the wavefront's store counter says so -- so that the count below
+      // needs no release: a release writes back every dirty line of the XCD's L2, and beside this kernel run the ones that
+      // write the most, pass B / edges / step of the previous call)
+      if (gate_count) asm volatile("global_store_short %0, %1, off sc1" :: "v"(&out(y, x)), "v"(v) : "memory");
+      else out(y, x) = (uint16_t)v;
+    }
   }
   SMX_STAMP(stamps, 5);
   ts_end(ts, kTsBlendEnd, blockIdx.x, gridDim.x);
+  // The hand-over to the internal stream by a device word instead of an event (smx_recon_set_handover_mode 1): every
+  // workgroup releases its output (device scope) and counts itself; k_front_gate, one wavefront in front of the
+  // integration on the internal stream, leaves when the count has reached this call's total.
+  // (no acquire anywhere -- an acquire drops the clean lines of the XCD's L2 under every kernel that runs beside this one: a
+  // first version fenced in every wavefront and polled with acquire loads, 4 300 instead of 6 150 frames/s -- and no release
+  // either, see the stores above)
+  if (gate_count) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this wavefront's write-through stores have been acknowledged)
+    __syncthreads();
+#if SMX_GATE_RELEASE
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(gate_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// One wavefront that leaves when `*count` has reached `expected` (compared as a signed difference: the count wraps).  Safe
+// as a wait because of WHERE it is enqueued: behind the launch it waits for (smx_recon_integrate enqueues the front of a
+// call before anything on the internal stream), like an event wait -- and one wavefront cannot keep the producer's workgroups
+// off the chip, which is why the poll is a launch of its own and not the head of the consumer (profiles/r6_ab_notes.md section 9).
+__global__ void __launch_bounds__(64)
+k_front_gate(const uint32_t* count, uint32_t expected) {
+  if (threadIdx.x == 0) {
+    // (relaxed: the launch boundary behind this kernel is the acquire)
+    while ((int32_t)(__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expected) < 0) __builtin_amdgcn_s_sleep(2);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1518,6 +1579,11 @@ __device__ __forceinline__ PixelIn load_pixel(const FrameCtx& c, const Scratch& 
   p.depth = in.depth(y, x); p.first = sc.first_depth[k]; p.key = sc.confl_key[k]; p.count = sc.counts[k];
   p.nxy = in.normals(y, x); p.col = in.color(y, x); p.radius = in.radius(y, x);
   return p;
+}
+
+__device__ __forceinline__ void keep(const PixelIn& p) {
+  keep((uint32_t)p.depth); keep(p.first); keep(p.key); keep(p.count); keep(p.nxy); keep(p.radius);
+  keep((uint32_t)p.col.x | ((uint32_t)p.col.y << 8) | ((uint32_t)p.col.z << 16));
 }
 
 // Register copy of the records of one surfel that the integration may touch.  Thread i is the only reader and
@@ -1625,6 +1691,7 @@ template <bool kUseList>
 __global__ void __launch_bounds__(kBlock)
 k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
             uint8_t* __restrict__ merge_flag, DevState* st, NewFlagsArgs nf, uint32_t n_flag_blocks) {
+  SMX_SET_WAVE_PRIO();
   // (workgroup 0 is always a flag block: the image has pixels)
   if (blockIdx.x < n_flag_blocks) { ts_begin(c.ts, kTsIntBegin); new_flags_scan_body(nf, sc, c.W, c.H, st, blockIdx.x); return; }
   const uint32_t block = blockIdx.x - n_flag_blocks, n_blocks = gridDim.x - n_flag_blocks;
@@ -1638,12 +1705,19 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
     uint32_t i;
     if (kUseList && !walk_step_valid(w, cntv)) continue;
     if (!walk_entry<kUseList>(L.vis_list, cur, w, n_scan, threadIdx.x, i)) continue;
-    if (merge_flag[i]) {
+    // the merge mark and the three records the integration works on, requested together (pinned: the compiler would ask for
+    // the mark, wait, ask for P, wait for the activity test, and only then for N and C -- three round trips on a kernel
+    // that sits on both cycles of the frame)
+    const uint32_t merge_mark = merge_flag[i];
+    SurfelRegs R;
+    R.P = *S.group(kGroupP, i); R.N = *S.group(kGroupN, i); R.C = *S.group(kGroupC, i);
+    keep_if<2>(merge_mark); keep_if<2>(R.P); keep_if<2>(R.N); keep_if<2>(R.C);
+    if (merge_mark) {
       // apply the merge marks, kernels.cu:1987-1989 (decided in k_merge_decide)
       merge_flag[i] = 0;
       S.u(kLastUpdateStamp, i) = 0;
       S.f(kRadiusSq, i) = -1;
-      const uint32_t col = (S.u(kColor, i) & 0x00FFFFFFu) | 0x01000000u;
+      const uint32_t col = (__float_as_uint(R.C.z) & 0x00FFFFFFu) | 0x01000000u;
       S.u(kColor, i) = col;
       L.flags8[i] = make_flags(0u, col, c.frame, c.reg_window);
       L.hot_epoch[i >> L.hot_shift] = (uint8_t)L.epoch;
@@ -1651,9 +1725,6 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
       ++merged_here;
       continue;  // r^2 < 0: the integrate kernel does nothing for it (:1050-1052)
     }
-    // the three records the integration works on, requested together
-    SurfelRegs R;
-    R.P = *S.group(kGroupP, i); R.N = *S.group(kGroupN, i); R.C = *S.group(kGroupC, i);
     R.dirty = false; R.replaced = false;
     const float4 p4 = R.P, n4 = R.N;
     if (!is_active(__float_as_uint(p4.w), c.frame, c.window)) continue;
@@ -1665,6 +1736,7 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
     const bool second = quadrant(p, c, ox, oy);
     const PixelIn px0 = load_pixel(c, sc, in, p.px, p.py);
     const PixelIn px1 = load_pixel(c, sc, in, ox, oy);  // (the main pixel again if there is no second one)
+    if (SMX_RT_MASK & 2) { keep(px0); keep(px1); }   // (fourteen loads, one round trip: see above)
     integrate_or_conflict(R, c, px0, true, p.px, p.py, p.l, i, st);
     integrate_or_conflict(R, c, px1, second, ox, oy, p.l, i, st);
     if (R.dirty) {
@@ -1711,6 +1783,7 @@ __device__ __forceinline__ void update_neighbors_body(const Surfels& S, const Fr
     // the slot's three records in flight together (P: position + stamp, N: normal + r^2, T: neighbour ids)
     const float4 p4 = *S.group(kGroupP, i), n4 = *S.group(kGroupN, i);
     const uint4 t4 = *reinterpret_cast<const uint4*>(S.group(kGroupT, i));
+    keep_if<4>(p4); keep_if<4>(n4); keep_if<4>(t4);   // (pinned: N and T would otherwise be asked for behind the tests on P)
     if (!is_active(__float_as_uint(p4.w), c.frame, c.window)) continue;
     const Vec3 g = {p4.x, p4.y, p4.z};
     const Vec3 cam = mul(c.L, g);
@@ -1724,6 +1797,9 @@ __device__ __forceinline__ void update_neighbors_body(const Surfels& S, const Fr
     uint32_t cand[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) cand[d] = sc.supporting[(size_t)(y + kDY[d]) * c.W + (x + kDX[d])];
+    keep_if<4>(measurement_depth); keep_if<4>(obs_r2);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) keep_if<4>(cand[d]);
     const float occlusion_depth = (1 + c.sensor_noise_factor) * measurement_depth;
     if (cam.z > occlusion_depth) continue;
     const float surfel_distance = sqrtf(cam.x * cam.x + cam.y * cam.y + cam.z * cam.z);
@@ -1945,6 +2021,7 @@ template <bool kUseList>
 __global__ void __launch_bounds__(kBlock)
 k_update_and_create(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L, CreateArgs a, uint32_t n_create_blocks,
                     DevState* st) {
+  SMX_SET_WAVE_PRIO();
   if (blockIdx.x < n_create_blocks) {
     ts_begin(c.ts, kTsUpdBegin);
     new_create_body(S, c, sc, in, a, st, blockIdx.x, n_create_blocks);
@@ -1999,6 +2076,7 @@ __device__ __forceinline__ void edge_segment(const Surfels& S, const EdgeArgs& e
 template <bool kDetach, bool kAccumulate, bool kFused = false>
 __global__ void __launch_bounds__(kBlockB, kFused ? SMX_FUSED_WGS_PER_CU : 1)
 k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, DevState* st, unsigned long long* ts, EdgeArgs ea, uint32_t descending) {
+  SMX_SET_WAVE_PRIO();
   ts_begin(ts, kTsRegBegin);
   static_assert(!kFused || kAccumulate, "the fused edge work belongs to the accumulating pass");
   __shared__ unsigned long long e_lacc[kFused ? kSegAcc * 2 : 1];
@@ -2014,12 +2092,22 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, DevState* st, unsign
   // occupancy stays high; the accumulation itself runs in k_reg_accumulate on the few segments that need it.
   __shared__ uint32_t wave_tot[kBlockB / 64];
   __shared__ __attribute__((aligned(4))) uint8_t lflags[kSegB];  // the segment's own flag bytes
+  // (the four things every workgroup begins with -- slot count, creation base, its slice of the hot-group table, its slice of
+  // the segment's target bitmap -- are requested together and pinned: the compiler had made three round trips in a row of
+  // them, which is all a skipped segment's workgroup does, and the launch churns through thousands of those)
   const uint32_t N = st->surfel_count;
   const uint32_t base = seg_id * kSegB;
-  if (base >= N) return;
   // The reference detaches BEFORE it creates new surfels (kernels.cc:333-339 precedes cc:264-286), so
   // slots created in this frame keep links to flagged surfels until the next frame.
   const uint32_t detach_limit = st->create_base;
+  uint4 he_first = make_uint4(0u, 0u, 0u, 0u);
+  uint32_t reached_first = 0;
+  if (use_hot) {
+    if (threadIdx.x * 16 < L.n_hot_groups) he_first = *reinterpret_cast<const uint4*>(&L.hot_epoch[threadIdx.x * 16]);
+    if (!stats) reached_first = L.seg_targets[(size_t)seg_id * kBlockB + threadIdx.x];
+  }
+  keep_if<16>(N); keep_if<16>(detach_limit); keep_if<16>(he_first); keep_if<16>(reached_first);
+  if (base >= N) return;
   // The far flag gathers (a link that leaves the segment: one random byte from the 5 MB table, 4.6 M per frame at C2,
   // 21 of this kernel's 55 us alone) are skipped where their result is known.  The flag byte of the target matters in
   // two ways: bit 0 (inside the window) -- zero if the target's group is not hot, because pass A found no such slot in
@@ -2044,7 +2132,7 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, DevState* st, unsign
   if (use_hot) {
     const uint32_t g = threadIdx.x * 16;
     if (g < L.n_hot_groups) {
-      const uint4 he = *reinterpret_cast<const uint4*>(&L.hot_epoch[g]);
+      const uint4 he = he_first;
       *reinterpret_cast<uint4*>(&lhot[g]) = he;
       const uint32_t w[4] = {he.x, he.y, he.z, he.w};
 #pragma unroll
@@ -2053,7 +2141,7 @@ k_neighbor_scan(Surfels S, int stats, int use_hot, Lists L, DevState* st, unsign
     }
     if (!stats) {   // (the edge statistics count every link of the map)
       const uint32_t own_group = base >> L.hot_shift;
-      const uint32_t reached = (uint32_t)L.seg_targets[(size_t)seg_id * kBlockB + threadIdx.x] | (threadIdx.x == own_group / 16 ? 1u << (own_group % 16) : 0u);
+      const uint32_t reached = reached_first | (threadIdx.x == own_group / 16 ? 1u << (own_group % 16) : 0u);
       if (!__syncthreads_or((reached & hot16) != 0)) {
         if (threadIdx.x == 0) {
           L.recent_seg[seg_id] = kInvalid;   // (no recent slot; the mark is what smx_recon_debug_count_skipped_segments counts)
@@ -2273,6 +2361,12 @@ __device__ __forceinline__ void far_term_spill(long long* __restrict__ grad_acc,
 #ifndef SMX_EXT_STOP_EVENTS
 #define SMX_EXT_STOP_EVENTS 1   // (0: event records as packets of their own, the arrangement up to r22)
 #endif
+#ifndef SMX_GATE_RELEASE
+#define SMX_GATE_RELEASE 0   // (1: a device-scope release in front of the count, on top of the write-through stores -- A/B)
+#endif
+#ifndef SMX_HANDOVER_FLAGS
+#define SMX_HANDOVER_FLAGS 1   // (default of smx_recon_set_handover_mode)
+#endif
 #ifndef SMX_REG_PRIORITY_HIGH
 #define SMX_REG_PRIORITY_HIGH 1
 #endif
@@ -2408,11 +2502,21 @@ __device__ __forceinline__ void edge_segment(const Surfels& S, const EdgeArgs& e
   }
   __syncthreads();
   // one lane per destination reserves the workgroup's run in that bin; the table then holds the next free place of the run
+  // (the lane's reservations are in flight together: written as `hcnt[e] = atomicAdd(..)` in one loop each of them is
+  // waited for before the next is sent -- four round trips per segment for a wavefront that has one destination per pass)
+  {
+    uint32_t dsegk[kFarHash / kBlockAcc], cntk[kFarHash / kBlockAcc], got[kFarHash / kBlockAcc];
 #pragma unroll
-  for (int k = 0; k < kFarHash / kBlockAcc; ++k) {
-    const uint32_t e = k * kBlockAcc + tid;
-    const uint32_t dseg = hkey[e];
-    if (dseg != kInvalid) hcnt[e] = atomicAdd(&fb.count[(size_t)dseg * kCountStride], hcnt[e]);
+    for (int k = 0; k < kFarHash / kBlockAcc; ++k) { dsegk[k] = hkey[k * kBlockAcc + tid]; cntk[k] = hcnt[k * kBlockAcc + tid]; }
+#pragma unroll
+    for (int k = 0; k < kFarHash / kBlockAcc; ++k) {
+      got[k] = 0;
+      if (dsegk[k] != kInvalid) got[k] = atomicAdd(&fb.count[(size_t)dsegk[k] * kCountStride], cntk[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < kFarHash / kBlockAcc; ++k) keep_if<8>(got[k]);
+#pragma unroll
+    for (int k = 0; k < kFarHash / kBlockAcc; ++k) if (dsegk[k] != kInvalid) hcnt[k * kBlockAcc + tid] = got[k];
   }
   __syncthreads();
   // 3. the chunks' terms
@@ -2691,6 +2795,7 @@ __global__ void __launch_bounds__(kBlockAcc, SMX_ACC_WGS_PER_CU)   // (second ar
 k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ grad_acc,
                  float4* __restrict__ reg_rec, size_t rec_own_offset, FarBins fb,
                  const uint32_t* __restrict__ act_list, Chunks acc, DevState* st, unsigned long long* ts, unsigned long long* stamps) {
+  SMX_SET_WAVE_PRIO();
   ts_begin(ts, kTsAccBegin);
 #ifdef SMX_STAMPS
   // (diagnosis, tools/acc_stamps.py: per workgroup the wall clock at entry and exit, steps, entries, the largest step)
@@ -2761,6 +2866,7 @@ constexpr int kStepSub = kSegB / kBlock;
 __global__ void __launch_bounds__(kBlock)
 k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, const float4* __restrict__ reg_rec, size_t rec_own_offset,
            FarBins fb, Lists L, DevState* st, unsigned long long* ts) {
+  SMX_SET_WAVE_PRIO();
   __shared__ unsigned long long lfar[kSegB * 2];   // per target of the segment: (gx | gy), (gz | sender classes)
   ts_begin(ts, kTsStepBegin);
   uint32_t desc, cntv;
@@ -2784,6 +2890,9 @@ k_reg_step(Surfels S, float weight, long long* __restrict__ grad_acc, const floa
       on[sub] = e < total;
       idx[sub] = on[sub] ? L.recent_list[seg_base + e] : seg_base;
     }
+    keep_if<32>(bin_state.x); keep_if<32>(bin_state.y);   // (the bin's state and the list entries: one round trip, not two)
+#pragma unroll
+    for (int sub = 0; sub < kStepSub; ++sub) keep_if<32>(idx[sub]);
     float4 rp[kStepSub], rs[kStepSub], rn[kStepSub], rgr[kStepSub];
     ulonglong2 rl[kStepSub];
 #pragma unroll
@@ -3213,6 +3322,9 @@ struct smx_recon_s {
   // caller's stream after the pending regulariser, so the API keeps its one-stream semantics.
   int overlap_enabled;
   hipStream_t reg_stream;     // high priority: the frame-to-frame critical path (integrate .. regulariser)
+  uint32_t* gate_count;       // blend workgroups that have released their output, all calls (k_front_gate)
+  uint32_t gate_expected;     // ... the value after the last call enqueued with the device-word hand-over
+  int handover_mode;          // smx_recon_set_handover_mode: 1 = device word + gate kernel for front -> integration, 0 = event
   hipEvent_t ev_front;        // caller's stream: pass A .. flags of a call are enqueued
   hipEvent_t ev_upd;          // internal stream: update + create of a call are enqueued (the inputs are consumed, the map is ready for the next pass A)
   hipEvent_t ev_reg;          // internal stream: end of the work enqueued so far (recorded on demand by join_regularizer)
@@ -3436,6 +3548,9 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   r->fuse_edges = SMX_FUSE_EDGES;
   r->hot_holdoff = 3;
   SMX_TRY(dev_alloc(&r->merge_flag, r->S.pitch, true));
+  SMX_TRY(dev_alloc(&r->gate_count, 32, true));   // (a line of its own)
+  r->gate_expected = 0;
+  r->handover_mode = SMX_HANDOVER_FLAGS;
   SMX_TRY(dev_alloc(&r->L.act_list, (size_t)r->nsegB * kSegB, true));
   SMX_TRY(dev_alloc(&r->sc.supporting, P, true));
   SMX_TRY(dev_alloc(&r->sc.counts, P, true));
@@ -3604,6 +3719,12 @@ int smx_recon_set_overlap(smx_recon r, int32_t enabled) {
   return SMX_OK;
 }
 
+int smx_recon_set_handover_mode(smx_recon r, int32_t mode) {
+  SMX_CHECK_ARG(r != nullptr && (mode == 0 || mode == 1));
+  r->handover_mode = mode;   // (takes effect with the next call: each call's wait matches the signal of its own front)
+  return SMX_OK;
+}
+
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
   SMX_CHECK_ARG(r != nullptr && mode >= 0 && mode <= 1023);
   SMX_ON_DEVICE(r->device);
@@ -3750,7 +3871,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   if (tm) { SMX_HIP(hipEventRecord(r->ev[1], sF)); SMX_HIP(hipEventRecord(r->ev[2], sF)); SMX_HIP(hipEventRecord(r->ev[3], sF)); SMX_HIP(hipEventRecord(r->ev[4], sF)); }
   const int halo = p->measurement_blending_radius - 1;
   const bool fused_blend = p->do_blending && halo <= kBlendMaxHalo && !r->blend_multi_launch;
-  bool front_by_launch = false;
+  bool front_by_launch = false, front_by_gate = false;
   const float ds = 1.0f / c.inv_depth_scaling;  // kernels.cc:179
   const float term = p->do_blending ? 1.0f / ((float)p->measurement_blending_radius - 1.0f) : 0.0f;  // kernels.cc:196
   const Img<uint16_t> blended = {r->blended_depth, r->H, r->W, (size_t)r->W * sizeof(uint16_t)};
@@ -3770,13 +3891,16 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     unsigned long long* stamps = r->stamps ? r->stamps + 16 * 8192 : nullptr;
     // (the hand-over to the internal stream as this launch's own completion event)
     front_by_launch = SMX_EXT_STOP_EVENTS && pipelined && !split && !tm && !(r->timing_enabled & 2) && r->prof_slot != kSlotBlend;
-    const hipEvent_t stop = front_by_launch ? r->ev_front : nullptr;
+    front_by_gate = front_by_launch && r->handover_mode == 1 && !(r->debug_skip & 4);
+    uint32_t* const gate = front_by_gate ? r->gate_count : nullptr;
+    if (front_by_gate) r->gate_expected += n_blend;
+    const hipEvent_t stop = (front_by_launch && !front_by_gate) ? r->ev_front : nullptr;
     if (tile == 40)
       hipExtLaunchKernelGGL(k_blend_tiles<40>, dim3(n_blend), dim3(kBlendThreads), (uint32_t)lds, sF, nullptr, stop, 0, p->measurement_blending_radius, term, ds,
-                            in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps, c.ts);
+                            in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps, c.ts, gate);
     else
       hipExtLaunchKernelGGL(k_blend_tiles<32>, dim3(n_blend), dim3(kBlendThreads), (uint32_t)lds, sF, nullptr, stop, 0, p->measurement_blending_radius, term, ds,
-                            in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps, c.ts);
+                            in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps, c.ts, gate);
   } else if (p->do_blending) {
     // the reference's own sequence (2 clears + start + iterations, kernels.cc:165-205), in place on the caller's depth
     SlotTimer t(r, sF, kSlotBlend);
@@ -3805,8 +3929,12 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   } else if (pipelined) {
     // (work on the internal stream from here on: whatever happens below, later entry points order themselves behind it)
     r->reg_pending = true;
-    if (!front_by_launch) SMX_HIP(hipEventRecord(r->ev_front, sF));
-    if (!(r->debug_skip & 4)) SMX_HIP(hipStreamWaitEvent(sR, r->ev_front, 0));   // (bit 2: timing only -- what is the hand-over worth?)
+    if (front_by_gate) {
+      hipLaunchKernelGGL(k_front_gate, dim3(1), dim3(64), 0, sR, r->gate_count, r->gate_expected);
+    } else {
+      if (!front_by_launch) SMX_HIP(hipEventRecord(r->ev_front, sF));
+      if (!(r->debug_skip & 4)) SMX_HIP(hipStreamWaitEvent(sR, r->ev_front, 0));   // (bit 2: timing only -- what is the hand-over worth?)
+    }
   }
   if (tm) SMX_HIP(hipEventRecord(r->ev[6], sR));
   const bool front_only = (r->debug_skip & 2) != 0, skip_reg = (r->debug_skip & 3) != 0;   // (timing only)

@@ -357,13 +357,15 @@ def test_stream_parity_parameter_variants(smx, kw):
     run_both(po, pg, s, list(range(4, 20)), lambda f: _compare_state(po, pg))
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_pipelined_frames_parity(smx, overlap):
+@pytest.mark.parametrize("overlap,handover", [(True, 1), (True, 0), (False, 1)])
+def test_pipelined_frames_parity(smx, overlap, handover):
     """No download between frames: with pipelining on, the regulariser of frame f really runs beside the first
-    kernels of frame f+1 (a per-frame state download would order them).  Same final state either way."""
+    kernels of frame f+1 (a per-frame state download would order them).  Same final state either way.  handover: how the
+    front of a call reaches the internal stream (smx_recon_set_handover_mode: 1 = device word + gate kernel, 0 = event)."""
     s = small_stream(obstacle_until=10)
     po, pg = _pipes(smx, s, 60000)
     pg.reconstruction.set_overlap(overlap)
+    pg.reconstruction.set_handover_mode(handover)
     run_both(po, pg, s, list(range(4, 30)), None)
     _compare_state(po, pg)
     # an extra Regularize() and a second run of frames on top of the pending regulariser
@@ -740,6 +742,29 @@ def test_streams_with_priority_and_explicit_stream(smx):
     st.close()
 
 
+def test_stream_on_a_subset_of_the_compute_units(smx):
+    """smx_stream_create_with_cu_mask (an experiment's plumbing, kept as API): Integrate on a stream that may only use
+    half of the compute units, the internal stream on the other half, gives the same map."""
+    s = small_stream(obstacle_until=8)
+    po, pg = _pipes(smx, s, 60000)
+    lo = [0xFFFFFFFF] * 4 + [0] * 4
+    hi = [0] * 4 + [0xFFFFFFFF] * 4
+    st = smx.Stream(cu_mask=lo)
+    smx.StreamSynchronize(None)                        # (construction used the default stream)
+    pg.stream = st
+    pg.reconstruction.set_internal_cu_mask(hi)
+    run_both(po, pg, s, list(range(4, 14)), None)
+    st.synchronize()
+    _compare_state(po, pg)
+    pg.reconstruction.set_internal_cu_mask([])   # (all of them again)
+    run_both(po, pg, s, list(range(14, 18)), None)
+    st.synchronize()
+    _compare_state(po, pg)
+    st.close()
+    with pytest.raises(smx.SmxError):
+        smx.Stream(cu_mask=[0, 0])
+
+
 def test_two_objects_on_two_host_threads(smx):
     """The 8-GPU code path minus the other seven GPUs: two host threads, each with its own native frame
     driver (reconstruction object, streams, work sets) and its own synthetic stream, run CONCURRENTLY on the one GPU;
@@ -888,9 +913,10 @@ def test_frame_loop_reads_stage_times_every_frame(smx):
     assert blocking[0] > 0 and blocking[6] > 0
 
 
-@pytest.mark.parametrize("run_ahead,fused_head,split_pre", [(False, False, False), (True, False, False), (False, True, False),
-                                                            (False, False, True), (True, False, True)])
-def test_native_driver_matches_oracle(smx, run_ahead, fused_head, split_pre):
+@pytest.mark.parametrize("run_ahead,fused_head,split_pre,handover", [(False, False, False, 1), (True, False, False, 1), (False, True, False, 1),
+                                                                     (False, False, True, 1), (True, False, True, 1), (False, False, False, 0),
+                                                                     (True, False, True, 0)])
+def test_native_driver_matches_oracle(smx, run_ahead, fused_head, split_pre, handover):
     """The C++ frame loop (include/smx_driver.h, written against the shim classes of smx_shim.hpp) produces the
     same state as the oracle; many frames are enqueued by one call.  run_ahead: the preprocessing two steps ahead with
     its dependencies routed through smx_recon_integrate_hooks.  fused_head: bilateral filter + outlier cull in one launch."""
@@ -903,6 +929,7 @@ def test_native_driver_matches_oracle(smx, run_ahead, fused_head, split_pre):
     pn.set_run_ahead(run_ahead)
     pn.set_fused_head(fused_head)
     pn.set_split_preprocessing(split_pre)     # two preprocessing queues: the filter of frame f + 1 beside the cull of frame f
+    pn.reconstruction.set_handover_mode(handover)   # front -> internal stream by a device word + gate kernel (1) or by an event (0)
     frames = list(range(4, 20))
     for f in range(0, 24):
         d, c = s.frame(f)
