@@ -81,7 +81,9 @@ int smx_driver_set_fused_head(smx_driver d, int32_t enabled);
 /* Two preprocessing queues (smx_driver_run with overlap on): the bilateral filter on one, the outlier cull and the
  * erosion / normals / radii launch of the same frame behind it on a second one, so that the filter of frame f + 1 -- VALU-bound,
  * one 310-register wavefront per SIMD -- runs beside the gathers of frame f's cull instead of behind them.  Same images.
- * Frames that arrive with their step (smx_driver_run_streamed) keep the single queue: the copy and its readers share it. */
+ * Frames that arrive with their step (smx_driver_run_streamed) keep the single queue: the copy and its readers share it.
+ * Default: on for images of 1024 x 768 pixels and more (where the preprocessing queue paces the frame: + 2 % at 1280 x 960), off
+ * below (- 2 to - 3 % at 640 x 480). */
 int smx_driver_set_split_preprocessing(smx_driver d, int32_t enabled);
 /* A/B switch: erosion + normals + radii as one fused launch (default) or as the reference's three calls; same images. */
 int smx_driver_set_fused_tail(smx_driver d, int32_t enabled);

@@ -50,8 +50,12 @@ struct WorkSet {
 #ifndef SMX_PRE2_PRIORITY
 #define SMX_PRE2_PRIORITY SMX_PRE_PRIORITY
 #endif
-#ifndef SMX_SPLIT_PRE_DEFAULT
-#define SMX_SPLIT_PRE_DEFAULT false
+// Two preprocessing queues by default from this many pixels on (smx_driver_set_split_preprocessing overrides): at 1280 x 960
+// the single queue is the frame's pace-maker -- the caller's stream waits 150 - 230 us a frame for its images -- and two
+// queues are worth + 2.0 % (1 866 - 1 871 against 1 825 - 1 836 frames/s, profiles/r8o_C3_timelines.jsonl); at 640 x 480 the
+// surfel chains pace the frame and the second queue costs 2 - 3 % (profiles/r6_ab_notes.md section 2, r8p).
+#ifndef SMX_SPLIT_PRE_MIN_PIXELS
+#define SMX_SPLIT_PRE_MIN_PIXELS (1024 * 768)
 #endif
 struct smx_driver_s {
   smx_driver_config cfg;
@@ -77,7 +81,7 @@ struct smx_driver_s {
   // Two preprocessing queues: the bilateral filter of frame f + 1 (VALU-bound, one 310-register wavefront per SIMD) runs
   // beside the outlier cull and the tail of frame f (gathers) instead of behind them.  At 1280 x 960 the single queue is
   // busy all of the time and the frame waits for it (profiles/r21_timeline_c3.md).
-  bool split_pre = SMX_SPLIT_PRE_DEFAULT;
+  bool split_pre = false;   // (set by the constructor from the image size)
   smx_event run_start = nullptr;
   bool overlap = true;
   bool run_ahead = false;  // smx_driver_run: preprocessing two steps ahead, dependencies routed off the caller's stream (A/B: -1 %)
@@ -103,6 +107,7 @@ struct smx_driver_s {
     SMX_SHIM_CHECK(smx_stream_create_with_priority(&pre_stream2, SMX_PRE2_PRIORITY));
     SMX_SHIM_CHECK(smx_event_create(&run_start));
     SMX_SHIM_CHECK(smx_stream_synchronize(nullptr));
+    split_pre = (long long)c.width * c.height >= (long long)SMX_SPLIT_PRE_MIN_PIXELS;
   }
   ~smx_driver_s() {
     smx_stream_synchronize(pre_stream); smx_stream_synchronize(pre_stream2); smx_stream_synchronize(nullptr);
