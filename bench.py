@@ -648,6 +648,9 @@ def main():
                     help="the frame loop reads GetTimings after every Integrate like APP/main.cc:1511: nowait = "
                          "GetTimingsNoWait, block = the reference's waiting call")
     ap.add_argument("--fused-head", action="store_true", help="A/B: bilateral filter and outlier cull in one launch (same images; slower)")
+    ap.add_argument("--profile-frames", type=int, default=0, help="A/B: only the first N timed launches of the roofline kernel carry the start / stop events (0 = all of them)")
+    ap.add_argument("--profile-kernel", default="", help="A/B: the kernel whose launches carry the start / stop events in the timed region (default: the longest HBM-side kernel)")
+    ap.add_argument("--dump-stamps", default="", help="-DSMX_STAMPS builds: the per-workgroup stamps of the last timed frames (tile kernel, blend, edge kernel) and the stage-stamp ring go to this .npz")
     ap.add_argument("--handover", type=int, default=-1, help="A/B: smx_recon_set_handover_mode (1 = device word + gate kernel, 0 = event; default: the library's)")
     ap.add_argument("--pre-cus", type=int, default=0, help="A/B: the preprocessing queues on the first N compute units of the CU mask (N / 8 per XCD); 0 = no partition")
     ap.add_argument("--cu-exclusive", action="store_true", help="with --pre-cus: the internal stream and the caller's stream on the OTHER compute units")
@@ -833,6 +836,13 @@ def run_integrate(args):
     in_timed = [n for n in cal_names if not ("hoist-pre" in ub and n in PRE_STAGES)]
     dominant = max(in_timed, key=lambda n: cal_ms[n])
     dominant_hbm = max((n for n in in_timed if n not in PRE_STAGES), key=lambda n: cal_ms[n])
+    # The kernel that is timed with events in the timed region is the frame's longest HBM-side kernel -- the edge kernel
+    # (reg_accumulate) in every kernel trace of rounds 3 - 6 -- unless the 4-frame calibration finds another one MORE THAN 15 %
+    # longer: pass B and the blend calibrate within a few per cent of it, the choice used to flip from run to run, and WHICH
+    # kernel carries the events changes the frame rate (blend, with the event hand-over of rounds 3 - 6: - 10 %, the "slow
+    # mode"; pass B: - 3.6 %; the edge kernel: - 0.6 %; profiles/r6_ab_notes.md section 14)
+    if "reg_accumulate" in in_timed and cal_ms.get("reg_accumulate", 0.0) > 0 and cal_ms[dominant_hbm] <= 1.15 * cal_ms["reg_accumulate"]:
+        dominant_hbm = "reg_accumulate"
 
     def sync_all():
         torch.cuda.synchronize()
@@ -853,10 +863,10 @@ def run_integrate(args):
     # (the roofline block is the HBM roofline of the longest HBM-side kernel; when a preprocessing stage is the longest kernel
     # of the frame -- the VALU-bound bilateral filter -- it is named in the block with its VALU fractions, `roofline_valu`)
     longest = dominant
-    dominant = dominant_hbm
+    dominant = args.profile_kernel or dominant_hbm
     rec.set_timing_enabled(timing_mode)
     wl.pipe.set_read_timings({"off": 0, "nowait": 1, "block": 2}[args.read_timings])
-    rec.profile_begin(dominant, K)
+    rec.profile_begin(dominant, args.profile_frames or K)
     _lib.check(_lib.load().smx_debug_marker(None, 1))   # delimits the timed region in rocprofv3 kernel traces
     sync_all()
     t_start = time.perf_counter()
@@ -874,6 +884,12 @@ def run_integrate(args):
     dom_ms, dom_n = rec.profile_end()
     wl.pipe.set_read_timings(0)
     timeline = stamp_timeline(rec) if timing_mode == 4 else None
+    if args.dump_stamps:   # (diagnosis: a -DSMX_STAMPS build only)
+        import ctypes as _C
+        wg = np.zeros((3, 8192, 16), np.uint64)
+        _lib.check(_lib.load().smx_recon_debug_download_stamps(rec._h, wg.ctypes.data_as(_C.c_void_p)))
+        ring, khz = rec.debug_stamp_ring()
+        np.savez_compressed(args.dump_stamps, wg=wg, ring=ring, khz=khz, fps=fps)
     read_sums, read_calls = wl.pipe.timing_sums()
     rec.set_timing_enabled(4)
     _lib.check(_lib.load().smx_debug_marker(None, 2))

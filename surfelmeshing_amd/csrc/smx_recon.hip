@@ -1281,6 +1281,9 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
   extern __shared__ __align__(16) unsigned char blend_lds[];
   ts_begin(ts, kTsBlendBegin);
   SMX_STAMP(stamps, 0);
+#ifdef SMX_STAMPS
+  if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + 6] = wall_clock64();   // (entry, 100 MHz wall clock: comparable across workgroups and kernels)
+#endif
   const int halo = radius - 1;
   const int rw = kBlendTile + 2 * halo;          // region width == height (<= 64)
   const int cells = rw * rw;
@@ -1450,6 +1453,9 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
     }
   }
   SMX_STAMP(stamps, 5);
+#ifdef SMX_STAMPS
+  if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + 7] = wall_clock64();   // (exit)
+#endif
   ts_end(ts, kTsBlendEnd, blockIdx.x, gridDim.x);
   // The hand-over to the internal stream by a device word instead of an event (smx_recon_set_handover_mode 1): every
   // workgroup releases its output (device scope) and counts itself; k_front_gate, one wavefront in front of the
@@ -1472,10 +1478,22 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
 // call before anything on the internal stream), like an event wait -- and one wavefront cannot keep the producer's workgroups
 // off the chip, which is why the poll is a launch of its own and not the head of the consumer (profiles/r6_ab_notes.md section 9).
 __global__ void __launch_bounds__(64)
-k_front_gate(const uint32_t* count, uint32_t expected) {
+k_front_gate(const uint32_t* count, uint32_t expected, unsigned long long* dbg) {
   if (threadIdx.x == 0) {
+#ifdef SMX_STAMPS
+    const unsigned long long t_in = wall_clock64();
+    unsigned long long polls = 0;
+#endif
     // (relaxed: the launch boundary behind this kernel is the acquire)
-    while ((int32_t)(__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expected) < 0) __builtin_amdgcn_s_sleep(2);
+    while ((int32_t)(__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expected) < 0) {
+      __builtin_amdgcn_s_sleep(2);
+#ifdef SMX_STAMPS
+      ++polls;
+#endif
+    }
+#ifdef SMX_STAMPS
+    if (dbg) { dbg[0] = t_in; dbg[1] = wall_clock64(); dbg[2] = polls; }
+#endif
   }
 }
 
@@ -1493,6 +1511,7 @@ constexpr int kScanPxPerBlock = kBlock * kScanPxPerThread;
 struct NewFlagsArgs {
   Img<const uint16_t> depth; Img<uint16_t> depth_out; int copy_back;
   uint8_t* flags; uint32_t* local_rank; uint32_t* block_sums;
+  unsigned long long* dbg;   // (-DSMX_STAMPS: the integration launch's first workgroup leaves the wall clock here)
 };
 __device__ __forceinline__ void new_flags_scan_body(const NewFlagsArgs& a, const Scratch& sc, int W, int H, DevState* st, uint32_t block) {
   const Img<const uint16_t>& depth = a.depth;
@@ -1693,6 +1712,9 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
             uint8_t* __restrict__ merge_flag, DevState* st, NewFlagsArgs nf, uint32_t n_flag_blocks) {
   SMX_SET_WAVE_PRIO();
   // (workgroup 0 is always a flag block: the image has pixels)
+#ifdef SMX_STAMPS
+  if (nf.dbg && blockIdx.x == 0 && threadIdx.x == 0) nf.dbg[0] = wall_clock64();
+#endif
   if (blockIdx.x < n_flag_blocks) { ts_begin(c.ts, kTsIntBegin); new_flags_scan_body(nf, sc, c.W, c.H, st, blockIdx.x); return; }
   const uint32_t block = blockIdx.x - n_flag_blocks, n_blocks = gridDim.x - n_flag_blocks;
   const uint32_t n_scan = kUseList ? 0u : st->surfel_count;
@@ -3423,7 +3445,7 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
     SlotTimer t(r, st, kSlotRegAccumulate, true);
     const bool done_by_launch = acc_done && !t.stop();
     hipExtLaunchKernelGGL(k_reg_accumulate, dim3(r->grid_acc), dim3(kBlockAcc), 0, st, t.start(), done_by_launch ? acc_done : t.stop(), 0, r->S, rf2, weight, r->grad_acc, r->reg_rec, (size_t)r->S.pitch + kSegAcc,
-                       r->fb, r->L.act_list, r->L.acc_chunks, r->st, ts_first, r->stamps ? r->stamps + 2 * 16 * 8192 : nullptr);
+                       r->fb, r->L.act_list, r->L.acc_chunks, r->st, ts_first, (r->stamps && (frame & 63u) == 31u) ? r->stamps + 2 * 16 * 8192 : nullptr);
     if (acc_done && !done_by_launch) SMX_HIP(hipEventRecord(acc_done, st));
   }
   if (copy_only) {
@@ -3876,7 +3898,9 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   const float term = p->do_blending ? 1.0f / ((float)p->measurement_blending_radius - 1.0f) : 0.0f;  // kernels.cc:196
   const Img<uint16_t> blended = {r->blended_depth, r->H, r->W, (size_t)r->W * sizeof(uint16_t)};
   if (fused_blend) {
-    SlotTimer t(r, sF, kSlotBlend);
+    // (the two measurement modes that bracket kernels with event records of their own keep the event hand-over)
+    front_by_gate = pipelined && !split && r->handover_mode == 1 && !(r->debug_skip & 4) && !tm && !(r->timing_enabled & 2);
+    SlotTimer t(r, sF, kSlotBlend, front_by_gate);   // (device-word hand-over: the launch's event slots are the timer's)
     // tile edge: the one that leaves the busiest CU the fewest cells (see k_blend_tiles)
     const int cus = r->cu_count;
     int tile = 32;
@@ -3888,18 +3912,24 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     const size_t lds = sizeof(BlendMasks) + (size_t)rw * rw * 10;
     const int tiles_x = div_up(r->W, tile);
     const uint32_t n_blend = (uint32_t)(tiles_x * div_up(r->H, tile));
-    unsigned long long* stamps = r->stamps ? r->stamps + 16 * 8192 : nullptr;
+    // (-DSMX_STAMPS builds: one call in 64 is recorded, so that what is read back after a run is a frame from the middle of the
+    // pipeline and not its last one, which drains)
+    unsigned long long* stamps = (r->stamps && (frame_index & 63u) == 32u) ? r->stamps + 16 * 8192 : nullptr;
     // (the hand-over to the internal stream as this launch's own completion event)
-    front_by_launch = SMX_EXT_STOP_EVENTS && pipelined && !split && !tm && !(r->timing_enabled & 2) && r->prof_slot != kSlotBlend;
-    front_by_gate = front_by_launch && r->handover_mode == 1 && !(r->debug_skip & 4);
+    // (With the device-word hand-over the launch's event slots are free for whoever times this kernel -- a profile of the
+    // blend used to push the hand-over onto an event record of its own behind the launch, and the profiled frame loop ran a
+    // tenth slower than the one it was meant to describe: the "slow mode" of rounds 5 - 6 was bench.py profiling this kernel,
+    // profiles/r6_ab_notes.md section 14.)
+    front_by_launch = !front_by_gate && SMX_EXT_STOP_EVENTS && pipelined && !split && !tm && !(r->timing_enabled & 2) && r->prof_slot != kSlotBlend;
     uint32_t* const gate = front_by_gate ? r->gate_count : nullptr;
     if (front_by_gate) r->gate_expected += n_blend;
-    const hipEvent_t stop = (front_by_launch && !front_by_gate) ? r->ev_front : nullptr;
+    const hipEvent_t start = front_by_gate ? t.start() : nullptr;
+    const hipEvent_t stop = front_by_gate ? t.stop() : front_by_launch ? r->ev_front : nullptr;
     if (tile == 40)
-      hipExtLaunchKernelGGL(k_blend_tiles<40>, dim3(n_blend), dim3(kBlendThreads), (uint32_t)lds, sF, nullptr, stop, 0, p->measurement_blending_radius, term, ds,
+      hipExtLaunchKernelGGL(k_blend_tiles<40>, dim3(n_blend), dim3(kBlendThreads), (uint32_t)lds, sF, start, stop, 0, p->measurement_blending_radius, term, ds,
                             in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps, c.ts, gate);
     else
-      hipExtLaunchKernelGGL(k_blend_tiles<32>, dim3(n_blend), dim3(kBlendThreads), (uint32_t)lds, sF, nullptr, stop, 0, p->measurement_blending_radius, term, ds,
+      hipExtLaunchKernelGGL(k_blend_tiles<32>, dim3(n_blend), dim3(kBlendThreads), (uint32_t)lds, sF, start, stop, 0, p->measurement_blending_radius, term, ds,
                             in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps, c.ts, gate);
   } else if (p->do_blending) {
     // the reference's own sequence (2 clears + start + iterations, kernels.cc:165-205), in place on the caller's depth
@@ -3918,6 +3948,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
   nf.depth = fused_blend ? Img<const uint16_t>{r->blended_depth, r->H, r->W, (size_t)r->W * sizeof(uint16_t)} : in.depth;
   nf.depth_out = depth_rw; nf.copy_back = fused_blend ? 1 : 0;
   nf.flags = r->new_flags; nf.local_rank = r->new_ranks; nf.block_sums = r->block_sums;
+  nf.dbg = (r->stamps && (frame_index & 63u) == 32u) ? r->stamps + (size_t)(2 * 8192 + 8189) * 16 : nullptr;
   FrameIn in_integrate = in;
   in_integrate.depth = nf.depth;
   // Everything up to here only read P and N records; from here on they (and T, S) are written, so the previous
@@ -3930,7 +3961,8 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     // (work on the internal stream from here on: whatever happens below, later entry points order themselves behind it)
     r->reg_pending = true;
     if (front_by_gate) {
-      hipLaunchKernelGGL(k_front_gate, dim3(1), dim3(64), 0, sR, r->gate_count, r->gate_expected);
+      hipLaunchKernelGGL(k_front_gate, dim3(1), dim3(64), 0, sR, r->gate_count, r->gate_expected,
+                         (r->stamps && (frame_index & 63u) == 32u) ? r->stamps + (size_t)(2 * 8192 + 8190) * 16 : nullptr);
     } else {
       if (!front_by_launch) SMX_HIP(hipEventRecord(r->ev_front, sF));
       if (!(r->debug_skip & 4)) SMX_HIP(hipStreamWaitEvent(sR, r->ev_front, 0));   // (bit 2: timing only -- what is the hand-over worth?)
