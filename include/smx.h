@@ -318,6 +318,11 @@ int smx_recon_get_timings_nowait(smx_recon r, float out_ms[7], uint64_t* call_nu
  * integration polls it (default; a queue that is found WAITING at an event is woken in ~20 us, the gate in 1 - 2:
  * profiles/r6_ab_notes.md section 12), 0 = an event (rounds 3 - 6).  Results identical. */
 int smx_recon_set_handover_mode(smx_recon r, int32_t mode);
+/* The mode in use.  smx_recon_create starts an object in mode 0 when the process runs under a profiler that collects hardware
+ * counters (ROCPROF_COUNTER_COLLECTION set, i.e. rocprofv3 --pmc): such a tool serialises the kernel dispatches of ALL queues, the
+ * gate can then reach the chip in front of the launch it waits for, and nothing else is let on.  The gate's poll is bounded
+ * (0.25 s); one that gives up invalidates the map and the next smx_recon_counts / smx_recon_get_stats returns SMX_ERR_UNSUPPORTED. */
+int smx_recon_get_handover_mode(smx_recon r, int32_t* mode);
 /* Experiment: the object's internal stream re-created on a subset of the compute units (mask as for
  * smx_stream_create_with_cu_mask; n_words = 0: all of them again, at the highest priority).  Waits for the object's work. */
 int smx_recon_set_internal_cu_mask(smx_recon r, const uint32_t* mask_words, uint32_t n_words);

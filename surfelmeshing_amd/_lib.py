@@ -81,7 +81,7 @@ class NNStats(C.Structure):
 # every symbol include/smx.h declares (tests/test_abi.py checks the .so exports them all)
 EXPORTS = [
     "smx_last_error", "smx_runtime_advice", "smx_host_is_page_locked", "smx_device_count", "smx_set_device", "smx_device_name",
-    "smx_stream_create", "smx_stream_create_with_priority", "smx_stream_create_with_cu_mask", "smx_recon_set_internal_cu_mask", "smx_recon_set_handover_mode", "smx_host_alloc", "smx_host_free", "smx_stream_destroy", "smx_stream_synchronize", "smx_debug_marker", "smx_debug_handover_probe",
+    "smx_stream_create", "smx_stream_create_with_priority", "smx_stream_create_with_cu_mask", "smx_recon_set_internal_cu_mask", "smx_recon_set_handover_mode", "smx_recon_get_handover_mode", "smx_host_alloc", "smx_host_free", "smx_stream_destroy", "smx_stream_synchronize", "smx_debug_marker", "smx_debug_handover_probe",
     "smx_event_create", "smx_event_create_timed", "smx_event_elapsed_ms", "smx_event_destroy", "smx_event_record", "smx_stream_wait_event",
     "smx_buffer_create", "smx_buffer_destroy", "smx_buffer_get_desc", "smx_buffer_upload", "smx_buffer_upload_by_kernel", "smx_buffer_download",
     "smx_buffer_upload_part", "smx_buffer_download_part", "smx_buffer_clear", "smx_buffer_set_to",

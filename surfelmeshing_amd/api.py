@@ -597,6 +597,11 @@ class CUDASurfelReconstruction:
         """smx_recon_set_handover_mode: 1 = device word + gate kernel (default), 0 = event"""
         _lib.check(_lib.load().smx_recon_set_handover_mode(self._h, C.c_int32(int(mode))))
 
+    def handover_mode(self):
+        m = C.c_int32(-1)
+        _lib.check(_lib.load().smx_recon_get_handover_mode(self._h, C.byref(m)))
+        return int(m.value)
+
     def set_internal_cu_mask(self, mask_words):
         """experiment (smx_recon_set_internal_cu_mask): the internal stream on the compute units of the mask (empty = all)"""
         arr = (C.c_uint32 * max(1, len(mask_words)))(*mask_words)

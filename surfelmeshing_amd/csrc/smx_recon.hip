@@ -26,6 +26,7 @@
 // no kernel launch needs a host round trip.
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <atomic>
@@ -1477,16 +1478,24 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
 // as a wait because of WHERE it is enqueued: behind the launch it waits for (smx_recon_integrate enqueues the front of a
 // call before anything on the internal stream), like an event wait -- and one wavefront cannot keep the producer's workgroups
 // off the chip, which is why the poll is a launch of its own and not the head of the consumer (profiles/r6_ab_notes.md section 9).
+// The poll is BOUNDED (kGateTimeoutTicks of the 100 MHz wall clock = 0.25 s, a thousand frames): where something serialises
+// kernel dispatches ACROSS queues -- a profiler collecting hardware counters does (rocprofv3 --pmc) -- the gate can be let onto
+// the chip in front of the launch it waits for, and an unbounded poll then hangs the process (it did: a whole evidence run of
+// this round).  A gate that gives up leaves a sticky mark (count[8]); the map is then wrong, and every entry point that
+// synchronises reports it (check_handover).  smx_recon_create switches to the event hand-over by itself when it finds the
+// process under a counter-collecting rocprofv3 (ROCPROF_COUNTER_COLLECTION).
+constexpr unsigned long long kGateTimeoutTicks = 25000000ull;
 __global__ void __launch_bounds__(64)
-k_front_gate(const uint32_t* count, uint32_t expected, unsigned long long* dbg) {
+k_front_gate(uint32_t* count, uint32_t expected, unsigned long long* dbg) {
   if (threadIdx.x == 0) {
-#ifdef SMX_STAMPS
     const unsigned long long t_in = wall_clock64();
+#ifdef SMX_STAMPS
     unsigned long long polls = 0;
 #endif
     // (relaxed: the launch boundary behind this kernel is the acquire)
     while ((int32_t)(__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expected) < 0) {
       __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t_in > kGateTimeoutTicks) { count[8] = 1u; break; }
 #ifdef SMX_STAMPS
       ++polls;
 #endif
@@ -3573,6 +3582,11 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->gate_count, 32, true));   // (a line of its own)
   r->gate_expected = 0;
   r->handover_mode = SMX_HANDOVER_FLAGS;
+  {
+    // (a rocprofv3 that collects hardware counters serialises the dispatches of all queues: see k_front_gate)
+    const char* cc = getenv("ROCPROF_COUNTER_COLLECTION");
+    if (cc && cc[0] && strcmp(cc, "0") != 0) r->handover_mode = 0;
+  }
   SMX_TRY(dev_alloc(&r->L.act_list, (size_t)r->nsegB * kSegB, true));
   SMX_TRY(dev_alloc(&r->sc.supporting, P, true));
   SMX_TRY(dev_alloc(&r->sc.counts, P, true));
@@ -3747,6 +3761,12 @@ int smx_recon_set_handover_mode(smx_recon r, int32_t mode) {
   return SMX_OK;
 }
 
+int smx_recon_get_handover_mode(smx_recon r, int32_t* mode) {
+  SMX_CHECK_ARG(r != nullptr && mode != nullptr);
+  *mode = r->handover_mode;
+  return SMX_OK;
+}
+
 int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
   SMX_CHECK_ARG(r != nullptr && mode >= 0 && mode <= 1023);
   SMX_ON_DEVICE(r->device);
@@ -3764,7 +3784,7 @@ int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
 }
 
 int smx_recon_debug_set_skip(smx_recon r, int32_t mask) {
-  SMX_CHECK_ARG(r != nullptr && mask >= 0 && mask <= 31);
+  SMX_CHECK_ARG(r != nullptr && mask >= 0 && mask <= 63);
   r->debug_skip = mask;
   return SMX_OK;
 }
@@ -3961,7 +3981,9 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     // (work on the internal stream from here on: whatever happens below, later entry points order themselves behind it)
     r->reg_pending = true;
     if (front_by_gate) {
-      hipLaunchKernelGGL(k_front_gate, dim3(1), dim3(64), 0, sR, r->gate_count, r->gate_expected,
+      // (debug_skip bit 5, test only: the gate is told to wait for one workgroup more than the blend has -- it gives up after its
+      // bound, and the next synchronising entry point reports it)
+      hipLaunchKernelGGL(k_front_gate, dim3(1), dim3(64), 0, sR, r->gate_count, r->gate_expected + ((r->debug_skip & 32) ? 1u : 0u),
                          (r->stamps && (frame_index & 63u) == 32u) ? r->stamps + (size_t)(2 * 8192 + 8190) * 16 : nullptr);
     } else {
       if (!front_by_launch) SMX_HIP(hipEventRecord(r->ev_front, sF));
@@ -4088,6 +4110,19 @@ int smx_recon_regularize(smx_recon r, smx_stream s, uint32_t frame_index, float 
                             regularizer_weight, regularization_frame_window_size, false, false, true);
 }
 
+// (behind a synchronisation of the object's work) did a gate kernel give up?  Sticky: the map is wrong from that call on.
+static int check_handover(smx_recon r, hipStream_t st) {
+  uint32_t mark = 0;
+  SMX_HIP(hipMemcpyAsync(&mark, r->gate_count + 8, sizeof(mark), hipMemcpyDeviceToHost, st));
+  SMX_HIP(hipStreamSynchronize(st));
+  if (mark) {
+    set_error("the front -> integration hand-over timed out: kernel dispatches of different queues are being serialised (a profiler "
+              "in counter mode?) -- the map is invalid; use smx_recon_set_handover_mode(r, 0) in such an environment");
+    return SMX_ERR_UNSUPPORTED;
+  }
+  return SMX_OK;
+}
+
 int smx_recon_counts(smx_recon r, smx_stream s, uint32_t* surfel_count, uint32_t* surfels_size) {
   SMX_CHECK_ARG(r != nullptr);
   SMX_ON_DEVICE(r->device);
@@ -4095,6 +4130,7 @@ int smx_recon_counts(smx_recon r, smx_stream s, uint32_t* surfel_count, uint32_t
   DevState h;
   SMX_HIP(hipMemcpyAsync(&h, r->st, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)s));
   SMX_HIP(hipStreamSynchronize((hipStream_t)s));
+  { const int rch = check_handover(r, (hipStream_t)s); if (rch != SMX_OK) return rch; }
   if (surfel_count) *surfel_count = h.surfel_count - h.merge_count;  // .h:125-128
   if (surfels_size) *surfels_size = h.surfel_count;
   return SMX_OK;
@@ -4107,6 +4143,7 @@ int smx_recon_get_stats(smx_recon r, smx_stream s, smx_recon_stats* out) {
   DevState h;
   SMX_HIP(hipMemcpyAsync(&h, r->st, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)s));
   SMX_HIP(hipStreamSynchronize((hipStream_t)s));
+  { const int rch = check_handover(r, (hipStream_t)s); if (rch != SMX_OK) return rch; }
   out->surfels_size = h.surfel_count; out->merge_count = h.merge_count;
   out->n_visible = h.n_visible; out->n_new = h.new_count; out->n_merged = h.n_merged;
   out->n_recent = h.recent_count; out->n_edges = h.n_edges;

@@ -765,6 +765,25 @@ def test_stream_on_a_subset_of_the_compute_units(smx):
         smx.Stream(cu_mask=[0, 0])
 
 
+def test_handover_gate_gives_up_instead_of_hanging(smx, monkeypatch):
+    """The device-word hand-over's safety net: a gate that waits for more than will ever come (debug_skip bit 5) gives up after its
+    bound instead of hanging the queue, and the next synchronising entry point says so; under a counter-collecting profiler
+    (ROCPROF_COUNTER_COLLECTION) an object starts with the event hand-over."""
+    s = small_stream(obstacle_until=8)
+    po, pg = _pipes(smx, s, 60000)
+    assert pg.reconstruction.handover_mode() == 1
+    run_both(po, pg, s, list(range(4, 8)), None)
+    _compare_state(po, pg)
+    pg.reconstruction.debug_set_skip(32)
+    run_both(po, pg, s, [8], None)
+    pg.reconstruction.debug_set_skip(0)
+    with pytest.raises(smx.SmxError, match="hand-over timed out"):
+        pg.reconstruction.surfels_size()
+    monkeypatch.setenv("ROCPROF_COUNTER_COLLECTION", "1")
+    _, pg2 = _pipes(smx, s, 60000)
+    assert pg2.reconstruction.handover_mode() == 0
+
+
 def test_two_objects_on_two_host_threads(smx):
     """The 8-GPU code path minus the other seven GPUs: two host threads, each with its own native frame
     driver (reconstruction object, streams, work sets) and its own synthetic stream, run CONCURRENTLY on the one GPU;
