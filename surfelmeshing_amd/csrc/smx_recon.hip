@@ -2825,7 +2825,8 @@ __device__ __forceinline__ void edge_segment(const Surfels& S, const EdgeArgs& e
 __global__ void __launch_bounds__(kBlockAcc, SMX_ACC_WGS_PER_CU)   // (second argument: wavefronts per SIMD = workgroups per CU here)
 k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ grad_acc,
                  float4* __restrict__ reg_rec, size_t rec_own_offset, FarBins fb,
-                 const uint32_t* __restrict__ act_list, Chunks acc, DevState* st, unsigned long long* ts, unsigned long long* stamps) {
+                 const uint32_t* __restrict__ act_list, Chunks acc, DevState* st, unsigned long long* ts, unsigned long long* stamps,
+                 uint32_t max_entries /* kSegAcc; less: TIMING ONLY (debug_skip bit 7), the map is wrong afterwards */) {
   SMX_SET_WAVE_PRIO();
   ts_begin(ts, kTsAccBegin);
 #ifdef SMX_STAMPS
@@ -2859,7 +2860,7 @@ k_reg_accumulate(Surfels S, float rf2, float weight, long long* __restrict__ gra
   const uint32_t ent_first = ent_next;
   ent_next = (w + gridDim.x < n_steps && tid <= (desc >> 22)) ? act_list[(size_t)(desc & 0x003FFFFFu) * kSegAcc + tid] : kNoActEntry;
   if (!walk_step_valid(w, cntv)) continue;
-  const uint32_t seg_id = cur & 0x003FFFFFu, n_act = (cur >> 22) + 1u;
+  const uint32_t seg_id = cur & 0x003FFFFFu, n_act = min((cur >> 22) + 1u, max_entries);
   const uint32_t base = seg_id * kSegAcc;
 #ifdef SMX_STAMPS
   ++dbg_steps; dbg_entries += n_act; dbg_max = max(dbg_max, n_act);
@@ -3454,7 +3455,8 @@ int enqueue_regularize(smx_recon r, hipStream_t st, uint32_t frame, float rf, fl
     SlotTimer t(r, st, kSlotRegAccumulate, true);
     const bool done_by_launch = acc_done && !t.stop();
     hipExtLaunchKernelGGL(k_reg_accumulate, dim3(r->grid_acc), dim3(kBlockAcc), 0, st, t.start(), done_by_launch ? acc_done : t.stop(), 0, r->S, rf2, weight, r->grad_acc, r->reg_rec, (size_t)r->S.pitch + kSegAcc,
-                       r->fb, r->L.act_list, r->L.acc_chunks, r->st, ts_first, (r->stamps && (frame & 63u) == 31u) ? r->stamps + 2 * 16 * 8192 : nullptr);
+                       r->fb, r->L.act_list, r->L.acc_chunks, r->st, ts_first, (r->stamps && (frame & 63u) == 31u) ? r->stamps + 2 * 16 * 8192 : nullptr,
+                       (r->debug_skip & 128) ? 256u : (uint32_t)kSegAcc);
     if (acc_done && !done_by_launch) SMX_HIP(hipEventRecord(acc_done, st));
   }
   if (copy_only) {
@@ -3784,7 +3786,7 @@ int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
 }
 
 int smx_recon_debug_set_skip(smx_recon r, int32_t mask) {
-  SMX_CHECK_ARG(r != nullptr && mask >= 0 && mask <= 63);
+  SMX_CHECK_ARG(r != nullptr && mask >= 0 && mask <= 255);
   r->debug_skip = mask;
   return SMX_OK;
 }
@@ -4000,6 +4002,9 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     if (r->scan_mode) hipExtLaunchKernelGGL((k_integrate<false>), gi, b, 0, sI, t.start(), t.stop(), 0, r->S, c, r->sc, in_integrate, r->L, r->merge_flag, r->st, nf, nfb);
     else hipExtLaunchKernelGGL((k_integrate<true>), gi, b, 0, sI, t.start(), t.stop(), 0, r->S, c, r->sc, in_integrate, r->L, r->merge_flag, r->st, nf, nfb); }
   if (tm) { SMX_HIP(hipEventRecord(r->ev[7], sR)); SMX_HIP(hipEventRecord(r->ev[8], sR)); }
+  // (debug_skip bit 6, TIMING ONLY -- the map is wrong afterwards: the caller's stream is released behind the INTEGRATION launch
+  // instead of behind update + create, an upper bound for "pass A needs the new slots, not the new links")
+  if ((r->debug_skip & 64) && pipelined) SMX_HIP(hipEventRecord(r->ev_front, sI));
   if (!front_only) { SlotTimer t(r, sI, kSlotUpdateNeighbors);
     CreateArgs ca;
     ca.flags = r->new_flags; ca.ranks = r->new_ranks; ca.block_sums = r->block_sums; ca.block_offsets_out = r->block_offsets;
@@ -4034,6 +4039,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     // (Every other entry point orders its stream after the whole internal stream: join_regularizer.)
     if (split) SMX_HIP(hipStreamWaitEvent(sR, mark, 0));   // (the internal stream's pass B waits; the caller's stream carries on)
     else if (r->debug_skip & 8) { }   // (bit 3: timing only -- the caller's stream does not wait for update + create)
+    else if ((r->debug_skip & 64) && pipelined) { if (hook_consumed) r->pending_mark = r->ev_front; else SMX_HIP(hipStreamWaitEvent(sF, r->ev_front, 0)); }
     else if (pipelined && hook_consumed) r->pending_mark = mark;
     else if (pipelined) SMX_HIP(hipStreamWaitEvent(sF, mark, 0));
   }
