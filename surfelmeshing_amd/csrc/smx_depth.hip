@@ -187,6 +187,9 @@ __device__ __forceinline__ void det_expf_nonpositive2(const f32x2 (&x)[N], f32x2
     e[k].y = (x[k].y < -86.0f) ? 0.0f : e[k].y;
   }
 }
+#ifndef SMX_BIL_PRIO
+#define SMX_BIL_PRIO 0
+#endif
 constexpr float kBilIgnore = -1.0e30f;
 constexpr int bil_half_width(int R, int dy) {
   int hw = 0;
@@ -241,6 +244,9 @@ template <int R, int kOthers = 0>
 __global__ void __launch_bounds__(kThreads)
 k_bilateral_p(float denom_xy, float sigma_value_factor, uint16_t value_to_ignore, uint16_t max_depth, float region_r2,
               Img<const uint16_t> in, Img<uint16_t> out, int tiles_x, int n_tiles, OutlierArgs oa) {
+#if SMX_BIL_PRIO
+  __builtin_amdgcn_s_setprio(SMX_BIL_PRIO);   // (A/B: the filter's wave priority against the surfel kernels' 1, profiles/r6_ab_notes.md section 17)
+#endif
   constexpr int TW = kBilTileW + 2 * R, TH = kBilTileH + 2 * R;
   __shared__ float tile[TH * TW];
   __shared__ float spatial[R * R + 1];
