@@ -751,7 +751,7 @@ def run_integrate(args):
     # (round 2: 4144 frames/s at --steps 20 --warmup 5 against 3873 at --steps 300 --warmup 20).
     first = g_end + 10
     ub = set(x for x in args.ub.split(",") if x)
-    assert ub <= {"hoist-pre", "no-reg", "front-only", "no-front-wait", "no-upd-wait", "split", "release-after-integrate", "edge-first-chunk"}, "unknown --ub item"
+    assert ub <= {"hoist-pre", "no-reg", "front-only", "no-front-wait", "no-upd-wait", "split", "release-after-integrate", "edge-first-chunk", "blend-first-ring"}, "unknown --ub item"
     rec0 = wl.pipe.reconstruction
     names = rec0.kernel_time_names()
     # kernels judged in the frame: the Integrate slots (not the empty slot that measures the time stamps themselves, not the
@@ -855,7 +855,7 @@ def run_integrate(args):
             wl.pipe.prepare_array(*warm_steps)
         wl.pipe.prepare_array(*timed_steps)
     rec.debug_set_skip((1 if "no-reg" in ub else 0) | (2 if "front-only" in ub else 0) | (4 if "no-front-wait" in ub else 0) |
-                       (8 if "no-upd-wait" in ub else 0) | (16 if "split" in ub else 0) | (64 if "release-after-integrate" in ub else 0) | (128 if "edge-first-chunk" in ub else 0))
+                       (8 if "no-upd-wait" in ub else 0) | (16 if "split" in ub else 0) | (64 if "release-after-integrate" in ub else 0) | (128 if "edge-first-chunk" in ub else 0) | (256 if "blend-first-ring" in ub else 0))
     # Time stamps around the dominant kernel only (2 records per frame on the stream it is launched on) stay on during
     # the timed region; everything else is measured in separate passes.
     if warm_steps is not None:

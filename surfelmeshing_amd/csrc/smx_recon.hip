@@ -1277,7 +1277,8 @@ __device__ __forceinline__ unsigned long long row_mask_from_bits(uint32_t bits) 
 template <int kBlendTile>
 __global__ void __launch_bounds__(kBlendThreads)
 k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<uint16_t> out, Scratch sc, int W, int H,
-              int tiles_x, unsigned long long* stamps, unsigned long long* ts, uint32_t* gate_count) {
+              int tiles_x, unsigned long long* stamps, unsigned long long* ts, uint32_t* gate_count,
+              int max_ring /* kBlendMaxRings; less: TIMING ONLY (debug_skip bit 8), the blended depths are wrong */) {
   SMX_SET_WAVE_PRIO();
   extern __shared__ __align__(16) unsigned char blend_lds[];
   ts_begin(ts, kTsBlendBegin);
@@ -1371,7 +1372,7 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
   }
   __syncthreads();
   SMX_STAMP(stamps, 3);
-  const int last_ring = M.last_ring;
+  const int last_ring = min(M.last_ring, max_ring);
   // no measurement / surfel border anywhere in tile + halo: the blend changes nothing here (dep = the input depths)
   if (last_ring >= 1) {
     // From here on a lane owns the cells (r0 + 16 j, 4 cq + j), j = 0..3: four different rows and columns, so that the
@@ -3786,7 +3787,7 @@ int smx_recon_set_scan_mode(smx_recon r, int32_t mode) {
 }
 
 int smx_recon_debug_set_skip(smx_recon r, int32_t mask) {
-  SMX_CHECK_ARG(r != nullptr && mask >= 0 && mask <= 255);
+  SMX_CHECK_ARG(r != nullptr && mask >= 0 && mask <= 511);
   r->debug_skip = mask;
   return SMX_OK;
 }
@@ -3949,10 +3950,10 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     const hipEvent_t stop = front_by_gate ? t.stop() : front_by_launch ? r->ev_front : nullptr;
     if (tile == 40)
       hipExtLaunchKernelGGL(k_blend_tiles<40>, dim3(n_blend), dim3(kBlendThreads), (uint32_t)lds, sF, start, stop, 0, p->measurement_blending_radius, term, ds,
-                            in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps, c.ts, gate);
+                            in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps, c.ts, gate, (r->debug_skip & 256) ? 1 : kBlendMaxRings);
     else
       hipExtLaunchKernelGGL(k_blend_tiles<32>, dim3(n_blend), dim3(kBlendThreads), (uint32_t)lds, sF, start, stop, 0, p->measurement_blending_radius, term, ds,
-                            in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps, c.ts, gate);
+                            in.depth, blended, r->sc, r->W, r->H, tiles_x, stamps, c.ts, gate, (r->debug_skip & 256) ? 1 : kBlendMaxRings);
   } else if (p->do_blending) {
     // the reference's own sequence (2 clears + start + iterations, kernels.cc:165-205), in place on the caller's depth
     SlotTimer t(r, sF, kSlotBlend);
