@@ -315,8 +315,10 @@ int smx_recon_get_timings(smx_recon r, float out_ms[7]);
 int smx_recon_get_timings_nowait(smx_recon r, float out_ms[7], uint64_t* call_number);
 /* How the front of a pipelined smx_recon_integrate call (pass A .. blend, on the caller's stream) hands over to the
  * internal stream: 1 = the blend's workgroups count themselves in a device word and a one-wavefront gate kernel in front of the
- * integration polls it (default; a queue that is found WAITING at an event is woken in ~20 us, the gate in 1 - 2:
- * profiles/r6_ab_notes.md section 12), 0 = an event (rounds 3 - 6).  Results identical. */
+ * integration polls it (default: no event packet on the internal stream, and no release of the XCDs' L2s behind the blend --
+ * its output leaves write-through -- + 3.6 % at 640 x 480, profiles/r6_ab_notes.md section 13), 0 = an event (rounds 3 - 6).
+ * Results identical.  The two measurement modes of smx_recon_set_timing_enabled that bracket kernels with event records of
+ * their own (bits 0 and 1) keep the event whatever the mode. */
 int smx_recon_set_handover_mode(smx_recon r, int32_t mode);
 /* The mode in use.  smx_recon_create starts an object in mode 0 when the process runs under a profiler that collects hardware
  * counters (ROCPROF_COUNTER_COLLECTION set, i.e. rocprofv3 --pmc): such a tool serialises the kernel dispatches of ALL queues, the
@@ -415,7 +417,10 @@ int smx_recon_set_scan_mode(smx_recon r, int32_t mode);
  * cross-stream hand-overs cost the frame -- results undefined; bit 4: another arrangement of the streams (integrate + update
  * stay on the caller's stream behind the blend and wait for the previous call's edge kernel only, the internal stream keeps
  * pass B / edges / step and waits for update + create: the step kernel off every cycle, two hand-overs on the critical one) --
- * measured 5 % slower even as an upper bound, profiles/r6_ab_notes.md.  0 = off. */
+ * measured 5 % slower even as an upper bound, profiles/r6_ab_notes.md; bit 5 (test only): the front gate waits for one workgroup
+ * more than the blend has and gives up after its bound; bit 6: the caller's stream is released behind the integration launch
+ * instead of behind update + create; bit 7: the edge kernel works on the first 256 entries of every segment only; bit 8: the blend
+ * stops behind its start ring (bits 6 - 8: upper bounds, profiles/r6_ab_notes.md sections 16, 21, 24).  0 = off. */
 int smx_recon_debug_set_skip(smx_recon r, int32_t mask);
 /* Frame pipelining (default on): the regulariser of a frame runs on an internal stream beside the first
  * kernels of the next smx_recon_integrate call (which only read what the regulariser does not write).
