@@ -1319,6 +1319,14 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
   }
 #pragma unroll
   for (int b = 0; b < 4; ++b) { keep(dv[b]); keep(sv[b]); keep((uint32_t)bs[b]); keep((uint32_t)(bs[b] >> 32)); keep(bc[b]); }
+  // The four cells' averages at once -- the division the start ring does for the border cells among them (:596 / :605), same
+  // operands, same result -- and PINNED, so that four floats stay live through the mask phases instead of twelve registers of sums
+  // and counts.  The kernel's 1 024-lane workgroup needs four wave slots and four times its register allocation free on every SIMD
+  // of one CU at once, beside kernels that fill the chip: every 8 registers of allocation are worth ~4.5 % of the FRAME
+  // (48 -> 56 -> 64: 6 375 -> 6 075 -> 5 947 frames/s, profiles/r6_ab_notes.md section 27).
+  float bavg[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { bavg[j] = q_to_float(bs[j]) / (float)bc[j]; keep(bavg[j]); }
   SMX_STAMP(stamps, 1);
   uint32_t zb = 0, sb0 = 0, eb = 0;
 #pragma unroll
@@ -1394,7 +1402,7 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
           if (!((hit_m | hit_n) & (1u << j))) continue;
           const int R = (r0 + 16 * j) & 63, C = 4 * cq + j, k = R * rw + C;
           const float own = (float)dep[k];
-          const float avg = q_to_float(bs[j]) / (float)bc[j];   // depth_sum_avg
+          const float avg = bavg[j];   // depth_sum_avg (formed above)
           if (hit_n & (1u << j)) ndelta[k] = avg - own / ds;
           if (hit_m & (1u << j)) {
             delta[k] = avg - own / ds;

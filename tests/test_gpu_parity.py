@@ -878,9 +878,12 @@ def test_get_timings_are_consistent(smx):
             f += 1
             sums[mode] += np.array(rec.GetTimings())
     st_, ev_ = sums[4] / 6, sums[1] / 6
-    assert abs(st_.sum() - ev_.sum()) < 0.35 * ev_.sum() + 0.03, (st_, ev_)
+    # (a band, not a distance: the event mode pays for its fourteen records -- a packet each between launches of 10 - 30 us -- and,
+    # since round 6, for the event hand-over it keeps while the stamp mode hands over by a device word; the stamps must never
+    # exceed the events by more than their noise and must not shrink to nothing)
+    assert 0.3 * ev_.sum() < st_.sum() < 1.2 * ev_.sum() + 0.03, (st_, ev_)
     for k in (0, 2, 3, 4, 6):
-        assert st_[k] > 0.001 and ev_[k] > 0.001 and abs(st_[k] - ev_[k]) < 0.5 * ev_[k] + 0.03, (k, st_, ev_)
+        assert st_[k] > 0.001 and ev_[k] > 0.001 and 0.2 * ev_[k] - 0.03 < st_[k] < 1.5 * ev_[k] + 0.03, (k, st_, ev_)
     rec.set_timing_enabled(3)
     smx.StreamSynchronize(None)
     t0 = time.perf_counter()
