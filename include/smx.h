@@ -323,7 +323,8 @@ int smx_recon_set_handover_mode(smx_recon r, int32_t mode);
 /* The mode in use.  smx_recon_create starts an object in mode 0 when the process runs under a profiler that collects hardware
  * counters (ROCPROF_COUNTER_COLLECTION set, i.e. rocprofv3 --pmc): such a tool serialises the kernel dispatches of ALL queues, the
  * gate can then reach the chip in front of the launch it waits for, and nothing else is let on.  The gate's poll is bounded
- * (0.25 s); one that gives up invalidates the map and the next smx_recon_counts / smx_recon_get_stats returns SMX_ERR_UNSUPPORTED. */
+ * (0.25 s); one that gives up invalidates the map, the next smx_recon_counts / smx_recon_get_stats returns SMX_ERR_UNSUPPORTED, and
+ * the object goes back to mode 0 with its next smx_recon_integrate call (the gate leaves its mark in page-locked memory). */
 int smx_recon_get_handover_mode(smx_recon r, int32_t* mode);
 /* Experiment: the object's internal stream re-created on a subset of the compute units (mask as for
  * smx_stream_create_with_cu_mask; n_words = 0: all of them again, at the highest priority).  Waits for the object's work. */

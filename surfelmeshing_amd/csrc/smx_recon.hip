@@ -1495,7 +1495,7 @@ k_blend_tiles(int radius, float term, float ds, Img<const uint16_t> depth, Img<u
 // process under a counter-collecting rocprofv3 (ROCPROF_COUNTER_COLLECTION).
 constexpr unsigned long long kGateTimeoutTicks = 25000000ull;
 __global__ void __launch_bounds__(64)
-k_front_gate(uint32_t* count, uint32_t expected, unsigned long long* dbg) {
+k_front_gate(uint32_t* count, uint32_t expected, unsigned long long* dbg, uint32_t* host_mark) {
   if (threadIdx.x == 0) {
     const unsigned long long t_in = wall_clock64();
 #ifdef SMX_STAMPS
@@ -1504,7 +1504,7 @@ k_front_gate(uint32_t* count, uint32_t expected, unsigned long long* dbg) {
     // (relaxed: the launch boundary behind this kernel is the acquire)
     while ((int32_t)(__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expected) < 0) {
       __builtin_amdgcn_s_sleep(2);
-      if (wall_clock64() - t_in > kGateTimeoutTicks) { count[8] = 1u; break; }
+      if (wall_clock64() - t_in > kGateTimeoutTicks) { count[8] = 1u; *host_mark = 1u; break; }
 #ifdef SMX_STAMPS
       ++polls;
 #endif
@@ -3561,8 +3561,9 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   SMX_TRY(dev_alloc(&r->sw.copy_list, (size_t)r->nseg + 65536, true));
   SMX_TRY(dev_alloc(&r->sw.count, 2, true));
   // (the direction word of segment_of_block: written by the tile kernel, read by the host without synchronisation)
-  SMX_TRY(hip_rc(hipHostMalloc(reinterpret_cast<void**>(&r->dir_host), sizeof(uint32_t), hipHostMallocMapped), "hipHostMalloc"));
-  *r->dir_host = 0;
+  SMX_TRY(hip_rc(hipHostMalloc(reinterpret_cast<void**>(&r->dir_host), 2 * sizeof(uint32_t), hipHostMallocMapped), "hipHostMalloc"));
+  r->dir_host[0] = 0;
+  r->dir_host[1] = 0;   // (a front gate that gave up leaves its mark here as well: smx_recon_integrate reads it without a synchronisation)
   SMX_TRY(hip_rc(hipHostGetDevicePointer(reinterpret_cast<void**>(&r->dir_dev), r->dir_host, 0), "hipHostGetDevicePointer"));
   SMX_TRY(dev_alloc(&r->L.recent_seg, (size_t)r->nsegB, true));
   // chunk descriptors: every chunk of every segment in the worst case, + room for the index a walk forms first
@@ -3824,6 +3825,9 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
     r->hot_holdoff = 3;
   }
   r->have_frame = true; r->last_frame = frame_index;
+  // (a front gate that gave up -- kernel dispatches serialised across queues: k_front_gate -- has left its mark in page-locked
+  // memory: no more gates, every one of them would sit out its bound; the map is invalid and smx_recon_counts / _get_stats say so)
+  if (r->handover_mode == 1 && reinterpret_cast<volatile uint32_t*>(r->dir_host)[1] != 0u) r->handover_mode = 0;
   FrameCtx c;
   memcpy(c.G.m, global_T_local, sizeof(float) * 12);
   c.L = se3_inverse(global_T_local);  // cc:144
@@ -3995,7 +3999,7 @@ int smx_recon_integrate(smx_recon r, smx_stream s, uint32_t frame_index, float d
       // (debug_skip bit 5, test only: the gate is told to wait for one workgroup more than the blend has -- it gives up after its
       // bound, and the next synchronising entry point reports it)
       hipLaunchKernelGGL(k_front_gate, dim3(1), dim3(64), 0, sR, r->gate_count, r->gate_expected + ((r->debug_skip & 32) ? 1u : 0u),
-                         (r->stamps && (frame_index & 63u) == 32u) ? r->stamps + (size_t)(2 * 8192 + 8190) * 16 : nullptr);
+                         (r->stamps && (frame_index & 63u) == 32u) ? r->stamps + (size_t)(2 * 8192 + 8190) * 16 : nullptr, r->dir_dev + 1);
     } else {
       if (!front_by_launch) SMX_HIP(hipEventRecord(r->ev_front, sF));
       if (!(r->debug_skip & 4)) SMX_HIP(hipStreamWaitEvent(sR, r->ev_front, 0));   // (bit 2: timing only -- what is the hand-over worth?)

@@ -779,6 +779,8 @@ def test_handover_gate_gives_up_instead_of_hanging(smx, monkeypatch):
     pg.reconstruction.debug_set_skip(0)
     with pytest.raises(smx.SmxError, match="hand-over timed out"):
         pg.reconstruction.surfels_size()
+    run_both(po, pg, s, [9], None)                      # the next call finds the gate's mark and goes back to the event
+    assert pg.reconstruction.handover_mode() == 0
     monkeypatch.setenv("ROCPROF_COUNTER_COLLECTION", "1")
     _, pg2 = _pipes(smx, s, 60000)
     assert pg2.reconstruction.handover_mode() == 0
