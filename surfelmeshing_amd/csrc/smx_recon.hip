@@ -274,9 +274,10 @@ constexpr uint32_t kSubLists = 16;
 constexpr uint32_t kAccCount = 16;        // acc_chunks.count = rec_chunks.count + kAccCount: the second half of the same lines
 struct Chunks { uint32_t* desc; uint32_t* count; uint32_t stride; };   // desc[k * stride + j], count[k * kCountStride]
 struct Lists {
-  Chunks vis_chunks, rec_chunks;
+  Chunks vis_chunks, rec_chunks;   // (vis_chunks: only the kSubLists counters = the lengths of the visible list's runs)
   Chunks acc_chunks;      // segments the edge kernel has work in (descriptor = segment); its counters share rec_chunks' lines (kAccCount)
-  uint32_t* vis_list;     // slots that project into the image this frame
+  uint32_t* vis_list;     // slots that project into the image this frame: kSubLists dense runs, run k at k * vis_region (vis_*)
+  uint32_t vis_region;    // entries per run: every kSubLists-th surviving segment's slots at most
   float* seg_box;         // per pass-A segment: min xyz, max xyz, covered slot count (u32), newest stamp (u32)
   uint32_t* vis_seg;
   uint8_t* seg_streak;      // per pass-A segment: in how many calls in a row pass A has culled it (k_scan_visible, step 2)
@@ -361,18 +362,6 @@ __device__ __forceinline__ void pair_store(const TileBins& tb, uint32_t key, uin
   const uint32_t tile = key >> 10, code = key & 1023u;
   if (pos < tb.cap) tb.pairs[(size_t)tile * tb.cap + pos] = make_uint2(slot, code);
   else tb.ovf[atomicAdd(tb.ovf_count, 1u)] = make_uint4(tile, slot, code, 0u);
-}
-
-// (thread 0 of the workgroup that built a segment's list; `deal` picks the sub-list: consecutive values for consecutive segments)
-__device__ __forceinline__ void emit_chunks(const Chunks& ch, uint32_t deal, uint32_t segment, uint32_t total, uint32_t chunks_per_segment) {
-  if (total == 0) return;
-  const uint32_t k = deal % kSubLists;
-  const uint32_t nc = (total + kBlock - 1) / kBlock;
-  const uint32_t pos = atomicAdd(&ch.count[k * kCountStride], nc);
-  for (uint32_t q = 0; q < nc; ++q) {
-    const uint32_t in_chunk = min((uint32_t)kBlock, total - q * kBlock);
-    ch.desc[(size_t)k * ch.stride + pos + q] = (segment * chunks_per_segment + q) | ((in_chunk - 1u) << 24);
-  }
 }
 
 // Work-list entry of the edge kernel (k_reg_accumulate), written by pass B: the slot's position in its segment, which of
@@ -657,6 +646,7 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, SegWork sw, const ui
   // one -- a word per tile, 38 KB at 1280 x 960 -- capped the chip at four workgroups per CU); pair_key = tile, later the
   // base of the workgroup's run
   __shared__ uint32_t pair_key[kPairHash], pair_cnt[kPairHash];
+  __shared__ uint32_t vis_run_pos;
   const bool lds_tables = use_lds_tables != 0;
   const uint32_t G = gridDim.x, wg = blockIdx.x;
   const uint32_t n_surv = sw.count[0], n_copy = sw.count[1];
@@ -789,7 +779,10 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, SegWork sw, const ui
         bp[7] = wave_recent ? 1.0f : 0.0f;
       }
       uint32_t total;
-      uint32_t off = base + block_excl_scan((uint32_t)__popc(vis_bits), wave_tot, total);  // (synchronises)
+      uint32_t off = block_excl_scan((uint32_t)__popc(vis_bits), wave_tot, total);  // (synchronises)
+      // the segment's place in its run of the visible list (vis_*): one returning atomic, in flight with the tile reservations below
+      uint32_t run_pos = 0;
+      if (tid == 0 && total) run_pos = atomicAdd(&L.vis_chunks.count[(e % kSubLists) * kCountStride], total);
       // the pair that drew rank 0 reserves the run of its (workgroup, tile); all reservations of the workgroup are in
       // flight together (the tile number goes through an opaque VGPR: with a visibly uniform address the compiler's atomic
       // optimizer wraps the operation in a wave reduction + readfirstlane, i.e. a wait for each result in turn)
@@ -808,11 +801,13 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, SegWork sw, const ui
         for (int j = 0; j < 8; ++j)
           if (key[j] != kNoPair && (rank[j] & 0xFFFFu) == 0 && rank[j] != kInvalid) pair_key[rank[j] >> 16] = got[j];   // (every probe is done: the barrier above)
       }
+      if (tid == 0) vis_run_pos = run_pos;
+      __syncthreads();
+      off += (e % kSubLists) * L.vis_region + vis_run_pos;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (vis_bits & (1u << j)) L.vis_list[off++] = i0 + j;
       if (lds_tables) {
-        __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           if (key[j] != kNoPair)
@@ -826,7 +821,6 @@ k_scan_visible(Surfels S, FrameCtx c, Lists L, TileBins tb, SegWork sw, const ui
       if (tid == 0) {
         L.vis_seg[seg_id] = total;
         L.seg_act[seg_id] = (total != 0 || box_part[0][7] + box_part[1][7] + box_part[2][7] + box_part[3][7] != 0.0f) ? 1 : 0;
-        emit_chunks(L.vis_chunks, e, seg_id, total, kSeg / kBlock);
         float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
         int ns = (int)0x80000000;
         for (int w = 0; w < kBlock / 64; ++w) {
@@ -872,15 +866,38 @@ __device__ __forceinline__ bool walk_step_valid(uint32_t c, uint32_t cntv) {
   const uint32_t k = __builtin_amdgcn_readfirstlane(c % kSubLists);
   return c / kSubLists < (uint32_t)__builtin_amdgcn_readlane((int)cntv, (int)k);
 }
-template <bool kUseList, int kSegSize = kSeg>
-__device__ __forceinline__ bool walk_entry(const uint32_t* __restrict__ list, uint32_t desc, uint32_t c, uint32_t n_slots_scan,
-                                           uint32_t lane, uint32_t& i) {
+// The VISIBLE list is dense: pass A appends a segment's visible slots to one of kSubLists runs (its counter = the run's length;
+// no chunk descriptors), walk step c = lanes' entries (c / kSubLists) * kBlock .. of run c % kSubLists.  Rounds 3 - 6 listed them
+// per segment in chunks of <= kBlock (a descriptor each): 57 % of the lanes of a step had an entry, and a workgroup found its slot
+// numbers two dependent round trips in (descriptor, then entry).  Here the first entries are requested together with the run
+// lengths (their address depends on neither), and a step is full except for the last one of each run.
+template <bool kUseList>
+__device__ __forceinline__ uint32_t vis_load(const Lists& L, uint32_t c) {
+  if (!kUseList) return 0u;
+  const uint32_t e = min((c / kSubLists) * (uint32_t)kBlock + threadIdx.x, L.vis_region - 1u);   // (in bounds whatever c: formed before the lengths are known)
+  return L.vis_list[(size_t)(c % kSubLists) * L.vis_region + e];
+}
+template <bool kUseList>
+__device__ __forceinline__ uint32_t vis_begin(const Lists& L, uint32_t n_slots_scan, uint32_t first, uint32_t& ent, uint32_t& cntv) {
   if (kUseList) {
-    constexpr uint32_t kChunksPerSeg = kSegSize / kBlock;
-    const uint32_t chunk = desc & 0x00FFFFFFu;
-    if (lane > (desc >> 24)) return false;
-    i = list[(chunk / kChunksPerSeg) * kSegSize + (chunk % kChunksPerSeg) * kBlock + lane];
-    return true;
+    ent = vis_load<true>(L, first);
+    cntv = L.vis_chunks.count[(threadIdx.x % kSubLists) * kCountStride];
+    keep_if<1>(ent); keep_if<1>(cntv);
+    uint32_t longest = (cntv + (uint32_t)kBlock - 1u) / (uint32_t)kBlock;
+#pragma unroll
+    for (uint32_t off = kSubLists / 2; off > 0; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, (int)off));
+    return __builtin_amdgcn_readfirstlane(longest) * kSubLists;
+  }
+  ent = 0; cntv = 0;
+  return (n_slots_scan + kBlock - 1) / kBlock;
+}
+template <bool kUseList>
+__device__ __forceinline__ bool vis_entry(uint32_t ent, uint32_t c, uint32_t cntv, uint32_t n_slots_scan, uint32_t lane, uint32_t& i) {
+  if (kUseList) {
+    const uint32_t k = __builtin_amdgcn_readfirstlane(c % kSubLists);
+    const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)cntv, (int)k);
+    i = ent;
+    return (c / kSubLists) * (uint32_t)kBlock + lane < len;
   }
   i = c * kBlock + lane;
   return i < n_slots_scan;
@@ -1737,14 +1754,13 @@ k_integrate(Surfels S, FrameCtx c, Scratch sc, FrameIn in, Lists L,
   const uint32_t block = blockIdx.x - n_flag_blocks, n_blocks = gridDim.x - n_flag_blocks;
   const uint32_t n_scan = kUseList ? 0u : st->surfel_count;
   uint32_t merged_here = 0;
-  uint32_t desc, cntv;
-  const uint32_t n_steps = walk_begin<kUseList>(L.vis_chunks, n_scan, block, desc, cntv);
+  uint32_t ent, cntv;
+  const uint32_t n_steps = vis_begin<kUseList>(L, n_scan, block, ent, cntv);
   for (uint32_t w = block; w < n_steps; w += n_blocks) {
-    const uint32_t cur = desc;
-    desc = walk_next<kUseList>(L.vis_chunks, w + n_blocks, n_steps);   // (the next step's descriptor travels while this one is worked on)
+    const uint32_t cur = ent;
+    ent = (w + n_blocks < n_steps) ? vis_load<kUseList>(L, w + n_blocks) : 0u;   // (the next step's entries travel while this one is worked on)
     uint32_t i;
-    if (kUseList && !walk_step_valid(w, cntv)) continue;
-    if (!walk_entry<kUseList>(L.vis_list, cur, w, n_scan, threadIdx.x, i)) continue;
+    if (!vis_entry<kUseList>(cur, w, cntv, n_scan, threadIdx.x, i)) continue;
     // the merge mark and the three records the integration works on, requested together (pinned: the compiler would ask for
     // the mark, wait, ask for P, wait for the activity test, and only then for N and C -- three round trips on a kernel
     // that sits on both cycles of the frame)
@@ -1812,14 +1828,13 @@ __device__ __forceinline__ void update_neighbors_body(const Surfels& S, const Fr
   const uint32_t n_scan = kUseList ? 0u : st->create_base_next;
   // (this launch precedes the regulariser's pass B on every path through Integrate: its chunk counter starts at zero)
   if (block == 0 && threadIdx.x < kSubLists) { L.rec_chunks.count[threadIdx.x * kCountStride] = 0; L.acc_chunks.count[threadIdx.x * kCountStride] = 0; }
-  uint32_t desc, cntv;
-  const uint32_t n_steps = walk_begin<kUseList>(L.vis_chunks, n_scan, block, desc, cntv);
+  uint32_t ent, cntv;
+  const uint32_t n_steps = vis_begin<kUseList>(L, n_scan, block, ent, cntv);
   for (uint32_t w = block; w < n_steps; w += n_blocks) {
-    const uint32_t cur = desc;
-    desc = walk_next<kUseList>(L.vis_chunks, w + n_blocks, n_steps);   // (the next step's descriptor travels while this one is worked on)
+    const uint32_t cur = ent;
+    ent = (w + n_blocks < n_steps) ? vis_load<kUseList>(L, w + n_blocks) : 0u;   // (the next step's entries travel while this one is worked on)
     uint32_t i;
-    if (kUseList && !walk_step_valid(w, cntv)) continue;
-    if (!walk_entry<kUseList>(L.vis_list, cur, w, n_scan, threadIdx.x, i)) continue;
+    if (!vis_entry<kUseList>(cur, w, cntv, n_scan, threadIdx.x, i)) continue;
     // the slot's three records in flight together (P: position + stamp, N: normal + r^2, T: neighbour ids)
     const float4 p4 = *S.group(kGroupP, i), n4 = *S.group(kGroupN, i);
     const uint4 t4 = *reinterpret_cast<const uint4*>(S.group(kGroupT, i));
@@ -3551,7 +3566,8 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   r->fb.cap = kFarBinCap; r->fb.hash_mask = (uint32_t)kFarHash - 1u;
   SMX_TRY(dev_alloc(&r->fb.rec, (size_t)r->nsegB * kFarBinCap, false));
   SMX_TRY(dev_alloc(&r->fb.count, ((size_t)r->nsegB + 1) * kCountStride, true));
-  SMX_TRY(dev_alloc(&r->L.vis_list, (size_t)r->nseg * kSeg, false));
+  r->L.vis_region = (uint32_t)(div_up(r->nseg, kSubLists) * kSeg);
+  SMX_TRY(dev_alloc(&r->L.vis_list, (size_t)kSubLists * r->L.vis_region, true));
   SMX_TRY(dev_alloc(&r->L.recent_list, (size_t)r->nsegB * kSegB, false));
   SMX_TRY(dev_alloc(&r->L.vis_seg, (size_t)r->nseg, true));
   SMX_TRY(dev_alloc(&r->L.seg_box, (size_t)r->nseg * 8, true));
@@ -3569,9 +3585,8 @@ int smx_recon_create(uint32_t max_surfel_count, int32_t width, int32_t height,
   // chunk descriptors: every chunk of every segment in the worst case, + room for the index a walk forms first
   // chunk descriptors: kSubLists interleaved sub-lists; one holds at most every kSubLists-th segment's chunks, + room for
   // the index a walk forms before it knows the lengths
-  r->L.vis_chunks.stride = (uint32_t)(div_up(r->nseg, kSubLists) * (kSeg / kBlock) + 8192);
+  r->L.vis_chunks.stride = 0; r->L.vis_chunks.desc = nullptr;   // (the visible list is dense: counters only, vis_begin)
   r->L.rec_chunks.stride = (uint32_t)(div_up(r->nsegB, kSubLists) + 8192);
-  SMX_TRY(dev_alloc(&r->L.vis_chunks.desc, (size_t)kSubLists * r->L.vis_chunks.stride, true));
   SMX_TRY(dev_alloc(&r->L.rec_chunks.desc, (size_t)kSubLists * r->L.rec_chunks.stride, true));
   SMX_TRY(dev_alloc(&r->L.rec_chunks.count, (size_t)kSubLists * kCountStride, true));
   static_assert(kSegAcc == kSegB && kAccCount < kCountStride, "pass B lists the edge kernel's segments by its own segment numbers");
